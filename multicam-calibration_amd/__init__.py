@@ -1,0 +1,12 @@
+"""mcba -- MI355X-native bundle adjustment behind the reference's `bundle_adjust()`.
+
+Only what the hot path needs lives here:
+  csrc/      HIP kernels for gfx950 + the C-ABI (`libmcba.so`, declared in include/mcba.h)
+  ops.py     ctypes binding of that ABI (fails loudly if the library is missing)
+  solver.py  host-side Levenberg-Marquardt / Schur driver
+  api.py     `bundle_adjust` with the reference's exact signature and return tuple
+  synth.py   deterministic synthetic board detections for tests and bench
+"""
+from . import synth  # noqa: F401
+
+__all__ = ["synth"]

@@ -1,0 +1,496 @@
+// mcba_math.h -- per-observation arithmetic of the bundle-adjustment hot path.
+//
+// Everything the kernels compute per (camera c, frame f, board point p) lives here as
+// small inlined functions, so the same text is compiled into the gfx950 kernels
+// (mcba_kernels.hip) and into the host-side unit harness (tests/hostcheck).
+//
+// Model (reference: multicam_calibration/geometry.py:277-325, bundle_adjustment.py:10-98):
+//   X_c = R(rho_c) (R(omega_f) X_o + tau_f) + t_c ;  a = x/z, b = y/z, s = a^2+b^2,
+//   d = 1 + k1 s + k2 s^2 ;  u = fx a d + cx, v = fy b d + cy ;  residual = observed - predicted.
+//
+// "Local" Jacobian.  With P = d(u,v)/dX_c (2x3), R_cf = R_c R_f and A = (X_o x (P R_cf)) row-wise,
+//   d(u,v)/d(camera 12)  = [ L_I | A Phi_a + P Phi_b | P ],   d(u,v)/d(pose 6) = [ A Psi_a | P Psi_b ]
+// where L_I is the 2x6 intrinsics part and, per (c,f) only (not per point),
+//   Phi_a = R_f^T Jr(rho_c), Phi_b = -R_c [tau_f]x Jr(rho_c), Psi_a = Jr(omega_f), Psi_b = R_c,
+// Jr = right Jacobian of SO(3).  So the kernels accumulate the 12x12 Gram matrix of the local rows
+// L = [L_I | A | P] over the points of one (c,f) -- lane-local, no cross-lane traffic -- and expand it
+// ONCE per (c,f) into U_cf (12x12), W_cf (12x6), V_cf (6x6) and the gradient pieces.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define MCBA_HD __host__ __device__ __forceinline__
+#else
+#define MCBA_HD inline
+#endif
+
+namespace mcba {
+
+enum Loss { LOSS_LINEAR = 0, LOSS_SOFT_L1 = 1, LOSS_HUBER = 2, LOSS_CAUCHY = 3, LOSS_ARCTAN = 4 };
+
+constexpr double MCBA_EPS = 2.220446049250313e-16;
+
+// ---------------------------------------------------------------- rotations
+// a = sin t/t, b = (1-cos t)/t^2, c = (t-sin t)/t^3 with series below t^2 = 1e-4.
+MCBA_HD void rot_coeffs(double th2, double& a, double& b, double& c) {
+  if (th2 < 1e-4) {
+    a = 1.0 - th2 * (1.0 / 6.0) * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0)));
+    b = 0.5 * (1.0 - th2 * (1.0 / 12.0) * (1.0 - th2 * (1.0 / 30.0) * (1.0 - th2 * (1.0 / 56.0))));
+    c = (1.0 / 6.0) * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0) * (1.0 - th2 * (1.0 / 72.0))));
+  } else {
+    double th = sqrt(th2);
+    double s = sin(th), co = cos(th);
+    a = s / th;
+    b = (1.0 - co) / th2;
+    c = (th - s) / (th * th2);
+  }
+}
+
+// R(r) = I + a [r]x + b [r]x^2  (reference convention, R(0) = I: geometry.py:8-35)
+// Jr(r) = I - b [r]x + c [r]x^2 (right Jacobian: R(r + e) ~ R(r) Exp(Jr e))
+MCBA_HD void rot_and_jr(const double r[3], double R[9], double Jr[9]) {
+  double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  double a, b, c;
+  rot_coeffs(th2, a, b, c);
+  double dR = 1.0 - b * th2, dJ = 1.0 - c * th2;
+  R[0] = dR + b * r[0] * r[0];
+  R[4] = dR + b * r[1] * r[1];
+  R[8] = dR + b * r[2] * r[2];
+  Jr[0] = dJ + c * r[0] * r[0];
+  Jr[4] = dJ + c * r[1] * r[1];
+  Jr[8] = dJ + c * r[2] * r[2];
+  double r01 = r[0] * r[1], r02 = r[0] * r[2], r12 = r[1] * r[2];
+  R[1] = b * r01 - a * r[2];
+  R[3] = b * r01 + a * r[2];
+  R[2] = b * r02 + a * r[1];
+  R[6] = b * r02 - a * r[1];
+  R[5] = b * r12 - a * r[0];
+  R[7] = b * r12 + a * r[0];
+  Jr[1] = c * r01 + b * r[2];
+  Jr[3] = c * r01 - b * r[2];
+  Jr[2] = c * r02 - b * r[1];
+  Jr[6] = c * r02 + b * r[1];
+  Jr[5] = c * r12 + b * r[0];
+  Jr[7] = c * r12 - b * r[0];
+}
+
+MCBA_HD void rot_only(const double r[3], double R[9]) {
+  double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  double a, b, c;
+  rot_coeffs(th2, a, b, c);
+  double dR = 1.0 - b * th2;
+  double r01 = r[0] * r[1], r02 = r[0] * r[2], r12 = r[1] * r[2];
+  R[0] = dR + b * r[0] * r[0];
+  R[4] = dR + b * r[1] * r[1];
+  R[8] = dR + b * r[2] * r[2];
+  R[1] = b * r01 - a * r[2];
+  R[3] = b * r01 + a * r[2];
+  R[2] = b * r02 + a * r[1];
+  R[6] = b * r02 - a * r[1];
+  R[5] = b * r12 - a * r[0];
+  R[7] = b * r12 + a * r[0];
+}
+
+// ---------------------------------------------------------------- 3x3 helpers (row-major)
+MCBA_HD void mm33(const double* A, const double* B, double* C) {  // C = A B
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+MCBA_HD void mtm33(const double* A, const double* B, double* C) {  // C = A^T B
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+MCBA_HD void mmt33(const double* A, const double* B, double* C) {  // C = A B^T
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
+}
+MCBA_HD void mv3(const double* A, const double* x, double* y) {  // y = A x
+#pragma unroll
+  for (int i = 0; i < 3; ++i) y[i] = A[3 * i] * x[0] + A[3 * i + 1] * x[1] + A[3 * i + 2] * x[2];
+}
+MCBA_HD void mtv3(const double* A, const double* x, double* y) {  // y = A^T x
+#pragma unroll
+  for (int i = 0; i < 3; ++i) y[i] = A[i] * x[0] + A[3 + i] * x[1] + A[6 + i] * x[2];
+}
+
+// ---------------------------------------------------------------- per-(camera, frame) constants
+struct CamConst {   // staged in LDS once per workgroup
+  double fx, fy, cx, cy, k1, k2;
+  double R[9], t[3], Jr[9];
+};
+MCBA_HD void make_cam_const(const double cam12[12], CamConst& cc) {
+  cc.fx = cam12[0]; cc.fy = cam12[1]; cc.cx = cam12[2]; cc.cy = cam12[3]; cc.k1 = cam12[4]; cc.k2 = cam12[5];
+  rot_and_jr(cam12 + 6, cc.R, cc.Jr);
+  cc.t[0] = cam12[9]; cc.t[1] = cam12[10]; cc.t[2] = cam12[11];
+}
+
+struct PairConst {  // what the point loop needs: X_c = Rcf X_o + tcf
+  double Rcf[9], tcf[3];
+};
+MCBA_HD void make_pair_const(const double* Rc, const double* tc, const double* Rf, const double* tau, PairConst& pc) {
+  mm33(Rc, Rf, pc.Rcf);
+  mv3(Rc, tau, pc.tcf);
+  pc.tcf[0] += tc[0]; pc.tcf[1] += tc[1]; pc.tcf[2] += tc[2];
+}
+
+// chain-rule matrices of one (c,f): Phi_a, Phi_b, Psi_a (= Jr_f), Psi_b (= R_c)
+struct ChainConst {
+  double Pa[9], Pb[9], Sa[9], Sb[9];
+};
+MCBA_HD void make_chain_const(const double* Rc, const double* Jrc, const double* Rf, const double* Jrf, const double* tau, ChainConst& ch) {
+  mtm33(Rf, Jrc, ch.Pa);  // R_f^T Jr_c
+  // -R_c [tau]x Jr_c :  [tau]x Jr_c has columns tau x Jr_c[:,j]
+  double TJ[9];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    double v0 = Jrc[j], v1 = Jrc[3 + j], v2 = Jrc[6 + j];
+    TJ[j] = tau[1] * v2 - tau[2] * v1;
+    TJ[3 + j] = tau[2] * v0 - tau[0] * v2;
+    TJ[6 + j] = tau[0] * v1 - tau[1] * v0;
+  }
+  mm33(Rc, TJ, ch.Pb);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    ch.Pb[i] = -ch.Pb[i];
+    ch.Sa[i] = Jrf[i];
+    ch.Sb[i] = Rc[i];
+  }
+}
+
+// ---------------------------------------------------------------- robust loss (scipy least_squares.py:160-227, common.py:720-731)
+// in : r (residual), inv_fs2 = 1/f_scale^2, fs2 = f_scale^2
+// out: rho_half = 0.5 f_scale^2 rho(z)  (this observation's share of the cost)
+//      gw = rho'(z)                      (gradient weight:  g = J^T (rho' f))
+//      w2 = max(rho' + 2 rho'' f^2, EPS) (Gauss-Newton weight: J~^T J~ = sum w2 j^T j)
+template <int LOSS>
+MCBA_HD void loss_weights(double r, double fs2, double inv_fs2, double& rho_half, double& gw, double& w2) {
+  double r2 = r * r;
+  if (LOSS == LOSS_LINEAR) {
+    rho_half = 0.5 * r2; gw = 1.0; w2 = 1.0;
+    return;
+  }
+  double z = r2 * inv_fs2;
+  double rho0, rho1, rho2;
+  if (LOSS == LOSS_SOFT_L1) {
+    double t = sqrt(1.0 + z);
+    double it = 1.0 / t;
+    rho0 = 2.0 * (t - 1.0); rho1 = it; rho2 = -0.5 * it * it * it;
+  } else if (LOSS == LOSS_HUBER) {
+    if (z <= 1.0) { rho0 = z; rho1 = 1.0; rho2 = 0.0; }
+    else { double sz = sqrt(z); rho0 = 2.0 * sz - 1.0; rho1 = 1.0 / sz; rho2 = -0.5 * rho1 / z; }
+  } else if (LOSS == LOSS_CAUCHY) {
+    double it = 1.0 / (1.0 + z);
+    rho0 = log1p(z); rho1 = it; rho2 = -it * it;
+  } else {
+    double it = 1.0 / (1.0 + z * z);
+    rho0 = atan(z); rho1 = it; rho2 = -2.0 * z * it * it;
+  }
+  rho_half = 0.5 * fs2 * rho0;
+  gw = rho1;
+  double js = rho1 + 2.0 * (rho2 * inv_fs2) * r2;
+  w2 = js < MCBA_EPS ? MCBA_EPS : js;
+}
+
+// ---------------------------------------------------------------- one point-observation
+struct ObsRows {
+  double up, vp;          // prediction
+  double l0, l1;          // d u/d fx = a d,  d v/d fy = b d
+  double l4u, l4v;        // d/d k1: fx a s, fy b s
+  double l5u, l5v;        // d/d k2: fx a s^2, fy b s^2
+  double Eu[6], Ev[6];    // [A | P] rows
+};
+
+struct Intr { double fx, fy, cx, cy, k1, k2; };
+
+MCBA_HD void project_only(const Intr& K, const PairConst& pc, const double Xo[3], double& up, double& vp) {
+  double x = pc.Rcf[0] * Xo[0] + pc.Rcf[1] * Xo[1] + pc.Rcf[2] * Xo[2] + pc.tcf[0];
+  double y = pc.Rcf[3] * Xo[0] + pc.Rcf[4] * Xo[1] + pc.Rcf[5] * Xo[2] + pc.tcf[1];
+  double z = pc.Rcf[6] * Xo[0] + pc.Rcf[7] * Xo[1] + pc.Rcf[8] * Xo[2] + pc.tcf[2];
+  double iz = 1.0 / z;
+  double a = x * iz, b = y * iz;
+  double s = a * a + b * b;
+  double d = 1.0 + s * (K.k1 + K.k2 * s);
+  up = K.fx * a * d + K.cx;
+  vp = K.fy * b * d + K.cy;
+}
+
+MCBA_HD void obs_rows(const Intr& K, const PairConst& pc, const double Xo[3], ObsRows& o) {
+  double x = pc.Rcf[0] * Xo[0] + pc.Rcf[1] * Xo[1] + pc.Rcf[2] * Xo[2] + pc.tcf[0];
+  double y = pc.Rcf[3] * Xo[0] + pc.Rcf[4] * Xo[1] + pc.Rcf[5] * Xo[2] + pc.tcf[1];
+  double z = pc.Rcf[6] * Xo[0] + pc.Rcf[7] * Xo[1] + pc.Rcf[8] * Xo[2] + pc.tcf[2];
+  double iz = 1.0 / z;
+  double a = x * iz, b = y * iz;
+  double s = a * a + b * b;
+  double d = 1.0 + s * (K.k1 + K.k2 * s);
+  double dp = K.k1 + 2.0 * K.k2 * s;
+  double fa = K.fx * a, fb = K.fy * b;
+  o.up = fa * d + K.cx;
+  o.vp = fb * d + K.cy;
+  o.l0 = a * d;
+  o.l1 = b * d;
+  o.l4u = fa * s;
+  o.l4v = fb * s;
+  o.l5u = o.l4u * s;
+  o.l5v = o.l4v * s;
+  // D_ab and P = D_ab [[iz,0,-a iz],[0,iz,-b iz]]
+  double abdp = 2.0 * a * b * dp;
+  double d00 = K.fx * (d + 2.0 * a * a * dp), d01 = K.fx * abdp;
+  double d10 = K.fy * abdp, d11 = K.fy * (d + 2.0 * b * b * dp);
+  double pu0 = d00 * iz, pu1 = d01 * iz, pu2 = -(pu0 * a + pu1 * b);
+  double pv0 = d10 * iz, pv1 = d11 * iz, pv2 = -(pv0 * a + pv1 * b);
+  o.Eu[3] = pu0; o.Eu[4] = pu1; o.Eu[5] = pu2;
+  o.Ev[3] = pv0; o.Ev[4] = pv1; o.Ev[5] = pv2;
+  // B = P Rcf (row vectors), A = X_o x B
+  double bu0 = pu0 * pc.Rcf[0] + pu1 * pc.Rcf[3] + pu2 * pc.Rcf[6];
+  double bu1 = pu0 * pc.Rcf[1] + pu1 * pc.Rcf[4] + pu2 * pc.Rcf[7];
+  double bu2 = pu0 * pc.Rcf[2] + pu1 * pc.Rcf[5] + pu2 * pc.Rcf[8];
+  double bv0 = pv0 * pc.Rcf[0] + pv1 * pc.Rcf[3] + pv2 * pc.Rcf[6];
+  double bv1 = pv0 * pc.Rcf[1] + pv1 * pc.Rcf[4] + pv2 * pc.Rcf[7];
+  double bv2 = pv0 * pc.Rcf[2] + pv1 * pc.Rcf[5] + pv2 * pc.Rcf[8];
+  o.Eu[0] = Xo[1] * bu2 - Xo[2] * bu1;
+  o.Eu[1] = Xo[2] * bu0 - Xo[0] * bu2;
+  o.Eu[2] = Xo[0] * bu1 - Xo[1] * bu0;
+  o.Ev[0] = Xo[1] * bv2 - Xo[2] * bv1;
+  o.Ev[1] = Xo[2] * bv0 - Xo[0] * bv2;
+  o.Ev[2] = Xo[0] * bv1 - Xo[1] * bv0;
+}
+
+// ---------------------------------------------------------------- local Gram accumulator of one (c,f)
+// H_II has 17 structural non-zeros (L_I rows are sparse); order of `ii`:
+//  0:(0,0) 1:(0,2) 2:(0,4) 3:(0,5) 4:(1,1) 5:(1,3) 6:(1,4) 7:(1,5) 8:(2,2) 9:(2,4) 10:(2,5)
+//  11:(3,3) 12:(3,4) 13:(3,5) 14:(4,4) 15:(4,5) 16:(5,5)
+struct Gram {
+  double ii[17];
+  double ie[36];  // 6 x 6 : intrinsics x [A|P]
+  double ee[21];  // upper triangle of [A|P]^T [A|P], row-major (i<=j)
+  double hi[6], he[6];  // gradient pieces  J_res^T (rho' r)  (residual = obs - pred => minus sign folded in)
+  double cost;
+};
+
+MCBA_HD void gram_zero(Gram& g) {
+#pragma unroll
+  for (int i = 0; i < 17; ++i) g.ii[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) g.ie[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 21; ++i) g.ee[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { g.hi[i] = 0.0; g.he[i] = 0.0; }
+  g.cost = 0.0;
+}
+
+// wu2, wv2: Gauss-Newton weights (0 for a missing scalar); gu, gv = rho' * residual (0 if missing)
+MCBA_HD void gram_add(Gram& g, const ObsRows& o, double wu2, double wv2, double gu, double gv) {
+  double Euw[6], Evw[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { Euw[j] = wu2 * o.Eu[j]; Evw[j] = wv2 * o.Ev[j]; }
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) { g.ee[k] += Euw[i] * o.Eu[j] + Evw[i] * o.Ev[j]; ++k; }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    g.ie[j] += o.l0 * Euw[j];
+    g.ie[6 + j] += o.l1 * Evw[j];
+    g.ie[12 + j] += Euw[j];
+    g.ie[18 + j] += Evw[j];
+    g.ie[24 + j] += o.l4u * Euw[j] + o.l4v * Evw[j];
+    g.ie[30 + j] += o.l5u * Euw[j] + o.l5v * Evw[j];
+    g.he[j] -= o.Eu[j] * gu + o.Ev[j] * gv;
+  }
+  double w0 = wu2 * o.l0, w1 = wv2 * o.l1, w4u = wu2 * o.l4u, w4v = wv2 * o.l4v, w5u = wu2 * o.l5u, w5v = wv2 * o.l5v;
+  g.ii[0] += w0 * o.l0;
+  g.ii[1] += w0;
+  g.ii[2] += w0 * o.l4u;
+  g.ii[3] += w0 * o.l5u;
+  g.ii[4] += w1 * o.l1;
+  g.ii[5] += w1;
+  g.ii[6] += w1 * o.l4v;
+  g.ii[7] += w1 * o.l5v;
+  g.ii[8] += wu2;
+  g.ii[9] += w4u;
+  g.ii[10] += w5u;
+  g.ii[11] += wv2;
+  g.ii[12] += w4v;
+  g.ii[13] += w5v;
+  g.ii[14] += w4u * o.l4u + w4v * o.l4v;
+  g.ii[15] += w4u * o.l5u + w4v * o.l5v;
+  g.ii[16] += w5u * o.l5u + w5v * o.l5v;
+  g.hi[0] -= o.l0 * gu;
+  g.hi[1] -= o.l1 * gv;
+  g.hi[2] -= gu;
+  g.hi[3] -= gv;
+  g.hi[4] -= o.l4u * gu + o.l4v * gv;
+  g.hi[5] -= o.l5u * gu + o.l5v * gv;
+}
+
+// ---------------------------------------------------------------- expansion of the local Gram matrix (once per (c,f))
+// Outputs (all for the ROBUST-RESCALED residual Jacobian, as scipy forms them):
+//   U   : 78 doubles, upper triangle (row-major, i<=j) of J_c^T J_c  (12x12, params fx fy cx cy k1 k2 rho t)
+//   gc  : 12        J_c^T f
+//   W   : 72        J_c^T J_f  (12x6 row-major; pose params omega, tau)
+//   V   : 21        upper triangle of J_f^T J_f
+//   gf  : 6         J_f^T f
+MCBA_HD int tri12(int i, int j) { return i * 12 - (i * (i - 1)) / 2 + (j - i); }  // i<=j
+MCBA_HD int tri6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+MCBA_HD void gram_expand(const Gram& g, const ChainConst& ch, double* U, double* gc, double* W, double* V, double* gf) {
+  // unpack the [A|P] blocks
+  double HAA[9], HAP[9], HPP[9], HPA[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      HAA[3 * i + j] = g.ee[i <= j ? tri6(i, j) : tri6(j, i)];
+      HPP[3 * i + j] = g.ee[i <= j ? tri6(3 + i, 3 + j) : tri6(3 + j, 3 + i)];
+      HAP[3 * i + j] = g.ee[tri6(i, 3 + j)];
+      HPA[3 * j + i] = HAP[3 * i + j];
+    }
+  // Q_A = Pa^T HAA + Pb^T HPA ; Q_P = Pa^T HAP + Pb^T HPP
+  double QA[9], QP[9], T1[9], T2[9];
+  mtm33(ch.Pa, HAA, T1); mtm33(ch.Pb, HPA, T2);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) QA[i] = T1[i] + T2[i];
+  mtm33(ch.Pa, HAP, T1); mtm33(ch.Pb, HPP, T2);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) QP[i] = T1[i] + T2[i];
+  // U_rr = QA Pa + QP Pb
+  double Urr[9];
+  mm33(QA, ch.Pa, T1); mm33(QP, ch.Pb, T2);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Urr[i] = T1[i] + T2[i];
+
+  // ---- U
+#pragma unroll
+  for (int i = 0; i < 78; ++i) U[i] = 0.0;
+  U[tri12(0, 0)] = g.ii[0];  U[tri12(0, 2)] = g.ii[1];  U[tri12(0, 4)] = g.ii[2];  U[tri12(0, 5)] = g.ii[3];
+  U[tri12(1, 1)] = g.ii[4];  U[tri12(1, 3)] = g.ii[5];  U[tri12(1, 4)] = g.ii[6];  U[tri12(1, 5)] = g.ii[7];
+  U[tri12(2, 2)] = g.ii[8];  U[tri12(2, 4)] = g.ii[9];  U[tri12(2, 5)] = g.ii[10];
+  U[tri12(3, 3)] = g.ii[11]; U[tri12(3, 4)] = g.ii[12]; U[tri12(3, 5)] = g.ii[13];
+  U[tri12(4, 4)] = g.ii[14]; U[tri12(4, 5)] = g.ii[15]; U[tri12(5, 5)] = g.ii[16];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double* hia = g.ie + 6 * i;      // H_IA row i
+    const double* hip = g.ie + 6 * i + 3;  // H_IP row i
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      U[tri12(i, 6 + j)] = hia[0] * ch.Pa[j] + hia[1] * ch.Pa[3 + j] + hia[2] * ch.Pa[6 + j] + hip[0] * ch.Pb[j] + hip[1] * ch.Pb[3 + j] + hip[2] * ch.Pb[6 + j];
+      U[tri12(i, 9 + j)] = hip[j];
+      // W rows of the intrinsics
+      W[6 * i + j] = hia[0] * ch.Sa[j] + hia[1] * ch.Sa[3 + j] + hia[2] * ch.Sa[6 + j];
+      W[6 * i + 3 + j] = hip[0] * ch.Sb[j] + hip[1] * ch.Sb[3 + j] + hip[2] * ch.Sb[6 + j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (i <= j) {
+        U[tri12(6 + i, 6 + j)] = Urr[3 * i + j];
+        U[tri12(9 + i, 9 + j)] = HPP[3 * i + j];
+      }
+      U[tri12(6 + i, 9 + j)] = QP[3 * i + j];
+    }
+  // ---- W rows of rho and t
+  double Wro[9], Wrt[9], Wto[9], Wtt[9];
+  mm33(QA, ch.Sa, Wro); mm33(QP, ch.Sb, Wrt); mm33(HPA, ch.Sa, Wto); mm33(HPP, ch.Sb, Wtt);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      W[6 * (6 + i) + j] = Wro[3 * i + j];
+      W[6 * (6 + i) + 3 + j] = Wrt[3 * i + j];
+      W[6 * (9 + i) + j] = Wto[3 * i + j];
+      W[6 * (9 + i) + 3 + j] = Wtt[3 * i + j];
+    }
+  // ---- V
+  double Voo[9], Vot[9], Vtt[9];
+  mm33(HAA, ch.Sa, T1); mtm33(ch.Sa, T1, Voo);
+  mm33(HAP, ch.Sb, T1); mtm33(ch.Sa, T1, Vot);
+  mm33(HPP, ch.Sb, T1); mtm33(ch.Sb, T1, Vtt);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (i <= j) { V[tri6(i, j)] = Voo[3 * i + j]; V[tri6(3 + i, 3 + j)] = Vtt[3 * i + j]; }
+      V[tri6(i, 3 + j)] = Vot[3 * i + j];
+    }
+  // ---- gradients
+  double ta[3], tb[3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) gc[i] = g.hi[i];
+  mtv3(ch.Pa, g.he, ta); mtv3(ch.Pb, g.he + 3, tb);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { gc[6 + i] = ta[i] + tb[i]; gc[9 + i] = g.he[3 + i]; }
+  mtv3(ch.Sa, g.he, gf); mtv3(ch.Sb, g.he + 3, gf + 3);
+}
+
+// ---------------------------------------------------------------- materialised Jacobian rows of one point-observation
+// Jc[12], Jf[6] for the u row and the v row of the PREDICTION (callers negate / rescale).
+MCBA_HD void expand_rows(const ObsRows& o, const ChainConst& ch, double* Jcu, double* Jcv, double* Jfu, double* Jfv) {
+  Jcu[0] = o.l0; Jcu[1] = 0.0; Jcu[2] = 1.0; Jcu[3] = 0.0; Jcu[4] = o.l4u; Jcu[5] = o.l5u;
+  Jcv[0] = 0.0; Jcv[1] = o.l1; Jcv[2] = 0.0; Jcv[3] = 1.0; Jcv[4] = o.l4v; Jcv[5] = o.l5v;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    Jcu[6 + j] = o.Eu[0] * ch.Pa[j] + o.Eu[1] * ch.Pa[3 + j] + o.Eu[2] * ch.Pa[6 + j] + o.Eu[3] * ch.Pb[j] + o.Eu[4] * ch.Pb[3 + j] + o.Eu[5] * ch.Pb[6 + j];
+    Jcv[6 + j] = o.Ev[0] * ch.Pa[j] + o.Ev[1] * ch.Pa[3 + j] + o.Ev[2] * ch.Pa[6 + j] + o.Ev[3] * ch.Pb[j] + o.Ev[4] * ch.Pb[3 + j] + o.Ev[5] * ch.Pb[6 + j];
+    Jcu[9 + j] = o.Eu[3 + j];
+    Jcv[9 + j] = o.Ev[3 + j];
+    Jfu[j] = o.Eu[0] * ch.Sa[j] + o.Eu[1] * ch.Sa[3 + j] + o.Eu[2] * ch.Sa[6 + j];
+    Jfv[j] = o.Ev[0] * ch.Sa[j] + o.Ev[1] * ch.Sa[3 + j] + o.Ev[2] * ch.Sa[6 + j];
+    Jfu[3 + j] = o.Eu[3] * ch.Sb[j] + o.Eu[4] * ch.Sb[3 + j] + o.Eu[5] * ch.Sb[6 + j];
+    Jfv[3 + j] = o.Ev[3] * ch.Sb[j] + o.Ev[4] * ch.Sb[3 + j] + o.Ev[5] * ch.Sb[6 + j];
+  }
+}
+
+// ---------------------------------------------------------------- 6x6 SPD helpers for the frame blocks
+// Cholesky of a packed upper-triangle 6x6 (tri6 order) -> L packed lower, row-major by (i>=j): Lp[i(i+1)/2 + j].
+// Returns false if a pivot is not positive.
+MCBA_HD bool chol6(const double* Vt, double* Lp) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double s = Vt[tri6(j, i)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= Lp[i * (i + 1) / 2 + k] * Lp[j * (j + 1) / 2 + k];
+      if (i == j) {
+        if (!(s > 0.0)) { ok = false; s = 1.0; }
+        Lp[i * (i + 1) / 2 + i] = sqrt(s);
+      } else {
+        Lp[i * (i + 1) / 2 + j] = s / Lp[j * (j + 1) / 2 + j];
+      }
+    }
+  }
+  return ok;
+}
+// y = L^-1 b   (forward substitution), idiag[i] = 1/L_ii
+MCBA_HD void fwd6(const double* Lp, const double* idiag, const double* b, double* y) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= Lp[i * (i + 1) / 2 + k] * y[k];
+    y[i] = s * idiag[i];
+  }
+}
+// x = L^-T y  (back substitution)
+MCBA_HD void bwd6(const double* Lp, const double* idiag, const double* y, double* x) {
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s -= Lp[k * (k + 1) / 2 + i] * x[k];
+    x[i] = s * idiag[i];
+  }
+}
+
+}  // namespace mcba

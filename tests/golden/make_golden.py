@@ -1,0 +1,206 @@
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Run in the build container only (the reference lives at /root/reference and never
+travels):      python tests/golden/make_golden.py [--slow]
+
+It loads the reference's own `geometry.py` and `bundle_adjustment.py` unmodified
+(recipe of SURVEY.md section 8c: an empty stub for `cv2`, which the hot path never calls)
+and records inputs + the reference's outputs as small .npz files.  Nothing here is
+reference source -- the fixtures are data.
+
+Files written
+  residuals.npz     residuals(x0) for four input variants                     (golden 1)
+  jacobian.npz      scipy 2-point / 3-point FD Jacobian of the reference residuals (golden 2)
+  sparsity.npz      bundle_adjustment_sparsity indices on a NaN-bearing input (golden 3)
+  prefilter.npz     use_frames / printed line for several n_frames, seeds     (golden 4)
+  default_run.npz   default bundle_adjust() on config 1 (2 x 50 x 54)         (golden 5)
+  robust.npz        scipy's soft_l1/huber/cauchy/arctan rho + rescale         (golden 7)
+  tight_*.npz       (--slow) tight-optimum runs, SURVEY.md section 7 protocol (golden 6)
+"""
+import contextlib
+import importlib.util
+import io
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+
+def load_reference():
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    pkg = types.ModuleType("multicam_calibration")
+    pkg.__path__ = ["/root/reference/multicam_calibration"]
+    sys.modules["multicam_calibration"] = pkg
+    mods = {}
+    for name in ("geometry", "bundle_adjustment"):
+        spec = importlib.util.spec_from_file_location(f"multicam_calibration.{name}", f"/root/reference/multicam_calibration/{name}.py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods["geometry"], mods["bundle_adjustment"]
+
+
+def problem_arrays(p):
+    """Flatten a synth problem into npz-storable arrays."""
+    K = np.stack([k for k, _ in p["intrinsics"]])
+    dist = np.stack([d for _, d in p["intrinsics"]])
+    return dict(uvs=p["uvs"], obj=p["obj"], extrinsics=p["extrinsics"], K=K, dist=dist, poses=p["poses"])
+
+
+def main(slow):
+    from multicam_calibration_amd import synth
+    from scipy.optimize._numdiff import approx_derivative, group_columns
+    from scipy.optimize._lsq.least_squares import construct_loss_function
+    from scipy.optimize._lsq.common import scale_for_robust_loss_function
+
+    geo, ba = load_reference()
+
+    # ---------------------------------------------------------------- golden 1: residuals
+    out = {}
+    variants = {
+        "complete": dict(n_cameras=2, n_frames=8, seed=10),
+        "missing": dict(n_cameras=3, n_frames=10, seed=11, missing=0.3, scalar_nans=7),
+        "fourcam": dict(n_cameras=4, n_frames=6, seed=12, rows=5, cols=7),
+    }
+    for name, kw in variants.items():
+        p = synth.make_problem(**kw)
+        x0 = ba.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+        for k, v in problem_arrays(p).items():
+            out[f"{name}_{k}"] = v
+        out[f"{name}_x0"] = x0
+        out[f"{name}_res"] = ba.residuals(x0, p["uvs"], p["obj"])
+        out[f"{name}_pred"] = ba.predict_calib_uvs(p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    # large r^2: push the board towards the image edge (big a, b) with stronger distortion
+    p = synth.make_problem(2, 6, seed=13)
+    p["poses"][:, 3] += 250.0
+    p["intrinsics"] = [(K, d * np.array([3.0, 3.0, 1, 1, 1])) for K, d in p["intrinsics"]]
+    x0 = ba.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    for k, v in problem_arrays(p).items():
+        out[f"edge_{k}"] = v
+    out["edge_x0"] = x0
+    out["edge_res"] = ba.residuals(x0, p["uvs"], p["obj"])
+    # rodrigues at and near theta = 0, and embed
+    rv = np.array([[0.0, 0, 0], [1e-9, -2e-9, 3e-9], [1e-5, 2e-5, -1e-5], [0.3, -0.2, 0.1], [2.0, 1.5, -1.0], [0, 0, np.pi - 1e-3]])
+    out["rodrigues_in"] = rv
+    out["rodrigues_out"] = geo.rodrigues(rv)
+    np.savez_compressed(os.path.join(HERE, "residuals.npz"), **out)
+    print("residuals.npz", {k: v.shape for k, v in out.items() if k.endswith("_res")})
+
+    # ---------------------------------------------------------------- golden 2: FD Jacobians of the reference residual
+    p = synth.make_problem(3, 6, seed=20, missing=0.2, scalar_nans=3)
+    x0 = ba.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    A = ba.bundle_adjustment_sparsity(p["uvs"])
+    groups = group_columns(A)
+    fun = lambda x: ba.residuals(x, p["uvs"], p["obj"])
+    J2 = approx_derivative(fun, x0, method="2-point", sparsity=(A, groups)).tocsr()
+    J3 = approx_derivative(fun, x0, method="3-point", sparsity=(A, groups)).tocsr()
+    J2.sort_indices(), J3.sort_indices()
+    out = problem_arrays(p)
+    out.update(x0=x0, J2_data=J2.data, J2_indices=J2.indices, J2_indptr=J2.indptr, J3_data=J3.data, J3_indices=J3.indices, J3_indptr=J3.indptr, n_groups=np.array(groups.max() + 1))
+    np.savez_compressed(os.path.join(HERE, "jacobian.npz"), **out)
+    print("jacobian.npz", J3.shape, J3.nnz, "groups", groups.max() + 1)
+
+    # ---------------------------------------------------------------- golden 3: sparsity
+    Acsr = A.tocsr()
+    Acsr.sort_indices()
+    np.savez_compressed(os.path.join(HERE, "sparsity.npz"), uvs=p["uvs"], indices=Acsr.indices, indptr=Acsr.indptr, shape=np.array(Acsr.shape))
+
+    # ---------------------------------------------------------------- golden 4: pre-filter (bundle_adjust up to the optimiser)
+    p = synth.make_problem(3, 40, seed=30, missing=0.25, outlier_frames=4, scalar_nans=5)
+    out = problem_arrays(p)
+    cases = []
+    for i, (n_frames, seed, thr) in enumerate([(None, 0, None), (1000, 1, None), (10, 2, None), (12, 3, 2.5), (None, 4, 1.0)]):
+        np.random.seed(seed)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            # max_nfev=1: we only want the wrapper behaviour (frame choice, printed line, x0)
+            r = ba.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=n_frames, outlier_threshold=thr, max_nfev=1, verbose=0)
+        use = r[3]
+        if n_frames is not None and n_frames == 10 and i == 2:
+            pass
+        out[f"case{i}_use"] = use
+        out[f"case{i}_line"] = np.array(buf.getvalue().splitlines()[0])
+        out[f"case{i}_rng_after"] = np.array(np.random.randint(0, 2**31 - 1))
+        out[f"case{i}_args"] = np.array([-1 if n_frames is None else n_frames, seed, -1.0 if thr is None else thr], dtype=float)
+        cases.append(i)
+    # n_frames == len(use_frames): the reference permutes the frames
+    np.random.seed(5)
+    n_eq = len(out["case0_use"])
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        r = ba.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=n_eq, max_nfev=1, verbose=0)
+    out["case5_use"] = r[3]
+    out["case5_line"] = np.array(buf.getvalue().splitlines()[0])
+    out["case5_rng_after"] = np.array(np.random.randint(0, 2**31 - 1))
+    out["case5_args"] = np.array([n_eq, 5, -1.0])
+    out["n_cases"] = np.array(6)
+    np.savez_compressed(os.path.join(HERE, "prefilter.npz"), **out)
+    print("prefilter.npz", [len(out[f"case{i}_use"]) for i in range(6)])
+
+    # ---------------------------------------------------------------- golden 5: default path on config 1
+    p = synth.make_problem(2, 50, seed=0, perturb_seed=1)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ext, intr, poses, use, res = ba.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None)
+    out = problem_arrays(p)
+    out.update(x=res.x, cost=np.array(res.cost), nfev=np.array(res.nfev), njev=np.array(res.njev), status=np.array(res.status), optimality=np.array(res.optimality), fun=res.fun, grad=res.grad, use=use, log=np.array(buf.getvalue()))
+    np.savez_compressed(os.path.join(HERE, "default_run.npz"), **out)
+    print("default_run.npz cost", res.cost, "nfev", res.nfev, "njev", res.njev, "status", res.status)
+
+    # ---------------------------------------------------------------- golden 7: robust loss (third-party scipy arithmetic)
+    f = np.concatenate([[0.0, 1e-8, 0.5, 1.0, 1.0 + 1e-12, 3.0, 50.0, 1e4], np.random.default_rng(70).normal(0, 2, 40)])
+    J = np.random.default_rng(71).normal(size=(f.size, 3))
+    out = dict(f=f, J=J)
+    for loss in ("soft_l1", "huber", "cauchy", "arctan"):
+        for fs in (1.0, 2.5):
+            lf = construct_loss_function(f.size, loss, fs)
+            rho = lf(f).copy()  # the closure reuses its buffer
+            Js, fsc = scale_for_robust_loss_function(J.copy(), f.copy(), rho)
+            out[f"{loss}_{fs}_rho"] = rho
+            out[f"{loss}_{fs}_cost"] = np.array(lf(f, cost_only=True))
+            out[f"{loss}_{fs}_J"] = Js
+            out[f"{loss}_{fs}_f"] = fsc
+    np.savez_compressed(os.path.join(HERE, "robust.npz"), **out)
+    print("robust.npz")
+
+    if not slow:
+        return
+
+    # ---------------------------------------------------------------- golden 6: tight optimum (hard part 1)
+    # The reference's own loop (scipy TRF) driven to a tight optimum through **opt_kwargs,
+    # with an analytic CSR Jacobian injected as the `jac=` callable (passes straight through
+    # bundle_adjustment.py:304,311).  Two different starts must agree (two-start validation).
+    from oracle import ba_oracle as orc
+
+    def tight(p, tag, **extra):
+        outs = {}
+        for s, pseed in enumerate(extra.pop("pseeds")):
+            q = synth.make_problem(perturb_seed=pseed, **p)
+            jac = lambda x, uvs, obj: orc.jacobian_csr(x, uvs, obj)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ext, intr, poses, use, res = ba.bundle_adjust(
+                    q["uvs"], q["extrinsics"], q["intrinsics"], q["obj"], q["poses"], n_frames=None,
+                    jac=jac, ftol=1e-15, xtol=1e-15, gtol=1e-10, max_nfev=400, verbose=0,
+                    tr_options=dict(atol=1e-15, btol=1e-15, maxiter=4000), **extra)
+            print(tag, "start", s, "cost %.15g" % res.cost, "nfev", res.nfev, "opt %.2e" % res.optimality, "status", res.status)
+            outs[f"s{s}_x"] = res.x
+            outs[f"s{s}_cost"] = np.array(res.cost)
+            outs[f"s{s}_use"] = use
+            outs[f"s{s}_optimality"] = np.array(res.optimality)
+            if s == 0:
+                outs.update({k: v for k, v in problem_arrays(q).items()})
+        np.savez_compressed(os.path.join(HERE, f"tight_{tag}.npz"), **outs)
+
+    tight(dict(n_cameras=2, n_frames=50, seed=0), "config1", pseeds=(1, 2))
+    tight(dict(n_cameras=3, n_frames=30, seed=40, missing=0.25, scalar_nans=6), "missing3", pseeds=(1, 2))
+    tight(dict(n_cameras=2, n_frames=50, seed=0), "config1_huber", pseeds=(1, 2), loss="huber", f_scale=0.3)
+
+
+if __name__ == "__main__":
+    main("--slow" in sys.argv)

@@ -1,0 +1,112 @@
+// Host-side unit harness for csrc/mcba_math.h -- TEST INFRASTRUCTURE ONLY.
+// Compiles the device math header with g++ and walks it over a small problem on the CPU so the
+// algebra (local Gram matrix + chain-rule expansion, Jacobian rows, robust weights, 6x6 solves)
+// can be checked against oracle/ba_oracle.py in the GPU-less build container.
+// It is never loaded by the product (multicam-calibration_amd/ops.py loads libmcba.so only).
+#include "../../multicam-calibration_amd/csrc/mcba_math.h"
+#include <cstring>
+
+using namespace mcba;
+
+template <int LOSS>
+static void weights(double r, bool valid, double fs2, double ifs2, double& cost, double& w2, double& gw) {
+  if (!valid) { w2 = 0; gw = 0; return; }
+  double rh, g1, ww;
+  loss_weights<LOSS>(r, fs2, ifs2, rh, g1, ww);
+  cost += rh; w2 = ww; gw = g1 * r;
+}
+
+static void weights_dyn(int loss, double r, bool valid, double fs2, double ifs2, double& cost, double& w2, double& gw) {
+  switch (loss) {
+    case LOSS_LINEAR: weights<LOSS_LINEAR>(r, valid, fs2, ifs2, cost, w2, gw); break;
+    case LOSS_SOFT_L1: weights<LOSS_SOFT_L1>(r, valid, fs2, ifs2, cost, w2, gw); break;
+    case LOSS_HUBER: weights<LOSS_HUBER>(r, valid, fs2, ifs2, cost, w2, gw); break;
+    case LOSS_CAUCHY: weights<LOSS_CAUCHY>(r, valid, fs2, ifs2, cost, w2, gw); break;
+    default: weights<LOSS_ARCTAN>(r, valid, fs2, ifs2, cost, w2, gw); break;
+  }
+}
+
+extern "C" {
+
+// x: 12C + 6F ; uvs (C,F,N,2) ; outputs U (C,78) gc (C,12) W (C,F,72) V (C,F,21) gf (C,F,6) cost (1)
+void hc_normal_eq(int C, int F, int N, const double* uvs, const double* obj, const double* x, int loss, double f_scale,
+                  double* U, double* gc, double* W, double* V, double* gf, double* cost) {
+  double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
+  *cost = 0;
+  memset(U, 0, sizeof(double) * C * 78);
+  memset(gc, 0, sizeof(double) * C * 12);
+  for (int c = 0; c < C; ++c) {
+    CamConst cc;
+    make_cam_const(x + 12 * c, cc);
+    Intr K{cc.fx, cc.fy, cc.cx, cc.cy, cc.k1, cc.k2};
+    for (int f = 0; f < F; ++f) {
+      const double* pose = x + 12 * C + 6 * f;
+      double Rf[9], Jrf[9];
+      rot_and_jr(pose, Rf, Jrf);
+      PairConst pc;
+      make_pair_const(cc.R, cc.t, Rf, pose + 3, pc);
+      Gram g;
+      gram_zero(g);
+      for (int p = 0; p < N; ++p) {
+        const double* o2 = uvs + (((size_t)c * F + f) * N + p) * 2;
+        bool vu = o2[0] == o2[0], vv = o2[1] == o2[1];
+        if (!(vu || vv)) continue;
+        ObsRows o;
+        obs_rows(K, pc, obj + 3 * p, o);
+        double wu2, wv2, gu, gv;
+        weights_dyn(loss, o2[0] - o.up, vu, fs2, ifs2, g.cost, wu2, gu);
+        weights_dyn(loss, o2[1] - o.vp, vv, fs2, ifs2, g.cost, wv2, gv);
+        gram_add(g, o, wu2, wv2, gu, gv);
+      }
+      ChainConst ch;
+      make_chain_const(cc.R, cc.Jr, Rf, Jrf, pose + 3, ch);
+      double Ul[78], gcl[12];
+      gram_expand(g, ch, Ul, gcl, W + ((size_t)c * F + f) * 72, V + ((size_t)c * F + f) * 21, gf + ((size_t)c * F + f) * 6);
+      for (int i = 0; i < 78; ++i) U[c * 78 + i] += Ul[i];
+      for (int i = 0; i < 12; ++i) gc[c * 12 + i] += gcl[i];
+      *cost += g.cost;
+    }
+  }
+}
+
+// prediction (C,F,N,2), Jc (C,F,N,2,12), Jf (C,F,N,2,6) of the PREDICTION
+void hc_jac_rows(int C, int F, int N, const double* obj, const double* x, double* pred, double* Jc, double* Jf) {
+  for (int c = 0; c < C; ++c) {
+    CamConst cc;
+    make_cam_const(x + 12 * c, cc);
+    Intr K{cc.fx, cc.fy, cc.cx, cc.cy, cc.k1, cc.k2};
+    for (int f = 0; f < F; ++f) {
+      const double* pose = x + 12 * C + 6 * f;
+      double Rf[9], Jrf[9];
+      rot_and_jr(pose, Rf, Jrf);
+      PairConst pc;
+      make_pair_const(cc.R, cc.t, Rf, pose + 3, pc);
+      ChainConst ch;
+      make_chain_const(cc.R, cc.Jr, Rf, Jrf, pose + 3, ch);
+      for (int p = 0; p < N; ++p) {
+        size_t i = ((size_t)c * F + f) * N + p;
+        ObsRows o;
+        obs_rows(K, pc, obj + 3 * p, o);
+        pred[2 * i] = o.up; pred[2 * i + 1] = o.vp;
+        double up2, vp2;
+        project_only(K, pc, obj + 3 * p, up2, vp2);
+        if (up2 != o.up || vp2 != o.vp) pred[2 * i] = NAN;  // the two code paths must agree bit for bit
+        expand_rows(o, ch, Jc + i * 24, Jc + i * 24 + 12, Jf + i * 12, Jf + i * 12 + 6);
+      }
+    }
+  }
+}
+
+// rotation constants
+void hc_rot(const double* r, double* R, double* Jr) { rot_and_jr(r, R, Jr); }
+
+// Cholesky solve of a packed 6x6: x = V^-1 b ; returns 1 if positive definite
+int hc_chol_solve(const double* Vt, const double* b, double* x) {
+  double Lp[21], id[6], y[6];
+  bool ok = chol6(Vt, Lp);
+  for (int i = 0; i < 6; ++i) id[i] = 1.0 / Lp[i * (i + 1) / 2 + i];
+  fwd6(Lp, id, b, y);
+  bwd6(Lp, id, y, x);
+  return ok ? 1 : 0;
+}
+}
