@@ -1,0 +1,126 @@
+/* mcba.h -- C ABI of libmcba.so, the MI355X (gfx950) bundle-adjustment hot path.
+ *
+ * The reference (dattalab-6-cam/multicam-calibration) is pure Python and has no FFI: the path sits
+ * behind two Python seams.  This header is the boundary a maintainer would
+ * bind with ctypes in place of them (INTEGRATION.md shows the stub):
+ *
+ *   outer seam  multicam_calibration/bundle_adjustment.py:195-204,307-327  bundle_adjust(...)
+ *   inner seam  scipy least_squares fun/jac callables:
+ *               residuals()                       bundle_adjustment.py:66-98
+ *               bundle_adjustment_sparsity()      bundle_adjustment.py:101-125  (structure is implicit here)
+ *               scipy 2-point FD Jacobian         scipy/optimize/_numdiff.py:628-705 (replaced by analytic blocks)
+ *               scipy TRF + LSMR linear algebra   scipy/optimize/_lsq/trf.py:401-560 (replaced by LM + Schur)
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (0 = MCBA_OK), never throws;
+ *     mcba_last_error() returns the message of the last failure on the calling thread.
+ *   - parameter vector x: [C x (fx fy cx cy k1 k2 rx ry rz tx ty tz) | F x (rx ry rz tx ty tz)]  float64,
+ *     exactly serialize_params() of the reference (bundle_adjustment.py:128-157).
+ *   - observations: float64 (C,F,N,2) C-order, NaN = missing scalar (bundle_adjustment.py:82-84,97).
+ *   - one handle = one GPU = one process (frames are sharded across processes by the caller);
+ *     calls on a handle come from one host thread.  The library owns its device buffers until
+ *     mcba_destroy(); host arrays belong to the caller.
+ *   - all kernels are enqueued on the handle's stream (mcba_set_stream; default: the null stream) and
+ *     functions that return host data synchronise that stream.
+ */
+#ifndef MCBA_H
+#define MCBA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCBA_OK 0
+#define MCBA_ERR_HIP 1        /* a HIP runtime call failed */
+#define MCBA_ERR_ARG 2        /* bad argument / wrong call order */
+#define MCBA_ERR_NONFINITE 3  /* a used observation projects to NaN/inf (scipy: "Residuals are not finite") */
+#define MCBA_ERR_NODEVICE 4   /* no usable gfx950 device */
+
+/* scipy.optimize.least_squares `loss=` (least_squares.py:160-227) */
+#define MCBA_LOSS_LINEAR 0
+#define MCBA_LOSS_SOFT_L1 1
+#define MCBA_LOSS_HUBER 2
+#define MCBA_LOSS_CAUCHY 3
+#define MCBA_LOSS_ARCTAN 4
+
+typedef struct mcba_handle mcba_handle;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int mcba_abi_version(void);            /* bumped when this header changes incompatibly */
+const char* mcba_last_error(void);
+int mcba_device_count(int* count);
+
+/* ---- problem life cycle -------------------------------------------------------------------- */
+/* n_cameras C, n_frames F (local shard), n_points N, HIP device ordinal. */
+int mcba_create(mcba_handle** out, int n_cameras, int n_frames, int n_points, int device);
+int mcba_destroy(mcba_handle* h);
+/* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = null stream. */
+int mcba_set_stream(mcba_handle* h, void* hip_stream);
+/* Observations (C,F,N,2) and board points (N,3), host pointers.  Re-laid out on the GPU as
+ * [camera][point][frame] (u,v) pairs so that a wavefront reads 64 consecutive frames coalesced. */
+int mcba_upload_observations(mcba_handle* h, const double* uvs, const double* objpoints);
+/* Robust loss and f_scale of least_squares (default soft_l1, 1.0: bundle_adjustment.py:301-303). */
+int mcba_set_loss(mcba_handle* h, int loss, double f_scale);
+
+/* ---- parameter slots (two flat vectors live on the GPU: 0 and 1) ----------------------------- */
+int mcba_set_params(mcba_handle* h, int slot, const double* x);   /* 12C+6F doubles, host */
+int mcba_get_params(mcba_handle* h, int slot, double* x);
+int mcba_copy_params(mcba_handle* h, int dst_slot, int src_slot);  /* device to device */
+
+/* ---- residual / Jacobian evaluation (replaces residuals() and scipy's FD Jacobian) ----------- */
+/* Robust cost 0.5*f_scale^2*sum rho((f/f_scale)^2) at x[slot]; *n_residuals = number of non-NaN scalars.
+ * MCBA_ERR_NONFINITE if the cost is not finite. */
+int mcba_cost(mcba_handle* h, int slot, double* cost, double* n_residuals);
+/* Dense residual array (C,F,N,2), observed - predicted, 0 where the observation is NaN (host). */
+int mcba_residuals(mcba_handle* h, int slot, double* res);
+/* Materialise residuals + analytic Jacobian blocks on the GPU: per scalar residual 18 doubles
+ * [12 camera columns | 6 frame-pose columns] in (C,F,N,2,18) order = the CSR `data` array of the
+ * reference's Jacobian when no observation is missing.  robust_scaled != 0 applies scipy's
+ * sqrt(rho' + 2 rho'' f^2) row scaling (common.py:720-731).  Result stays on the GPU. */
+int mcba_jacobian_eval(mcba_handle* h, int slot, int robust_scaled);
+/* Copy the last mcba_jacobian_eval() result to the host: jac (C,F,N,2,18), res (C,F,N,2); either may be NULL. */
+int mcba_jacobian_download(mcba_handle* h, double* jac, double* res);
+
+/* ---- Levenberg-Marquardt building blocks (replace trf.py:450-551 + LSMR) ---------------------- */
+/* Linearise at x[slot]: per (camera, frame) local Gram matrices expanded to W_cf (12x6), V_cf (6x6),
+ * g_f and per-wave partial sums of U_c (12x12), g_c and the robust cost.  Kept on the GPU. */
+int mcba_linearize(mcba_handle* h, int slot);
+/* Schur-reduce the current linearisation with damping lambda (frame blocks damped by
+ * lambda*diag(V_f)) into the reduce buffer (device), laid out as doubles, n = 12C:
+ *   [0,n*n)      S0  = blockdiag(U_c) - sum_f W_f (V_f + lambda D_f)^-1 W_f^T      (undamped camera block)
+ *   [n*n,+n)     rhs = -g_c + sum_f W_f (V_f + lambda D_f)^-1 g_f
+ *   [..,+n)      diag(U)          [..,+n)  g_c
+ *   [..,+16)     scalars: 0 cost, 1 n_residuals, 2 n_cholesky_failures, 3 reserved,
+ *                         4..15 per-rank slots: max |g_f| of THIS shard goes to slot 4+rank_slot, others 0
+ * so that one all-reduce(SUM) of the whole buffer over the frame shards gives the global system. */
+int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot);
+size_t mcba_reduced_size(const mcba_handle* h);          /* doubles in the reduce buffer (+ trial scalars) */
+/* Let the caller own the reduce buffer (device pointer, mcba_reduced_size() doubles), e.g. a torch
+ * tensor handed to torch.distributed.all_reduce (RCCL).  NULL restores the internal buffer. */
+int mcba_bind_reduce_buffer(mcba_handle* h, double* device_ptr);
+int mcba_get_reduced(mcba_handle* h, double* host);      /* D2H of the system part (n*n+3n+16 doubles) */
+/* Back-substitute: given the camera step (12C doubles, host) solve every frame step,
+ * write x[dst_slot] = x[src_slot] + delta and evaluate the robust cost there.  Trial scalars
+ * (8 doubles, appended to the reduce buffer at offset n*n+3n+16):
+ *   0 cost(x_dst)  1 sum_f d_f^T (lambda D_f d_f - g_f)  2 sum |d_f|^2  3 sum |x_f|^2  4 n_nonfinite  5..7 reserved */
+int mcba_step(mcba_handle* h, const double* delta_cam, double lambda, int src_slot, int dst_slot);
+int mcba_get_trial(mcba_handle* h, double* host8);
+/* Frame part of the gradient J^T f of the last mcba_build_reduced(): (F,6) doubles, host.
+ * (The camera part is the g_c block of the reduce buffer.)  Feeds OptimizeResult.grad (trf.py:557-560). */
+int mcba_get_frame_gradient(mcba_handle* h, double* host);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* When enabled every kernel launch is bracketed by hipEvents on the handle's stream. */
+int mcba_profile_enable(mcba_handle* h, int on);
+/* Drains the recorded events.  names: '\n'-separated kernel names in the order of ms[] / calls[]. */
+int mcba_profile_read(mcba_handle* h, double* ms_total, int* calls, int capacity, int* n_kernels);
+const char* mcba_profile_names(void);
+int mcba_synchronize(mcba_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCBA_H */

@@ -2,11 +2,14 @@
 
 Only what the hot path needs lives here:
   csrc/      HIP kernels for gfx950 + the C-ABI (`libmcba.so`, declared in include/mcba.h)
+  build.py   hipcc driver that compiles csrc/ in-tree
   ops.py     ctypes binding of that ABI (fails loudly if the library is missing)
   solver.py  host-side Levenberg-Marquardt / Schur driver
   api.py     `bundle_adjust` with the reference's exact signature and return tuple
   synth.py   deterministic synthetic board detections for tests and bench
 """
 from . import synth  # noqa: F401
+from . import ops, solver  # noqa: F401
+from .api import bundle_adjust, bundle_adjustment, serialize_params, deserialize_params  # noqa: F401
 
-__all__ = ["synth"]
+__all__ = ["bundle_adjust", "bundle_adjustment", "serialize_params", "deserialize_params", "ops", "solver", "synth"]

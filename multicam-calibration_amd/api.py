@@ -1,0 +1,153 @@
+"""`bundle_adjust` -- the reference's entry point (multicam_calibration/bundle_adjustment.py:195-327),
+same signature, same 5-tuple, computed on the MI355X.
+
+What is kept from the reference, line for line in behaviour:
+  * frame pre-filter: frames complete in >= 2 cameras (:266), worst-camera mean reprojection error against
+    5 x nan-median or `outlier_threshold` (:269-285), the printed "Excluding ..." line (:287-290, which
+    reports the post-filter count), the global-RNG `np.random.choice` subsample (:293-296);
+  * parameter layout of `result.x` (:128-157), `dist_coefs` padded to 5 with p1=p2=k3=0 on output (:187);
+  * defaults verbose=2, x_scale='jac', ftol=1e-4, method='trf', loss='soft_l1', overridable through
+    **opt_kwargs (:301-304); scipy's xtol = gtol = 1e-8 otherwise.
+What differs: the optimiser is Levenberg-Marquardt with an analytic Jacobian and an
+exact Schur solve instead of scipy's TRF/LSMR on a finite-difference Jacobian.  It minimises the same robust
+cost, so it converges to the same minimiser (gauge aside); the iterate sequence is not reproduced.
+"""
+import warnings
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import ops, solver
+
+# least_squares kwargs that only steer scipy's own iteration (no effect on the minimiser): accepted, ignored
+_PATH_ONLY = ("jac", "tr_solver", "tr_options", "jac_sparsity", "diff_step", "x_scale", "method", "workers", "callback")
+
+
+def serialize_params(all_extrinsics, all_intrinsics, calib_poses):
+    """[C x (fx fy cx cy k1 k2 rx ry rz tx ty tz) | F x pose6]  (bundle_adjustment.py:128-157)."""
+    cams = np.empty((len(all_extrinsics), 12))
+    for c, (ext, (K, dist)) in enumerate(zip(all_extrinsics, all_intrinsics)):
+        K = np.asarray(K, dtype=float)
+        cams[c, :4] = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+        cams[c, 4:6] = np.asarray(dist, dtype=float)[:2]
+        cams[c, 6:] = ext
+    return np.concatenate([cams.ravel(), np.asarray(calib_poses, dtype=float).ravel()])
+
+
+def deserialize_params(x, n_cameras):
+    """Inverse of serialize_params (bundle_adjustment.py:160-192)."""
+    cams = np.asarray(x[: 12 * n_cameras]).reshape(n_cameras, 12)
+    intr = []
+    for c in range(n_cameras):
+        K = np.eye(3)
+        K[0, 0], K[1, 1], K[0, 2], K[1, 2] = cams[c, :4]
+        intr.append((K, np.pad(cams[c, 4:6], (0, 3))))
+    return cams[:, 6:].copy(), intr, np.asarray(x[12 * n_cameras :]).reshape(-1, 6).copy()
+
+
+def jacobian_structure(all_calib_uvs):
+    """CSR (indices, indptr, shape) of the reference's sparsity pattern (bundle_adjustment.py:101-125)."""
+    C, F, N, _ = all_calib_uvs.shape
+    mask = ~np.isnan(all_calib_uvs)
+    cam = np.broadcast_to(np.arange(C, dtype=np.int32)[:, None, None, None], mask.shape)[mask]
+    frm = np.broadcast_to(np.arange(F, dtype=np.int32)[None, :, None, None], mask.shape)[mask]
+    m = cam.size
+    idx = np.empty((m, 18), dtype=np.int32 if 12 * C + 6 * F < 2**31 else np.int64)
+    idx[:, :12] = cam[:, None] * 12 + np.arange(12)
+    idx[:, 12:] = 12 * C + frm[:, None] * 6 + np.arange(6)
+    return idx.ravel(), np.arange(m + 1, dtype=np.int64) * 18, (m, 12 * C + 6 * F), mask
+
+
+def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device=0):
+    """The reference's pre-filter (bundle_adjustment.py:265-296); the reprojection pass runs on the GPU."""
+    use_frames = np.nonzero((~np.isnan(all_calib_uvs).any((-1, -2))).sum(0) > 1)[0]
+    sub = all_calib_uvs[:, use_frames]
+    if use_frames.size:
+        prob = ops.Problem(sub, calib_objpoints, device=device)
+        prob.set_params(0, serialize_params(all_extrinsics, all_intrinsics, np.asarray(calib_poses)[use_frames]))
+        res = prob.residuals(0)
+        prob.close()
+        res[np.isnan(sub)] = np.nan
+        err = np.sqrt((res**2).sum(-1))  # NaN wherever either coordinate is missing, like norm(obs - pred)
+    else:
+        err = np.empty(sub.shape[:-1])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)
+        worst_mean_err = np.nanmax(np.nanmean(err, axis=-1), axis=0) if use_frames.size else np.empty(0)
+        if outlier_threshold is None:
+            outlier_threshold = 5 * np.nanmedian(err)
+    exclude = np.nan_to_num(worst_mean_err) > outlier_threshold
+    use_frames = use_frames[~exclude]
+    print(f"Excluding {int(exclude.sum())} out of {len(use_frames)} frames based on an outlier threshold of {outlier_threshold}")
+    if not (n_frames is None or n_frames > len(use_frames)):
+        use_frames = np.random.choice(use_frames, n_frames, replace=False)
+    return use_frames
+
+
+def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames=10000, outlier_threshold=None, **opt_kwargs):
+    """Bundle adjustment for camera parameters and calibration-object poses on the MI355X.
+
+    Parameters and return value are those of the reference `multicam_calibration.bundle_adjust`.
+    Extra keyword arguments (defaults preserve reference behaviour):
+      device=0             HIP device ordinal
+      fix_intrinsics=False hold fx fy cx cy k1 k2 of every camera (BASELINE config 2); extrinsics + poses only
+      return_jac=True      attach the robust-rescaled CSR Jacobian as `result.jac` (18 nnz/row; 1.4 GB at 6x10k x54)
+    """
+    device = opt_kwargs.pop("device", 0)
+    fix_intrinsics = opt_kwargs.pop("fix_intrinsics", False)
+    return_jac = opt_kwargs.pop("return_jac", True)
+    lm_kwargs = {k: opt_kwargs.pop(k) for k in ("lam0",) if k in opt_kwargs}
+
+    all_calib_uvs = np.asarray(all_calib_uvs, dtype=np.float64)
+    calib_objpoints = np.asarray(calib_objpoints, dtype=np.float64)
+    calib_poses = np.asarray(calib_poses, dtype=np.float64)
+    n_cameras = all_calib_uvs.shape[0]
+
+    use_frames = select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device)
+
+    kw = dict(verbose=2, x_scale="jac", ftol=1e-4, method="trf", loss="soft_l1")
+    kw.update(opt_kwargs)
+    if "bounds" in kw:
+        raise NotImplementedError("bounds are not supported by the GPU solver")
+    if callable(kw.get("loss")):
+        raise NotImplementedError("callable losses are not supported by the GPU solver")
+    if not (isinstance(kw["x_scale"], str) and kw["x_scale"] == "jac"):
+        warnings.warn("x_scale is ignored: the GPU solver always uses Jacobian (Marquardt) scaling", stacklevel=2)
+    unknown = set(kw) - set(_PATH_ONLY) - {"verbose", "ftol", "xtol", "gtol", "max_nfev", "loss", "f_scale"}
+    if unknown:
+        raise TypeError(f"unsupported least_squares keyword(s) for the GPU solver: {sorted(unknown)}")
+
+    uvs = np.ascontiguousarray(all_calib_uvs[:, use_frames])
+    x0 = serialize_params(all_extrinsics, all_intrinsics, calib_poses[use_frames])
+    prob = ops.Problem(uvs, calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0))
+    free = None
+    if fix_intrinsics:
+        free = np.tile(np.r_[np.zeros(6, bool), np.ones(6, bool)], n_cameras)
+    tol = lambda name, default: default if kw.get(name, default) is None else kw.get(name, default)
+    result = solver.lm_solve(prob, x0, ftol=tol("ftol", 1e-4), xtol=tol("xtol", 1e-8), gtol=tol("gtol", 1e-8),
+                             max_nfev=kw.get("max_nfev"), verbose=kw["verbose"], free_cam_mask=free, **lm_kwargs)
+
+    # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560)
+    slot = result.lm["slot"]
+    idx, indptr, shape, mask = jacobian_structure(uvs)
+    if return_jac:
+        prob.jacobian_eval(slot, robust_scaled=kw["loss"] != "linear")
+        jac, res = prob.jacobian_download()
+        result.jac = sp.csr_matrix((jac[mask].ravel(), idx, indptr), shape=shape)
+        result.fun = res[mask]
+        del jac
+    else:
+        result.fun = prob.residuals(slot)[mask]
+    red = prob.get_reduced()
+    grad = np.concatenate([red["gc"], prob.frame_gradient().ravel()])
+    if free is not None:
+        grad[: 12 * n_cameras][~free] = 0.0
+    result.grad = grad
+    prob.close()
+
+    adjusted_extrinsics, adjusted_intrinsics, adjusted_calib_poses = deserialize_params(result.x, n_cameras)
+    return adjusted_extrinsics, adjusted_intrinsics, adjusted_calib_poses, use_frames, result
+
+
+# BASELINE.json's north star calls the entry point `bundle_adjustment()`; the reference function is `bundle_adjust`.
+bundle_adjustment = bundle_adjust

@@ -1,0 +1,434 @@
+// mcba_api.hip -- the C ABI of include/mcba.h: handle, device buffers, kernel sequencing.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mcba.h"
+#include "mcba_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+enum KernelId { K_TRANSPOSE = 0, K_GRAM, K_COST, K_SCHUR_FRAMES, K_SYRK, K_REDUCE, K_BACKSUB, K_SUM_TRIAL, K_JACOBIAN, K_COUNT };
+const char* kKernelNames = "k_transpose_obs\nk_gram\nk_cost\nk_schur_frames\nk_syrk\nk_reduce_system\nk_backsub\nk_sum_trial\nk_jacobian";
+
+struct EvRec { int kid; hipEvent_t a, b; };
+
+}  // namespace
+
+struct mcba_handle {
+  int C = 0, F = 0, N = 0, Fpad = 0, nfb = 0, n = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int loss = MCBA_LOSS_SOFT_L1;
+  double f_scale = 1.0;
+  bool have_obs = false, have_lin = false, have_red = false, have_jac = false;
+  // device buffers
+  double *obs_t = nullptr, *obj = nullptr, *x[2] = {nullptr, nullptr};
+  double *rec = nullptr, *gpart = nullptr, *ybuf = nullptr, *fbuf = nullptr, *fpart = nullptr;
+  double *spart = nullptr, *rpart = nullptr, *cpart = nullptr, *bpart = nullptr, *dc = nullptr;
+  double *red_own = nullptr, *red = nullptr;
+  double *jac = nullptr, *res = nullptr;
+  int *pair_ci = nullptr, *pair_cj = nullptr;
+  int npairs = 0, G = 0, fpc = 0, B = 0, nfblocks = 0, nbblocks = 0;
+  size_t nx = 0, nsys = 0;
+  double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
+  // profiling
+  bool prof = false;
+  std::vector<EvRec> evs;
+  std::vector<hipEvent_t> pool;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) {                                                                              \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                                         \
+      return MCBA_ERR_HIP;                                                                               \
+    }                                                                                                    \
+  } while (0)
+
+int fail(int code, const char* msg) { g_err = msg; return code; }
+
+hipEvent_t get_event(mcba_handle* h) {
+  if (!h->pool.empty()) { hipEvent_t e = h->pool.back(); h->pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct Scope {  // brackets one launch with events when profiling
+  mcba_handle* h; int kid; hipEvent_t a{}, b{};
+  Scope(mcba_handle* h_, int k) : h(h_), kid(k) {
+    if (h->prof) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
+  }
+  ~Scope() {
+    if (h->prof) { (void)hipEventRecord(b, h->stream); h->evs.push_back({kid, a, b}); }
+  }
+};
+
+int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_err = std::string("kernel launch: ") + hipGetErrorString(e); return MCBA_ERR_HIP; }
+  return MCBA_OK;
+}
+
+template <class T>
+int dalloc(T** p, size_t count) {
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+  HIPCHK(hipMemset(*p, 0, count * sizeof(T)));
+  return MCBA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcba_abi_version(void) { return 1; }
+const char* mcba_last_error(void) { return g_err.c_str(); }
+const char* mcba_profile_names(void) { return kKernelNames; }
+
+int mcba_device_count(int* count) {
+  if (!count) return fail(MCBA_ERR_ARG, "count is NULL");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) { *count = 0; g_err = hipGetErrorString(e); return MCBA_ERR_NODEVICE; }
+  return MCBA_OK;
+}
+
+int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
+  if (!out || C < 1 || F < 1 || N < 1 || C > 40) return fail(MCBA_ERR_ARG, "mcba_create: need 1 <= C <= 40, F >= 1, N >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MCBA_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(MCBA_ERR_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  mcba_handle* h = new mcba_handle();
+  h->C = C; h->F = F; h->N = N; h->device = device;
+  h->Fpad = (F + 63) / 64 * 64;
+  h->nfb = h->Fpad / 64;
+  h->n = 12 * C;
+  h->nx = (size_t)12 * C + (size_t)6 * h->Fpad;
+  h->nsys = (size_t)h->n * h->n + 3 * h->n + 16;
+  h->npairs = C * (C + 1) / 2;
+  // syrk geometry: B frames per LDS stage (<= 150 KiB), G frame chunks
+  size_t per_frame = ((size_t)h->n * 6 + 6) * sizeof(double);
+  h->B = (int)std::min<size_t>(8, (150 * 1024) / per_frame);
+  if (h->B < 1) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for the LDS staging of k_syrk"); }
+  int nbatch = (F + h->B - 1) / h->B;
+  h->G = std::min(nbatch, 256);
+  h->fpc = ((nbatch + h->G - 1) / h->G) * h->B;
+  h->G = (F + h->fpc - 1) / h->fpc;
+  h->nfblocks = (int)(((size_t)F * C + 255) / 256);
+  h->nbblocks = (F + 255) / 256;
+  int rc;
+#define DA(p, cnt) if ((rc = dalloc(&h->p, (cnt))) != MCBA_OK) { mcba_destroy(h); return rc; }
+  DA(obs_t, (size_t)2 * C * N * h->Fpad);
+  DA(obj, (size_t)3 * N);
+  DA(x[0], h->nx);
+  DA(x[1], h->nx);
+  DA(rec, (size_t)h->Fpad * C * MCBA_REC);
+  DA(gpart, (size_t)C * h->nfb * MCBA_GP);
+  DA(ybuf, (size_t)h->Fpad * C * 72);
+  DA(fbuf, (size_t)h->Fpad * MCBA_FB);
+  DA(fpart, (size_t)2 * h->nfblocks);
+  DA(spart, (size_t)h->G * h->npairs * 144);
+  DA(rpart, (size_t)h->G * h->n);
+  DA(cpart, (size_t)2 * C * h->nfb);
+  DA(bpart, (size_t)3 * h->nbblocks);
+  DA(dc, (size_t)h->n);
+  DA(red_own, h->nsys + 8);
+  DA(pair_ci, (size_t)h->npairs);
+  DA(pair_cj, (size_t)h->npairs);
+#undef DA
+  h->red = h->red_own;
+  std::vector<int> ci, cj;
+  for (int a = 0; a < C; ++a) for (int b = a; b < C; ++b) { ci.push_back(a); cj.push_back(b); }
+  HIPCHK(hipMemcpy(h->pair_ci, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->pair_cj, cj.data(), cj.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pinned), (h->nsys + 8 + h->n) * sizeof(double), hipHostMallocDefault));
+  size_t lds = (size_t)h->B * per_frame;
+  if (lds > 64 * 1024) {
+    if (mcba::syrk_set_lds_limit(lds) != 0) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_syrk"); }
+  }
+  *out = h;
+  return MCBA_OK;
+}
+
+int mcba_destroy(mcba_handle* h) {
+  if (!h) return MCBA_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  double* bufs[] = {h->obs_t, h->obj, h->x[0], h->x[1], h->rec, h->gpart, h->ybuf, h->fbuf, h->fpart, h->spart, h->rpart, h->cpart, h->bpart, h->dc, h->red_own, h->jac, h->res};
+  for (double* p : bufs) if (p) (void)hipFree(p);
+  if (h->pair_ci) (void)hipFree(h->pair_ci);
+  if (h->pair_cj) (void)hipFree(h->pair_cj);
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& e : h->pool) (void)hipEventDestroy(e);
+  delete h;
+  return MCBA_OK;
+}
+
+int mcba_set_stream(mcba_handle* h, void* s) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  h->stream = reinterpret_cast<hipStream_t>(s);
+  return MCBA_OK;
+}
+
+int mcba_synchronize(mcba_handle* h) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+int mcba_upload_observations(mcba_handle* h, const double* uvs, const double* objpoints) {
+  if (!h || !uvs || !objpoints) return fail(MCBA_ERR_ARG, "mcba_upload_observations: NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  size_t raw_count = (size_t)2 * h->C * h->F * h->N;
+  double* raw = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&raw), raw_count * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(raw, uvs, raw_count * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h->obj, objpoints, (size_t)3 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    Scope sc(h, K_TRANSPOSE);
+    mcba::launch_transpose_obs(h->stream, raw, h->obs_t, h->C, h->F, h->N, h->Fpad);
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  hipError_t e2 = hipStreamSynchronize(h->stream);
+  (void)hipFree(raw);
+  if (e != hipSuccess || e2 != hipSuccess) { g_err = std::string("upload: ") + hipGetErrorString(e != hipSuccess ? e : e2); return MCBA_ERR_HIP; }
+  h->have_obs = true;
+  h->have_lin = h->have_red = h->have_jac = false;
+  return MCBA_OK;
+}
+
+int mcba_set_loss(mcba_handle* h, int loss, double f_scale) {
+  if (!h || loss < 0 || loss > 4 || !(f_scale > 0.0)) return fail(MCBA_ERR_ARG, "mcba_set_loss: loss in 0..4 and f_scale > 0 required");
+  h->loss = loss; h->f_scale = f_scale;
+  h->have_lin = h->have_red = false;
+  return MCBA_OK;
+}
+
+static int slot_ok(mcba_handle* h, int slot) { return h && (slot == 0 || slot == 1); }
+
+int mcba_set_params(mcba_handle* h, int slot, const double* x) {
+  if (!slot_ok(h, slot) || !x) return fail(MCBA_ERR_ARG, "mcba_set_params: bad handle/slot/pointer");
+  HIPCHK(hipSetDevice(h->device));
+  // pageable host memory: the async copy is staged by the runtime before it returns
+  HIPCHK(hipMemcpyAsync(h->x[slot], x, ((size_t)12 * h->C + (size_t)6 * h->F) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+int mcba_get_params(mcba_handle* h, int slot, double* x) {
+  if (!slot_ok(h, slot) || !x) return fail(MCBA_ERR_ARG, "mcba_get_params: bad handle/slot/pointer");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(x, h->x[slot], ((size_t)12 * h->C + (size_t)6 * h->F) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+int mcba_copy_params(mcba_handle* h, int dst, int src) {
+  if (!slot_ok(h, dst) || !slot_ok(h, src)) return fail(MCBA_ERR_ARG, "mcba_copy_params: bad slot");
+  if (dst == src) return MCBA_OK;
+  HIPCHK(hipMemcpyAsync(h->x[dst], h->x[src], h->nx * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  return MCBA_OK;
+}
+
+static int run_cost(mcba_handle* h, int slot, double* res_dev, const double* bpart, int nbp) {
+  {
+    Scope sc(h, K_COST);
+    mcba::launch_cost(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->cpart, res_dev, h->C, h->F, h->N, h->Fpad);
+  }
+  int rc = check_launch();
+  if (rc) return rc;
+  {
+    Scope sc(h, K_SUM_TRIAL);
+    mcba::launch_sum_trial(h->stream, h->cpart, h->C * h->nfb, bpart, nbp, h->red + h->nsys);
+  }
+  return check_launch();
+}
+
+static int fetch_trial(mcba_handle* h, double* host8) {
+  HIPCHK(hipMemcpyAsync(h->pinned + h->nsys, h->red + h->nsys, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  memcpy(host8, h->pinned + h->nsys, 8 * sizeof(double));
+  return MCBA_OK;
+}
+
+int mcba_cost(mcba_handle* h, int slot, double* cost, double* n_residuals) {
+  if (!slot_ok(h, slot) || !cost) return fail(MCBA_ERR_ARG, "mcba_cost: bad argument");
+  if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_cost: upload observations first");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = run_cost(h, slot, nullptr, nullptr, 0);
+  if (rc) return rc;
+  double t[8];
+  rc = fetch_trial(h, t);
+  if (rc) return rc;
+  *cost = t[0];
+  if (n_residuals) *n_residuals = t[4];
+  if (!isfinite(t[0])) return fail(MCBA_ERR_NONFINITE, "Residuals are not finite");
+  return MCBA_OK;
+}
+
+static int ensure_res(mcba_handle* h) {
+  if (!h->res) return dalloc(&h->res, (size_t)2 * h->C * h->F * h->N);
+  return MCBA_OK;
+}
+
+int mcba_residuals(mcba_handle* h, int slot, double* res) {
+  if (!slot_ok(h, slot) || !res) return fail(MCBA_ERR_ARG, "mcba_residuals: bad argument");
+  if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_residuals: upload observations first");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_res(h);
+  if (rc) return rc;
+  rc = run_cost(h, slot, h->res, nullptr, 0);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(res, h->res, (size_t)2 * h->C * h->F * h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+int mcba_jacobian_eval(mcba_handle* h, int slot, int robust_scaled) {
+  if (!slot_ok(h, slot)) return fail(MCBA_ERR_ARG, "mcba_jacobian_eval: bad argument");
+  if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_jacobian_eval: upload observations first");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_res(h);
+  if (rc) return rc;
+  if (!h->jac) {
+    rc = dalloc(&h->jac, (size_t)36 * h->C * h->F * h->N);
+    if (rc) return rc;
+  }
+  {
+    Scope sc(h, K_JACOBIAN);
+    mcba::launch_jacobian(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->jac, h->res, h->C, h->F, h->N, h->Fpad, robust_scaled);
+  }
+  rc = check_launch();
+  if (rc) return rc;
+  h->have_jac = true;
+  return MCBA_OK;
+}
+
+int mcba_jacobian_download(mcba_handle* h, double* jac, double* res) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  if (!h->have_jac) return fail(MCBA_ERR_ARG, "mcba_jacobian_download: call mcba_jacobian_eval first");
+  size_t cnt = (size_t)h->C * h->F * h->N;
+  if (jac) HIPCHK(hipMemcpyAsync(jac, h->jac, cnt * 36 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (res) HIPCHK(hipMemcpyAsync(res, h->res, cnt * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+int mcba_linearize(mcba_handle* h, int slot) {
+  if (!slot_ok(h, slot)) return fail(MCBA_ERR_ARG, "mcba_linearize: bad argument");
+  if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_linearize: upload observations first");
+  HIPCHK(hipSetDevice(h->device));
+  {
+    Scope sc(h, K_GRAM);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->rec, h->gpart, h->C, h->N, h->Fpad);
+  }
+  int rc = check_launch();
+  if (rc) return rc;
+  h->have_lin = true;
+  h->have_red = false;
+  return MCBA_OK;
+}
+
+int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot) {
+  if (!h || !(lambda >= 0.0) || rank_slot < 0 || rank_slot > 11) return fail(MCBA_ERR_ARG, "mcba_build_reduced: lambda >= 0 and rank_slot in 0..11 required");
+  if (!h->have_lin) return fail(MCBA_ERR_ARG, "mcba_build_reduced: call mcba_linearize first");
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  {
+    Scope sc(h, K_SCHUR_FRAMES);
+    mcba::launch_schur_frames(h->stream, h->rec, h->ybuf, h->fbuf, h->fpart, h->C, h->F, lambda);
+  }
+  if ((rc = check_launch())) return rc;
+  {
+    Scope sc(h, K_SYRK);
+    mcba::launch_syrk(h->stream, h->ybuf, h->fbuf, h->pair_ci, h->pair_cj, h->spart, h->rpart, h->C, h->F, h->npairs, h->G, h->fpc, h->B);
+  }
+  if ((rc = check_launch())) return rc;
+  {
+    Scope sc(h, K_REDUCE);
+    mcba::launch_reduce_system(h->stream, h->gpart, h->spart, h->rpart, h->fpart, h->red, h->C, h->nfb, h->G, h->npairs, h->nfblocks, rank_slot);
+  }
+  if ((rc = check_launch())) return rc;
+  h->have_red = true;
+  return MCBA_OK;
+}
+
+size_t mcba_reduced_size(const mcba_handle* h) { return h ? h->nsys + 8 : 0; }
+
+int mcba_bind_reduce_buffer(mcba_handle* h, double* p) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  h->red = p ? p : h->red_own;
+  h->have_red = false;
+  return MCBA_OK;
+}
+
+int mcba_get_reduced(mcba_handle* h, double* host) {
+  if (!h || !host) return fail(MCBA_ERR_ARG, "mcba_get_reduced: bad argument");
+  if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_get_reduced: call mcba_build_reduced first");
+  HIPCHK(hipMemcpyAsync(h->pinned, h->red, h->nsys * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  memcpy(host, h->pinned, h->nsys * sizeof(double));
+  return MCBA_OK;
+}
+
+int mcba_step(mcba_handle* h, const double* delta_cam, double lambda, int src, int dst) {
+  if (!slot_ok(h, src) || !slot_ok(h, dst) || src == dst || !delta_cam) return fail(MCBA_ERR_ARG, "mcba_step: bad argument (slots must differ)");
+  if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_step: call mcba_build_reduced first");
+  HIPCHK(hipSetDevice(h->device));
+  double* stage = h->pinned + h->nsys + 8;
+  memcpy(stage, delta_cam, h->n * sizeof(double));
+  HIPCHK(hipMemcpyAsync(h->dc, stage, h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  {
+    Scope sc(h, K_BACKSUB);
+    mcba::launch_backsub(h->stream, h->ybuf, h->fbuf, h->dc, h->x[src], h->x[dst], h->bpart, h->C, h->F, lambda);
+  }
+  int rc = check_launch();
+  if (rc) return rc;
+  return run_cost(h, dst, nullptr, h->bpart, h->nbblocks);
+}
+
+int mcba_get_trial(mcba_handle* h, double* host8) {
+  if (!h || !host8) return fail(MCBA_ERR_ARG, "mcba_get_trial: bad argument");
+  return fetch_trial(h, host8);
+}
+
+int mcba_get_frame_gradient(mcba_handle* h, double* host) {
+  if (!h || !host) return fail(MCBA_ERR_ARG, "mcba_get_frame_gradient: bad argument");
+  if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_get_frame_gradient: call mcba_build_reduced first");
+  HIPCHK(hipMemcpy2DAsync(host, 6 * sizeof(double), h->fbuf + 27, MCBA_FB * sizeof(double), 6 * sizeof(double), h->F, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+int mcba_profile_enable(mcba_handle* h, int on) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  h->prof = on != 0;
+  return MCBA_OK;
+}
+
+int mcba_profile_read(mcba_handle* h, double* ms_total, int* calls, int capacity, int* n_kernels) {
+  if (!h || !ms_total || !calls || capacity < K_COUNT) return fail(MCBA_ERR_ARG, "mcba_profile_read: need capacity >= number of kernels");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < K_COUNT; ++i) { ms_total[i] = 0.0; calls[i] = 0; }
+  for (auto& e : h->evs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { ms_total[e.kid] += ms; calls[e.kid] += 1; }
+    h->pool.push_back(e.a);
+    h->pool.push_back(e.b);
+  }
+  h->evs.clear();
+  if (n_kernels) *n_kernels = K_COUNT;
+  return MCBA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,625 @@
+// mcba_kernels.hip -- gfx950 kernels of the bundle-adjustment hot path (FP64, no MFMA: HBM/VALU bound).
+//
+// Work decomposition:
+//   k_gram / k_cost     one LANE per (camera c, frame f): lanes of a wavefront are 64 consecutive frames of
+//                       one camera, the loop runs over the board points.  Observations are stored
+//                       [camera][point][frame] so each iteration's load is one coalesced 1 KiB line group;
+//                       all accumulation (12x12 local Gram matrix) is lane-local -- no shuffles in the loop.
+//                       Camera intrinsics + pose are staged in LDS once per workgroup.
+//   k_schur_frames      one lane per (frame, camera): 6x6 Cholesky of the damped frame block, Y = W L^-T.
+//   k_syrk              S -= Y Y^T, register-tiled over 12x12 camera-block pairs, Y staged through LDS.
+//   k_reduce_system     fixed-order second-stage reduction (deterministic; no FP64 atomics anywhere).
+//   k_backsub           one lane per frame: frame steps, trial parameters, predicted-reduction terms.
+//   k_jacobian          one wavefront per (camera, frame), one lane per board point; rows transposed through
+//                       LDS so the 288 B/observation Jacobian blocks leave as coalesced 16 B/lane stores.
+#include <hip/hip_runtime.h>
+#include "mcba_math.h"
+#include "mcba_kernels.h"
+
+namespace mcba {
+
+// ---------------------------------------------------------------- small device helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// value known to be wave-uniform -> SGPR pair (frees two VGPRs and a ds_read per use)
+__device__ __forceinline__ double uni(double v) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
+__device__ __forceinline__ bool is_num(double v) { return v == v; }
+
+template <int LOSS>
+__device__ __forceinline__ void obs_weights(double r, bool valid, double fs2, double ifs2, double& cost, double& w2, double& g) {
+  double rh, gw, ww;
+  loss_weights<LOSS>(r, fs2, ifs2, rh, gw, ww);
+  cost += valid ? rh : 0.0;
+  w2 = valid ? ww : 0.0;
+  g = valid ? gw * r : 0.0;
+}
+
+// ---------------------------------------------------------------- observation re-layout
+// raw (C,F,N,2) -> obs_t [C][N][Fpad] (u,v); frames f >= F are NaN (= missing, contribute nothing)
+__global__ void k_transpose_obs(const double2* __restrict__ raw, double2* __restrict__ obs_t, int C, int F, int N, int Fpad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)C * N * Fpad;
+  if (i >= total) return;
+  int f = (int)(i % Fpad);
+  size_t cp = i / Fpad;
+  int p = (int)(cp % N);
+  int c = (int)(cp / N);
+  double2 v;
+  v.x = v.y = __builtin_nan("");
+  if (f < F) v = raw[((size_t)c * F + f) * N + p];
+  obs_t[i] = v;
+}
+
+// ---------------------------------------------------------------- k_gram: linearise
+// grid (ceil(nfb/4), C), block 256 = 4 wavefronts = 4 frame blocks of one camera.
+template <int LOSS>
+__global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
+                                              double* __restrict__ rec, double* __restrict__ gpart, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+  __shared__ CamConst s_cam;
+  const int c = blockIdx.y;
+  if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int fb = blockIdx.x * 4 + wave;
+  if (fb >= nfb) return;
+  const int f = fb * 64 + lane;
+
+  Intr K;
+  K.fx = uni(s_cam.fx); K.fy = uni(s_cam.fy); K.cx = uni(s_cam.cx); K.cy = uni(s_cam.cy); K.k1 = uni(s_cam.k1); K.k2 = uni(s_cam.k2);
+  double Rc[9], tc[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rc[i] = uni(s_cam.R[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tc[i] = uni(s_cam.t[i]);
+
+  const double* pose = x + 12 * C + 6 * (size_t)f;
+  double pz[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) pz[i] = pose[i];
+  PairConst pc;
+  {
+    double Rf[9];
+    rot_only(pz, Rf);
+    make_pair_const(Rc, tc, Rf, pz + 3, pc);
+  }
+
+  Gram g;
+  gram_zero(g);
+  const double2* op = obs_t + (size_t)c * N * Fpad + f;
+  double2 o_next = op[0];
+  for (int p = 0; p < N; ++p) {
+    double2 o2 = o_next;
+    if (p + 1 < N) o_next = op[(size_t)(p + 1) * Fpad];
+    bool vu = is_num(o2.x), vv = is_num(o2.y);
+    if (vu || vv) {
+      double Xo[3] = {obj[3 * p], obj[3 * p + 1], obj[3 * p + 2]};
+      ObsRows o;
+      obs_rows(K, pc, Xo, o);
+      double wu2, wv2, gu, gv;
+      obs_weights<LOSS>(o2.x - o.up, vu, fs2, ifs2, g.cost, wu2, gu);
+      obs_weights<LOSS>(o2.y - o.vp, vv, fs2, ifs2, g.cost, wv2, gv);
+      gram_add(g, o, wu2, wv2, gu, gv);
+    }
+  }
+
+  // ---- expand once per (c,f):  H -> W, V, g_f (record) and U, g_c (reduced over the wave)
+  ChainConst ch;
+  {
+    double Rf[9], Jrf[9], Jrc[9];
+    rot_and_jr(pz, Rf, Jrf);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Jrc[i] = uni(s_cam.Jr[i]);
+    make_chain_const(Rc, Jrc, Rf, Jrf, pz + 3, ch);
+  }
+  double U[78], gc[12], W[72], V[21], gf[6];
+  gram_expand(g, ch, U, gc, W, V, gf);
+  double* r = rec + ((size_t)f * C + c) * MCBA_REC;
+#pragma unroll
+  for (int i = 0; i < 72; i += 2) *reinterpret_cast<double2*>(r + i) = make_double2(W[i], W[i + 1]);
+#pragma unroll
+  for (int i = 0; i < 20; i += 2) *reinterpret_cast<double2*>(r + 72 + i) = make_double2(V[i], V[i + 1]);
+  *reinterpret_cast<double2*>(r + 92) = make_double2(V[20], gf[0]);
+  *reinterpret_cast<double2*>(r + 94) = make_double2(gf[1], gf[2]);
+  *reinterpret_cast<double2*>(r + 96) = make_double2(gf[3], gf[4]);
+  *reinterpret_cast<double2*>(r + 98) = make_double2(gf[5], 0.0);
+
+  double* gp = gpart + ((size_t)c * nfb + fb) * MCBA_GP;
+#pragma unroll
+  for (int i = 0; i < 78; ++i) {
+    double s = wave_sum(U[i]);
+    if (lane == 0) gp[i] = s;
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    double s = wave_sum(gc[i]);
+    if (lane == 0) gp[78 + i] = s;
+  }
+  double cs = wave_sum(g.cost);
+  double nv = wave_sum(g.ii[8] > 0.0 || g.ii[11] > 0.0 ? 1.0 : 0.0);
+  if (lane == 0) { gp[90] = cs; gp[91] = nv; }
+}
+
+// ---------------------------------------------------------------- k_cost: robust cost only (trial points), optional residual vector
+template <int LOSS, bool WRITE_RES>
+__global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
+                                              double* __restrict__ cpart, double* __restrict__ res, int C, int F, int N, int Fpad, int nfb, double fs2, double ifs2) {
+  __shared__ CamConst s_cam;
+  const int c = blockIdx.y;
+  if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int fb = blockIdx.x * 4 + wave;
+  if (fb >= nfb) return;
+  const int f = fb * 64 + lane;
+  Intr K;
+  K.fx = uni(s_cam.fx); K.fy = uni(s_cam.fy); K.cx = uni(s_cam.cx); K.cy = uni(s_cam.cy); K.k1 = uni(s_cam.k1); K.k2 = uni(s_cam.k2);
+  double Rc[9], tc[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rc[i] = uni(s_cam.R[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tc[i] = uni(s_cam.t[i]);
+  const double* pose = x + 12 * C + 6 * (size_t)f;
+  double pz[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) pz[i] = pose[i];
+  PairConst pc;
+  {
+    double Rf[9];
+    rot_only(pz, Rf);
+    make_pair_const(Rc, tc, Rf, pz + 3, pc);
+  }
+  double cost = 0.0, nres = 0.0;
+  const double2* op = obs_t + (size_t)c * N * Fpad + f;
+  double2 o_next = op[0];
+  for (int p = 0; p < N; ++p) {
+    double2 o2 = o_next;
+    if (p + 1 < N) o_next = op[(size_t)(p + 1) * Fpad];
+    bool vu = is_num(o2.x), vv = is_num(o2.y);
+    double ru = 0.0, rv = 0.0;
+    if (vu || vv) {
+      double Xo[3] = {obj[3 * p], obj[3 * p + 1], obj[3 * p + 2]};
+      double up, vp;
+      project_only(K, pc, Xo, up, vp);
+      double rh, gw, w2;
+      ru = o2.x - up; rv = o2.y - vp;
+      loss_weights<LOSS>(ru, fs2, ifs2, rh, gw, w2);
+      cost += vu ? rh : 0.0;
+      loss_weights<LOSS>(rv, fs2, ifs2, rh, gw, w2);
+      cost += vv ? rh : 0.0;
+      nres += (vu ? 1.0 : 0.0) + (vv ? 1.0 : 0.0);
+    }
+    if (WRITE_RES && f < F) {
+      // (C,F,N,2) order of the reference's residual vector before NaN removal
+      *reinterpret_cast<double2*>(res + (((size_t)c * F + f) * N + p) * 2) = make_double2(vu ? ru : 0.0, vv ? rv : 0.0);
+    }
+  }
+  double cs = wave_sum(cost), ns = wave_sum(nres);
+  if (lane == 0) { cpart[2 * ((size_t)c * nfb + fb)] = cs; cpart[2 * ((size_t)c * nfb + fb) + 1] = ns; }
+}
+
+// ---------------------------------------------------------------- k_schur_frames
+// lane i = f*C + c.  V_f = sum_c V_cf; D_f = diag(V_f) (Marquardt); L L^T = V_f + lambda D_f; z = L^-1 g_f;
+// Y_cf = W_cf L^-T.  fbuf[f] = {L(21), z(6), g_f(6), D_f(6), pad}.
+__global__ __launch_bounds__(256) void k_schur_frames(const double* __restrict__ rec, double* __restrict__ ybuf, double* __restrict__ fbuf, double* __restrict__ fpart,
+                                                      int C, int F, double lambda) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)F * C;
+  double gmax = 0.0, nfail = 0.0;
+  if (i < total) {
+    const int f = (int)(i / C), c = (int)(i % C);
+    double V[21], gf[6];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) V[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gf[k] = 0.0;
+    for (int cc = 0; cc < C; ++cc) {
+      const double* r = rec + ((size_t)f * C + cc) * MCBA_REC + 72;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) V[k] += r[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gf[k] += r[21 + k];
+    }
+    double D[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      double d = V[tri6(k, k)];
+      D[k] = d > 0.0 ? d : 1.0;
+      V[tri6(k, k)] = d + lambda * D[k];
+    }
+    double Lp[21], id[6], z[6];
+    bool ok = chol6(V, Lp);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) id[k] = 1.0 / Lp[k * (k + 1) / 2 + k];
+    fwd6(Lp, id, gf, z);
+    const double* w = rec + ((size_t)f * C + c) * MCBA_REC;
+    double* y = ybuf + ((size_t)f * C + c) * 72;
+#pragma unroll
+    for (int row = 0; row < 12; ++row) {
+      double wr[6], yr[6];
+#pragma unroll
+      for (int k = 0; k < 6; k += 2) {
+        double2 t = *reinterpret_cast<const double2*>(w + 6 * row + k);
+        wr[k] = t.x; wr[k + 1] = t.y;
+      }
+      fwd6(Lp, id, wr, yr);
+#pragma unroll
+      for (int k = 0; k < 6; k += 2) *reinterpret_cast<double2*>(y + 6 * row + k) = make_double2(yr[k], yr[k + 1]);
+    }
+    if (c == 0) {
+      double* fbp = fbuf + (size_t)f * MCBA_FB;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) fbp[k] = Lp[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { fbp[21 + k] = z[k]; fbp[27 + k] = gf[k]; fbp[33 + k] = D[k]; gmax = fmax(gmax, fabs(gf[k])); }
+      fbp[39] = 0.0;
+      nfail = ok ? 0.0 : 1.0;
+    }
+  }
+  // per-block partials (max |g_f|, #failed factorizations)
+  __shared__ double s_m[4], s_n[4];
+  double wm = wave_max(gmax), wn = wave_sum(nfail);
+  if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = wm; s_n[threadIdx.x >> 6] = wn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fpart[2 * blockIdx.x] = fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]));
+    fpart[2 * blockIdx.x + 1] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+  }
+}
+
+// ---------------------------------------------------------------- k_syrk:  partial  sum_f Y_f Y_f^T  and  sum_f Y_f z_f
+// grid (G, npg), block 256.  Thread t < 252 owns a 3x4 tile of one 12x12 block pair (ci <= cj):
+// 21 block pairs per workgroup, 12 tiles per pair.  Y of `B` frames is staged in LDS (one contiguous copy).
+__global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ ybuf, const double* __restrict__ fbuf, const int* __restrict__ pair_ci, const int* __restrict__ pair_cj,
+                                              double* __restrict__ spart, double* __restrict__ rpart, int C, int F, int npairs, int fpc, int B) {
+  extern __shared__ __align__(16) double s_y[];  // [B][n*6] then [B][6]
+  const int n = 12 * C, n6 = n * 6;
+  double* s_z = s_y + (size_t)B * n6;
+  const int t = threadIdx.x;
+  const int q = blockIdx.y * 21 + t / 12;
+  const bool active = (t < 252) && (q < npairs);
+  int ra = 0, rb = 0;
+  if (active) {
+    int tt = t % 12;
+    ra = pair_ci[q] * 12 + 3 * (tt / 3);
+    rb = pair_cj[q] * 12 + 4 * (tt % 3);
+  }
+  double acc[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[r][s] = 0.0;
+  // rhs rows handled by this thread (blockIdx.y == 0 only): t, t+256, ...
+  double racc[2] = {0.0, 0.0};
+  const int f0 = blockIdx.x * fpc, f1 = min(F, f0 + fpc);
+  for (int fb = f0; fb < f1; fb += B) {
+    const int nb = min(B, f1 - fb);
+    const double2* src = reinterpret_cast<const double2*>(ybuf + (size_t)fb * n6);
+    double2* dst = reinterpret_cast<double2*>(s_y);
+    for (int i = t; i < nb * n6 / 2; i += 256) dst[i] = src[i];
+    for (int i = t; i < nb * 6; i += 256) s_z[i] = fbuf[(size_t)(fb + i / 6) * MCBA_FB + 21 + (i % 6)];
+    __syncthreads();
+    if (active) {
+      for (int b = 0; b < nb; ++b) {
+        const double* ya = s_y + (size_t)b * n6 + ra * 6;
+        const double* yb = s_y + (size_t)b * n6 + rb * 6;
+        double a[3][6], bb[4][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int k = 0; k < 6; k += 2) { double2 v = *reinterpret_cast<const double2*>(ya + 6 * r + k); a[r][k] = v.x; a[r][k + 1] = v.y; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int k = 0; k < 6; k += 2) { double2 v = *reinterpret_cast<const double2*>(yb + 6 * s + k); bb[s][k] = v.x; bb[s][k + 1] = v.y; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[r][s] += a[r][k] * bb[s][k];
+      }
+    }
+    if (blockIdx.y == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int row = t + 256 * j;
+        if (row < n) {
+          for (int b = 0; b < nb; ++b) {
+            const double* yr = s_y + (size_t)b * n6 + row * 6;
+            const double* z = s_z + b * 6;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) racc[j] += yr[k] * z[k];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (active) {
+    int tt = t % 12;
+    double* o = spart + ((size_t)blockIdx.x * npairs + q) * 144 + (3 * (tt / 3)) * 12 + 4 * (tt % 3);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 4; s += 2) *reinterpret_cast<double2*>(o + 12 * r + s) = make_double2(acc[r][s], acc[r][s + 1]);
+  }
+  if (blockIdx.y == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int row = t + 256 * j;
+      if (row < n) rpart[(size_t)blockIdx.x * n + row] = racc[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- k_reduce_system: fixed-order second stage
+// One thread per output double of the reduce buffer (layout in include/mcba.h).
+__global__ void k_reduce_system(const double* __restrict__ gpart, const double* __restrict__ spart, const double* __restrict__ rpart, const double* __restrict__ fpart,
+                                double* __restrict__ red, int C, int nfb, int G, int npairs, int nfblocks, int rank_slot) {
+  const int n = 12 * C;
+  const int nsys = n * n + 3 * n + 16;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsys) return;
+  if (i < n * n) {
+    int row = i / n, col = i % n;
+    int ci = row / 12, cj = col / 12, li = row % 12, lj = col % 12;
+    double s = 0.0;
+    if (ci == cj) {
+      int a = li <= lj ? li : lj, b = li <= lj ? lj : li;
+      const double* gp = gpart + (size_t)ci * nfb * MCBA_GP + tri12(a, b);
+      for (int k = 0; k < nfb; ++k) s += gp[(size_t)k * MCBA_GP];
+    }
+    int pa = ci <= cj ? ci : cj, pb = ci <= cj ? cj : ci;
+    int q = pa * C - (pa * (pa - 1)) / 2 + (pb - pa);
+    int loc = ci <= cj ? li * 12 + lj : lj * 12 + li;
+    const double* sp = spart + (size_t)q * 144 + loc;
+    double y = 0.0;
+    for (int g = 0; g < G; ++g) y += sp[(size_t)g * npairs * 144];
+    red[i] = s - y;
+    return;
+  }
+  int j = i - n * n;
+  if (j < n) {  // rhs
+    int c = j / 12, l = j % 12;
+    const double* gp = gpart + (size_t)c * nfb * MCBA_GP + 78 + l;
+    double s = 0.0;
+    for (int k = 0; k < nfb; ++k) s += gp[(size_t)k * MCBA_GP];
+    double y = 0.0;
+    for (int g = 0; g < G; ++g) y += rpart[(size_t)g * n + j];
+    red[i] = y - s;
+    return;
+  }
+  j -= n;
+  if (j < n) {  // diag U
+    int c = j / 12, l = j % 12;
+    const double* gp = gpart + (size_t)c * nfb * MCBA_GP + tri12(l, l);
+    double s = 0.0;
+    for (int k = 0; k < nfb; ++k) s += gp[(size_t)k * MCBA_GP];
+    red[i] = s;
+    return;
+  }
+  j -= n;
+  if (j < n) {  // g_c
+    int c = j / 12, l = j % 12;
+    const double* gp = gpart + (size_t)c * nfb * MCBA_GP + 78 + l;
+    double s = 0.0;
+    for (int k = 0; k < nfb; ++k) s += gp[(size_t)k * MCBA_GP];
+    red[i] = s;
+    return;
+  }
+  j -= n;
+  double out = 0.0;
+  if (j == 0 || j == 1) {  // cost, number of (camera,frame) pairs with data (diagnostic)
+    for (int k = 0; k < C * nfb; ++k) out += gpart[(size_t)k * MCBA_GP + 90 + j];
+  } else if (j == 2) {
+    for (int k = 0; k < nfblocks; ++k) out += fpart[2 * k + 1];
+  } else if (j == 4 + rank_slot) {
+    for (int k = 0; k < nfblocks; ++k) out = fmax(out, fpart[2 * k]);
+  }
+  red[i] = out;
+}
+
+// ---------------------------------------------------------------- k_backsub: frame steps + trial parameters
+// lane = frame.  d_f = -L^-T (z + Y_f^T d_c);  x_dst = x_src + d.  Per-block partials of
+// sum d^T(lambda D d - g_f), sum |d_f|^2, sum |x_f|^2.
+__global__ __launch_bounds__(256) void k_backsub(const double* __restrict__ ybuf, const double* __restrict__ fbuf, const double* __restrict__ dc, const double* __restrict__ xs,
+                                                 double* __restrict__ xd, double* __restrict__ bpart, int C, int F, double lambda) {
+  extern __shared__ double s_dc[];
+  const int n = 12 * C;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s_dc[i] = dc[i];
+  __syncthreads();
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) xd[i] = xs[i] + s_dc[i];
+  double pred = 0.0, dn2 = 0.0, xn2 = 0.0;
+  if (f < F) {
+    const double* fbp = fbuf + (size_t)f * MCBA_FB;
+    double Lp[21], id[6], t[6], gf[6], D[6];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) Lp[k] = fbp[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { t[k] = fbp[21 + k]; gf[k] = fbp[27 + k]; D[k] = fbp[33 + k]; id[k] = 1.0 / Lp[k * (k + 1) / 2 + k]; }
+    const double* y = ybuf + (size_t)f * n * 6;
+    for (int row = 0; row < n; ++row) {
+      double d = s_dc[row];
+#pragma unroll
+      for (int k = 0; k < 6; k += 2) {
+        double2 v = *reinterpret_cast<const double2*>(y + 6 * row + k);
+        t[k] += v.x * d; t[k + 1] += v.y * d;
+      }
+    }
+    double dl[6];
+    bwd6(Lp, id, t, dl);
+    const double* xf = xs + n + 6 * (size_t)f;
+    double* xo = xd + n + 6 * (size_t)f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      double d = -dl[k], xv = xf[k];
+      xo[k] = xv + d;
+      pred += d * (lambda * D[k] * d - gf[k]);
+      dn2 += d * d;
+      xn2 += xv * xv;
+    }
+  }
+  __shared__ double s_p[3][4];
+  double a = wave_sum(pred), b = wave_sum(dn2), c = wave_sum(xn2);
+  if ((threadIdx.x & 63) == 0) { s_p[0][threadIdx.x >> 6] = a; s_p[1][threadIdx.x >> 6] = b; s_p[2][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x < 3) bpart[3 * blockIdx.x + threadIdx.x] = s_p[threadIdx.x][0] + s_p[threadIdx.x][1] + s_p[threadIdx.x][2] + s_p[threadIdx.x][3];
+}
+
+// trial scalars: [cost, pred_f, dn2_f, xn2_f, n_residuals, 0, 0, 0]
+__global__ void k_sum_trial(const double* __restrict__ cpart, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out) {
+  int t = threadIdx.x;
+  double s = 0.0;
+  if (t == 0) for (int k = 0; k < ncp; ++k) s += cpart[2 * k];
+  else if (t >= 1 && t <= 3) { if (bpart) for (int k = 0; k < nbp; ++k) s += bpart[3 * k + (t - 1)]; }
+  else if (t == 4) for (int k = 0; k < ncp; ++k) s += cpart[2 * k + 1];
+  if (t < 8) out[t] = s;
+}
+
+// ---------------------------------------------------------------- k_jacobian: materialised residual Jacobian blocks
+// grid (F, C), block 64: one wavefront per (camera, frame), lane = board point (chunks of 64 points).
+// Output (C,F,N,2,18): per scalar residual [12 camera columns | 6 pose columns] of d(residual)/dx = -d(pred)/dx,
+// optionally robust-rescaled.  Rows go through LDS (stride 37 doubles: 2-way bank conflicts at most) so that the
+// global stores are contiguous 16 B per lane.
+template <int LOSS>
+__global__ __launch_bounds__(64) void k_jacobian(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x, double* __restrict__ jac,
+                                                 double* __restrict__ res, int C, int F, int N, int Fpad, int robust, double fs2, double ifs2) {
+  __shared__ double s_rows[64 * 37];
+  const int f = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+  // pose / camera constants: computed by every lane of the wave from the same (uniform) inputs
+  CamConst cc;
+  make_cam_const(x + 12 * c, cc);
+  const double* pose = x + 12 * C + 6 * (size_t)f;
+  double pz[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) pz[i] = pose[i];
+  double Rf[9], Jrf[9];
+  rot_and_jr(pz, Rf, Jrf);
+  PairConst pc;
+  make_pair_const(cc.R, cc.t, Rf, pz + 3, pc);
+  ChainConst ch;
+  make_chain_const(cc.R, cc.Jr, Rf, Jrf, pz + 3, ch);
+  Intr K{cc.fx, cc.fy, cc.cx, cc.cy, cc.k1, cc.k2};
+  for (int p0 = 0; p0 < N; p0 += 64) {
+    const int p = p0 + lane;
+    const int np = min(64, N - p0);
+    if (p < N) {
+      double2 o2 = obs_t[((size_t)c * N + p) * Fpad + f];
+      bool vu = is_num(o2.x), vv = is_num(o2.y);
+      double Xo[3] = {obj[3 * p], obj[3 * p + 1], obj[3 * p + 2]};
+      ObsRows o;
+      obs_rows(K, pc, Xo, o);
+      double ru = o2.x - o.up, rv = o2.y - o.vp;
+      double su = -1.0, sv = -1.0;  // residual = obs - pred
+      if (robust) {
+        double rh, gw, w2;
+        loss_weights<LOSS>(ru, fs2, ifs2, rh, gw, w2);
+        su = -sqrt(w2);
+        loss_weights<LOSS>(rv, fs2, ifs2, rh, gw, w2);
+        sv = -sqrt(w2);
+      }
+      su = vu ? su : 0.0;
+      sv = vv ? sv : 0.0;
+      double Jcu[12], Jcv[12], Jfu[6], Jfv[6];
+      expand_rows(o, ch, Jcu, Jcv, Jfu, Jfv);
+      double* sr = s_rows + lane * 37;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) { sr[k] = su * Jcu[k]; sr[18 + k] = sv * Jcv[k]; }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { sr[12 + k] = su * Jfu[k]; sr[30 + k] = sv * Jfv[k]; }
+      if (res) *reinterpret_cast<double2*>(res + (((size_t)c * F + f) * N + p) * 2) = make_double2(vu ? ru : 0.0, vv ? rv : 0.0);
+    }
+    __syncthreads();
+    // contiguous tile of np*36 doubles
+    double2* out = reinterpret_cast<double2*>(jac + (((size_t)c * F + f) * N + p0) * 36);
+    for (int j = lane; j < np * 18; j += 64) {
+      int pp = j / 18, kk = (j % 18) * 2;
+      out[j] = make_double2(s_rows[pp * 37 + kk], s_rows[pp * 37 + kk + 1]);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- launch wrappers (host)
+#define DISPATCH_LOSS(loss, CALL)                                  \
+  switch (loss) {                                                  \
+    case LOSS_LINEAR: { constexpr int L = LOSS_LINEAR; CALL; } break;   \
+    case LOSS_SOFT_L1: { constexpr int L = LOSS_SOFT_L1; CALL; } break; \
+    case LOSS_HUBER: { constexpr int L = LOSS_HUBER; CALL; } break;     \
+    case LOSS_CAUCHY: { constexpr int L = LOSS_CAUCHY; CALL; } break;   \
+    default: { constexpr int L = LOSS_ARCTAN; CALL; } break;            \
+  }
+
+void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int C, int F, int N, int Fpad) {
+  size_t total = (size_t)C * N * Fpad;
+  k_transpose_obs<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(raw), reinterpret_cast<double2*>(obs_t), C, F, N, Fpad);
+}
+
+void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* rec, double* gpart, int C, int N, int Fpad) {
+  int nfb = Fpad / 64;
+  dim3 grid((nfb + 3) / 4, C), block(256);
+  double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
+  DISPATCH_LOSS(loss, (k_gram<L><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, rec, gpart, C, N, Fpad, nfb, fs2, ifs2)));
+}
+
+void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad) {
+  int nfb = Fpad / 64;
+  dim3 grid((nfb + 3) / 4, C), block(256);
+  double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
+  if (res) {
+    DISPATCH_LOSS(loss, (k_cost<L, true><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, cpart, res, C, F, N, Fpad, nfb, fs2, ifs2)));
+  } else {
+    DISPATCH_LOSS(loss, (k_cost<L, false><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, cpart, res, C, F, N, Fpad, nfb, fs2, ifs2)));
+  }
+}
+
+void launch_schur_frames(hipStream_t st, const double* rec, double* ybuf, double* fbuf, double* fpart, int C, int F, double lambda) {
+  size_t total = (size_t)F * C;
+  k_schur_frames<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(rec, ybuf, fbuf, fpart, C, F, lambda);
+}
+
+void launch_syrk(hipStream_t st, const double* ybuf, const double* fbuf, const int* pair_ci, const int* pair_cj, double* spart, double* rpart, int C, int F, int npairs, int G, int fpc, int B) {
+  int npg = (npairs + 20) / 21;
+  size_t lds = (size_t)B * (12 * C * 6 + 6) * sizeof(double);
+  k_syrk<<<dim3(G, npg), dim3(256), lds, st>>>(ybuf, fbuf, pair_ci, pair_cj, spart, rpart, C, F, npairs, fpc, B);
+}
+
+void launch_reduce_system(hipStream_t st, const double* gpart, const double* spart, const double* rpart, const double* fpart, double* red, int C, int nfb, int G, int npairs, int nfblocks, int rank_slot) {
+  int n = 12 * C, nsys = n * n + 3 * n + 16;
+  k_reduce_system<<<dim3((nsys + 127) / 128), dim3(128), 0, st>>>(gpart, spart, rpart, fpart, red, C, nfb, G, npairs, nfblocks, rank_slot);
+}
+
+void launch_backsub(hipStream_t st, const double* ybuf, const double* fbuf, const double* dc, const double* xs, double* xd, double* bpart, int C, int F, double lambda) {
+  k_backsub<<<dim3((F + 255) / 256), dim3(256), (size_t)12 * C * sizeof(double), st>>>(ybuf, fbuf, dc, xs, xd, bpart, C, F, lambda);
+}
+
+void launch_sum_trial(hipStream_t st, const double* cpart, int ncp, const double* bpart, int nbp, double* out) {
+  k_sum_trial<<<dim3(1), dim3(64), 0, st>>>(cpart, ncp, bpart, nbp, out);
+}
+
+void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust) {
+  double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
+  DISPATCH_LOSS(loss, (k_jacobian<L><<<dim3(F, C), dim3(64), 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, jac, res, C, F, N, Fpad, robust, fs2, ifs2)));
+}
+
+int syrk_set_lds_limit(size_t bytes) {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace mcba

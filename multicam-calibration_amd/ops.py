@@ -1,0 +1,220 @@
+"""ctypes binding of include/mcba.h (libmcba.so).  Thin: no arithmetic happens here.
+
+The library is the ONLY compute path.  If it is missing or fails to load this module raises --
+there is no CPU fallback (oracle/ is test infrastructure and is never imported from here)."""
+import ctypes
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libmcba.so")
+
+LOSSES = {"linear": 0, "soft_l1": 1, "huber": 2, "cauchy": 3, "arctan": 4}
+OK, ERR_HIP, ERR_ARG, ERR_NONFINITE, ERR_NODEVICE = 0, 1, 2, 3, 4
+
+# every symbol include/mcba.h declares: (name, restype, argtypes)
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_h = ctypes.c_void_p
+SYMBOLS = [
+    ("mcba_abi_version", ctypes.c_int, []),
+    ("mcba_last_error", ctypes.c_char_p, []),
+    ("mcba_device_count", ctypes.c_int, [_ip]),
+    ("mcba_create", ctypes.c_int, [ctypes.POINTER(_h), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    ("mcba_destroy", ctypes.c_int, [_h]),
+    ("mcba_set_stream", ctypes.c_int, [_h, ctypes.c_void_p]),
+    ("mcba_upload_observations", ctypes.c_int, [_h, _dp, _dp]),
+    ("mcba_set_loss", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_double]),
+    ("mcba_set_params", ctypes.c_int, [_h, ctypes.c_int, _dp]),
+    ("mcba_get_params", ctypes.c_int, [_h, ctypes.c_int, _dp]),
+    ("mcba_copy_params", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int]),
+    ("mcba_cost", ctypes.c_int, [_h, ctypes.c_int, _dp, _dp]),
+    ("mcba_residuals", ctypes.c_int, [_h, ctypes.c_int, _dp]),
+    ("mcba_jacobian_eval", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int]),
+    ("mcba_jacobian_download", ctypes.c_int, [_h, _dp, _dp]),
+    ("mcba_linearize", ctypes.c_int, [_h, ctypes.c_int]),
+    ("mcba_build_reduced", ctypes.c_int, [_h, ctypes.c_double, ctypes.c_int]),
+    ("mcba_reduced_size", ctypes.c_size_t, [_h]),
+    ("mcba_bind_reduce_buffer", ctypes.c_int, [_h, ctypes.c_void_p]),
+    ("mcba_get_reduced", ctypes.c_int, [_h, _dp]),
+    ("mcba_step", ctypes.c_int, [_h, _dp, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
+    ("mcba_get_trial", ctypes.c_int, [_h, _dp]),
+    ("mcba_get_frame_gradient", ctypes.c_int, [_h, _dp]),
+    ("mcba_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
+    ("mcba_profile_read", ctypes.c_int, [_h, _dp, _ip, ctypes.c_int, _ip]),
+    ("mcba_profile_names", ctypes.c_char_p, []),
+    ("mcba_synchronize", ctypes.c_int, [_h]),
+]
+
+_lib = None
+
+
+class McbaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmcba error {code}: {msg}")
+        self.code = code
+
+
+def load_library():
+    """Load libmcba.so once.  torch is imported first so both share one HIP runtime (same soname)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is the only compute path of this package. "
+            "Build it with `python -m multicam_calibration_amd.build` (needs hipcc)."
+        )
+    try:
+        import torch  # noqa: F401  (plumbing: device memory for collectives, streams, torch.distributed)
+    except Exception:
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Problem:
+    """One handle = one GPU = this process's shard of frames."""
+
+    def __init__(self, uvs, objpoints, device=0, loss="soft_l1", f_scale=1.0, stream=None):
+        self.lib = load_library()
+        uvs = _f64(uvs)
+        objpoints = _f64(objpoints)
+        if uvs.ndim != 4 or uvs.shape[3] != 2 or objpoints.shape != (uvs.shape[2], 3):
+            raise ValueError("uvs must be (C,F,N,2) and objpoints (N,3)")
+        self.C, self.F, self.N = uvs.shape[:3]
+        self.n = 12 * self.C
+        self.nx = 12 * self.C + 6 * self.F
+        self.handle = _h()
+        self._chk(self.lib.mcba_create(ctypes.byref(self.handle), self.C, self.F, self.N, int(device)))
+        if stream is not None:
+            self._chk(self.lib.mcba_set_stream(self.handle, ctypes.c_void_p(int(stream))))
+        self._chk(self.lib.mcba_upload_observations(self.handle, _p(uvs), _p(objpoints)))
+        self.set_loss(loss, f_scale)
+        self.nsys = self.n * self.n + 3 * self.n + 16
+        self._red = np.empty(self.nsys)
+        self._trial = np.empty(8)
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise McbaError(rc, self.lib.mcba_last_error().decode())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mcba_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_loss(self, loss, f_scale=1.0):
+        if loss not in LOSSES:
+            raise ValueError(f"loss must be one of {sorted(LOSSES)} (callable losses are not supported on the GPU path)")
+        self._chk(self.lib.mcba_set_loss(self.handle, LOSSES[loss], float(f_scale)))
+
+    def set_params(self, slot, x):
+        x = _f64(x)
+        if x.shape != (self.nx,):
+            raise ValueError(f"x must have {self.nx} entries")
+        self._chk(self.lib.mcba_set_params(self.handle, slot, _p(x)))
+
+    def get_params(self, slot):
+        x = np.empty(self.nx)
+        self._chk(self.lib.mcba_get_params(self.handle, slot, _p(x)))
+        return x
+
+    def copy_params(self, dst, src):
+        self._chk(self.lib.mcba_copy_params(self.handle, dst, src))
+
+    def cost(self, slot):
+        c, n = ctypes.c_double(), ctypes.c_double()
+        self._chk(self.lib.mcba_cost(self.handle, slot, ctypes.byref(c), ctypes.byref(n)))
+        return c.value, n.value
+
+    def residuals(self, slot):
+        """(C,F,N,2) observed - predicted, 0 where the observation is missing."""
+        r = np.empty((self.C, self.F, self.N, 2))
+        self._chk(self.lib.mcba_residuals(self.handle, slot, _p(r)))
+        return r
+
+    def jacobian_eval(self, slot, robust_scaled=False):
+        self._chk(self.lib.mcba_jacobian_eval(self.handle, slot, int(bool(robust_scaled))))
+
+    def jacobian_download(self, want_res=True):
+        jac = np.empty((self.C, self.F, self.N, 2, 18))
+        res = np.empty((self.C, self.F, self.N, 2)) if want_res else None
+        self._chk(self.lib.mcba_jacobian_download(self.handle, _p(jac), _p(res) if want_res else None))
+        return jac, res
+
+    def linearize(self, slot):
+        self._chk(self.lib.mcba_linearize(self.handle, slot))
+
+    def build_reduced(self, lam, rank_slot=0):
+        self._chk(self.lib.mcba_build_reduced(self.handle, float(lam), int(rank_slot)))
+
+    def reduced_size(self):
+        return int(self.lib.mcba_reduced_size(self.handle))
+
+    def bind_reduce_buffer(self, device_ptr):
+        self._chk(self.lib.mcba_bind_reduce_buffer(self.handle, ctypes.c_void_p(int(device_ptr) if device_ptr else None)))
+
+    def get_reduced(self):
+        """dict(S0 (n,n), rhs, diagU, gc, scal(16)) of this shard (or of all shards after an all-reduce)."""
+        self._chk(self.lib.mcba_get_reduced(self.handle, _p(self._red)))
+        return self.split_reduced(self._red)
+
+    def split_reduced(self, r):
+        n = self.n
+        return dict(S0=r[: n * n].reshape(n, n), rhs=r[n * n : n * n + n], diagU=r[n * n + n : n * n + 2 * n], gc=r[n * n + 2 * n : n * n + 3 * n], scal=r[n * n + 3 * n : n * n + 3 * n + 16])
+
+    def step(self, delta_cam, lam, src, dst):
+        d = _f64(delta_cam)
+        self._chk(self.lib.mcba_step(self.handle, _p(d), float(lam), src, dst))
+
+    def get_trial(self):
+        self._chk(self.lib.mcba_get_trial(self.handle, _p(self._trial)))
+        return self._trial.copy()
+
+    def frame_gradient(self):
+        g = np.empty((self.F, 6))
+        self._chk(self.lib.mcba_get_frame_gradient(self.handle, _p(g)))
+        return g
+
+    def enable_collective(self, device):
+        """Own the reduce buffer as a torch tensor so torch.distributed (RCCL) can all-reduce it in place."""
+        import torch
+
+        self.reduce_tensor = torch.zeros(self.reduced_size(), dtype=torch.float64, device=device)
+        self.bind_reduce_buffer(self.reduce_tensor.data_ptr())
+
+    def synchronize(self):
+        self._chk(self.lib.mcba_synchronize(self.handle))
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.mcba_profile_enable(self.handle, int(on)))
+
+    def profile_read(self):
+        """{kernel name: (total ms, calls)} since the last read."""
+        names = self.lib.mcba_profile_names().decode().split("\n")
+        ms = (ctypes.c_double * len(names))()
+        calls = (ctypes.c_int * len(names))()
+        nk = ctypes.c_int()
+        self._chk(self.lib.mcba_profile_read(self.handle, ms, calls, len(names), ctypes.byref(nk)))
+        return {names[i]: (ms[i], calls[i]) for i in range(nk.value)}

@@ -1,0 +1,290 @@
+"""GPU parity tests: the HIP path (through the C ABI / ctypes) against the CPU oracle and the
+reference-generated golden fixtures.  Run with `-m gpu` on an MI355X."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import problem_from_npz
+from oracle import ba_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mc():
+    import multicam_calibration_amd as m
+
+    m.ops.load_library()
+    return m
+
+
+def tri_full(t, n):
+    out = np.zeros(t.shape[:-1] + (n, n))
+    iu = np.triu_indices(n)
+    out[..., iu[0], iu[1]] = t
+    out[..., iu[1], iu[0]] = t
+    return out
+
+
+# ------------------------------------------------------------------ residual kernel vs the reference's own outputs
+@pytest.mark.parametrize("name", ["complete", "missing", "fourcam", "edge"])
+def test_residuals_vs_reference_golden(mc, golden, name):
+    z = golden("residuals.npz")
+    uvs, ext, intr, obj, poses = problem_from_npz(z, name + "_")
+    x0 = z[name + "_x0"]
+    prob = mc.ops.Problem(uvs, obj)
+    prob.set_params(0, x0)
+    r = prob.residuals(0)
+    mask = ~np.isnan(uvs)
+    assert np.all(r[~mask] == 0.0)
+    # FP64 tolerance: closed form vs the reference's homogeneous 4x4 chain, |uv| ~ 1e3 px -> 1e-10 px absolute
+    np.testing.assert_allclose(r[mask], z[name + "_res"], rtol=0, atol=1e-10)
+    np.testing.assert_array_equal(prob.get_params(0), x0)
+    prob.close()
+
+
+@pytest.mark.parametrize("loss,fs", [("soft_l1", 1.0), ("linear", 1.0), ("huber", 0.4), ("cauchy", 2.0), ("arctan", 1.5)])
+def test_cost_vs_oracle(mc, loss, fs):
+    p = mc.synth.make_problem(3, 70, seed=21, missing=0.2, scalar_nans=11)  # 70 frames: a full and a ragged wavefront
+    x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = mc.ops.Problem(p["uvs"], p["obj"], loss=loss, f_scale=fs)
+    prob.set_params(1, x)
+    cost, nres = prob.cost(1)
+    f = orc.residuals(x, p["uvs"], p["obj"])
+    assert nres == f.size
+    assert abs(cost - orc.robust_cost(f, loss, fs)) <= 1e-12 * cost  # FP64 sum of ~2e4 terms
+    prob.close()
+
+
+# ------------------------------------------------------------------ Jacobian kernel
+def test_jacobian_vs_reference_fd_golden(mc, golden):
+    z = golden("jacobian.npz")
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    prob = mc.ops.Problem(uvs, obj)
+    prob.set_params(0, z["x0"])
+    prob.jacobian_eval(0, robust_scaled=False)
+    jac, res = prob.jacobian_download()
+    idx, indptr, shape, mask = mc.api.jacobian_structure(uvs)
+    J = sp.csr_matrix((jac[mask].ravel(), idx, indptr), shape=shape)
+    J.sort_indices()
+    np.testing.assert_array_equal(J.indices, z["J3_indices"])
+    np.testing.assert_array_equal(J.indptr, z["J3_indptr"])
+    J3 = sp.csr_matrix((z["J3_data"], z["J3_indices"], z["J3_indptr"]), shape=shape)
+    assert sp.linalg.norm(J - J3) / sp.linalg.norm(J3) < 1e-8  # analytic vs 3-point FD of the reference residual
+    Jo = orc.jacobian_csr(z["x0"], uvs, obj)
+    assert abs(J - Jo).max() <= 1e-11 * abs(Jo).max()
+    np.testing.assert_allclose(res[mask], orc.residuals(z["x0"], uvs, obj), rtol=0, atol=1e-10)
+    prob.close()
+
+
+@pytest.mark.parametrize("loss,fs", [("soft_l1", 1.0), ("huber", 0.4)])
+def test_jacobian_robust_scaling(mc, loss, fs):
+    p = mc.synth.make_problem(2, 9, seed=22, rows=9, cols=11)  # 99 points: two point chunks per wavefront
+    x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = mc.ops.Problem(p["uvs"], p["obj"], loss=loss, f_scale=fs)
+    prob.set_params(0, x)
+    prob.jacobian_eval(0, robust_scaled=True)
+    jac, res = prob.jacobian_download()
+    Jc, Jf = orc.jacobian_blocks(x, 2, p["obj"])
+    f = p["uvs"] - orc.predict_from_x(x, 2, p["obj"])
+    js, _ = orc.robust_scales(f, loss, fs)
+    want = -np.concatenate([Jc, Jf], -1) * js[..., None]
+    assert np.abs(jac - want).max() <= 1e-11 * np.abs(want).max()
+    np.testing.assert_allclose(res, f, rtol=0, atol=1e-10)
+    prob.close()
+
+
+# ------------------------------------------------------------------ normal equations / Schur / back-substitution
+@pytest.mark.parametrize("kw,loss", [
+    (dict(n_cameras=3, n_frames=20, seed=23, missing=0.25, scalar_nans=9), "soft_l1"),
+    (dict(n_cameras=2, n_frames=130, seed=24), "cauchy"),
+    (dict(n_cameras=7, n_frames=11, seed=25, missing=0.3), "soft_l1"),   # 28 block pairs: two pair groups in k_syrk
+])
+def test_reduced_system_and_step_vs_oracle(mc, kw, loss):
+    p = mc.synth.make_problem(**kw)
+    C, F = p["uvs"].shape[:2]
+    x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = mc.ops.Problem(p["uvs"], p["obj"], loss=loss)
+    prob.set_params(0, x)
+    prob.linearize(0)
+    lam = 3e-3
+    prob.build_reduced(lam, rank_slot=2)
+    red = prob.get_reduced()
+
+    U, gc, V, gf, W, cost = orc.normal_equations(x, p["uvs"], p["obj"], loss)
+    Dc2 = np.stack([np.diag(U[c]) for c in range(C)])
+    Df2 = np.stack([np.diag(V[f]) for f in range(F)])
+    S, rhs = orc.schur_reduce(U, gc, V, gf, W, lam, np.zeros_like(Dc2), Df2)  # S0 carries no camera damping
+    scale = np.abs(S).max()
+    assert np.abs(red["S0"] - S).max() <= 1e-10 * scale
+    assert np.abs(red["S0"] - red["S0"].T).max() <= 1e-12 * scale
+    assert np.abs(red["rhs"] - rhs).max() <= 1e-10 * np.abs(rhs).max()
+    np.testing.assert_allclose(red["diagU"], Dc2.ravel(), rtol=1e-11)
+    assert np.abs(red["gc"] - gc.ravel()).max() <= 1e-10 * np.abs(gc).max()
+    assert abs(red["scal"][0] - cost) <= 1e-12 * cost
+    assert red["scal"][2] == 0
+    assert abs(red["scal"][4 + 2] - np.abs(gf).max()) <= 1e-10 * np.abs(gf).max()
+    assert np.all(np.delete(red["scal"][4:], 2) == 0)
+    assert np.abs(prob.frame_gradient() - gf).max() <= 1e-10 * np.abs(gf).max()
+
+    # one damped Gauss-Newton step
+    Sd = S + lam * np.diag(Dc2.ravel())
+    dc = np.linalg.solve(Sd, rhs)
+    df = orc.back_substitute(dc, V, gf, W, lam, Df2)
+    prob.step(dc, lam, 0, 1)
+    t = prob.get_trial()
+    x1 = prob.get_params(1)
+    want = x + np.concatenate([dc, df.ravel()])
+    assert np.abs(x1 - want).max() <= 1e-9 * np.abs(np.concatenate([dc, df.ravel()])).max() + 1e-13 * np.abs(x).max()
+    f1 = orc.residuals(want, p["uvs"], p["obj"])
+    assert abs(t[0] - orc.robust_cost(f1, loss)) <= 1e-10 * t[0]
+    pred_f = np.sum(df * (lam * Df2 * df - gf))
+    assert abs(t[1] - pred_f) <= 1e-8 * abs(pred_f)
+    assert abs(t[2] - np.sum(df * df)) <= 1e-9 * np.sum(df * df)
+    assert abs(t[3] - np.sum(x[12 * C:] ** 2)) <= 1e-12 * np.sum(x[12 * C:] ** 2)
+    # the full damped step must equal the dense LM step of the whole system
+    n = 12 * C
+    Jd = orc.jacobian_csr(x, p["uvs"], p["obj"]).toarray()
+    fr = orc.residuals(x, p["uvs"], p["obj"])
+    js, fs_ = orc.robust_scales(fr, loss)
+    Jd *= js[:, None]
+    H = Jd.T @ Jd
+    full = np.linalg.solve(H + lam * np.diag(np.diag(H)), -Jd.T @ fs_)
+    assert np.abs(full - np.concatenate([dc, df.ravel()])).max() <= 1e-6 * np.abs(full).max()
+    prob.close()
+
+
+# ------------------------------------------------------------------ converged solution vs the reference driven to a tight optimum
+def _compare_to_tight(mc, z, x, C, tol):
+    ext, intr, poses = orc.deserialize_params(x, C)
+    ext_g, intr_g, poses_g = orc.deserialize_params(z["s0_x"], C)
+    cam = np.asarray(x[:12 * C]).reshape(C, 12)
+    cam_g = z["s0_x"][:12 * C].reshape(C, 12)
+    # (fx fy cx cy k1 k2) are gauge invariant
+    rel = np.abs(cam[:, :6] - cam_g[:, :6]) / np.abs(cam_g[:, :6])
+    assert rel.max() < tol, rel
+    # gauge-align to the golden's camera 0 and compare every extrinsic / pose component
+    ext_a, poses_a = orc.gauge_align(ext, poses, ext_g[0])
+    scale_e = np.maximum(np.abs(ext_g), np.abs(ext_g).max(0) * 1e-3 + 1e-12)
+    assert (np.abs(ext_a - ext_g) / scale_e).max() < tol
+    Ta, Tg = orc.to_matrix(poses_a), orc.to_matrix(poses_g)
+    assert np.abs(Ta - Tg)[..., :3, :3].max() < tol
+    assert (np.abs(Ta - Tg)[..., :3, 3] / np.abs(Tg[..., :3, 3]).max()).max() < tol
+
+
+@pytest.mark.parametrize("tag,kwargs", [("config1", {}), ("missing3", {})])
+def test_solution_matches_tight_reference_optimum(mc, golden, tag, kwargs):
+    """north_star: parameters match the reference's least_squares path within 1e-6 relative.
+    Golden = the REFERENCE's bundle_adjust driven to a tight optimum (tests/golden/make_golden.py --slow);
+    its own two-start agreement bounds the golden's accuracy."""
+    z = golden(f"tight_{tag}.npz")
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    C = uvs.shape[0]
+    # accuracy of the golden itself (two different starts of the reference)
+    c0 = z["s0_x"][:12 * C].reshape(C, 12)[:, :6]
+    c1 = z["s1_x"][:12 * C].reshape(C, 12)[:, :6]
+    golden_acc = (np.abs(c0 - c1) / np.abs(c0)).max()
+    assert golden_acc < 5e-7
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, i, p_, use, res = mc.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=None, ftol=1e-15, xtol=1e-15, gtol=1e-9, verbose=0, max_nfev=200)
+    np.testing.assert_array_equal(use, z["s0_use"])
+    assert abs(res.cost - float(z["s0_cost"])) <= 1e-10 * res.cost
+    _compare_to_tight(mc, z, res.x, C, 1e-6)
+
+
+def test_bundle_adjust_wrapper_matches_reference_prefilter(mc, golden):
+    z = golden("prefilter.npz")
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    for i in range(int(z["n_cases"])):
+        n_frames, seed, thr = z[f"case{i}_args"]
+        n_frames = None if n_frames < 0 else int(n_frames)
+        thr = None if thr < 0 else float(thr)
+        if len(z[f"case{i}_use"]) == 0:
+            continue
+        np.random.seed(int(seed))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            e, it, p_, use, res = mc.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=n_frames, outlier_threshold=thr, verbose=0, max_nfev=3)
+        np.testing.assert_array_equal(use, z[f"case{i}_use"])
+        a, b = buf.getvalue().splitlines()[0].rsplit(" ", 1), str(z[f"case{i}_line"]).rsplit(" ", 1)
+        assert a[0] == b[0] and abs(float(a[1]) - float(b[1])) <= 1e-9 * float(b[1])
+        assert np.random.randint(0, 2**31 - 1) == int(z[f"case{i}_rng_after"])
+        C = uvs.shape[0]
+        assert e.shape == (C, 6) and p_.shape == (len(use), 6) and len(it) == C and it[0][1].shape == (5,)
+        assert res.x.shape == (12 * C + 6 * len(use),)
+        m = int((~np.isnan(uvs[:, use])).sum())
+        assert res.fun.shape == (m,) and res.jac.shape == (m, res.x.size) and res.grad.shape == res.x.shape
+        # grad = J^T f of the robust-rescaled pair (trf.py:557-560)
+        _, fsc = orc.robust_scales(res.fun)
+        assert np.abs(res.jac.T @ fsc - res.grad).max() <= 1e-9 * np.abs(res.grad).max()
+
+
+def test_default_tolerance_run_reaches_reference_cost(mc, golden):
+    """Informational parity with the reference's DEFAULT run (ftol=1e-4): our final cost is at least as low."""
+    z = golden("default_run.npz")
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        e, i, p_, use, res = mc.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=None)
+    assert res.status in (1, 2, 3, 4) and res.success
+    assert res.cost <= float(z["cost"]) * (1 + 1e-6)
+    out = buf.getvalue()
+    assert "Iteration" in out and "Optimality" in out and "termination condition is satisfied" in out
+
+
+def test_fix_intrinsics(mc):
+    p = mc.synth.make_problem(3, 40, seed=26)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, intr, poses, use, res = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, fix_intrinsics=True, verbose=0, ftol=1e-12)
+    for (K, d), (K0, d0) in zip(intr, p["intrinsics"]):
+        np.testing.assert_array_equal(K, K0)
+        np.testing.assert_array_equal(d[:2], d0[:2])
+    x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    assert res.cost < orc.robust_cost(orc.residuals(x0, p["uvs"], p["obj"]))
+
+
+def test_nonfinite_initial_point_raises(mc):
+    p = mc.synth.make_problem(2, 6, seed=27)
+    bad = p["poses"].copy()
+    bad[0] = np.nan
+    with pytest.raises(ValueError, match="Residuals are not finite in the initial point"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], bad, n_frames=None, outlier_threshold=1e9, verbose=0)
+
+
+# ------------------------------------------------------------------ full-size, size-independent properties (6 x 10k x 54)
+def test_full_size_properties(mc):
+    p = mc.synth.make_problem(6, 10000, seed=0)
+    C, F, N = p["uvs"].shape[:3]
+    x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = mc.ops.Problem(p["uvs"], p["obj"])
+    prob.set_params(0, x)
+    prob.linearize(0)
+    prob.build_reduced(1e-3)
+    full = {k: v.copy() for k, v in prob.get_reduced().items()}
+    cost, nres = prob.cost(0)
+    assert nres == 2 * C * F * N
+    assert abs(cost - full["scal"][0]) <= 1e-12 * cost           # k_cost and k_gram agree
+    # the oracle on a 200-frame sample of the same problem
+    sub = slice(4000, 4200)
+    xs = np.concatenate([x[:12 * C], x[12 * C:].reshape(F, 6)[sub].ravel()])
+    r = prob.residuals(0)
+    np.testing.assert_allclose(r[:, sub][~np.isnan(p["uvs"][:, sub])], orc.residuals(xs, p["uvs"][:, sub], p["obj"]), rtol=0, atol=1e-10)
+    assert np.abs(full["S0"] - full["S0"].T).max() <= 1e-12 * np.abs(full["S0"]).max()
+    prob.close()
+    # frame shards: the reduced systems of two half shards add up to the unsharded one (what the all-reduce computes)
+    acc = None
+    for sl in (slice(0, 5000), slice(5000, F)):
+        ps = mc.ops.Problem(p["uvs"][:, sl], p["obj"])
+        ps.set_params(0, np.concatenate([x[:12 * C], x[12 * C:].reshape(F, 6)[sl].ravel()]))
+        ps.linearize(0)
+        ps.build_reduced(1e-3)
+        part = ps.get_reduced()
+        acc = {k: v.copy() for k, v in part.items()} if acc is None else {k: acc[k] + part[k] for k in acc}
+        ps.close()
+    for k in ("S0", "rhs", "diagU", "gc"):
+        assert np.abs(acc[k] - full[k]).max() <= 1e-11 * np.abs(full[k]).max(), k
+    assert abs(acc["scal"][0] - full["scal"][0]) <= 1e-12 * full["scal"][0]
