@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- LM iterations/sec + ms per Jacobian-eval of the bundle-adjustment hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+For N > 1 it is launched under torch.distributed.run (one rank per GPU, RCCL).
+
+Workload (BASELINE.json metric / configs[2]): 6 cameras x 10 000 frames x 54 points, full
+intrinsics + distortion + extrinsics + poses, soft-L1 loss, synthetic board detections
+(multicam_calibration_amd.synth, seed 0) -- PER GPU.  Frames are the sharding axis (weak scaling:
+every rank owns 10 000 frames of one rig; the reduced camera system is all-reduced once per solve).
+
+A "step" is ONE complete Levenberg-Marquardt iteration on the rank's shard: linearise (k_gram),
+Schur-reduce (k_schur_frames, k_syrk, k_reduce_system), [all-reduce], host Cholesky of the 72x72
+reduced system, back-substitution + trial cost (k_backsub, k_cost, k_sum_trial), [all-reduce],
+accept/reject.  Every step re-linearises, also after a rejected one (never less work than a real
+iteration).  `value` = steps x n_gpus / time, i.e. LM iterations/sec in units of one 6x10kx54
+problem: at N = 1 it is exactly BASELINE's "LM iterations/sec" on config 3.
+
+Extra objects on the same line: `roofline` (dominant kernel of the timed region, HIP-event timed on
+the launch stream), `jacobian_eval` (BASELINE's second figure: ms per materialised Jacobian-eval,
+with its own HBM roofline), `cpu_baseline` (the oracle's scipy path on a bounded sample of the same
+workload, rank 0 at N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (AMD datasheet; 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
+
+C, F_PER_GPU, ROWS, COLS = 6, 10000, 6, 9
+
+
+def algorithmic_bytes(kernel, C, F, N):
+    """Bytes one launch must move if every operand is read / written exactly once."""
+    n = 12 * C
+    obs = 16 * C * F * N
+    poses = 48 * F
+    rec = 800 * C * F
+    return {
+        "k_gram": obs + poses + rec + 736 * C * ((F + 63) // 64),
+        "k_cost": obs + poses,
+        "k_schur_frames": rec + 576 * C * F + 320 * F,
+        "k_syrk": 576 * C * F + 48 * F,
+        "k_backsub": 576 * C * F + 320 * F + 2 * poses,
+        "k_jacobian": obs + poses + (288 + 16) * C * F * N,
+        "k_reduce_system": 8 * (n * n + 3 * n),
+        "k_sum_trial": 64,
+    }[kernel]
+
+
+def algorithmic_flops(kernel, C, F, N):
+    """FP64 flops of the per-observation arithmetic (2 per FMA), for the VALU cross-check of k_gram."""
+    if kernel == "k_gram":
+        return 2 * (270 * C * F * N + 900 * C * F)
+    return None
+
+
+def cpu_baseline(sample_frames=120, max_nfev=8):
+    """The oracle's CPU path (numpy residual + the reference's scipy.least_squares call) on a bounded sample."""
+    from oracle import ba_oracle as orc
+    from multicam_calibration_amd import synth
+    from scipy.optimize import least_squares
+
+    p = synth.make_problem(C, sample_frames, rows=ROWS, cols=COLS, seed=0)
+    x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    t0 = time.perf_counter()
+    A = orc.sparsity_csr(p["uvs"])
+    t_pat = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res = least_squares(orc.residuals, x0, jac_sparsity=A, verbose=0, x_scale="jac", ftol=1e-4, method="trf", loss="soft_l1", max_nfev=max_nfev, args=(p["uvs"], p["obj"]))
+    dt = time.perf_counter() - t0
+    iters = max(res.njev - 1, 1)  # accepted iterations = Jacobian evaluations after the first
+    it_per_s_sample = iters / dt
+    scale = sample_frames / F_PER_GPU
+    return {
+        "value": it_per_s_sample * scale, "unit": "it/s", "cores": 1, "kind": "port",
+        "sample": f"{C}x{sample_frames}x{ROWS * COLS} frames sample, {iters} TRF iterations (nfev {res.nfev}) in {dt:.1f}s = {it_per_s_sample:.3f} it/s on the sample; "
+                  f"scaled x{scale:g} to 10k frames (cost per iteration is linear in frames: BASELINE.md section 2); pattern build {t_pat:.2f}s excluded; host cpu_count={os.cpu_count()}",
+        "ms_per_jacobian_eval_sample": None,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=F_PER_GPU, help="frames per GPU (default = BASELINE config 3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import multicam_calibration_amd as m
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        comm = m.solver.TorchDistributed()
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+
+    F = args.frames
+    N = ROWS * COLS
+    p = m.synth.make_problem(C, F, rows=ROWS, cols=COLS, seed=0, frame_seed=rank if world > 1 else None)
+    x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = m.ops.Problem(p["uvs"], p["obj"], device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    if world > 1:
+        prob.enable_collective(torch.device(f"cuda:{local_rank}"))
+
+    lm = m.solver.LevenbergMarquardt(prob, comm, ftol=0.0, xtol=0.0, gtol=0.0)
+    lm.start(x0)
+    cost0 = lm.cost
+    for _ in range(args.warmup):
+        lm.iterate(always_linearize=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    prob.profile_enable(True)
+    prob.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lm.iterate(always_linearize=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = prob.profile_read()
+    prob.profile_enable(False)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- second figure of the metric: one materialised Jacobian evaluation (not part of the timed steps)
+    prob.profile_enable(True)
+    for _ in range(3):
+        prob.jacobian_eval(lm.cur, robust_scaled=True)
+    prob.profile_read()
+    nj = 10
+    for _ in range(nj):
+        prob.jacobian_eval(lm.cur, robust_scaled=True)
+    pj = prob.profile_read()["k_jacobian"]
+    prob.profile_enable(False)
+    ms_jac = pj[0] / pj[1]
+
+    if rank == 0:
+        kern = {k: (ms, n) for k, (ms, n) in prof.items() if n}
+        dom = max(kern, key=lambda k: kern[k][0])
+        dom_ms = kern[dom][0] / kern[dom][1]
+        dom_bytes = algorithmic_bytes(dom, C, F, N)
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_file):
+            with open(pmc_file) as fh:
+                traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
+        ach = dom_bytes / (dom_ms * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "avg_launch_us": dom_ms * 1e3, "algorithmic_bytes_per_launch": dom_bytes}
+        fl = algorithmic_flops(dom, C, F, N)
+        if fl:
+            tf = fl / (dom_ms * 1e-3) / 1e12
+            roofline["valu_f64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                                    "note": "k_gram does ~50 FP64 flop per byte: the FP64 vector pipe, not HBM, is its nearer roof"}
+        jb = algorithmic_bytes("k_jacobian", C, F, N)
+        jach = jb / (ms_jac * 1e-3) / 1e9
+        out = {
+            "metric": "LM iterations/sec (6 cams x 10k frames x 54 pts per GPU shard; + ms/Jacobian-eval)",
+            "value": args.steps * world * (F / F_PER_GPU) / dt,
+            "unit": "it/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"bundle adjustment, {C} cameras x {F} frames/GPU x {N} points, intrinsics+distortion+extrinsics+poses free, soft_l1 (BASELINE configs[2])",
+                       "frames_total": F * world, "parallelism": f"frames sharded over {world} GPU(s), all-reduce of the {12 * C}x{12 * C} reduced camera system"},
+            "ms_per_jacobian_eval": ms_jac,
+            "roofline": roofline,
+            "jacobian_eval": {"kernel": "k_jacobian", "ms": ms_jac, "roofline": {"bound": "hbm", "achieved": jach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jach / HBM_PEAK_GBS,
+                              "traffic": None, "algorithmic_bytes_per_launch": jb}},
+            "kernels_us": {k: round(1e3 * ms / n, 3) for k, (ms, n) in kern.items()},
+            "kernel_calls": {k: n for k, (ms, n) in kern.items()},
+            "lm": {"cost_start": cost0, "cost_end": lm.cost, "accepted": lm.iteration, "steps_total": lm.steps, "lambda": lm.lam},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"]["reference_measured_in_survey_container"] = {"value": 0.0098, "unit": "it/s", "ms_per_jacobian_eval": 68679, "source": "BASELINE.md section 2 (the reference itself, 6x10kx54)"}
+        print(json.dumps(out))
+    prob.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -367,70 +367,70 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ ybuf, c
 }
 
 // ---------------------------------------------------------------- k_reduce_system: fixed-order second stage
-// One thread per output double of the reduce buffer (layout in include/mcba.h).
-__global__ void k_reduce_system(const double* __restrict__ gpart, const double* __restrict__ spart, const double* __restrict__ rpart, const double* __restrict__ fpart,
-                                double* __restrict__ red, int C, int nfb, int G, int npairs, int nfblocks, int rank_slot) {
+// 16 lanes per output double of the reduce buffer (layout in include/mcba.h): lane l sums partials
+// l, l+16, l+32, ... (independent loads in flight), then a 4-step xor tree -- a fixed summation order,
+// so the result is bit-reproducible run to run (no FP64 atomics anywhere).
+__device__ __forceinline__ double strided_sum16(const double* __restrict__ p, size_t stride, int count, int l) {
+  double s0 = 0.0, s1 = 0.0;
+  int k = l;
+  for (; k + 16 < count; k += 32) { s0 += p[(size_t)k * stride]; s1 += p[(size_t)(k + 16) * stride]; }
+  if (k < count) s0 += p[(size_t)k * stride];
+  double s = s0 + s1;
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  return s;
+}
+__device__ __forceinline__ double strided_max16(const double* __restrict__ p, size_t stride, int count, int l) {
+  double s = 0.0;
+  for (int k = l; k < count; k += 16) s = fmax(s, p[(size_t)k * stride]);
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) s = fmax(s, __shfl_xor(s, off, 64));
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_system(const double* __restrict__ gpart, const double* __restrict__ spart, const double* __restrict__ rpart, const double* __restrict__ fpart,
+                                                       double* __restrict__ red, int C, int nfb, int G, int npairs, int nfblocks, int rank_slot) {
   const int n = 12 * C;
   const int nsys = n * n + 3 * n + 16;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nsys) return;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int l = threadIdx.x & 15;
+  if (i >= nsys) return;  // whole 16-lane groups leave together
+  double out;
   if (i < n * n) {
     int row = i / n, col = i % n;
     int ci = row / 12, cj = col / 12, li = row % 12, lj = col % 12;
     double s = 0.0;
     if (ci == cj) {
       int a = li <= lj ? li : lj, b = li <= lj ? lj : li;
-      const double* gp = gpart + (size_t)ci * nfb * MCBA_GP + tri12(a, b);
-      for (int k = 0; k < nfb; ++k) s += gp[(size_t)k * MCBA_GP];
+      s = strided_sum16(gpart + (size_t)ci * nfb * MCBA_GP + tri12(a, b), MCBA_GP, nfb, l);
     }
     int pa = ci <= cj ? ci : cj, pb = ci <= cj ? cj : ci;
     int q = pa * C - (pa * (pa - 1)) / 2 + (pb - pa);
     int loc = ci <= cj ? li * 12 + lj : lj * 12 + li;
-    const double* sp = spart + (size_t)q * 144 + loc;
-    double y = 0.0;
-    for (int g = 0; g < G; ++g) y += sp[(size_t)g * npairs * 144];
-    red[i] = s - y;
-    return;
+    double y = strided_sum16(spart + (size_t)q * 144 + loc, (size_t)npairs * 144, G, l);
+    out = s - y;
+  } else {
+    int j = i - n * n;
+    if (j < n) {  // rhs = sum Y z - g_c
+      int c = j / 12, lc = j % 12;
+      double s = strided_sum16(gpart + (size_t)c * nfb * MCBA_GP + 78 + lc, MCBA_GP, nfb, l);
+      double y = strided_sum16(rpart + j, (size_t)n, G, l);
+      out = y - s;
+    } else if (j < 2 * n) {  // diag U
+      int jj = j - n, c = jj / 12, lc = jj % 12;
+      out = strided_sum16(gpart + (size_t)c * nfb * MCBA_GP + tri12(lc, lc), MCBA_GP, nfb, l);
+    } else if (j < 3 * n) {  // g_c
+      int jj = j - 2 * n, c = jj / 12, lc = jj % 12;
+      out = strided_sum16(gpart + (size_t)c * nfb * MCBA_GP + 78 + lc, MCBA_GP, nfb, l);
+    } else {
+      int jj = j - 3 * n;
+      out = 0.0;
+      if (jj == 0 || jj == 1) out = strided_sum16(gpart + 90 + jj, MCBA_GP, C * nfb, l);  // cost, (camera,frame) pairs with data
+      else if (jj == 2) out = strided_sum16(fpart + 1, 2, nfblocks, l);
+      else if (jj == 4 + rank_slot) out = strided_max16(fpart, 2, nfblocks, l);
+    }
   }
-  int j = i - n * n;
-  if (j < n) {  // rhs
-    int c = j / 12, l = j % 12;
-    const double* gp = gpart + (size_t)c * nfb * MCBA_GP + 78 + l;
-    double s = 0.0;
-    for (int k = 0; k < nfb; ++k) s += gp[(size_t)k * MCBA_GP];
-    double y = 0.0;
-    for (int g = 0; g < G; ++g) y += rpart[(size_t)g * n + j];
-    red[i] = y - s;
-    return;
-  }
-  j -= n;
-  if (j < n) {  // diag U
-    int c = j / 12, l = j % 12;
-    const double* gp = gpart + (size_t)c * nfb * MCBA_GP + tri12(l, l);
-    double s = 0.0;
-    for (int k = 0; k < nfb; ++k) s += gp[(size_t)k * MCBA_GP];
-    red[i] = s;
-    return;
-  }
-  j -= n;
-  if (j < n) {  // g_c
-    int c = j / 12, l = j % 12;
-    const double* gp = gpart + (size_t)c * nfb * MCBA_GP + 78 + l;
-    double s = 0.0;
-    for (int k = 0; k < nfb; ++k) s += gp[(size_t)k * MCBA_GP];
-    red[i] = s;
-    return;
-  }
-  j -= n;
-  double out = 0.0;
-  if (j == 0 || j == 1) {  // cost, number of (camera,frame) pairs with data (diagnostic)
-    for (int k = 0; k < C * nfb; ++k) out += gpart[(size_t)k * MCBA_GP + 90 + j];
-  } else if (j == 2) {
-    for (int k = 0; k < nfblocks; ++k) out += fpart[2 * k + 1];
-  } else if (j == 4 + rank_slot) {
-    for (int k = 0; k < nfblocks; ++k) out = fmax(out, fpart[2 * k]);
-  }
-  red[i] = out;
+  if (l == 0) red[i] = out;
 }
 
 // ---------------------------------------------------------------- k_backsub: frame steps + trial parameters
@@ -482,14 +482,21 @@ __global__ __launch_bounds__(256) void k_backsub(const double* __restrict__ ybuf
   if (threadIdx.x < 3) bpart[3 * blockIdx.x + threadIdx.x] = s_p[threadIdx.x][0] + s_p[threadIdx.x][1] + s_p[threadIdx.x][2] + s_p[threadIdx.x][3];
 }
 
-// trial scalars: [cost, pred_f, dn2_f, xn2_f, n_residuals, 0, 0, 0]
-__global__ void k_sum_trial(const double* __restrict__ cpart, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out) {
-  int t = threadIdx.x;
-  double s = 0.0;
-  if (t == 0) for (int k = 0; k < ncp; ++k) s += cpart[2 * k];
-  else if (t >= 1 && t <= 3) { if (bpart) for (int k = 0; k < nbp; ++k) s += bpart[3 * k + (t - 1)]; }
-  else if (t == 4) for (int k = 0; k < ncp; ++k) s += cpart[2 * k + 1];
-  if (t < 8) out[t] = s;
+// trial scalars: [cost, pred_f, dn2_f, xn2_f, n_residuals, 0, 0, 0].  One block of 512 threads:
+// wavefront w produces scalar w; its 64 lanes stride over the partials, then a fixed xor tree.
+__global__ __launch_bounds__(512) void k_sum_trial(const double* __restrict__ cpart, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const double* p = nullptr;
+  int stride = 1, count = 0;
+  if (w == 0) { p = cpart; stride = 2; count = ncp; }
+  else if (w >= 1 && w <= 3 && bpart) { p = bpart + (w - 1); stride = 3; count = nbp; }
+  else if (w == 4) { p = cpart + 1; stride = 2; count = ncp; }
+  double s0 = 0.0, s1 = 0.0;
+  int k = l;
+  for (; k + 64 < count; k += 128) { s0 += p[(size_t)k * stride]; s1 += p[(size_t)(k + 64) * stride]; }
+  if (k < count) s0 += p[(size_t)k * stride];
+  double s = wave_sum(s0 + s1);
+  if (l == 0) out[w] = s;
 }
 
 // ---------------------------------------------------------------- k_jacobian: materialised residual Jacobian blocks
@@ -602,7 +609,7 @@ void launch_syrk(hipStream_t st, const double* ybuf, const double* fbuf, const i
 
 void launch_reduce_system(hipStream_t st, const double* gpart, const double* spart, const double* rpart, const double* fpart, double* red, int C, int nfb, int G, int npairs, int nfblocks, int rank_slot) {
   int n = 12 * C, nsys = n * n + 3 * n + 16;
-  k_reduce_system<<<dim3((nsys + 127) / 128), dim3(128), 0, st>>>(gpart, spart, rpart, fpart, red, C, nfb, G, npairs, nfblocks, rank_slot);
+  k_reduce_system<<<dim3((nsys * 16 + 255) / 256), dim3(256), 0, st>>>(gpart, spart, rpart, fpart, red, C, nfb, G, npairs, nfblocks, rank_slot);
 }
 
 void launch_backsub(hipStream_t st, const double* ybuf, const double* fbuf, const double* dc, const double* xs, double* xd, double* bpart, int C, int F, double lambda) {
@@ -610,7 +617,7 @@ void launch_backsub(hipStream_t st, const double* ybuf, const double* fbuf, cons
 }
 
 void launch_sum_trial(hipStream_t st, const double* cpart, int ncp, const double* bpart, int nbp, double* out) {
-  k_sum_trial<<<dim3(1), dim3(64), 0, st>>>(cpart, ncp, bpart, nbp, out);
+  k_sum_trial<<<dim3(1), dim3(512), 0, st>>>(cpart, ncp, bpart, nbp, out);
 }
 
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust) {

@@ -287,6 +287,8 @@ MCBA_HD void gram_zero(Gram& g) {
 
 // wu2, wv2: Gauss-Newton weights (0 for a missing scalar); gu, gv = rho' * residual (0 if missing)
 MCBA_HD void gram_add(Gram& g, const ObsRows& o, double wu2, double wv2, double gu, double gv) {
+  // every accumulation is written as a chain of single-product "+=" so each becomes ONE v_fma_f64
+  // (a += x*y + z*w would cost mul + fma + add without -ffast-math reassociation)
   double Euw[6], Evw[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) { Euw[j] = wu2 * o.Eu[j]; Evw[j] = wv2 * o.Ev[j]; }
@@ -294,16 +296,23 @@ MCBA_HD void gram_add(Gram& g, const ObsRows& o, double wu2, double wv2, double 
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int j = i; j < 6; ++j) { g.ee[k] += Euw[i] * o.Eu[j] + Evw[i] * o.Ev[j]; ++k; }
+    for (int j = i; j < 6; ++j) {
+      g.ee[k] += Euw[i] * o.Eu[j];
+      g.ee[k] += Evw[i] * o.Ev[j];
+      ++k;
+    }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     g.ie[j] += o.l0 * Euw[j];
     g.ie[6 + j] += o.l1 * Evw[j];
     g.ie[12 + j] += Euw[j];
     g.ie[18 + j] += Evw[j];
-    g.ie[24 + j] += o.l4u * Euw[j] + o.l4v * Evw[j];
-    g.ie[30 + j] += o.l5u * Euw[j] + o.l5v * Evw[j];
-    g.he[j] -= o.Eu[j] * gu + o.Ev[j] * gv;
+    g.ie[24 + j] += o.l4u * Euw[j];
+    g.ie[24 + j] += o.l4v * Evw[j];
+    g.ie[30 + j] += o.l5u * Euw[j];
+    g.ie[30 + j] += o.l5v * Evw[j];
+    g.he[j] -= o.Eu[j] * gu;
+    g.he[j] -= o.Ev[j] * gv;
   }
   double w0 = wu2 * o.l0, w1 = wv2 * o.l1, w4u = wu2 * o.l4u, w4v = wv2 * o.l4v, w5u = wu2 * o.l5u, w5v = wv2 * o.l5v;
   g.ii[0] += w0 * o.l0;
@@ -320,15 +329,20 @@ MCBA_HD void gram_add(Gram& g, const ObsRows& o, double wu2, double wv2, double 
   g.ii[11] += wv2;
   g.ii[12] += w4v;
   g.ii[13] += w5v;
-  g.ii[14] += w4u * o.l4u + w4v * o.l4v;
-  g.ii[15] += w4u * o.l5u + w4v * o.l5v;
-  g.ii[16] += w5u * o.l5u + w5v * o.l5v;
+  g.ii[14] += w4u * o.l4u;
+  g.ii[14] += w4v * o.l4v;
+  g.ii[15] += w4u * o.l5u;
+  g.ii[15] += w4v * o.l5v;
+  g.ii[16] += w5u * o.l5u;
+  g.ii[16] += w5v * o.l5v;
   g.hi[0] -= o.l0 * gu;
   g.hi[1] -= o.l1 * gv;
   g.hi[2] -= gu;
   g.hi[3] -= gv;
-  g.hi[4] -= o.l4u * gu + o.l4v * gv;
-  g.hi[5] -= o.l5u * gu + o.l5v * gv;
+  g.hi[4] -= o.l4u * gu;
+  g.hi[4] -= o.l4v * gv;
+  g.hi[5] -= o.l5u * gu;
+  g.hi[5] -= o.l5v * gv;
 }
 
 // ---------------------------------------------------------------- expansion of the local Gram matrix (once per (c,f))

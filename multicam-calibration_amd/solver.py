@@ -51,7 +51,8 @@ class SingleProcess:
 class TorchDistributed:
     """Frame shards on several GPUs: ONE all-reduce (SUM, f64) of the reduced camera system per
     linear solve and one of the 8 trial scalars per trial step, via torch.distributed
-    (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests)."""
+    (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).  `problem.reduce_tensor` is the
+    torch tensor that aliases the library's reduce buffer (ops.Problem.enable_collective)."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -62,16 +63,14 @@ class TorchDistributed:
         self.world = dist.get_world_size(group)
 
     def all_reduce_system(self, problem):
-        t = problem.reduce_tensor
-        self.dist.all_reduce(t[: problem.nsys], group=self.group)
+        self.dist.all_reduce(problem.reduce_tensor[: problem.nsys], group=self.group)
 
     def all_reduce_trial(self, problem):
-        t = problem.reduce_tensor
-        self.dist.all_reduce(t[problem.nsys : problem.nsys + 8], group=self.group)
+        self.dist.all_reduce(problem.reduce_tensor[problem.nsys : problem.nsys + 8], group=self.group)
 
 
-def _solve_reduced(S, rhs):
-    """(S symmetric positive definite) -> step, or None if the factorisation fails."""
+def _solve_spd(S, rhs):
+    """S symmetric positive definite -> step, or None if the Cholesky factorisation fails."""
     try:
         c, low = sla.cho_factor(S, lower=True, check_finite=False)
     except (sla.LinAlgError, ValueError):
@@ -80,149 +79,141 @@ def _solve_reduced(S, rhs):
     return d if np.all(np.isfinite(d)) else None
 
 
-def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None,
-             lam0=1e-4, lam_min=1e-12, lam_max=1e12, max_iterations=None, callback=None):
-    """Minimise the robust reprojection cost starting from x0 (this shard's flat vector, a7 layout).
+class LevenbergMarquardt:
+    """State machine: `start(x0)` then `iterate()` until it returns a status.
 
-    Returns an OptimizeResult with x, cost, grad-related scalars, nfev, njev, status, message, success and
-    `lm` diagnostics.  `fun` / `jac` / `grad` are attached by the caller (api.bundle_adjust) on request.
-    `max_iterations` stops after that many ACCEPTED-or-REJECTED LM iterations regardless of tolerances
-    (used by bench.py to time a fixed number of steps)."""
-    comm = comm or SingleProcess()
-    n = problem.n
-    x0 = np.ascontiguousarray(x0, dtype=np.float64)
-    n_total = problem.nx if comm.world == 1 else None
-    if max_nfev is None:
-        max_nfev = 100 * (x0.size if n_total is None else n_total)
-    free = np.ones(n, dtype=bool) if free_cam_mask is None else np.asarray(free_cam_mask, dtype=bool)
-    all_free = bool(free.all())
+    One `iterate()` = one LM iteration: (re)build the reduced system for the current damping, solve it on the
+    host, back-substitute, evaluate the trial cost, accept or reject, and re-linearise at the accepted point."""
 
-    cur = 0
-    problem.set_params(cur, x0)
-    x_cam = x0[:n].copy()
-    problem.linearize(cur)
-    nfev, njev = 1, 1
-    lam, nu = float(lam0), 2.0
-    iteration, n_steps = 0, 0
-    status = None
-    cost = None
-    step_norm = None
-    actual_reduction = None
-    g_inf = np.inf
-    need_system = True
-    history = []
+    def __init__(self, problem, comm=None, free_cam_mask=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, lam0=1e-4, lam_min=1e-12, lam_max=1e12):
+        self.p = problem
+        self.comm = comm or SingleProcess()
+        n = problem.n
+        self.free = np.ones(n, dtype=bool) if free_cam_mask is None else np.asarray(free_cam_mask, dtype=bool)
+        self.all_free = bool(self.free.all())
+        self.ftol, self.xtol, self.gtol = ftol, xtol, gtol
+        self.lam0, self.lam_min, self.lam_max = float(lam0), lam_min, lam_max
 
-    while True:
-        if need_system:
-            problem.build_reduced(lam, comm.rank % 12)
-            comm.all_reduce_system(problem)
-            red = problem.get_reduced()
-            scal = red["scal"]
-            cost = float(scal[0])
-            if not np.isfinite(cost):
-                if nfev == 1:
-                    raise ValueError("Residuals are not finite in the initial point.")
-                raise FloatingPointError("non-finite cost at an accepted point")
-            gc = red["gc"]
-            g_inf = max(float(np.abs(gc[free]).max()) if free.any() else 0.0, float(scal[4:16].max()))
-            if verbose == 2:
-                if iteration == 0 and n_steps == 0:
-                    _print_header()
-                if actual_reduction is None or accepted_last:
-                    _print_iteration(iteration, nfev, cost, actual_reduction, step_norm, g_inf)
-            if g_inf < gtol:
-                status = 1
-                break
-        accepted_last = False
-        if max_iterations is not None and n_steps >= max_iterations:
-            status = 0
-            break
-        if nfev >= max_nfev:
-            status = 0
-            break
+    # ------------------------------------------------------------------ set-up
+    def start(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        self.cur = 0
+        self.p.set_params(0, x0)
+        self.x_cam = x0[: self.p.n].copy()
+        self.p.linearize(0)
+        self.nfev, self.njev = 1, 1
+        self.lam, self.nu = self.lam0, 2.0
+        self.iteration, self.steps = 0, 0
+        self.cost = None
+        self.step_norm = None
+        self.actual_reduction = None
+        self.g_inf = np.inf
+        self.red = None
+        self.history = []
+        self._refresh_system()
+        if not np.isfinite(self.cost):
+            raise ValueError("Residuals are not finite in the initial point.")
 
+    def _refresh_system(self):
+        p = self.p
+        p.build_reduced(self.lam, self.comm.rank % 12)
+        self.comm.all_reduce_system(p)
+        red = p.get_reduced()
+        self.red = red
+        self.cost = float(red["scal"][0])
+        gc = red["gc"]
+        self.g_inf = max(float(np.abs(gc[self.free]).max()) if self.free.any() else 0.0, float(red["scal"][4:16].max()))
+
+    # ------------------------------------------------------------------ one iteration
+    def iterate(self, always_linearize=False):
+        """Returns None to continue or a scipy-style status (1 gtol, 2 ftol, 3 xtol, 4 both).
+        always_linearize: re-linearise even after a rejected step (bench: identical work every step)."""
+        p, red = self.p, self.red
+        self.steps += 1
+        if self.g_inf < self.gtol:
+            return 1
+        lam = self.lam
         Dc = np.where(red["diagU"] > 0, red["diagU"], 1.0)
         S = red["S0"] + np.diag(lam * Dc)
         rhs = red["rhs"]
-        if all_free:
-            dc = _solve_reduced(S, rhs)
-        else:
-            dfree = _solve_reduced(S[np.ix_(free, free)], rhs[free])
-            dc = None
-            if dfree is not None:
-                dc = np.zeros(n)
-                dc[free] = dfree
-        n_steps += 1
-        if dc is None or scal[2] > 0:  # reduced system or a frame block not positive definite: more damping
-            lam = min(lam * nu, lam_max)
-            nu *= 2
-            need_system = True
-            if lam >= lam_max:
+        dc = None
+        if red["scal"][2] == 0:  # every frame block factorised
+            if self.all_free:
+                dc = _solve_spd(S, rhs)
+            else:
+                dfree = _solve_spd(S[np.ix_(self.free, self.free)], rhs[self.free])
+                if dfree is not None:
+                    dc = np.zeros(p.n)
+                    dc[self.free] = dfree
+        status = None
+        accepted = False
+        if dc is not None:
+            p.step(dc, lam, self.cur, 1 - self.cur)
+            self.comm.all_reduce_trial(p)
+            t = p.get_trial()
+            self.nfev += 1
+            cost_new = float(t[0])
+            pred = 0.5 * (float(t[1]) + float(dc @ (lam * Dc * dc - red["gc"])))
+            step_norm = float(np.sqrt(t[2] + dc @ dc))
+            x_norm = float(np.sqrt(t[3] + self.x_cam @ self.x_cam))
+            ratio = (self.cost - cost_new) / pred if (np.isfinite(cost_new) and pred > 0) else -1.0
+            dF = self.cost - cost_new
+            self.history.append((self.nfev, self.cost, cost_new, pred, ratio, lam, step_norm))
+            ftol_ok = dF < self.ftol * self.cost and ratio > 0.25
+            xtol_ok = step_norm < self.xtol * (self.xtol + x_norm)
+            status = 4 if (ftol_ok and xtol_ok) else 2 if ftol_ok else 3 if xtol_ok else None
+            accepted = ratio > 0 and dF >= 0
+            if accepted:
+                self.cur = 1 - self.cur
+                self.x_cam = self.x_cam + dc
+                self.lam = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3), self.lam_min)
+                self.nu = 2.0
+                self.actual_reduction, self.step_norm = dF, step_norm
+                self.iteration += 1
+            elif status == 2:
+                status = None  # ftol needs an accepted step (ratio > 0.25)
+        if not accepted:
+            self.lam = min(lam * self.nu, self.lam_max)
+            self.nu *= 2
+            if self.lam >= self.lam_max and status is None:
                 status = 3
-                break
-            continue
+        if accepted or always_linearize:
+            p.linearize(self.cur)
+            self.njev += 1
+        self._refresh_system()
+        self.accepted = accepted
+        return status
 
-        problem.step(dc, lam, cur, 1 - cur)
-        comm.all_reduce_trial(problem)
-        t = problem.get_trial()
-        nfev += 1
-        cost_new = float(t[0])
-        pred = 0.5 * (float(t[1]) + float(dc @ (lam * Dc * dc - gc)))
-        step_norm = float(np.sqrt(t[2] + dc @ dc))
-        x_norm = float(np.sqrt(t[3] + x_cam @ x_cam))
-        if np.isfinite(cost_new) and pred > 0:
-            ratio = (cost - cost_new) / pred
-        else:
-            ratio = -1.0
-        history.append((nfev, cost, cost_new, pred, ratio, lam, step_norm))
+    def result(self, status):
+        x = self.p.get_params(self.cur)
+        return OptimizeResult(
+            x=x, cost=self.cost, optimality=self.g_inf, nfev=self.nfev, njev=self.njev, status=status, message=TERMINATION_MESSAGES[status],
+            success=status > 0, active_mask=np.zeros_like(x),
+            lm=dict(iterations=self.iteration, steps=self.steps, lam=self.lam, slot=self.cur, history=self.history),
+        )
 
-        dF = cost - cost_new
-        ftol_ok = dF < ftol * cost and ratio > 0.25
-        xtol_ok = step_norm < xtol * (xtol + x_norm)
-        term = 4 if (ftol_ok and xtol_ok) else 2 if ftol_ok else 3 if xtol_ok else None
 
-        if ratio > 0 and dF >= 0:
-            cur = 1 - cur
-            x_cam = x_cam + dc
-            lam = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3), lam_min)
-            nu = 2.0
-            actual_reduction = dF
-            iteration += 1
-            accepted_last = True
-            problem.linearize(cur)
-            njev += 1
-            need_system = True
-            if callback is not None:
-                callback(iteration, cost_new)
-            if term is not None:
-                status = term
-                # one more system build so cost/optimality describe the returned point
-                problem.build_reduced(lam, comm.rank % 12)
-                comm.all_reduce_system(problem)
-                red = problem.get_reduced()
-                cost = float(red["scal"][0])
-                g_inf = max(float(np.abs(red["gc"][free]).max()) if free.any() else 0.0, float(red["scal"][4:16].max()))
-                if verbose == 2:
-                    _print_iteration(iteration, nfev, cost, actual_reduction, step_norm, g_inf)
-                break
-        else:
-            lam = min(lam * nu, lam_max)
-            nu *= 2
-            need_system = True
-            if term == 3 or term == 4:
-                status = 3
-                break
-            if lam >= lam_max:
-                status = 3
-                break
-
-    x = problem.get_params(cur)
-    res = OptimizeResult(
-        x=x, cost=cost, optimality=g_inf, nfev=nfev, njev=njev, status=status, message=TERMINATION_MESSAGES[status],
-        success=status > 0, active_mask=np.zeros_like(x), lm=dict(iterations=iteration, steps=n_steps, lam=lam, slot=cur, history=history),
-    )
+def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=1e-4, max_iterations=None):
+    """Minimise the robust reprojection cost from x0 (this shard's flat vector, a7 layout of SURVEY.md).
+    `fun` / `jac` / `grad` of the OptimizeResult are attached by api.bundle_adjust."""
+    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0)
+    if max_nfev is None:
+        max_nfev = 100 * np.size(x0)  # trf.py:437-438
+    lm.start(x0)
+    cost0 = lm.cost
+    if verbose == 2:
+        _print_header()
+        _print_iteration(0, lm.nfev, lm.cost, None, None, lm.g_inf)
+    status = None
+    while status is None:
+        if lm.nfev >= max_nfev or (max_iterations is not None and lm.steps >= max_iterations):
+            status = 0
+            break
+        status = lm.iterate()
+        if verbose == 2 and getattr(lm, "accepted", False):
+            _print_iteration(lm.iteration, lm.nfev, lm.cost, lm.actual_reduction, lm.step_norm, lm.g_inf)
+    res = lm.result(status)
     if verbose >= 1:
         print(TERMINATION_MESSAGES[status])
-        print("Function evaluations {}, initial cost {:.4e}, final cost {:.4e}, first-order optimality {:.2e}.".format(
-            nfev, history[0][1] if history else cost, cost, g_inf))
+        print("Function evaluations {}, initial cost {:.4e}, final cost {:.4e}, first-order optimality {:.2e}.".format(res.nfev, cost0, res.cost, res.optimality))
     return res

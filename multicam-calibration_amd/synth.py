@@ -65,14 +65,16 @@ def project(cam12, poses, obj):
     return np.stack(out)
 
 
-def make_problem(n_cameras, n_frames, rows=6, cols=9, pitch=12.5, seed=0, perturb_seed=1, noise=0.2, missing=0.0, outlier_frames=0, scalar_nans=0):
+def make_problem(n_cameras, n_frames, rows=6, cols=9, pitch=12.5, seed=0, perturb_seed=1, noise=0.2, missing=0.0, outlier_frames=0, scalar_nans=0, frame_seed=None):
     """Returns a dict:
       uvs (C,F,N,2) f64 with NaN = missing, obj (N,3),
       true_cam (C,12), true_poses (F,6),
       extrinsics (C,6), intrinsics [(K 3x3, dist 5)]*C, poses (F,6)  -- the perturbed initial guess
     `missing`  : Bernoulli probability that a whole (camera, frame) detection is NaN.
     `outlier_frames` : that many frames get a grossly wrong initial pose (exercise the pre-filter).
-    `scalar_nans` : that many single (u or v) scalars are set to NaN (per-coordinate masking)."""
+    `scalar_nans` : that many single (u or v) scalars are set to NaN (per-coordinate masking).
+    `frame_seed` : if given, board poses / noise / pose perturbations come from this seed while the cameras
+                   still come from `seed` and `perturb_seed` -- frame shards of ONE rig for multi-GPU runs."""
     rng = np.random.default_rng(seed)
     obj = board_points(rows, cols, pitch)
     N = obj.shape[0]
@@ -99,6 +101,8 @@ def make_problem(n_cameras, n_frames, rows=6, cols=9, pitch=12.5, seed=0, pertur
     cam[:, 5] = 0.02 + rng.uniform(-0.005, 0.005, C)
 
     # board poses: rotate about the board centre, then scatter around the origin
+    if frame_seed is not None:
+        rng = np.random.default_rng([int(frame_seed), 0x6672616D])
     rv = rng.normal(0, 0.6, (F, 3))
     tr = rng.normal(0, 60.0, (F, 3))
     poses = np.concatenate([rv, tr - np.einsum("fij,j->fi", _rot(rv), centre)], -1)
@@ -126,6 +130,8 @@ def make_problem(n_cameras, n_frames, rows=6, cols=9, pitch=12.5, seed=0, pertur
     cam0[:, 4:6] *= 1 + 0.1 * prng.normal(size=(C, 2))
     cam0[1:, 6:9] += 1e-3 * prng.normal(size=(C - 1, 3))
     cam0[1:, 9:12] += 0.5 * prng.normal(size=(C - 1, 3))
+    if frame_seed is not None:
+        prng = np.random.default_rng([int(frame_seed), int(perturb_seed), 0x70657274])
     poses0 = poses.copy()
     poses0[:, :3] += 1e-3 * prng.normal(size=(F, 3))
     poses0[:, 3:] += 0.5 * prng.normal(size=(F, 3))

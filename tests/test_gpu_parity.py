@@ -92,7 +92,13 @@ def test_jacobian_robust_scaling(mc, loss, fs):
     f = p["uvs"] - orc.predict_from_x(x, 2, p["obj"])
     js, _ = orc.robust_scales(f, loss, fs)
     want = -np.concatenate([Jc, Jf], -1) * js[..., None]
-    assert np.abs(jac - want).max() <= 1e-11 * np.abs(want).max()
+    # huber beyond z = 1: rho' + 2 rho'' f^2 is analytically ZERO, scipy clamps it to EPS (common.py:724-726);
+    # either side's rounding leaves sqrt(a few EPS) x |J| there, so those rows agree only to that level.
+    tol = 1e-11 if loss != "huber" else 8 * np.sqrt(orc.EPS)
+    assert np.abs(jac - want).max() <= tol * np.abs(want).max()
+    if loss == "huber":
+        quad = (np.abs(f) <= fs)[..., None] & np.ones(18, bool)  # the quadratic zone is exact
+        assert np.abs(jac - want)[quad].max() <= 1e-11 * np.abs(want).max()
     np.testing.assert_allclose(res, f, rtol=0, atol=1e-10)
     prob.close()
 
