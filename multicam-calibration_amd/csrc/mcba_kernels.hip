@@ -44,7 +44,7 @@ __device__ __forceinline__ void obs_weights(double r, bool valid, double fs2, do
   double rh, gw, ww;
   loss_weights<LOSS>(r, fs2, ifs2, rh, gw, ww);
   cost += valid ? rh : 0.0;
-  w2 = valid ? ww : 0.0;
+  w2 = valid ? lm_weight(gw, ww) : 0.0;
   g = valid ? gw * r : 0.0;
 }
 

@@ -29,6 +29,13 @@ namespace mcba {
 enum Loss { LOSS_LINEAR = 0, LOSS_SOFT_L1 = 1, LOSS_HUBER = 2, LOSS_CAUCHY = 3, LOSS_ARCTAN = 4 };
 
 constexpr double MCBA_EPS = 2.220446049250313e-16;
+// Curvature floor of the LM's internal Gauss-Newton weight, as a fraction of the IRLS weight rho'.
+// scipy clamps the Triggs weight rho' + 2 rho'' f^2 at EPS (common.py:724-726); for the concave zone of
+// huber/cauchy/arctan (and far outliers of soft_l1) that leaves J^T J ~ 0 and Marquardt scaling cannot
+// regularise.  rho' J^T J is the majorising (always descending) quadratic, so a fraction of it is a safe floor.
+// The floor only steers the iteration: the stationary point (J^T rho' f = 0) does not depend on it, and the
+// materialised Jacobian (k_jacobian -> result.jac) keeps scipy's exact scaling.
+constexpr double MCBA_CURV_FLOOR = 0.1;
 
 // ---------------------------------------------------------------- rotations
 // a = sin t/t, b = (1-cos t)/t^2, c = (t-sin t)/t^3 with series below t^2 = 1e-4.
@@ -167,7 +174,12 @@ MCBA_HD void make_chain_const(const double* Rc, const double* Jrc, const double*
 // in : r (residual), inv_fs2 = 1/f_scale^2, fs2 = f_scale^2
 // out: rho_half = 0.5 f_scale^2 rho(z)  (this observation's share of the cost)
 //      gw = rho'(z)                      (gradient weight:  g = J^T (rho' f))
-//      w2 = max(rho' + 2 rho'' f^2, EPS) (Gauss-Newton weight: J~^T J~ = sum w2 j^T j)
+//      w2 = max(rho' + 2 rho'' f^2, EPS) (scipy's J_scale^2: J~^T J~ = sum w2 j^T j)
+// lm_weight() turns (gw, w2) into the curvature weight the LM normal equations use.
+MCBA_HD double lm_weight(double gw, double w2) {
+  double fl = MCBA_CURV_FLOOR * gw;
+  return w2 > fl ? w2 : fl;
+}
 template <int LOSS>
 MCBA_HD void loss_weights(double r, double fs2, double inv_fs2, double& rho_half, double& gw, double& w2) {
   double r2 = r * r;

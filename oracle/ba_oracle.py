@@ -301,25 +301,29 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
 
 
 # --------------------------------------------------------------------------- dense normal equations / Schur (checker for the GPU assembly)
-def normal_equations(x, all_calib_uvs, calib_objpoints, loss="soft_l1", f_scale=1.0):
+CURV_FLOOR = 0.1  # csrc/mcba_math.h MCBA_CURV_FLOOR: the LM's curvature weight is max(Triggs, 0.1 rho')
+
+
+def normal_equations(x, all_calib_uvs, calib_objpoints, loss="soft_l1", f_scale=1.0, curv_floor=CURV_FLOOR):
     """Dense pieces of the robust Gauss-Newton system at x, for SMALL problems:
     U (C,12,12), gc (C,12), V (F,6,6), gf (F,6), W (C,F,12,6), cost.
-    J and f are rescaled exactly as scipy does before forming J^T J and J^T f."""
+    The gradient is J^T (rho' f) exactly as scipy forms it (J and f rescaled, common.py:720-731); the
+    curvature weight is scipy's rho' + 2 rho'' f^2 floored at curv_floor * rho' (0 reproduces scipy's J~^T J~)."""
     C, F, N, _ = all_calib_uvs.shape
     Jc, Jf = jacobian_blocks(x, C, calib_objpoints)
     pred = predict_from_x(x, C, calib_objpoints)
     valid = ~np.isnan(all_calib_uvs)
     f = np.where(valid, all_calib_uvs - pred, 0.0)
     js, fs = robust_scales(f, loss, f_scale)
-    js = np.where(valid, js, 0.0)
-    fs = np.where(valid, fs, 0.0)
-    Jc = -Jc * js[..., None]
-    Jf = -Jf * js[..., None]
-    U = np.einsum("cfnri,cfnrj->cij", Jc, Jc)
-    gc = np.einsum("cfnri,cfnr->ci", Jc, fs)
-    V = np.einsum("cfnri,cfnrj->fij", Jf, Jf)
-    gf = np.einsum("cfnri,cfnr->fi", Jf, fs)
-    W = np.einsum("cfnri,cfnrj->cfij", Jc, Jf)
+    rho1 = loss_rho((f / f_scale) ** 2, loss)[1]
+    gw = np.where(valid, rho1 * f, 0.0)                       # = js * fs
+    w = np.where(valid, np.maximum(js * js, curv_floor * rho1), 0.0)
+    Jc, Jf = -Jc, -Jf
+    U = np.einsum("cfnri,cfnr,cfnrj->cij", Jc, w, Jc)
+    gc = np.einsum("cfnri,cfnr->ci", Jc, gw)
+    V = np.einsum("cfnri,cfnr,cfnrj->fij", Jf, w, Jf)
+    gf = np.einsum("cfnri,cfnr->fi", Jf, gw)
+    W = np.einsum("cfnri,cfnr,cfnrj->cfij", Jc, w, Jf)
     cost = robust_cost(f[valid], loss, f_scale)
     return U, gc, V, gf, W, cost
 

@@ -1,0 +1,82 @@
+"""Test double for `ops.Problem` built on the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+It implements the same interface the host-side LM driver (solver.py) talks to, so the driver's logic
+(damping schedule, termination, fixed intrinsics, frame sharding + all-reduce layout) can be exercised
+without a GPU.  The product never constructs it; `ops.Problem` (libmcba.so) is the only product backend."""
+import numpy as np
+
+from oracle import ba_oracle as orc
+
+
+class OracleProblem:
+    def __init__(self, uvs, objpoints, loss="soft_l1", f_scale=1.0):
+        self.uvs, self.obj = np.asarray(uvs, float), np.asarray(objpoints, float)
+        self.C, self.F, self.N = self.uvs.shape[:3]
+        self.n = 12 * self.C
+        self.nx = self.n + 6 * self.F
+        self.nsys = self.n * self.n + 3 * self.n + 16
+        self.loss, self.f_scale = loss, f_scale
+        self.x = [np.zeros(self.nx), np.zeros(self.nx)]
+        self.reduce_tensor = None
+        self._red = np.zeros(self.nsys + 8)
+        self.calls = dict(linearize=0, build_reduced=0, step=0)
+
+    def enable_collective(self, device="cpu"):
+        import torch
+
+        self.reduce_tensor = torch.zeros(self.nsys + 8, dtype=torch.float64)
+        self._red = self.reduce_tensor.numpy()
+
+    def set_params(self, slot, x):
+        self.x[slot] = np.array(x, dtype=float)
+
+    def get_params(self, slot):
+        return self.x[slot].copy()
+
+    def linearize(self, slot):
+        self.calls["linearize"] += 1
+        self.lin = orc.normal_equations(self.x[slot], self.uvs, self.obj, self.loss, self.f_scale)
+        self.lin_x = self.x[slot].copy()
+
+    def build_reduced(self, lam, rank_slot=0):
+        self.calls["build_reduced"] += 1
+        U, gc, V, gf, W, cost = self.lin
+        n = self.n
+        Df2 = np.stack([np.where(np.diag(V[f]) > 0, np.diag(V[f]), 1.0) for f in range(self.F)])
+        S, rhs = orc.schur_reduce(U, gc, V, gf, W, lam, np.zeros((self.C, 12)), Df2)
+        r = self._red
+        r[:] = 0
+        r[: n * n] = S.ravel()
+        r[n * n : n * n + n] = rhs
+        r[n * n + n : n * n + 2 * n] = np.concatenate([np.diag(U[c]) for c in range(self.C)])
+        r[n * n + 2 * n : n * n + 3 * n] = gc.ravel()
+        sc = r[n * n + 3 * n : n * n + 3 * n + 16]
+        sc[0] = cost
+        sc[4 + rank_slot] = np.abs(gf).max()
+        self.Df2, self.lam = Df2, lam
+
+    def get_reduced(self):
+        n, r = self.n, self._red
+        return dict(S0=r[: n * n].reshape(n, n).copy(), rhs=r[n * n : n * n + n].copy(), diagU=r[n * n + n : n * n + 2 * n].copy(),
+                    gc=r[n * n + 2 * n : n * n + 3 * n].copy(), scal=r[n * n + 3 * n : n * n + 3 * n + 16].copy())
+
+    def step(self, dc, lam, src, dst):
+        self.calls["step"] += 1
+        U, gc, V, gf, W, cost = self.lin
+        df = orc.back_substitute(np.asarray(dc), V, gf, W, lam, self.Df2)
+        xs = self.x[src]
+        self.x[dst] = xs + np.concatenate([dc, df.ravel()])
+        f = orc.residuals(self.x[dst], self.uvs, self.obj)
+        t = self._red[self.nsys :]
+        t[:] = 0
+        t[0] = orc.robust_cost(f, self.loss, self.f_scale)
+        t[1] = np.sum(df * (lam * self.Df2 * df - gf))
+        t[2] = np.sum(df * df)
+        t[3] = np.sum(xs[self.n :] ** 2)
+        t[4] = f.size
+
+    def get_trial(self):
+        return self._red[self.nsys :].copy()
+
+    def frame_gradient(self):
+        return self.lin[3].copy()

@@ -13,7 +13,7 @@ static void weights(double r, bool valid, double fs2, double ifs2, double& cost,
   if (!valid) { w2 = 0; gw = 0; return; }
   double rh, g1, ww;
   loss_weights<LOSS>(r, fs2, ifs2, rh, g1, ww);
-  cost += rh; w2 = ww; gw = g1 * r;
+  cost += rh; w2 = lm_weight(g1, ww); gw = g1 * r;
 }
 
 static void weights_dyn(int loss, double r, bool valid, double fs2, double ifs2, double& cost, double& w2, double& gw) {

@@ -156,9 +156,10 @@ def test_reduced_system_and_step_vs_oracle(mc, kw, loss):
     Jd = orc.jacobian_csr(x, p["uvs"], p["obj"]).toarray()
     fr = orc.residuals(x, p["uvs"], p["obj"])
     js, fs_ = orc.robust_scales(fr, loss)
-    Jd *= js[:, None]
-    H = Jd.T @ Jd
-    full = np.linalg.solve(H + lam * np.diag(np.diag(H)), -Jd.T @ fs_)
+    rho1 = orc.loss_rho(fr ** 2, loss)[1]
+    wl = np.maximum(js * js, orc.CURV_FLOOR * rho1)           # the LM's curvature weight (csrc/mcba_math.h)
+    H = Jd.T @ (Jd * wl[:, None])
+    full = np.linalg.solve(H + lam * np.diag(np.diag(H)), -Jd.T @ (rho1 * fr))
     assert np.abs(full - np.concatenate([dc, df.ravel()])).max() <= 1e-6 * np.abs(full).max()
     prob.close()
 
@@ -181,7 +182,7 @@ def _compare_to_tight(mc, z, x, C, tol):
     assert (np.abs(Ta - Tg)[..., :3, 3] / np.abs(Tg[..., :3, 3]).max()).max() < tol
 
 
-@pytest.mark.parametrize("tag,kwargs", [("config1", {}), ("missing3", {})])
+@pytest.mark.parametrize("tag,kwargs", [("config1", {}), ("missing3", {}), ("config1_cauchy", dict(loss="cauchy", f_scale=0.5))])
 def test_solution_matches_tight_reference_optimum(mc, golden, tag, kwargs):
     """north_star: parameters match the reference's least_squares path within 1e-6 relative.
     Golden = the REFERENCE's bundle_adjust driven to a tight optimum (tests/golden/make_golden.py --slow);
@@ -195,7 +196,7 @@ def test_solution_matches_tight_reference_optimum(mc, golden, tag, kwargs):
     golden_acc = (np.abs(c0 - c1) / np.abs(c0)).max()
     assert golden_acc < 5e-7
     with contextlib.redirect_stdout(io.StringIO()):
-        e, i, p_, use, res = mc.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=None, ftol=1e-15, xtol=1e-15, gtol=1e-9, verbose=0, max_nfev=200)
+        e, i, p_, use, res = mc.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=None, ftol=1e-15, xtol=1e-15, gtol=1e-9, verbose=0, max_nfev=200, **kwargs)
     np.testing.assert_array_equal(use, z["s0_use"])
     assert abs(res.cost - float(z["s0_cost"])) <= 1e-10 * res.cost
     _compare_to_tight(mc, z, res.x, C, 1e-6)
