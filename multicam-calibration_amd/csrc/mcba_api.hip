@@ -2,7 +2,9 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -13,8 +15,8 @@ namespace {
 
 thread_local std::string g_err;
 
-enum KernelId { K_TRANSPOSE = 0, K_GRAM, K_COST, K_SCHUR_FRAMES, K_SYRK, K_REDUCE, K_BACKSUB, K_SUM_TRIAL, K_JACOBIAN, K_COUNT };
-const char* kKernelNames = "k_transpose_obs\nk_gram\nk_cost\nk_schur_frames\nk_syrk\nk_reduce_system\nk_backsub\nk_sum_trial\nk_jacobian";
+enum KernelId { K_TRANSPOSE = 0, K_GRAM, K_COST, K_FRAME_FACTOR, K_SYRK, K_REDUCE, K_BACKSUB, K_SUM_TRIAL, K_JACOBIAN, K_COUNT };
+const char* kKernelNames = "k_transpose_obs\nk_gram\nk_cost\nk_frame_factor\nk_syrk\nk_reduce_system\nk_backsub\nk_sum_trial\nk_jacobian";
 
 struct EvRec { int kid; hipEvent_t a, b; };
 
@@ -28,13 +30,14 @@ struct mcba_handle {
   double f_scale = 1.0;
   bool have_obs = false, have_lin = false, have_red = false, have_jac = false;
   // device buffers
-  double *obs_t = nullptr, *obj = nullptr, *x[2] = {nullptr, nullptr};
-  double *rec = nullptr, *gpart = nullptr, *ybuf = nullptr, *fbuf = nullptr, *fpart = nullptr;
+  double *obs_t = nullptr, *obs_raw = nullptr, *obj = nullptr, *x[2] = {nullptr, nullptr};
+  double *rec = nullptr, *gpart = nullptr, *fbuf = nullptr, *fpart = nullptr;
   double *spart = nullptr, *rpart = nullptr, *cpart = nullptr, *bpart = nullptr, *dc = nullptr;
   double *red_own = nullptr, *red = nullptr;
   double *jac = nullptr, *res = nullptr;
   int *pair_ci = nullptr, *pair_cj = nullptr;
-  int npairs = 0, G = 0, fpc = 0, B = 0, nfblocks = 0, nbblocks = 0;
+  int npairs = 0, G = 0, fpc = 0, B = 0, nfblocks = 0, nbblocks = 0, nch = 1;
+  int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD
   size_t nx = 0, nsys = 0;
   double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
   // profiling
@@ -116,29 +119,32 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   h->nsys = (size_t)h->n * h->n + 3 * h->n + 16;
   h->npairs = C * (C + 1) / 2;
   // syrk geometry: B frames per LDS stage (<= 150 KiB), G frame chunks
-  size_t per_frame = ((size_t)h->n * 6 + 6) * sizeof(double);
-  h->B = (int)std::min<size_t>(8, (150 * 1024) / per_frame);
+  size_t per_frame = ((size_t)h->n * 6 + 34) * sizeof(double);
+  h->B = (int)std::min<size_t>(16, (96 * 1024) / per_frame);  // 16 frames per LDS stage when they fit in 96 KiB
   if (h->B < 1) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for the LDS staging of k_syrk"); }
   int nbatch = (F + h->B - 1) / h->B;
   h->G = std::min(nbatch, 256);
   h->fpc = ((nbatch + h->G - 1) / h->G) * h->B;
   h->G = (F + h->fpc - 1) / h->fpc;
-  h->nfblocks = (int)(((size_t)F * C + 255) / 256);
-  h->nbblocks = (F + 255) / 256;
+  h->nfblocks = (F + 255) / 256;
+  h->nbblocks = h->Fpad / 64;
+  if (const char* e = getenv("MCBA_GRAM_SPLIT")) h->gram_split = atoi(e) != 0;  // tuning knob, see DESIGN.md
+  // k_cost: split the board points so that ~4 waves per SIMD (1024 SIMDs) are in flight
+  h->nch = std::max(1, std::min(std::min(8, N / 8), (4096 + C * h->nfb - 1) / (C * h->nfb)));
   int rc;
 #define DA(p, cnt) if ((rc = dalloc(&h->p, (cnt))) != MCBA_OK) { mcba_destroy(h); return rc; }
   DA(obs_t, (size_t)2 * C * N * h->Fpad);
+  DA(obs_raw, (size_t)2 * C * F * N);
   DA(obj, (size_t)3 * N);
   DA(x[0], h->nx);
   DA(x[1], h->nx);
   DA(rec, (size_t)h->Fpad * C * MCBA_REC);
   DA(gpart, (size_t)C * h->nfb * MCBA_GP);
-  DA(ybuf, (size_t)h->Fpad * C * 72);
   DA(fbuf, (size_t)h->Fpad * MCBA_FB);
   DA(fpart, (size_t)2 * h->nfblocks);
   DA(spart, (size_t)h->G * h->npairs * 144);
   DA(rpart, (size_t)h->G * h->n);
-  DA(cpart, (size_t)2 * C * h->nfb);
+  DA(cpart, (size_t)2 * C * h->nfb * h->nch);
   DA(bpart, (size_t)3 * h->nbblocks);
   DA(dc, (size_t)h->n);
   DA(red_own, h->nsys + 8);
@@ -163,7 +169,7 @@ int mcba_destroy(mcba_handle* h) {
   if (!h) return MCBA_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  double* bufs[] = {h->obs_t, h->obj, h->x[0], h->x[1], h->rec, h->gpart, h->ybuf, h->fbuf, h->fpart, h->spart, h->rpart, h->cpart, h->bpart, h->dc, h->red_own, h->jac, h->res};
+  double* bufs[] = {h->obs_t, h->obs_raw, h->obj, h->x[0], h->x[1], h->rec, h->gpart, h->fbuf, h->fpart, h->spart, h->rpart, h->cpart, h->bpart, h->dc, h->red_own, h->jac, h->res};
   for (double* p : bufs) if (p) (void)hipFree(p);
   if (h->pair_ci) (void)hipFree(h->pair_ci);
   if (h->pair_cj) (void)hipFree(h->pair_cj);
@@ -190,17 +196,15 @@ int mcba_upload_observations(mcba_handle* h, const double* uvs, const double* ob
   if (!h || !uvs || !objpoints) return fail(MCBA_ERR_ARG, "mcba_upload_observations: NULL argument");
   HIPCHK(hipSetDevice(h->device));
   size_t raw_count = (size_t)2 * h->C * h->F * h->N;
-  double* raw = nullptr;
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&raw), raw_count * sizeof(double)));
-  hipError_t e = hipMemcpyAsync(raw, uvs, raw_count * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  // both layouts live in HBM: raw (C,F,N) for k_jacobian (lane = point), [C][N][Fpad] for k_gram / k_cost (lane = frame)
+  hipError_t e = hipMemcpyAsync(h->obs_raw, uvs, raw_count * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(h->obj, objpoints, (size_t)3 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) {
     Scope sc(h, K_TRANSPOSE);
-    mcba::launch_transpose_obs(h->stream, raw, h->obs_t, h->C, h->F, h->N, h->Fpad);
+    mcba::launch_transpose_obs(h->stream, h->obs_raw, h->obs_t, h->C, h->F, h->N, h->Fpad);
   }
   if (e == hipSuccess) e = hipGetLastError();
   hipError_t e2 = hipStreamSynchronize(h->stream);
-  (void)hipFree(raw);
   if (e != hipSuccess || e2 != hipSuccess) { g_err = std::string("upload: ") + hipGetErrorString(e != hipSuccess ? e : e2); return MCBA_ERR_HIP; }
   h->have_obs = true;
   h->have_lin = h->have_red = h->have_jac = false;
@@ -243,13 +247,13 @@ int mcba_copy_params(mcba_handle* h, int dst, int src) {
 static int run_cost(mcba_handle* h, int slot, double* res_dev, const double* bpart, int nbp) {
   {
     Scope sc(h, K_COST);
-    mcba::launch_cost(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->cpart, res_dev, h->C, h->F, h->N, h->Fpad);
+    mcba::launch_cost(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->cpart, res_dev, h->C, h->F, h->N, h->Fpad, h->nch);
   }
   int rc = check_launch();
   if (rc) return rc;
   {
     Scope sc(h, K_SUM_TRIAL);
-    mcba::launch_sum_trial(h->stream, h->cpart, h->C * h->nfb, bpart, nbp, h->red + h->nsys);
+    mcba::launch_sum_trial(h->stream, h->cpart, h->C * h->nfb * h->nch, bpart, nbp, h->red + h->nsys);
   }
   return check_launch();
 }
@@ -306,7 +310,7 @@ int mcba_jacobian_eval(mcba_handle* h, int slot, int robust_scaled) {
   }
   {
     Scope sc(h, K_JACOBIAN);
-    mcba::launch_jacobian(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->jac, h->res, h->C, h->F, h->N, h->Fpad, robust_scaled);
+    mcba::launch_jacobian(h->stream, h->loss, h->f_scale, h->obs_raw, h->obj, h->x[slot], h->jac, h->res, h->C, h->F, h->N, h->Fpad, robust_scaled);
   }
   rc = check_launch();
   if (rc) return rc;
@@ -330,7 +334,7 @@ int mcba_linearize(mcba_handle* h, int slot) {
   HIPCHK(hipSetDevice(h->device));
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->rec, h->gpart, h->C, h->N, h->Fpad);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->rec, h->gpart, h->C, h->N, h->Fpad, h->gram_split);
   }
   int rc = check_launch();
   if (rc) return rc;
@@ -345,13 +349,13 @@ int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot) {
   HIPCHK(hipSetDevice(h->device));
   int rc;
   {
-    Scope sc(h, K_SCHUR_FRAMES);
-    mcba::launch_schur_frames(h->stream, h->rec, h->ybuf, h->fbuf, h->fpart, h->C, h->F, lambda);
+    Scope sc(h, K_FRAME_FACTOR);
+    mcba::launch_frame_factor(h->stream, h->rec, h->fbuf, h->fpart, h->C, h->F, h->Fpad, lambda);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, h->ybuf, h->fbuf, h->pair_ci, h->pair_cj, h->spart, h->rpart, h->C, h->F, h->npairs, h->G, h->fpc, h->B);
+    mcba::launch_syrk(h->stream, h->rec, h->fbuf, h->pair_ci, h->pair_cj, h->spart, h->rpart, h->C, h->F, h->Fpad, h->npairs, h->G, h->fpc, h->B);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -390,7 +394,7 @@ int mcba_step(mcba_handle* h, const double* delta_cam, double lambda, int src, i
   HIPCHK(hipMemcpyAsync(h->dc, stage, h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   {
     Scope sc(h, K_BACKSUB);
-    mcba::launch_backsub(h->stream, h->ybuf, h->fbuf, h->dc, h->x[src], h->x[dst], h->bpart, h->C, h->F, lambda);
+    mcba::launch_backsub(h->stream, h->rec, h->fbuf, h->dc, h->x[src], h->x[dst], h->bpart, h->C, h->F, h->Fpad, lambda);
   }
   int rc = check_launch();
   if (rc) return rc;

@@ -6,13 +6,14 @@
 //                       [camera][point][frame] so each iteration's load is one coalesced 1 KiB line group;
 //                       all accumulation (12x12 local Gram matrix) is lane-local -- no shuffles in the loop.
 //                       Camera intrinsics + pose are staged in LDS once per workgroup.
-//   k_schur_frames      one lane per (frame, camera): 6x6 Cholesky of the damped frame block, Y = W L^-T.
-//   k_syrk              S -= Y Y^T, register-tiled over 12x12 camera-block pairs, Y staged through LDS.
+//   k_frame_factor      one lane per frame: 6x6 Cholesky of the damped frame block, z = L^-1 g_f.
+//   k_syrk              Y = W L^-T built in LDS from the records, S -= Y Y^T register-tiled over 12x12 camera-block pairs.
 //   k_reduce_system     fixed-order second-stage reduction (deterministic; no FP64 atomics anywhere).
 //   k_backsub           one lane per frame: frame steps, trial parameters, predicted-reduction terms.
 //   k_jacobian          one wavefront per (camera, frame), one lane per board point; rows transposed through
 //                       LDS so the 288 B/observation Jacobian blocks leave as coalesced 16 B/lane stores.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "mcba_math.h"
 #include "mcba_kernels.h"
 
@@ -22,6 +23,26 @@ namespace mcba {
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// Sum over the 64 lanes, result valid in lane 63 only.  DPP moves (pure VALU, no LDS round trip):
+// xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror -> every lane holds its 16-lane row total;
+// row_bcast15 (rows 1,3) and row_bcast31 (rows 2,3) fold the four rows into row 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  union { double d; int i[2]; } a, b;
+  a.d = v;
+  b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, ROW_MASK, 0xF, false);
+  b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, ROW_MASK, 0xF, false);
+  return v + b.d;
+}
+__device__ __forceinline__ double wave_sum63(double v) {
+  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);  // row_mirror
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
   return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
@@ -65,19 +86,14 @@ __global__ void k_transpose_obs(const double2* __restrict__ raw, double2* __rest
 }
 
 // ---------------------------------------------------------------- k_gram: linearise
-// grid (ceil(nfb/4), C), block 256 = 4 wavefronts = 4 frame blocks of one camera.
-template <int LOSS>
-__global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
-                                              double* __restrict__ rec, double* __restrict__ gpart, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
-  __shared__ CamConst s_cam;
-  const int c = blockIdx.y;
-  if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int fb = blockIdx.x * 4 + wave;
-  if (fb >= nfb) return;
+// grid (ceil(nfb/4), C, 2), block 256 = 4 wavefronts = 4 frame blocks of one camera; blockIdx.z is the ROLE
+// (mcba_math.h: role A = [A|P] block -> V, g_f, W rows of rho/t, U_(rho,t)x(rho,t); role B = intrinsics blocks).
+// Splitting the 87 accumulators over two wavefronts keeps each under 256 VGPRs, so two waves share a SIMD and
+// hide each other's FP64 / memory latency; the roles never exchange data.
+template <int LOSS, int ROLE>
+__device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
+                                          double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
   const int f = fb * 64 + lane;
-
   Intr K;
   K.fx = uni(s_cam.fx); K.fy = uni(s_cam.fy); K.cx = uni(s_cam.cx); K.cy = uni(s_cam.cy); K.k1 = uni(s_cam.k1); K.k2 = uni(s_cam.k2);
   double Rc[9], tc[3];
@@ -87,76 +103,140 @@ __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t,
   for (int i = 0; i < 3; ++i) tc[i] = uni(s_cam.t[i]);
 
   const double* pose = x + 12 * C + 6 * (size_t)f;
-  double pz[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) pz[i] = pose[i];
   PairConst pc;
   {
-    double Rf[9];
+    double pz[6], Rf[9];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pz[i] = pose[i];
     rot_only(pz, Rf);
     make_pair_const(Rc, tc, Rf, pz + 3, pc);
   }
 
-  Gram g;
-  gram_zero(g);
+  constexpr bool DO_A = ROLE != 1, DO_B = ROLE != 0;
+  GramA ga;
+  GramB gb;
+  if (DO_A) gram_zero(ga);
+  if (DO_B) gram_zero(gb);
+  double cost = 0.0;
+  bool any = false;
   const double2* op = obs_t + (size_t)c * N * Fpad + f;
   double2 o_next = op[0];
+  double xn0 = obj[0], xn1 = obj[1], xn2 = obj[2];  // wave-uniform (scalar) loads, prefetched one point ahead
   for (int p = 0; p < N; ++p) {
     double2 o2 = o_next;
-    if (p + 1 < N) o_next = op[(size_t)(p + 1) * Fpad];
+    double Xo[3] = {xn0, xn1, xn2};
+    if (p + 1 < N) {
+      o_next = op[(size_t)(p + 1) * Fpad];
+      xn0 = obj[3 * p + 3]; xn1 = obj[3 * p + 4]; xn2 = obj[3 * p + 5];
+    }
     bool vu = is_num(o2.x), vv = is_num(o2.y);
     if (vu || vv) {
-      double Xo[3] = {obj[3 * p], obj[3 * p + 1], obj[3 * p + 2]};
+      any = true;
       ObsRows o;
-      obs_rows(K, pc, Xo, o);
+      obs_rows_t<DO_B>(K, pc, Xo, o);
       double wu2, wv2, gu, gv;
-      obs_weights<LOSS>(o2.x - o.up, vu, fs2, ifs2, g.cost, wu2, gu);
-      obs_weights<LOSS>(o2.y - o.vp, vv, fs2, ifs2, g.cost, wv2, gv);
-      gram_add(g, o, wu2, wv2, gu, gv);
+      obs_weights<LOSS>(o2.x - o.up, vu, fs2, ifs2, cost, wu2, gu);
+      obs_weights<LOSS>(o2.y - o.vp, vv, fs2, ifs2, cost, wv2, gv);
+      if (DO_A) gram_add(ga, o, wu2, wv2, gu, gv);
+      if (DO_B) gram_add(gb, o, wu2, wv2, gu, gv);
     }
   }
 
-  // ---- expand once per (c,f):  H -> W, V, g_f (record) and U, g_c (reduced over the wave)
+  // ---- expand once per (c,f): this role's part of W, V, g_f (record) and of U, g_c (reduced over the wave)
   ChainConst ch;
   {
-    double Rf[9], Jrf[9], Jrc[9];
+    double pz[6], Rf[9], Jrf[9], Jrc[9];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pz[i] = pose[i];
     rot_and_jr(pz, Rf, Jrf);
 #pragma unroll
     for (int i = 0; i < 9; ++i) Jrc[i] = uni(s_cam.Jr[i]);
     make_chain_const(Rc, Jrc, Rf, Jrf, pz + 3, ch);
   }
-  double U[78], gc[12], W[72], V[21], gf[6];
-  gram_expand(g, ch, U, gc, W, V, gf);
-  double* r = rec + ((size_t)f * C + c) * MCBA_REC;
-#pragma unroll
-  for (int i = 0; i < 72; i += 2) *reinterpret_cast<double2*>(r + i) = make_double2(W[i], W[i + 1]);
-#pragma unroll
-  for (int i = 0; i < 20; i += 2) *reinterpret_cast<double2*>(r + 72 + i) = make_double2(V[i], V[i + 1]);
-  *reinterpret_cast<double2*>(r + 92) = make_double2(V[20], gf[0]);
-  *reinterpret_cast<double2*>(r + 94) = make_double2(gf[1], gf[2]);
-  *reinterpret_cast<double2*>(r + 96) = make_double2(gf[3], gf[4]);
-  *reinterpret_cast<double2*>(r + 98) = make_double2(gf[5], 0.0);
-
+  // records are wave tiles rec[camera][frame block][k = 0..99][lane]: every store below is 512 contiguous bytes
+  double* r = rec + ((size_t)c * nfb + fb) * (MCBA_REC * 64) + lane;
   double* gp = gpart + ((size_t)c * nfb + fb) * MCBA_GP;
+  const bool writer = lane == 63;
+  if constexpr (DO_A) {
+    double U[78], gc[12], W[72], V[21], gf[6];
+    gram_expand(ga, ch, U, gc, W, V, gf);
 #pragma unroll
-  for (int i = 0; i < 78; ++i) {
-    double s = wave_sum(U[i]);
-    if (lane == 0) gp[i] = s;
-  }
+    for (int i = 36; i < 72; ++i) r[i * 64] = W[i];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) {
-    double s = wave_sum(gc[i]);
-    if (lane == 0) gp[78 + i] = s;
+    for (int i = 0; i < 21; ++i) r[(72 + i) * 64] = V[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r[(93 + i) * 64] = gf[i];
+#pragma unroll
+    for (int a = 6; a < 12; ++a)
+#pragma unroll
+      for (int b = a; b < 12; ++b) {
+        double sm = wave_sum63(U[tri12(a, b)]);
+        if (writer) gp[tri12(a, b)] = sm;
+      }
+#pragma unroll
+    for (int a = 6; a < 12; ++a) {
+      double sm = wave_sum63(gc[a]);
+      if (writer) gp[78 + a] = sm;
+    }
+    double cs = wave_sum63(cost);
+    double nv = wave_sum63(any ? 1.0 : 0.0);
+    if (writer) { gp[90] = cs; gp[91] = nv; }
   }
-  double cs = wave_sum(g.cost);
-  double nv = wave_sum(g.ii[8] > 0.0 || g.ii[11] > 0.0 ? 1.0 : 0.0);
-  if (lane == 0) { gp[90] = cs; gp[91] = nv; }
+  if constexpr (DO_B) {
+    double U[78], gc[12], W[72];
+    gram_expand(gb, ch, U, gc, W);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) r[i * 64] = W[i];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = a; b < 12; ++b) {
+        double sm = wave_sum63(U[tri12(a, b)]);
+        if (writer) gp[tri12(a, b)] = sm;
+      }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double sm = wave_sum63(gc[a]);
+      if (writer) gp[78 + a] = sm;
+    }
+  }
+}
+
+// Split roles: grid.z = 2, <= 256 VGPRs, two waves per SIMD.
+template <int LOSS>
+__global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
+                                                       double* __restrict__ rec, double* __restrict__ gpart, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+  __shared__ CamConst s_cam;
+  const int c = blockIdx.y;
+  if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int fb = blockIdx.x * 4 + wave;
+  if (fb >= nfb) return;
+  if (blockIdx.z == 0) gram_body<LOSS, 0>(s_cam, obs_t, obj, x, rec, gpart, c, fb, lane, C, N, Fpad, nfb, fs2, ifs2);
+  else gram_body<LOSS, 1>(s_cam, obs_t, obj, x, rec, gpart, c, fb, lane, C, N, Fpad, nfb, fs2, ifs2);
+}
+
+// Both roles in one lane: grid.z = 1, one wave per SIMD (all 87 accumulators + temporaries in the 512-register file).
+template <int LOSS>
+__global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
+                                                 double* __restrict__ rec, double* __restrict__ gpart, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+  __shared__ CamConst s_cam;  // camera intrinsics + pose (R, t, Jr) staged once per workgroup
+  const int c = blockIdx.y;
+  if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int fb = blockIdx.x * 4 + wave;
+  if (fb >= nfb) return;
+  gram_body<LOSS, 2>(s_cam, obs_t, obj, x, rec, gpart, c, fb, lane, C, N, Fpad, nfb, fs2, ifs2);
 }
 
 // ---------------------------------------------------------------- k_cost: robust cost only (trial points), optional residual vector
+// grid (ceil(nfb/4), C, nch): like k_gram, but the board points are split into nch chunks (blockIdx.z) so that
+// ~4 wavefronts per SIMD are in flight -- the loop body is short and latency-bound at one wave per SIMD.
 template <int LOSS, bool WRITE_RES>
 __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
-                                              double* __restrict__ cpart, double* __restrict__ res, int C, int F, int N, int Fpad, int nfb, double fs2, double ifs2) {
+                                              double* __restrict__ cpart, double* __restrict__ res, int C, int F, int N, int Fpad, int nfb, int nch, double fs2, double ifs2) {
   __shared__ CamConst s_cam;
   const int c = blockIdx.y;
   if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
@@ -165,6 +245,8 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
   const int fb = blockIdx.x * 4 + wave;
   if (fb >= nfb) return;
   const int f = fb * 64 + lane;
+  const int ch = blockIdx.z;
+  const int p0 = (int)(((long long)N * ch) / nch), p1 = (int)(((long long)N * (ch + 1)) / nch);
   Intr K;
   K.fx = uni(s_cam.fx); K.fy = uni(s_cam.fy); K.cx = uni(s_cam.cx); K.cy = uni(s_cam.cy); K.k1 = uni(s_cam.k1); K.k2 = uni(s_cam.k2);
   double Rc[9], tc[3];
@@ -184,10 +266,10 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
   }
   double cost = 0.0, nres = 0.0;
   const double2* op = obs_t + (size_t)c * N * Fpad + f;
-  double2 o_next = op[0];
-  for (int p = 0; p < N; ++p) {
+  double2 o_next = op[(size_t)p0 * Fpad];
+  for (int p = p0; p < p1; ++p) {
     double2 o2 = o_next;
-    if (p + 1 < N) o_next = op[(size_t)(p + 1) * Fpad];
+    if (p + 1 < p1) o_next = op[(size_t)(p + 1) * Fpad];
     bool vu = is_num(o2.x), vv = is_num(o2.y);
     double ru = 0.0, rv = 0.0;
     if (vu || vv) {
@@ -208,30 +290,32 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
     }
   }
   double cs = wave_sum(cost), ns = wave_sum(nres);
-  if (lane == 0) { cpart[2 * ((size_t)c * nfb + fb)] = cs; cpart[2 * ((size_t)c * nfb + fb) + 1] = ns; }
+  size_t o = 2 * (((size_t)c * nfb + fb) * nch + ch);
+  if (lane == 0) { cpart[o] = cs; cpart[o + 1] = ns; }
 }
 
-// ---------------------------------------------------------------- k_schur_frames
-// lane i = f*C + c.  V_f = sum_c V_cf; D_f = diag(V_f) (Marquardt); L L^T = V_f + lambda D_f; z = L^-1 g_f;
-// Y_cf = W_cf L^-T.  fbuf[f] = {L(21), z(6), g_f(6), D_f(6), pad}.
-__global__ __launch_bounds__(256) void k_schur_frames(const double* __restrict__ rec, double* __restrict__ ybuf, double* __restrict__ fbuf, double* __restrict__ fpart,
-                                                      int C, int F, double lambda) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)F * C;
+// ---------------------------------------------------------------- k_frame_factor
+// lane = frame.  V_f = sum_c V_cf; D_f = diag(V_f) (Marquardt); L L^T = V_f + lambda D_f; z = L^-1 g_f.
+// fbuf[f] = {L(21), z(6), g_f(6), D_f(6), pad}.  Per-block partials: max |g_f|, #failed factorisations.
+__global__ __launch_bounds__(256) void k_frame_factor(const double* __restrict__ rec, double* __restrict__ fbuf, double* __restrict__ fpart, int C, int F, int Fpad, double lambda) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
   double gmax = 0.0, nfail = 0.0;
-  if (i < total) {
-    const int f = (int)(i / C), c = (int)(i % C);
+  if (f < F) {
     double V[21], gf[6];
 #pragma unroll
     for (int k = 0; k < 21; ++k) V[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) gf[k] = 0.0;
+    const int nfb = Fpad >> 6;
     for (int cc = 0; cc < C; ++cc) {
-      const double* r = rec + ((size_t)f * C + cc) * MCBA_REC + 72;
+      const double* r = rec + ((size_t)cc * nfb + (f >> 6)) * (MCBA_REC * 64) + 72 * 64 + (f & 63);
+      double t[27];
 #pragma unroll
-      for (int k = 0; k < 21; ++k) V[k] += r[k];
+      for (int k = 0; k < 27; ++k) t[k] = r[k * 64];  // 27 coalesced loads in flight
 #pragma unroll
-      for (int k = 0; k < 6; ++k) gf[k] += r[21 + k];
+      for (int k = 0; k < 21; ++k) V[k] += t[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gf[k] += t[21 + k];
     }
     double D[6];
 #pragma unroll
@@ -245,31 +329,17 @@ __global__ __launch_bounds__(256) void k_schur_frames(const double* __restrict__
 #pragma unroll
     for (int k = 0; k < 6; ++k) id[k] = 1.0 / Lp[k * (k + 1) / 2 + k];
     fwd6(Lp, id, gf, z);
-    const double* w = rec + ((size_t)f * C + c) * MCBA_REC;
-    double* y = ybuf + ((size_t)f * C + c) * 72;
+    double o[40];
 #pragma unroll
-    for (int row = 0; row < 12; ++row) {
-      double wr[6], yr[6];
+    for (int k = 0; k < 21; ++k) o[k] = Lp[k];
 #pragma unroll
-      for (int k = 0; k < 6; k += 2) {
-        double2 t = *reinterpret_cast<const double2*>(w + 6 * row + k);
-        wr[k] = t.x; wr[k + 1] = t.y;
-      }
-      fwd6(Lp, id, wr, yr);
+    for (int k = 0; k < 6; ++k) { o[21 + k] = z[k]; o[27 + k] = gf[k]; o[33 + k] = D[k]; gmax = fmax(gmax, fabs(gf[k])); }
+    o[39] = 0.0;
+    double* fbp = fbuf + (size_t)f * MCBA_FB;
 #pragma unroll
-      for (int k = 0; k < 6; k += 2) *reinterpret_cast<double2*>(y + 6 * row + k) = make_double2(yr[k], yr[k + 1]);
-    }
-    if (c == 0) {
-      double* fbp = fbuf + (size_t)f * MCBA_FB;
-#pragma unroll
-      for (int k = 0; k < 21; ++k) fbp[k] = Lp[k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) { fbp[21 + k] = z[k]; fbp[27 + k] = gf[k]; fbp[33 + k] = D[k]; gmax = fmax(gmax, fabs(gf[k])); }
-      fbp[39] = 0.0;
-      nfail = ok ? 0.0 : 1.0;
-    }
+    for (int k = 0; k < 40; k += 2) *reinterpret_cast<double2*>(fbp + k) = make_double2(o[k], o[k + 1]);
+    nfail = ok ? 0.0 : 1.0;
   }
-  // per-block partials (max |g_f|, #failed factorizations)
   __shared__ double s_m[4], s_n[4];
   double wm = wave_max(gmax), wn = wave_sum(nfail);
   if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = wm; s_n[threadIdx.x >> 6] = wn; }
@@ -280,14 +350,16 @@ __global__ __launch_bounds__(256) void k_schur_frames(const double* __restrict__
   }
 }
 
-// ---------------------------------------------------------------- k_syrk:  partial  sum_f Y_f Y_f^T  and  sum_f Y_f z_f
-// grid (G, npg), block 256.  Thread t < 252 owns a 3x4 tile of one 12x12 block pair (ci <= cj):
-// 21 block pairs per workgroup, 12 tiles per pair.  Y of `B` frames is staged in LDS (one contiguous copy).
-__global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ ybuf, const double* __restrict__ fbuf, const int* __restrict__ pair_ci, const int* __restrict__ pair_cj,
-                                              double* __restrict__ spart, double* __restrict__ rpart, int C, int F, int npairs, int fpc, int B) {
-  extern __shared__ __align__(16) double s_y[];  // [B][n*6] then [B][6]
+// ---------------------------------------------------------------- k_syrk:  partial  sum_f Y_f Y_f^T  and  sum_f Y_f z_f,  Y_f = W_f L_f^-T
+// grid (G, npg), block 256.  Per batch of B frames: W rows (12C x 6 per frame) are copied from the linearisation
+// records into LDS together with L, 1/diag(L) and z of each frame; every thread then forward-substitutes a few rows
+// in place (Y = W L^-T never touches HBM); thread t < 252 owns a 3x4 tile of one 12x12 block pair (ci <= cj):
+// 21 block pairs per workgroup, 12 tiles per pair.
+__global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ rec, const double* __restrict__ fbuf, const int* __restrict__ pair_ci, const int* __restrict__ pair_cj,
+                                              double* __restrict__ spart, double* __restrict__ rpart, int C, int F, int Fpad, int npairs, int fpc, int B) {
+  extern __shared__ __align__(16) double s_y[];  // [B][n*6] Y, then [B][34]: L(21) 1/diag(6) z(6) pad
   const int n = 12 * C, n6 = n * 6;
-  double* s_z = s_y + (size_t)B * n6;
+  double* s_f = s_y + (size_t)B * n6;
   const int t = threadIdx.x;
   const int q = blockIdx.y * 21 + t / 12;
   const bool active = (t < 252) && (q < npairs);
@@ -302,15 +374,39 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ ybuf, c
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[r][s] = 0.0;
-  // rhs rows handled by this thread (blockIdx.y == 0 only): t, t+256, ...
-  double racc[2] = {0.0, 0.0};
+  double racc[2] = {0.0, 0.0};  // rhs rows t, t+256 (blockIdx.y == 0 only)
   const int f0 = blockIdx.x * fpc, f1 = min(F, f0 + fpc);
   for (int fb = f0; fb < f1; fb += B) {
     const int nb = min(B, f1 - fb);
-    const double2* src = reinterpret_cast<const double2*>(ybuf + (size_t)fb * n6);
-    double2* dst = reinterpret_cast<double2*>(s_y);
-    for (int i = t; i < nb * n6 / 2; i += 256) dst[i] = src[i];
-    for (int i = t; i < nb * 6; i += 256) s_z[i] = fbuf[(size_t)(fb + i / 6) * MCBA_FB + 21 + (i % 6)];
+    // gather W of nb consecutive frames out of the wave tiles: for one (camera, element) the nb frames are
+    // contiguous doubles, so consecutive threads (b fastest) read contiguous 8*nb-byte runs
+    const int nfb = Fpad >> 6;
+    for (int i = t; i < nb * C * 72; i += 256) {
+      int b = i % nb, ce = i / nb, c = ce / 72, e = ce - c * 72;
+      int f = fb + b;
+      s_y[(size_t)b * n6 + c * 72 + e] = rec[((size_t)c * nfb + (f >> 6)) * (MCBA_REC * 64) + e * 64 + (f & 63)];
+    }
+    for (int i = t; i < nb * 27; i += 256) {
+      int b = i / 27, k = i - b * 27;
+      s_f[b * 34 + (k < 21 ? k : k + 6)] = fbuf[(size_t)(fb + b) * MCBA_FB + k];  // L -> [0,21), z -> [27,33)
+    }
+    __syncthreads();
+    if (t < nb * 6) {
+      int b = t / 6, k = t - b * 6;
+      s_f[b * 34 + 21 + k] = 1.0 / s_f[b * 34 + k * (k + 1) / 2 + k];
+    }
+    __syncthreads();
+    for (int i = t; i < nb * n; i += 256) {  // Y rows in place: L y = w
+      int b = i / n;
+      double* w = s_y + (size_t)i * 6;
+      const double* Lp = s_f + b * 34;
+      double wr[6], yr[6];
+#pragma unroll
+      for (int k = 0; k < 6; k += 2) { double2 v = *reinterpret_cast<const double2*>(w + k); wr[k] = v.x; wr[k + 1] = v.y; }
+      fwd6(Lp, Lp + 21, wr, yr);
+#pragma unroll
+      for (int k = 0; k < 6; k += 2) *reinterpret_cast<double2*>(w + k) = make_double2(yr[k], yr[k + 1]);
+    }
     __syncthreads();
     if (active) {
       for (int b = 0; b < nb; ++b) {
@@ -340,7 +436,7 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ ybuf, c
         if (row < n) {
           for (int b = 0; b < nb; ++b) {
             const double* yr = s_y + (size_t)b * n6 + row * 6;
-            const double* z = s_z + b * 6;
+            const double* z = s_f + b * 34 + 27;
 #pragma unroll
             for (int k = 0; k < 6; ++k) racc[j] += yr[k] * z[k];
           }
@@ -371,11 +467,17 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ ybuf, c
 // l, l+16, l+32, ... (independent loads in flight), then a 4-step xor tree -- a fixed summation order,
 // so the result is bit-reproducible run to run (no FP64 atomics anywhere).
 __device__ __forceinline__ double strided_sum16(const double* __restrict__ p, size_t stride, int count, int l) {
-  double s0 = 0.0, s1 = 0.0;
-  int k = l;
-  for (; k + 16 < count; k += 32) { s0 += p[(size_t)k * stride]; s1 += p[(size_t)(k + 16) * stride]; }
-  if (k < count) s0 += p[(size_t)k * stride];
-  double s = s0 + s1;
+  double s = 0.0;
+  for (int base = 0; base < count; base += 256) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {  // 16 independent loads in flight per lane
+      int idx = base + l + 16 * k;
+      v[k] = idx < count ? p[(size_t)idx * stride] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += v[k];
+  }
 #pragma unroll
   for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
   return s;
@@ -434,36 +536,38 @@ __global__ __launch_bounds__(256) void k_reduce_system(const double* __restrict_
 }
 
 // ---------------------------------------------------------------- k_backsub: frame steps + trial parameters
-// lane = frame.  d_f = -L^-T (z + Y_f^T d_c);  x_dst = x_src + d.  Per-block partials of
-// sum d^T(lambda D d - g_f), sum |d_f|^2, sum |x_f|^2.
-__global__ __launch_bounds__(256) void k_backsub(const double* __restrict__ ybuf, const double* __restrict__ fbuf, const double* __restrict__ dc, const double* __restrict__ xs,
-                                                 double* __restrict__ xd, double* __restrict__ bpart, int C, int F, double lambda) {
-  extern __shared__ double s_dc[];
-  const int n = 12 * C;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s_dc[i] = dc[i];
-  __syncthreads();
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+// lane = frame.  t = g_f + W_f^T d_c with W read from the wave tiles (each load = 64 consecutive frames, 512 B),
+// d_f = -(L L^T)^-1 t with the Cholesky factor k_frame_factor left in fbuf, x_dst = x_src + d.
+// Per-block partials of  sum d^T(lambda D d - g_f),  sum |d_f|^2,  sum |x_f|^2.
+__global__ __launch_bounds__(64) void k_backsub(const double* __restrict__ rec, const double* __restrict__ fbuf, const double* __restrict__ dc, const double* __restrict__ xs,
+                                                double* __restrict__ xd, double* __restrict__ bpart, int C, int F, int Fpad, double lambda) {
+  const int n = 12 * C, nfb = Fpad >> 6;
+  const int f = blockIdx.x * 64 + threadIdx.x;
   if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < n; i += blockDim.x) xd[i] = xs[i] + s_dc[i];
+    for (int i = threadIdx.x; i < n; i += 64) xd[i] = xs[i] + dc[i];
   double pred = 0.0, dn2 = 0.0, xn2 = 0.0;
   if (f < F) {
+    double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < C; ++c) {
+      const double* w = rec + ((size_t)c * nfb + blockIdx.x) * (MCBA_REC * 64) + threadIdx.x;
+#pragma unroll 4
+      for (int lr = 0; lr < 12; ++lr) {
+        double d = dc[12 * c + lr];  // wave-uniform: scalar load
+        double v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = w[(6 * lr + k) * 64];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = fma(v[k], d, t[k]);
+      }
+    }
     const double* fbp = fbuf + (size_t)f * MCBA_FB;
-    double Lp[21], id[6], t[6], gf[6], D[6];
+    double Lp[21], id[6], gf[6], D[6], y[6], dl[6];
 #pragma unroll
     for (int k = 0; k < 21; ++k) Lp[k] = fbp[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { t[k] = fbp[21 + k]; gf[k] = fbp[27 + k]; D[k] = fbp[33 + k]; id[k] = 1.0 / Lp[k * (k + 1) / 2 + k]; }
-    const double* y = ybuf + (size_t)f * n * 6;
-    for (int row = 0; row < n; ++row) {
-      double d = s_dc[row];
-#pragma unroll
-      for (int k = 0; k < 6; k += 2) {
-        double2 v = *reinterpret_cast<const double2*>(y + 6 * row + k);
-        t[k] += v.x * d; t[k + 1] += v.y * d;
-      }
-    }
-    double dl[6];
-    bwd6(Lp, id, t, dl);
+    for (int k = 0; k < 6; ++k) { gf[k] = fbp[27 + k]; D[k] = fbp[33 + k]; id[k] = 1.0 / Lp[k * (k + 1) / 2 + k]; t[k] += gf[k]; }
+    fwd6(Lp, id, t, y);
+    bwd6(Lp, id, y, dl);
     const double* xf = xs + n + 6 * (size_t)f;
     double* xo = xd + n + 6 * (size_t)f;
 #pragma unroll
@@ -475,11 +579,8 @@ __global__ __launch_bounds__(256) void k_backsub(const double* __restrict__ ybuf
       xn2 += xv * xv;
     }
   }
-  __shared__ double s_p[3][4];
-  double a = wave_sum(pred), b = wave_sum(dn2), c = wave_sum(xn2);
-  if ((threadIdx.x & 63) == 0) { s_p[0][threadIdx.x >> 6] = a; s_p[1][threadIdx.x >> 6] = b; s_p[2][threadIdx.x >> 6] = c; }
-  __syncthreads();
-  if (threadIdx.x < 3) bpart[3 * blockIdx.x + threadIdx.x] = s_p[threadIdx.x][0] + s_p[threadIdx.x][1] + s_p[threadIdx.x][2] + s_p[threadIdx.x][3];
+  double a = wave_sum63(pred), b = wave_sum63(dn2), cc = wave_sum63(xn2);
+  if (threadIdx.x == 63) { bpart[3 * blockIdx.x] = a; bpart[3 * blockIdx.x + 1] = b; bpart[3 * blockIdx.x + 2] = cc; }
 }
 
 // trial scalars: [cost, pred_f, dn2_f, xn2_f, n_residuals, 0, 0, 0].  One block of 512 threads:
@@ -501,11 +602,12 @@ __global__ __launch_bounds__(512) void k_sum_trial(const double* __restrict__ cp
 
 // ---------------------------------------------------------------- k_jacobian: materialised residual Jacobian blocks
 // grid (F, C), block 64: one wavefront per (camera, frame), lane = board point (chunks of 64 points).
+// Reads the observations in their ORIGINAL (C,F,N,2) layout (kept next to the frame-major copy).
 // Output (C,F,N,2,18): per scalar residual [12 camera columns | 6 pose columns] of d(residual)/dx = -d(pred)/dx,
 // optionally robust-rescaled.  Rows go through LDS (stride 37 doubles: 2-way bank conflicts at most) so that the
 // global stores are contiguous 16 B per lane.
 template <int LOSS>
-__global__ __launch_bounds__(64) void k_jacobian(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x, double* __restrict__ jac,
+__global__ __launch_bounds__(64) void k_jacobian(const double2* __restrict__ obs_raw, const double* __restrict__ obj, const double* __restrict__ x, double* __restrict__ jac,
                                                  double* __restrict__ res, int C, int F, int N, int Fpad, int robust, double fs2, double ifs2) {
   __shared__ double s_rows[64 * 37];
   const int f = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
@@ -527,7 +629,7 @@ __global__ __launch_bounds__(64) void k_jacobian(const double2* __restrict__ obs
     const int p = p0 + lane;
     const int np = min(64, N - p0);
     if (p < N) {
-      double2 o2 = obs_t[((size_t)c * N + p) * Fpad + f];
+      double2 o2 = obs_raw[((size_t)c * F + f) * N + p];  // raw (C,F,N) layout: lanes = consecutive points, coalesced
       bool vu = is_num(o2.x), vv = is_num(o2.y);
       double Xo[3] = {obj[3 * p], obj[3 * p + 1], obj[3 * p + 2]};
       ObsRows o;
@@ -578,33 +680,38 @@ void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int 
   k_transpose_obs<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(raw), reinterpret_cast<double2*>(obs_t), C, F, N, Fpad);
 }
 
-void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* rec, double* gpart, int C, int N, int Fpad) {
+void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* rec, double* gpart, int C, int N, int Fpad, int split) {
   int nfb = Fpad / 64;
-  dim3 grid((nfb + 3) / 4, C), block(256);
+  dim3 block(256);
   double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
-  DISPATCH_LOSS(loss, (k_gram<L><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, rec, gpart, C, N, Fpad, nfb, fs2, ifs2)));
-}
-
-void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad) {
-  int nfb = Fpad / 64;
-  dim3 grid((nfb + 3) / 4, C), block(256);
-  double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
-  if (res) {
-    DISPATCH_LOSS(loss, (k_cost<L, true><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, cpart, res, C, F, N, Fpad, nfb, fs2, ifs2)));
+  if (split) {
+    dim3 grid((nfb + 3) / 4, C, 2);
+    DISPATCH_LOSS(loss, (k_gram_split<L><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, rec, gpart, C, N, Fpad, nfb, fs2, ifs2)));
   } else {
-    DISPATCH_LOSS(loss, (k_cost<L, false><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, cpart, res, C, F, N, Fpad, nfb, fs2, ifs2)));
+    dim3 grid((nfb + 3) / 4, C, 1);
+    DISPATCH_LOSS(loss, (k_gram<L><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, rec, gpart, C, N, Fpad, nfb, fs2, ifs2)));
   }
 }
 
-void launch_schur_frames(hipStream_t st, const double* rec, double* ybuf, double* fbuf, double* fpart, int C, int F, double lambda) {
-  size_t total = (size_t)F * C;
-  k_schur_frames<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(rec, ybuf, fbuf, fpart, C, F, lambda);
+void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch) {
+  int nfb = Fpad / 64;
+  dim3 grid((nfb + 3) / 4, C, nch), block(256);
+  double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
+  if (res) {
+    DISPATCH_LOSS(loss, (k_cost<L, true><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, cpart, res, C, F, N, Fpad, nfb, nch, fs2, ifs2)));
+  } else {
+    DISPATCH_LOSS(loss, (k_cost<L, false><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, cpart, res, C, F, N, Fpad, nfb, nch, fs2, ifs2)));
+  }
 }
 
-void launch_syrk(hipStream_t st, const double* ybuf, const double* fbuf, const int* pair_ci, const int* pair_cj, double* spart, double* rpart, int C, int F, int npairs, int G, int fpc, int B) {
+void launch_frame_factor(hipStream_t st, const double* rec, double* fbuf, double* fpart, int C, int F, int Fpad, double lambda) {
+  k_frame_factor<<<dim3((F + 255) / 256), dim3(256), 0, st>>>(rec, fbuf, fpart, C, F, Fpad, lambda);
+}
+
+void launch_syrk(hipStream_t st, const double* rec, const double* fbuf, const int* pair_ci, const int* pair_cj, double* spart, double* rpart, int C, int F, int Fpad, int npairs, int G, int fpc, int B) {
   int npg = (npairs + 20) / 21;
-  size_t lds = (size_t)B * (12 * C * 6 + 6) * sizeof(double);
-  k_syrk<<<dim3(G, npg), dim3(256), lds, st>>>(ybuf, fbuf, pair_ci, pair_cj, spart, rpart, C, F, npairs, fpc, B);
+  size_t lds = (size_t)B * (12 * C * 6 + 34) * sizeof(double);
+  k_syrk<<<dim3(G, npg), dim3(256), lds, st>>>(rec, fbuf, pair_ci, pair_cj, spart, rpart, C, F, Fpad, npairs, fpc, B);
 }
 
 void launch_reduce_system(hipStream_t st, const double* gpart, const double* spart, const double* rpart, const double* fpart, double* red, int C, int nfb, int G, int npairs, int nfblocks, int rank_slot) {
@@ -612,17 +719,17 @@ void launch_reduce_system(hipStream_t st, const double* gpart, const double* spa
   k_reduce_system<<<dim3((nsys * 16 + 255) / 256), dim3(256), 0, st>>>(gpart, spart, rpart, fpart, red, C, nfb, G, npairs, nfblocks, rank_slot);
 }
 
-void launch_backsub(hipStream_t st, const double* ybuf, const double* fbuf, const double* dc, const double* xs, double* xd, double* bpart, int C, int F, double lambda) {
-  k_backsub<<<dim3((F + 255) / 256), dim3(256), (size_t)12 * C * sizeof(double), st>>>(ybuf, fbuf, dc, xs, xd, bpart, C, F, lambda);
+void launch_backsub(hipStream_t st, const double* rec, const double* fbuf, const double* dc, const double* xs, double* xd, double* bpart, int C, int F, int Fpad, double lambda) {
+  k_backsub<<<dim3(Fpad / 64), dim3(64), 0, st>>>(rec, fbuf, dc, xs, xd, bpart, C, F, Fpad, lambda);
 }
 
 void launch_sum_trial(hipStream_t st, const double* cpart, int ncp, const double* bpart, int nbp, double* out) {
   k_sum_trial<<<dim3(1), dim3(512), 0, st>>>(cpart, ncp, bpart, nbp, out);
 }
 
-void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust) {
+void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust) {
   double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
-  DISPATCH_LOSS(loss, (k_jacobian<L><<<dim3(F, C), dim3(64), 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, jac, res, C, F, N, Fpad, robust, fs2, ifs2)));
+  DISPATCH_LOSS(loss, (k_jacobian<L><<<dim3(F, C), dim3(64), 0, st>>>(reinterpret_cast<const double2*>(obs_raw), obj, x, jac, res, C, F, N, Fpad, robust, fs2, ifs2)));
 }
 
 int syrk_set_lds_limit(size_t bytes) {

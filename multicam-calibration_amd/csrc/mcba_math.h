@@ -37,6 +37,33 @@ constexpr double MCBA_EPS = 2.220446049250313e-16;
 // materialised Jacobian (k_jacobian -> result.jac) keeps scipy's exact scaling.
 constexpr double MCBA_CURV_FLOOR = 0.1;
 
+// ---------------------------------------------------------------- fast reciprocal / reciprocal square root
+// On the GPU: the hardware seed (v_rcp_f64 / v_rsq_f64) plus two Newton steps in FMA form -- ~1 ulp, a third of
+// the instructions of the IEEE division / sqrt expansions (no denormal / inf fix-ups: arguments here are
+// depths z and 1 + (f/f_scale)^2 >= 1).  On the host (unit harness) plain division / sqrt.
+MCBA_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+#else
+  return 1.0 / x;
+#endif
+}
+MCBA_HD double fast_rsqrt(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(a);
+  double e = fma(-a * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-a * y, y, 1.0);
+  return fma(0.5 * y, e, y);
+#else
+  return 1.0 / sqrt(a);
+#endif
+}
+
 // ---------------------------------------------------------------- rotations
 // a = sin t/t, b = (1-cos t)/t^2, c = (t-sin t)/t^3 with series below t^2 = 1e-4.
 MCBA_HD void rot_coeffs(double th2, double& a, double& b, double& c) {
@@ -190,9 +217,15 @@ MCBA_HD void loss_weights(double r, double fs2, double inv_fs2, double& rho_half
   double z = r2 * inv_fs2;
   double rho0, rho1, rho2;
   if (LOSS == LOSS_SOFT_L1) {
-    double t = sqrt(1.0 + z);
-    double it = 1.0 / t;
-    rho0 = 2.0 * (t - 1.0); rho1 = it; rho2 = -0.5 * it * it * it;
+    // rho = 2(sqrt(1+z)-1): rho' = (1+z)^-1/2, rho' + 2 rho'' z = (1+z)^-3/2 -- one rsqrt, no division
+    double a = 1.0 + z;
+    double it = fast_rsqrt(a);
+    double t = a * it;
+    rho_half = fs2 * (t - 1.0);
+    gw = it;
+    double js = it * it * it;
+    w2 = js < MCBA_EPS ? MCBA_EPS : js;
+    return;
   } else if (LOSS == LOSS_HUBER) {
     if (z <= 1.0) { rho0 = z; rho1 = 1.0; rho2 = 0.0; }
     else { double sz = sqrt(z); rho0 = 2.0 * sz - 1.0; rho1 = 1.0 / sz; rho2 = -0.5 * rho1 / z; }
@@ -221,86 +254,104 @@ struct ObsRows {
 struct Intr { double fx, fy, cx, cy, k1, k2; };
 
 MCBA_HD void project_only(const Intr& K, const PairConst& pc, const double Xo[3], double& up, double& vp) {
-  double x = pc.Rcf[0] * Xo[0] + pc.Rcf[1] * Xo[1] + pc.Rcf[2] * Xo[2] + pc.tcf[0];
-  double y = pc.Rcf[3] * Xo[0] + pc.Rcf[4] * Xo[1] + pc.Rcf[5] * Xo[2] + pc.tcf[1];
-  double z = pc.Rcf[6] * Xo[0] + pc.Rcf[7] * Xo[1] + pc.Rcf[8] * Xo[2] + pc.tcf[2];
-  double iz = 1.0 / z;
+  double x = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], fma(pc.Rcf[2], Xo[2], pc.tcf[0])));
+  double y = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], fma(pc.Rcf[5], Xo[2], pc.tcf[1])));
+  double z = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], fma(pc.Rcf[8], Xo[2], pc.tcf[2])));
+  double iz = fast_rcp(z);
   double a = x * iz, b = y * iz;
-  double s = a * a + b * b;
-  double d = 1.0 + s * (K.k1 + K.k2 * s);
-  up = K.fx * a * d + K.cx;
-  vp = K.fy * b * d + K.cy;
+  double s = fma(a, a, b * b);
+  double d = fma(s, fma(K.k2, s, K.k1), 1.0);
+  up = fma(K.fx * a, d, K.cx);
+  vp = fma(K.fy * b, d, K.cy);
 }
 
-MCBA_HD void obs_rows(const Intr& K, const PairConst& pc, const double Xo[3], ObsRows& o) {
-  double x = pc.Rcf[0] * Xo[0] + pc.Rcf[1] * Xo[1] + pc.Rcf[2] * Xo[2] + pc.tcf[0];
-  double y = pc.Rcf[3] * Xo[0] + pc.Rcf[4] * Xo[1] + pc.Rcf[5] * Xo[2] + pc.tcf[1];
-  double z = pc.Rcf[6] * Xo[0] + pc.Rcf[7] * Xo[1] + pc.Rcf[8] * Xo[2] + pc.tcf[2];
-  double iz = 1.0 / z;
+// Every expression is spelled as an FMA chain (hipcc does not re-associate a*b + c*d + e into two FMAs).
+template <bool WITH_INTR>
+MCBA_HD void obs_rows_t(const Intr& K, const PairConst& pc, const double Xo[3], ObsRows& o) {
+  double x = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], fma(pc.Rcf[2], Xo[2], pc.tcf[0])));
+  double y = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], fma(pc.Rcf[5], Xo[2], pc.tcf[1])));
+  double z = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], fma(pc.Rcf[8], Xo[2], pc.tcf[2])));
+  double iz = fast_rcp(z);
   double a = x * iz, b = y * iz;
-  double s = a * a + b * b;
-  double d = 1.0 + s * (K.k1 + K.k2 * s);
-  double dp = K.k1 + 2.0 * K.k2 * s;
+  double aa = a * a, bb = b * b;
+  double s = aa + bb;
+  double d = fma(s, fma(K.k2, s, K.k1), 1.0);
+  double dp2 = 2.0 * fma(2.0 * K.k2, s, K.k1);  // 2 d'
   double fa = K.fx * a, fb = K.fy * b;
-  o.up = fa * d + K.cx;
-  o.vp = fb * d + K.cy;
-  o.l0 = a * d;
-  o.l1 = b * d;
-  o.l4u = fa * s;
-  o.l4v = fb * s;
-  o.l5u = o.l4u * s;
-  o.l5v = o.l4v * s;
+  o.up = fma(fa, d, K.cx);
+  o.vp = fma(fb, d, K.cy);
+  if (WITH_INTR) {
+    o.l0 = a * d;
+    o.l1 = b * d;
+    o.l4u = fa * s;
+    o.l4v = fb * s;
+    o.l5u = o.l4u * s;
+    o.l5v = o.l4v * s;
+  }
   // D_ab and P = D_ab [[iz,0,-a iz],[0,iz,-b iz]]
-  double abdp = 2.0 * a * b * dp;
-  double d00 = K.fx * (d + 2.0 * a * a * dp), d01 = K.fx * abdp;
-  double d10 = K.fy * abdp, d11 = K.fy * (d + 2.0 * b * b * dp);
-  double pu0 = d00 * iz, pu1 = d01 * iz, pu2 = -(pu0 * a + pu1 * b);
-  double pv0 = d10 * iz, pv1 = d11 * iz, pv2 = -(pv0 * a + pv1 * b);
+  double abdp = (a * b) * dp2;
+  double izx = K.fx * iz, izy = K.fy * iz;
+  double pu0 = fma(aa, dp2, d) * izx, pu1 = abdp * izx, pu2 = -fma(pu0, a, pu1 * b);
+  double pv0 = abdp * izy, pv1 = fma(bb, dp2, d) * izy, pv2 = -fma(pv0, a, pv1 * b);
   o.Eu[3] = pu0; o.Eu[4] = pu1; o.Eu[5] = pu2;
   o.Ev[3] = pv0; o.Ev[4] = pv1; o.Ev[5] = pv2;
   // B = P Rcf (row vectors), A = X_o x B
-  double bu0 = pu0 * pc.Rcf[0] + pu1 * pc.Rcf[3] + pu2 * pc.Rcf[6];
-  double bu1 = pu0 * pc.Rcf[1] + pu1 * pc.Rcf[4] + pu2 * pc.Rcf[7];
-  double bu2 = pu0 * pc.Rcf[2] + pu1 * pc.Rcf[5] + pu2 * pc.Rcf[8];
-  double bv0 = pv0 * pc.Rcf[0] + pv1 * pc.Rcf[3] + pv2 * pc.Rcf[6];
-  double bv1 = pv0 * pc.Rcf[1] + pv1 * pc.Rcf[4] + pv2 * pc.Rcf[7];
-  double bv2 = pv0 * pc.Rcf[2] + pv1 * pc.Rcf[5] + pv2 * pc.Rcf[8];
-  o.Eu[0] = Xo[1] * bu2 - Xo[2] * bu1;
-  o.Eu[1] = Xo[2] * bu0 - Xo[0] * bu2;
-  o.Eu[2] = Xo[0] * bu1 - Xo[1] * bu0;
-  o.Ev[0] = Xo[1] * bv2 - Xo[2] * bv1;
-  o.Ev[1] = Xo[2] * bv0 - Xo[0] * bv2;
-  o.Ev[2] = Xo[0] * bv1 - Xo[1] * bv0;
+  double bu0 = fma(pu0, pc.Rcf[0], fma(pu1, pc.Rcf[3], pu2 * pc.Rcf[6]));
+  double bu1 = fma(pu0, pc.Rcf[1], fma(pu1, pc.Rcf[4], pu2 * pc.Rcf[7]));
+  double bu2 = fma(pu0, pc.Rcf[2], fma(pu1, pc.Rcf[5], pu2 * pc.Rcf[8]));
+  double bv0 = fma(pv0, pc.Rcf[0], fma(pv1, pc.Rcf[3], pv2 * pc.Rcf[6]));
+  double bv1 = fma(pv0, pc.Rcf[1], fma(pv1, pc.Rcf[4], pv2 * pc.Rcf[7]));
+  double bv2 = fma(pv0, pc.Rcf[2], fma(pv1, pc.Rcf[5], pv2 * pc.Rcf[8]));
+  o.Eu[0] = fma(Xo[1], bu2, -(Xo[2] * bu1));
+  o.Eu[1] = fma(Xo[2], bu0, -(Xo[0] * bu2));
+  o.Eu[2] = fma(Xo[0], bu1, -(Xo[1] * bu0));
+  o.Ev[0] = fma(Xo[1], bv2, -(Xo[2] * bv1));
+  o.Ev[1] = fma(Xo[2], bv0, -(Xo[0] * bv2));
+  o.Ev[2] = fma(Xo[0], bv1, -(Xo[1] * bv0));
 }
+MCBA_HD void obs_rows(const Intr& K, const PairConst& pc, const double Xo[3], ObsRows& o) { obs_rows_t<true>(K, pc, Xo, o); }
 
-// ---------------------------------------------------------------- local Gram accumulator of one (c,f)
-// H_II has 17 structural non-zeros (L_I rows are sparse); order of `ii`:
-//  0:(0,0) 1:(0,2) 2:(0,4) 3:(0,5) 4:(1,1) 5:(1,3) 6:(1,4) 7:(1,5) 8:(2,2) 9:(2,4) 10:(2,5)
-//  11:(3,3) 12:(3,4) 13:(3,5) 14:(4,4) 15:(4,5) 16:(5,5)
-struct Gram {
-  double ii[17];
-  double ie[36];  // 6 x 6 : intrinsics x [A|P]
-  double ee[21];  // upper triangle of [A|P]^T [A|P], row-major (i<=j)
-  double hi[6], he[6];  // gradient pieces  J_res^T (rho' r)  (residual = obs - pred => minus sign folded in)
+// ---------------------------------------------------------------- local Gram accumulators of one (c,f)
+// The 12x12 Gram matrix of the local rows L = [L_I | A | P] is accumulated by TWO independent roles (two
+// wavefronts in k_gram, so each keeps its accumulators in VGPRs with room for a second wave per SIMD):
+//   role A: GramA = [A|P]^T [A|P] (21) + its gradient piece (6) + the robust cost
+//           -> V_cf, g_f, W rows of (rho, t), U blocks (rho,rho) (rho,t) (t,t), g_c[6:12]
+//   role B: GramB = L_I^T L_I (17 structural non-zeros) + L_I^T [A|P] (36) + its gradient piece (6)
+//           -> W rows of the intrinsics, U blocks (I,I) (I,rho) (I,t), g_c[0:6]
+// Neither needs the other's sums: the expansion splits along the same line.
+// Order of `ii`: 0:(0,0) 1:(0,2) 2:(0,4) 3:(0,5) 4:(1,1) 5:(1,3) 6:(1,4) 7:(1,5) 8:(2,2) 9:(2,4) 10:(2,5)
+//                11:(3,3) 12:(3,4) 13:(3,5) 14:(4,4) 15:(4,5) 16:(5,5)
+// Every accumulation is a chain of single-product "+=" so each becomes ONE v_fma_f64
+// (a += x*y + z*w would cost mul + fma + add without -ffast-math reassociation).
+struct GramA {
+  double ee[21];  // upper triangle of [A|P]^T W [A|P], row-major (i<=j)
+  double he[6];   // -[A|P]^T (rho' r)   (residual = obs - pred: minus sign folded in)
   double cost;
 };
+struct GramB {
+  double ii[17];
+  double ie[36];  // 6 x 6 : intrinsics x [A|P]
+  double hi[6];
+};
 
-MCBA_HD void gram_zero(Gram& g) {
+MCBA_HD void gram_zero(GramA& g) {
+#pragma unroll
+  for (int i = 0; i < 21; ++i) g.ee[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g.he[i] = 0.0;
+  g.cost = 0.0;
+}
+MCBA_HD void gram_zero(GramB& g) {
 #pragma unroll
   for (int i = 0; i < 17; ++i) g.ii[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 36; ++i) g.ie[i] = 0.0;
 #pragma unroll
-  for (int i = 0; i < 21; ++i) g.ee[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { g.hi[i] = 0.0; g.he[i] = 0.0; }
-  g.cost = 0.0;
+  for (int i = 0; i < 6; ++i) g.hi[i] = 0.0;
 }
 
-// wu2, wv2: Gauss-Newton weights (0 for a missing scalar); gu, gv = rho' * residual (0 if missing)
-MCBA_HD void gram_add(Gram& g, const ObsRows& o, double wu2, double wv2, double gu, double gv) {
-  // every accumulation is written as a chain of single-product "+=" so each becomes ONE v_fma_f64
-  // (a += x*y + z*w would cost mul + fma + add without -ffast-math reassociation)
+// wu2, wv2: curvature weights (0 for a missing scalar); gu, gv = rho' * residual (0 if missing)
+MCBA_HD void gram_add(GramA& g, const ObsRows& o, double wu2, double wv2, double gu, double gv) {
   double Euw[6], Evw[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) { Euw[j] = wu2 * o.Eu[j]; Evw[j] = wv2 * o.Ev[j]; }
@@ -315,6 +366,17 @@ MCBA_HD void gram_add(Gram& g, const ObsRows& o, double wu2, double wv2, double 
     }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
+    g.he[j] -= o.Eu[j] * gu;
+    g.he[j] -= o.Ev[j] * gv;
+  }
+}
+
+MCBA_HD void gram_add(GramB& g, const ObsRows& o, double wu2, double wv2, double gu, double gv) {
+  double Euw[6], Evw[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { Euw[j] = wu2 * o.Eu[j]; Evw[j] = wv2 * o.Ev[j]; }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
     g.ie[j] += o.l0 * Euw[j];
     g.ie[6 + j] += o.l1 * Evw[j];
     g.ie[12 + j] += Euw[j];
@@ -323,8 +385,6 @@ MCBA_HD void gram_add(Gram& g, const ObsRows& o, double wu2, double wv2, double 
     g.ie[24 + j] += o.l4v * Evw[j];
     g.ie[30 + j] += o.l5u * Euw[j];
     g.ie[30 + j] += o.l5v * Evw[j];
-    g.he[j] -= o.Eu[j] * gu;
-    g.he[j] -= o.Ev[j] * gv;
   }
   double w0 = wu2 * o.l0, w1 = wv2 * o.l1, w4u = wu2 * o.l4u, w4v = wv2 * o.l4v, w5u = wu2 * o.l5u, w5v = wv2 * o.l5v;
   g.ii[0] += w0 * o.l0;
@@ -358,7 +418,7 @@ MCBA_HD void gram_add(Gram& g, const ObsRows& o, double wu2, double wv2, double 
 }
 
 // ---------------------------------------------------------------- expansion of the local Gram matrix (once per (c,f))
-// Outputs (all for the ROBUST-RESCALED residual Jacobian, as scipy forms them):
+// Outputs are pieces of (for the robust-weighted residual Jacobian):
 //   U   : 78 doubles, upper triangle (row-major, i<=j) of J_c^T J_c  (12x12, params fx fy cx cy k1 k2 rho t)
 //   gc  : 12        J_c^T f
 //   W   : 72        J_c^T J_f  (12x6 row-major; pose params omega, tau)
@@ -367,8 +427,8 @@ MCBA_HD void gram_add(Gram& g, const ObsRows& o, double wu2, double wv2, double 
 MCBA_HD int tri12(int i, int j) { return i * 12 - (i * (i - 1)) / 2 + (j - i); }  // i<=j
 MCBA_HD int tri6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 
-MCBA_HD void gram_expand(const Gram& g, const ChainConst& ch, double* U, double* gc, double* W, double* V, double* gf) {
-  // unpack the [A|P] blocks
+// role A: writes U[(6..11) x (6..11)], gc[6..11], W rows 6..11, V, gf.  (U, gc, W are full-size arrays.)
+MCBA_HD void gram_expand(const GramA& g, const ChainConst& ch, double* U, double* gc, double* W, double* V, double* gf) {
   double HAA[9], HAP[9], HPP[9], HPA[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -379,7 +439,7 @@ MCBA_HD void gram_expand(const Gram& g, const ChainConst& ch, double* U, double*
       HAP[3 * i + j] = g.ee[tri6(i, 3 + j)];
       HPA[3 * j + i] = HAP[3 * i + j];
     }
-  // Q_A = Pa^T HAA + Pb^T HPA ; Q_P = Pa^T HAP + Pb^T HPP
+  // Q_A = Pa^T HAA + Pb^T HPA ; Q_P = Pa^T HAP + Pb^T HPP   (= J_rho^T L_A, J_rho^T L_P)
   double QA[9], QP[9], T1[9], T2[9];
   mtm33(ch.Pa, HAA, T1); mtm33(ch.Pb, HPA, T2);
 #pragma unroll
@@ -387,15 +447,55 @@ MCBA_HD void gram_expand(const Gram& g, const ChainConst& ch, double* U, double*
   mtm33(ch.Pa, HAP, T1); mtm33(ch.Pb, HPP, T2);
 #pragma unroll
   for (int i = 0; i < 9; ++i) QP[i] = T1[i] + T2[i];
-  // U_rr = QA Pa + QP Pb
   double Urr[9];
   mm33(QA, ch.Pa, T1); mm33(QP, ch.Pb, T2);
 #pragma unroll
   for (int i = 0; i < 9; ++i) Urr[i] = T1[i] + T2[i];
-
-  // ---- U
 #pragma unroll
-  for (int i = 0; i < 78; ++i) U[i] = 0.0;
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (i <= j) {
+        U[tri12(6 + i, 6 + j)] = Urr[3 * i + j];
+        U[tri12(9 + i, 9 + j)] = HPP[3 * i + j];
+      }
+      U[tri12(6 + i, 9 + j)] = QP[3 * i + j];
+    }
+  double Wro[9], Wrt[9], Wto[9], Wtt[9];
+  mm33(QA, ch.Sa, Wro); mm33(QP, ch.Sb, Wrt); mm33(HPA, ch.Sa, Wto); mm33(HPP, ch.Sb, Wtt);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      W[6 * (6 + i) + j] = Wro[3 * i + j];
+      W[6 * (6 + i) + 3 + j] = Wrt[3 * i + j];
+      W[6 * (9 + i) + j] = Wto[3 * i + j];
+      W[6 * (9 + i) + 3 + j] = Wtt[3 * i + j];
+    }
+  double Voo[9], Vot[9], Vtt[9];
+  mm33(HAA, ch.Sa, T1); mtm33(ch.Sa, T1, Voo);
+  mm33(HAP, ch.Sb, T1); mtm33(ch.Sa, T1, Vot);
+  mm33(HPP, ch.Sb, T1); mtm33(ch.Sb, T1, Vtt);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (i <= j) { V[tri6(i, j)] = Voo[3 * i + j]; V[tri6(3 + i, 3 + j)] = Vtt[3 * i + j]; }
+      V[tri6(i, 3 + j)] = Vot[3 * i + j];
+    }
+  double ta[3], tb[3];
+  mtv3(ch.Pa, g.he, ta); mtv3(ch.Pb, g.he + 3, tb);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { gc[6 + i] = ta[i] + tb[i]; gc[9 + i] = g.he[3 + i]; }
+  mtv3(ch.Sa, g.he, gf); mtv3(ch.Sb, g.he + 3, gf + 3);
+}
+
+// role B: writes U[(0..5) x (0..11)], gc[0..5], W rows 0..5.
+MCBA_HD void gram_expand(const GramB& g, const ChainConst& ch, double* U, double* gc, double* W) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) U[tri12(i, j)] = 0.0;
   U[tri12(0, 0)] = g.ii[0];  U[tri12(0, 2)] = g.ii[1];  U[tri12(0, 4)] = g.ii[2];  U[tri12(0, 5)] = g.ii[3];
   U[tri12(1, 1)] = g.ii[4];  U[tri12(1, 3)] = g.ii[5];  U[tri12(1, 4)] = g.ii[6];  U[tri12(1, 5)] = g.ii[7];
   U[tri12(2, 2)] = g.ii[8];  U[tri12(2, 4)] = g.ii[9];  U[tri12(2, 5)] = g.ii[10];
@@ -409,53 +509,11 @@ MCBA_HD void gram_expand(const Gram& g, const ChainConst& ch, double* U, double*
     for (int j = 0; j < 3; ++j) {
       U[tri12(i, 6 + j)] = hia[0] * ch.Pa[j] + hia[1] * ch.Pa[3 + j] + hia[2] * ch.Pa[6 + j] + hip[0] * ch.Pb[j] + hip[1] * ch.Pb[3 + j] + hip[2] * ch.Pb[6 + j];
       U[tri12(i, 9 + j)] = hip[j];
-      // W rows of the intrinsics
       W[6 * i + j] = hia[0] * ch.Sa[j] + hia[1] * ch.Sa[3 + j] + hia[2] * ch.Sa[6 + j];
       W[6 * i + 3 + j] = hip[0] * ch.Sb[j] + hip[1] * ch.Sb[3 + j] + hip[2] * ch.Sb[6 + j];
     }
+    gc[i] = g.hi[i];
   }
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if (i <= j) {
-        U[tri12(6 + i, 6 + j)] = Urr[3 * i + j];
-        U[tri12(9 + i, 9 + j)] = HPP[3 * i + j];
-      }
-      U[tri12(6 + i, 9 + j)] = QP[3 * i + j];
-    }
-  // ---- W rows of rho and t
-  double Wro[9], Wrt[9], Wto[9], Wtt[9];
-  mm33(QA, ch.Sa, Wro); mm33(QP, ch.Sb, Wrt); mm33(HPA, ch.Sa, Wto); mm33(HPP, ch.Sb, Wtt);
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      W[6 * (6 + i) + j] = Wro[3 * i + j];
-      W[6 * (6 + i) + 3 + j] = Wrt[3 * i + j];
-      W[6 * (9 + i) + j] = Wto[3 * i + j];
-      W[6 * (9 + i) + 3 + j] = Wtt[3 * i + j];
-    }
-  // ---- V
-  double Voo[9], Vot[9], Vtt[9];
-  mm33(HAA, ch.Sa, T1); mtm33(ch.Sa, T1, Voo);
-  mm33(HAP, ch.Sb, T1); mtm33(ch.Sa, T1, Vot);
-  mm33(HPP, ch.Sb, T1); mtm33(ch.Sb, T1, Vtt);
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if (i <= j) { V[tri6(i, j)] = Voo[3 * i + j]; V[tri6(3 + i, 3 + j)] = Vtt[3 * i + j]; }
-      V[tri6(i, 3 + j)] = Vot[3 * i + j];
-    }
-  // ---- gradients
-  double ta[3], tb[3];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) gc[i] = g.hi[i];
-  mtv3(ch.Pa, g.he, ta); mtv3(ch.Pb, g.he + 3, tb);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { gc[6 + i] = ta[i] + tb[i]; gc[9 + i] = g.he[3 + i]; }
-  mtv3(ch.Sa, g.he, gf); mtv3(ch.Sb, g.he + 3, gf + 3);
 }
 
 // ---------------------------------------------------------------- materialised Jacobian rows of one point-observation

@@ -1,4 +1,5 @@
 """Quick per-kernel timing on one GPU (development aid; bench.py is the contract)."""
+import os
 import sys
 import time
 
@@ -8,31 +9,41 @@ sys.path.insert(0, ".")
 import multicam_calibration_amd as m
 
 C, F = int(sys.argv[1]) if len(sys.argv) > 1 else 6, int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "1"]
 p = m.synth.make_problem(C, F, seed=0)
 x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
-t0 = time.perf_counter()
-prob = m.ops.Problem(p["uvs"], p["obj"])
-print("create+upload %.1f ms" % ((time.perf_counter() - t0) * 1e3))
-prob.set_params(0, x0)
-prob.profile_enable(True)
-for it in range(12):
-    prob.linearize(0)
-    prob.build_reduced(1e-3)
-    red = prob.get_reduced()
-    dc = np.linalg.solve(red["S0"] + 1e-3 * np.diag(red["diagU"]), red["rhs"])
-    prob.step(dc, 1e-3, 0, 1)
-    t = prob.get_trial()
-    if it == 1:
-        prob.profile_read()
-prob.jacobian_eval(0, False)
-prob.jacobian_eval(0, True)
-prof = prob.profile_read()
-for k, (ms, n) in prof.items():
-    if n:
-        print("%-18s %4d calls  %9.3f us avg" % (k, n, 1e3 * ms / n))
-print("cost", red["scal"][0], "trial", t[:5])
-prob.profile_enable(False)
-t0 = time.perf_counter()
-res = m.solver.lm_solve(prob, x0, ftol=1e-10, xtol=1e-12, gtol=1e-8, verbose=2, max_nfev=60)
-dt = time.perf_counter() - t0
-print("lm_solve: %d iterations, nfev %d in %.3f s -> %.1f it/s; status %d cost %.10g opt %.2e" % (res.lm["iterations"], res.nfev, dt, res.lm["steps"] / dt, res.status, res.cost, res.optimality))
+for mode in modes:
+    os.environ["MCBA_GRAM_SPLIT"] = mode
+    prob = m.ops.Problem(p["uvs"], p["obj"])
+    prob.set_params(0, x0)
+    prob.profile_enable(True)
+    for it in range(12):
+        prob.linearize(0)
+        prob.build_reduced(1e-3)
+        red = prob.get_reduced()
+        dc = np.linalg.solve(red["S0"] + 1e-3 * np.diag(red["diagU"]), red["rhs"])
+        prob.step(dc, 1e-3, 0, 1)
+        t = prob.get_trial()
+        if it == 1:
+            prob.profile_read()
+    prob.jacobian_eval(0, False)
+    prob.jacobian_eval(0, True)
+    prof = prob.profile_read()
+    print("== MCBA_GRAM_SPLIT=%s" % mode)
+    for k, (ms, n) in prof.items():
+        if n:
+            print("%-18s %4d calls  %9.3f us avg" % (k, n, 1e3 * ms / n))
+    print("cost %.12g trial %s" % (red["scal"][0], t[:3]))
+    prob.profile_enable(False)
+    lm = m.solver.LevenbergMarquardt(prob, ftol=0.0, xtol=0.0, gtol=0.0)
+    lm.start(x0)
+    for _ in range(20):
+        lm.iterate(always_linearize=True)
+    prob.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        lm.iterate(always_linearize=True)
+    prob.synchronize()
+    dt = time.perf_counter() - t0
+    print("LM loop: %.1f us/iter -> %.0f it/s ; cost %.12g" % (dt / 200 * 1e6, 200 / dt, lm.cost))
+    prob.close()

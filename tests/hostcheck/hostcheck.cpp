@@ -45,8 +45,10 @@ void hc_normal_eq(int C, int F, int N, const double* uvs, const double* obj, con
       rot_and_jr(pose, Rf, Jrf);
       PairConst pc;
       make_pair_const(cc.R, cc.t, Rf, pose + 3, pc);
-      Gram g;
-      gram_zero(g);
+      GramA ga;
+      GramB gb;
+      gram_zero(ga);
+      gram_zero(gb);
       for (int p = 0; p < N; ++p) {
         const double* o2 = uvs + (((size_t)c * F + f) * N + p) * 2;
         bool vu = o2[0] == o2[0], vv = o2[1] == o2[1];
@@ -54,17 +56,19 @@ void hc_normal_eq(int C, int F, int N, const double* uvs, const double* obj, con
         ObsRows o;
         obs_rows(K, pc, obj + 3 * p, o);
         double wu2, wv2, gu, gv;
-        weights_dyn(loss, o2[0] - o.up, vu, fs2, ifs2, g.cost, wu2, gu);
-        weights_dyn(loss, o2[1] - o.vp, vv, fs2, ifs2, g.cost, wv2, gv);
-        gram_add(g, o, wu2, wv2, gu, gv);
+        weights_dyn(loss, o2[0] - o.up, vu, fs2, ifs2, ga.cost, wu2, gu);
+        weights_dyn(loss, o2[1] - o.vp, vv, fs2, ifs2, ga.cost, wv2, gv);
+        gram_add(ga, o, wu2, wv2, gu, gv);
+        gram_add(gb, o, wu2, wv2, gu, gv);
       }
       ChainConst ch;
       make_chain_const(cc.R, cc.Jr, Rf, Jrf, pose + 3, ch);
       double Ul[78], gcl[12];
-      gram_expand(g, ch, Ul, gcl, W + ((size_t)c * F + f) * 72, V + ((size_t)c * F + f) * 21, gf + ((size_t)c * F + f) * 6);
+      gram_expand(ga, ch, Ul, gcl, W + ((size_t)c * F + f) * 72, V + ((size_t)c * F + f) * 21, gf + ((size_t)c * F + f) * 6);
+      gram_expand(gb, ch, Ul, gcl, W + ((size_t)c * F + f) * 72);
       for (int i = 0; i < 78; ++i) U[c * 78 + i] += Ul[i];
       for (int i = 0; i < 12; ++i) gc[c * 12 + i] += gcl[i];
-      *cost += g.cost;
+      *cost += ga.cost;
     }
   }
 }
