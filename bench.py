@@ -47,8 +47,8 @@ def algorithmic_bytes(kernel, C, F, N):
     return {
         "k_gram": obs + poses + rec + 736 * C * ((F + 63) // 64),
         "k_cost": obs + poses,
-        "k_frame_factor": 224 * C * F + 320 * F,
-        "k_syrk": 576 * C * F + 272 * F,
+        "k_frame_factor": 216 * C * F + 320 * F,
+        "k_syrk": 576 * C * F + 216 * F,
         "k_backsub": 576 * C * F + 320 * F + 2 * poses,
         "k_jacobian": obs + poses + (288 + 16) * C * F * N,
         "k_reduce_system": 8 * (n * n + 3 * n),

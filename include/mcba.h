@@ -105,8 +105,14 @@ int mcba_get_reduced(mcba_handle* h, double* host);      /* D2H of the system pa
 /* Back-substitute: given the camera step (12C doubles, host) solve every frame step,
  * write x[dst_slot] = x[src_slot] + delta and evaluate the robust cost there.  Trial scalars
  * (8 doubles, appended to the reduce buffer at offset n*n+3n+16):
- *   0 cost(x_dst)  1 sum_f d_f^T (lambda D_f d_f - g_f)  2 sum |d_f|^2  3 sum |x_f|^2  4 n_nonfinite  5..7 reserved */
+ *   0 cost(x_dst)  1 sum_f d_f^T (lambda D_f d_f - g_f)  2 sum |d_f|^2  3 sum |x_f|^2  4 n_residuals  5..7 reserved */
 int mcba_step(mcba_handle* h, const double* delta_cam, double lambda, int src_slot, int dst_slot);
+/* Same, but instead of a cost-only pass the trial point x[dst] is LINEARISED (as mcba_linearize) into the
+ * handle's second linearisation buffer; its robust cost fills trial scalar 0 (scalar 4 = number of
+ * (camera, frame) pairs with data).  If the step is accepted, mcba_accept_linearization() makes that buffer the
+ * current one at no GPU cost -- an accepted LM iteration then needs ONE pass over the observations, not two. */
+int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, int src_slot, int dst_slot);
+int mcba_accept_linearization(mcba_handle* h);
 int mcba_get_trial(mcba_handle* h, double* host8);
 /* Frame part of the gradient J^T f of the last mcba_build_reduced(): (F,6) doubles, host.
  * (The camera part is the g_c block of the reduce buffer.)  Feeds OptimizeResult.grad (trf.py:557-560). */

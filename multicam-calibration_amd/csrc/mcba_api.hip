@@ -31,12 +31,14 @@ struct mcba_handle {
   bool have_obs = false, have_lin = false, have_red = false, have_jac = false;
   // device buffers
   double *obs_t = nullptr, *obs_raw = nullptr, *obj = nullptr, *x[2] = {nullptr, nullptr};
-  double *rec = nullptr, *gpart = nullptr, *fbuf = nullptr, *fpart = nullptr;
-  double *spart = nullptr, *rpart = nullptr, *cpart = nullptr, *bpart = nullptr, *dc = nullptr;
+  double *rec2[2] = {nullptr, nullptr}, *gpart2[2] = {nullptr, nullptr}, *fbuf = nullptr, *fpart = nullptr;
+  int lin = 0;          // which of the two linearisation buffers holds the accepted point
+  bool have_spec = false;  // the other one holds a speculative linearisation of the last trial point
+  double *spart = nullptr, *cpart = nullptr, *bpart = nullptr, *dc = nullptr;
   double *red_own = nullptr, *red = nullptr;
   double *jac = nullptr, *res = nullptr;
-  int *pair_ci = nullptr, *pair_cj = nullptr;
-  int npairs = 0, G = 0, fpc = 0, B = 0, nfblocks = 0, nbblocks = 0, nch = 1;
+  int *tile_i = nullptr, *tile_j = nullptr;
+  int NT = 0, NP = 0, G = 0, fpc = 0, FS = 0, ppw = 4, nfblocks = 0, nbblocks = 0, nch = 1;
   int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD
   size_t nx = 0, nsys = 0;
   double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
@@ -117,16 +119,22 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   h->n = 12 * C;
   h->nx = (size_t)12 * C + (size_t)6 * h->Fpad;
   h->nsys = (size_t)h->n * h->n + 3 * h->n + 16;
-  h->npairs = C * (C + 1) / 2;
-  // syrk geometry: B frames per LDS stage (<= 150 KiB), G frame chunks
-  size_t per_frame = ((size_t)h->n * 6 + 34) * sizeof(double);
-  h->B = (int)std::min<size_t>(16, (96 * 1024) / per_frame);  // 16 frames per LDS stage when they fit in 96 KiB
-  if (h->B < 1) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for the LDS staging of k_syrk"); }
-  int nbatch = (F + h->B - 1) / h->B;
-  h->G = std::min(nbatch, 256);
-  h->fpc = ((nbatch + h->G - 1) / h->G) * h->B;
-  h->G = (F + h->fpc - 1) / h->fpc;
-  h->nfblocks = (F + 255) / 256;
+  // k_syrk geometry: (12C + 1) rows of [Y ; z^T] padded to NT tiles of 16, NP tile pairs (ti <= tj);
+  // FS frames per LDS stage (a divisor of 64; <= 96 KiB so that two workgroups fit a CU when C is small)
+  h->NT = (h->n + 1 + 15) / 16;
+  h->NP = h->NT * (h->NT + 1) / 2;
+  h->ppw = h->NP <= 64 ? 4 : 16;
+  h->FS = 16;
+  while (h->FS > 2 && (mcba::syrk_lds_bytes(C, h->FS) > 96 * 1024 || (h->n + 1) * h->FS > 256 * mcba::syrk_items_per_thread())) h->FS /= 2;
+  if ((h->n + 1) * h->FS > 256 * mcba::syrk_items_per_thread()) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for k_syrk's per-thread item budget"); }
+  if (mcba::syrk_lds_bytes(C, h->FS) > 160 * 1024) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for the LDS staging of k_syrk"); }
+  {
+    int nstage = (F + h->FS - 1) / h->FS;
+    int g = std::min(nstage, 256);
+    h->fpc = ((nstage + g - 1) / g) * h->FS;
+    h->G = (F + h->fpc - 1) / h->fpc;
+  }
+  h->nfblocks = h->Fpad / 64;
   h->nbblocks = h->Fpad / 64;
   if (const char* e = getenv("MCBA_GRAM_SPLIT")) h->gram_split = atoi(e) != 0;  // tuning knob, see DESIGN.md
   // k_cost: split the board points so that ~4 waves per SIMD (1024 SIMDs) are in flight
@@ -138,26 +146,27 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   DA(obj, (size_t)3 * N);
   DA(x[0], h->nx);
   DA(x[1], h->nx);
-  DA(rec, (size_t)h->Fpad * C * MCBA_REC);
-  DA(gpart, (size_t)C * h->nfb * MCBA_GP);
+  DA(rec2[0], (size_t)h->Fpad * C * MCBA_REC);
+  DA(rec2[1], (size_t)h->Fpad * C * MCBA_REC);
+  DA(gpart2[0], (size_t)C * h->nfb * MCBA_GP);
+  DA(gpart2[1], (size_t)C * h->nfb * MCBA_GP);
   DA(fbuf, (size_t)h->Fpad * MCBA_FB);
   DA(fpart, (size_t)2 * h->nfblocks);
-  DA(spart, (size_t)h->G * h->npairs * 144);
-  DA(rpart, (size_t)h->G * h->n);
+  DA(spart, (size_t)h->G * h->NP * 256);
   DA(cpart, (size_t)2 * C * h->nfb * h->nch);
   DA(bpart, (size_t)3 * h->nbblocks);
   DA(dc, (size_t)h->n);
   DA(red_own, h->nsys + 8);
-  DA(pair_ci, (size_t)h->npairs);
-  DA(pair_cj, (size_t)h->npairs);
+  DA(tile_i, (size_t)h->NP);
+  DA(tile_j, (size_t)h->NP);
 #undef DA
   h->red = h->red_own;
   std::vector<int> ci, cj;
-  for (int a = 0; a < C; ++a) for (int b = a; b < C; ++b) { ci.push_back(a); cj.push_back(b); }
-  HIPCHK(hipMemcpy(h->pair_ci, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->pair_cj, cj.data(), cj.size() * sizeof(int), hipMemcpyHostToDevice));
+  for (int a = 0; a < h->NT; ++a) for (int b = a; b < h->NT; ++b) { ci.push_back(a); cj.push_back(b); }
+  HIPCHK(hipMemcpy(h->tile_i, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->tile_j, cj.data(), cj.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pinned), (h->nsys + 8 + h->n) * sizeof(double), hipHostMallocDefault));
-  size_t lds = (size_t)h->B * per_frame;
+  size_t lds = mcba::syrk_lds_bytes(C, h->FS);
   if (lds > 64 * 1024) {
     if (mcba::syrk_set_lds_limit(lds) != 0) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_syrk"); }
   }
@@ -169,10 +178,10 @@ int mcba_destroy(mcba_handle* h) {
   if (!h) return MCBA_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  double* bufs[] = {h->obs_t, h->obs_raw, h->obj, h->x[0], h->x[1], h->rec, h->gpart, h->fbuf, h->fpart, h->spart, h->rpart, h->cpart, h->bpart, h->dc, h->red_own, h->jac, h->res};
+  double* bufs[] = {h->obs_t, h->obs_raw, h->obj, h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->fbuf, h->fpart, h->spart, h->cpart, h->bpart, h->dc, h->red_own, h->jac, h->res};
   for (double* p : bufs) if (p) (void)hipFree(p);
-  if (h->pair_ci) (void)hipFree(h->pair_ci);
-  if (h->pair_cj) (void)hipFree(h->pair_cj);
+  if (h->tile_i) (void)hipFree(h->tile_i);
+  if (h->tile_j) (void)hipFree(h->tile_j);
   if (h->pinned) (void)hipHostFree(h->pinned);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->pool) (void)hipEventDestroy(e);
@@ -253,7 +262,7 @@ static int run_cost(mcba_handle* h, int slot, double* res_dev, const double* bpa
   if (rc) return rc;
   {
     Scope sc(h, K_SUM_TRIAL);
-    mcba::launch_sum_trial(h->stream, h->cpart, h->C * h->nfb * h->nch, bpart, nbp, h->red + h->nsys);
+    mcba::launch_sum_trial(h->stream, h->cpart, 2, h->C * h->nfb * h->nch, bpart, nbp, h->red + h->nsys);
   }
   return check_launch();
 }
@@ -334,12 +343,13 @@ int mcba_linearize(mcba_handle* h, int slot) {
   HIPCHK(hipSetDevice(h->device));
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->rec, h->gpart, h->C, h->N, h->Fpad, h->gram_split);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->rec2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split);
   }
   int rc = check_launch();
   if (rc) return rc;
   h->have_lin = true;
   h->have_red = false;
+  h->have_spec = false;
   return MCBA_OK;
 }
 
@@ -350,17 +360,17 @@ int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot) {
   int rc;
   {
     Scope sc(h, K_FRAME_FACTOR);
-    mcba::launch_frame_factor(h->stream, h->rec, h->fbuf, h->fpart, h->C, h->F, h->Fpad, lambda);
+    mcba::launch_frame_factor(h->stream, h->rec2[h->lin], h->fbuf, h->fpart, h->C, h->F, h->Fpad, lambda);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, h->rec, h->fbuf, h->pair_ci, h->pair_cj, h->spart, h->rpart, h->C, h->F, h->Fpad, h->npairs, h->G, h->fpc, h->B);
+    mcba::launch_syrk(h->stream, h->rec2[h->lin], h->fbuf, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_REDUCE);
-    mcba::launch_reduce_system(h->stream, h->gpart, h->spart, h->rpart, h->fpart, h->red, h->C, h->nfb, h->G, h->npairs, h->nfblocks, rank_slot);
+    mcba::launch_reduce_system(h->stream, h->gpart2[h->lin], h->spart, h->fpart, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
   }
   if ((rc = check_launch())) return rc;
   h->have_red = true;
@@ -385,20 +395,55 @@ int mcba_get_reduced(mcba_handle* h, double* host) {
   return MCBA_OK;
 }
 
-int mcba_step(mcba_handle* h, const double* delta_cam, double lambda, int src, int dst) {
-  if (!slot_ok(h, src) || !slot_ok(h, dst) || src == dst || !delta_cam) return fail(MCBA_ERR_ARG, "mcba_step: bad argument (slots must differ)");
-  if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_step: call mcba_build_reduced first");
-  HIPCHK(hipSetDevice(h->device));
+static int step_common(mcba_handle* h, const double* delta_cam, double lambda, int src, int dst) {
   double* stage = h->pinned + h->nsys + 8;
   memcpy(stage, delta_cam, h->n * sizeof(double));
   HIPCHK(hipMemcpyAsync(h->dc, stage, h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   {
     Scope sc(h, K_BACKSUB);
-    mcba::launch_backsub(h->stream, h->rec, h->fbuf, h->dc, h->x[src], h->x[dst], h->bpart, h->C, h->F, h->Fpad, lambda);
+    mcba::launch_backsub(h->stream, h->rec2[h->lin], h->fbuf, h->dc, h->x[src], h->x[dst], h->bpart, h->C, h->F, h->Fpad, lambda);
   }
-  int rc = check_launch();
+  return check_launch();
+}
+
+int mcba_step(mcba_handle* h, const double* delta_cam, double lambda, int src, int dst) {
+  if (!slot_ok(h, src) || !slot_ok(h, dst) || src == dst || !delta_cam) return fail(MCBA_ERR_ARG, "mcba_step: bad argument (slots must differ)");
+  if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_step: call mcba_build_reduced first");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = step_common(h, delta_cam, lambda, src, dst);
   if (rc) return rc;
+  h->have_spec = false;
   return run_cost(h, dst, nullptr, h->bpart, h->nbblocks);
+}
+
+int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, int src, int dst) {
+  if (!slot_ok(h, src) || !slot_ok(h, dst) || src == dst || !delta_cam) return fail(MCBA_ERR_ARG, "mcba_step_linearize: bad argument (slots must differ)");
+  if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_step_linearize: call mcba_build_reduced first");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = step_common(h, delta_cam, lambda, src, dst);
+  if (rc) return rc;
+  const int alt = 1 - h->lin;
+  {
+    Scope sc(h, K_GRAM);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[dst], h->rec2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split);
+  }
+  if ((rc = check_launch())) return rc;
+  {
+    Scope sc(h, K_SUM_TRIAL);
+    mcba::launch_sum_trial(h->stream, h->gpart2[alt] + 90, MCBA_GP, h->C * h->nfb, h->bpart, h->nbblocks, h->red + h->nsys);
+  }
+  if ((rc = check_launch())) return rc;
+  h->have_spec = true;
+  return MCBA_OK;
+}
+
+int mcba_accept_linearization(mcba_handle* h) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  if (!h->have_spec) return fail(MCBA_ERR_ARG, "mcba_accept_linearization: no speculative linearisation (call mcba_step_linearize first)");
+  h->lin = 1 - h->lin;
+  h->have_spec = false;
+  h->have_red = false;
+  return MCBA_OK;
 }
 
 int mcba_get_trial(mcba_handle* h, double* host8) {

@@ -11,11 +11,13 @@ namespace mcba {
 void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int C, int F, int N, int Fpad);
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* rec, double* gpart, int C, int N, int Fpad, int split);
 void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch);
+size_t syrk_lds_bytes(int C, int FS);
 void launch_frame_factor(hipStream_t st, const double* rec, double* fbuf, double* fpart, int C, int F, int Fpad, double lambda);
-void launch_syrk(hipStream_t st, const double* rec, const double* fbuf, const int* pair_ci, const int* pair_cj, double* spart, double* rpart, int C, int F, int Fpad, int npairs, int G, int fpc, int B);
-void launch_reduce_system(hipStream_t st, const double* gpart, const double* spart, const double* rpart, const double* fpart, double* red, int C, int nfb, int G, int npairs, int nfblocks, int rank_slot);
+void launch_syrk(hipStream_t st, const double* rec, const double* fbuf, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw);
+int syrk_items_per_thread();
+void launch_reduce_system(hipStream_t st, const double* gpart, const double* spart, const double* fpart, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot);
 void launch_backsub(hipStream_t st, const double* rec, const double* fbuf, const double* dc, const double* xs, double* xd, double* bpart, int C, int F, int Fpad, double lambda);
-void launch_sum_trial(hipStream_t st, const double* cpart, int ncp, const double* bpart, int nbp, double* out);
+void launch_sum_trial(hipStream_t st, const double* cpart, int cstride, int ncp, const double* bpart, int nbp, double* out);
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);
 int syrk_set_lds_limit(size_t bytes);
 }  // namespace mcba

@@ -7,7 +7,8 @@
 //                       all accumulation (12x12 local Gram matrix) is lane-local -- no shuffles in the loop.
 //                       Camera intrinsics + pose are staged in LDS once per workgroup.
 //   k_frame_factor      one lane per frame: 6x6 Cholesky of the damped frame block, z = L^-1 g_f.
-//   k_syrk              Y = W L^-T built in LDS from the records, S -= Y Y^T register-tiled over 12x12 camera-block pairs.
+//   k_syrk              per stage of frames: Y = W L^-T built in LDS, S -= Y Y^T on v_mfma_f64_16x16x4 (the one
+//                       GEMM-shaped step); the next stage's operands are prefetched into registers meanwhile.
 //   k_reduce_system     fixed-order second-stage reduction (deterministic; no FP64 atomics anywhere).
 //   k_backsub           one lane per frame: frame steps, trial parameters, predicted-reduction terms.
 //   k_jacobian          one wavefront per (camera, frame), one lane per board point; rows transposed through
@@ -297,26 +298,36 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
 // ---------------------------------------------------------------- k_frame_factor
 // lane = frame.  V_f = sum_c V_cf; D_f = diag(V_f) (Marquardt); L L^T = V_f + lambda D_f; z = L^-1 g_f.
 // fbuf[f] = {L(21), z(6), g_f(6), D_f(6), pad}.  Per-block partials: max |g_f|, #failed factorisations.
-__global__ __launch_bounds__(256) void k_frame_factor(const double* __restrict__ rec, double* __restrict__ fbuf, double* __restrict__ fpart, int C, int F, int Fpad, double lambda) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+// The V_cf / g_cf reads are coalesced tile rows; three cameras (81 loads) are in flight per lane at a time.
+__global__ __launch_bounds__(64) void k_frame_factor(const double* __restrict__ rec, double* __restrict__ fbuf, double* __restrict__ fpart, int C, int F, int Fpad, double lambda) {
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  const int nfb = Fpad >> 6;
   double gmax = 0.0, nfail = 0.0;
-  if (f < F) {
-    double V[21], gf[6];
+  double V[21], gf[6];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) V[k] = 0.0;
+  for (int k = 0; k < 21; ++k) V[k] = 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) gf[k] = 0.0;
-    const int nfb = Fpad >> 6;
-    for (int cc = 0; cc < C; ++cc) {
-      const double* r = rec + ((size_t)cc * nfb + (f >> 6)) * (MCBA_REC * 64) + 72 * 64 + (f & 63);
-      double t[27];
+  for (int k = 0; k < 6; ++k) gf[k] = 0.0;
+  for (int c0 = 0; c0 < C; c0 += 3) {
+    double t[3][27];
 #pragma unroll
-      for (int k = 0; k < 27; ++k) t[k] = r[k * 64];  // 27 coalesced loads in flight
+    for (int j = 0; j < 3; ++j) {
+      const int cc = min(c0 + j, C - 1);  // clamped duplicate loads are ignored below
+      const double* r = rec + ((size_t)cc * nfb + blockIdx.x) * (MCBA_REC * 64) + 72 * 64 + threadIdx.x;
 #pragma unroll
-      for (int k = 0; k < 21; ++k) V[k] += t[k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) gf[k] += t[21 + k];
+      for (int k = 0; k < 27; ++k) t[j][k] = r[k * 64];
     }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (c0 + j < C) {
+#pragma unroll
+        for (int k = 0; k < 21; ++k) V[k] += t[j][k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gf[k] += t[j][21 + k];
+      }
+    }
+  }
+  if (f < F) {
     double D[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -340,124 +351,137 @@ __global__ __launch_bounds__(256) void k_frame_factor(const double* __restrict__
     for (int k = 0; k < 40; k += 2) *reinterpret_cast<double2*>(fbp + k) = make_double2(o[k], o[k + 1]);
     nfail = ok ? 0.0 : 1.0;
   }
-  __shared__ double s_m[4], s_n[4];
-  double wm = wave_max(gmax), wn = wave_sum(nfail);
-  if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = wm; s_n[threadIdx.x >> 6] = wn; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    fpart[2 * blockIdx.x] = fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]));
-    fpart[2 * blockIdx.x + 1] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
-  }
+  double wm = wave_max(gmax), wn = wave_sum63(nfail);
+  if (threadIdx.x == 63) { fpart[2 * blockIdx.x] = wm; fpart[2 * blockIdx.x + 1] = wn; }
 }
 
-// ---------------------------------------------------------------- k_syrk:  partial  sum_f Y_f Y_f^T  and  sum_f Y_f z_f,  Y_f = W_f L_f^-T
-// grid (G, npg), block 256.  Per batch of B frames: W rows (12C x 6 per frame) are copied from the linearisation
-// records into LDS together with L, 1/diag(L) and z of each frame; every thread then forward-substitutes a few rows
-// in place (Y = W L^-T never touches HBM); thread t < 252 owns a 3x4 tile of one 12x12 block pair (ci <= cj):
-// 21 block pairs per workgroup, 12 tiles per pair.
-__global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ rec, const double* __restrict__ fbuf, const int* __restrict__ pair_ci, const int* __restrict__ pair_cj,
-                                              double* __restrict__ spart, double* __restrict__ rpart, int C, int F, int Fpad, int npairs, int fpc, int B) {
-  extern __shared__ __align__(16) double s_y[];  // [B][n*6] Y, then [B][34]: L(21) 1/diag(6) z(6) pad
-  const int n = 12 * C, n6 = n * 6;
-  double* s_f = s_y + (size_t)B * n6;
-  const int t = threadIdx.x;
-  const int q = blockIdx.y * 21 + t / 12;
-  const bool active = (t < 252) && (q < npairs);
-  int ra = 0, rb = 0;
-  if (active) {
-    int tt = t % 12;
-    ra = pair_ci[q] * 12 + 3 * (tt / 3);
-    rb = pair_cj[q] * 12 + 4 * (tt % 3);
+// ---------------------------------------------------------------- k_syrk:  partial  sum_f Yx_f Yx_f^T  on the FP64 matrix cores
+// The Schur reduction  S = U - sum_f Y_f Y_f^T,  rhs = sum_f Y_f z_f - g_c  is a genuine GEMM (K = 6 F), so it runs
+// on v_mfma_f64_16x16x4_f64.  Yx_f = [Y_f ; z_f^T] is (12C+1) x 6: with z as an extra ROW the right-hand side is
+// column 12C of the same product.  Rows are padded to NT*16.
+// grid (G, ceil(NP / (4*PPW))), block 256 = 4 wavefronts.  Per stage of FS frames:
+//   1. (prefetched) L_f, z_f -> LDS, 1/diag(L);
+//   2. every thread forward-substitutes its IPT (row, frame) items from PREFETCHED registers: y = L_f^-1 w, written
+//      to LDS as s_y[row][frame*6 + k]  (row stride 6 FS + 2 doubles: conflict-free ds_read_b64 for the MFMA operands);
+//   3. the loads of the NEXT stage (W rows from the wave tiles, 6 coalesced loads per item, and L/z) are issued,
+//      then wavefront w accumulates its PPW output tiles (pair q = w + 4k): per K-step of 4 the A operand of tile
+//      row ti is one ds_read_b64 per lane (lane l <- s_y[16 ti + (l & 15)][4 ks + (l >> 4)]); B is the same pattern
+//      of tile row tj (B = Y^T).  The global-load latency hides under the matrix-core phase.
+// Partials: spart[g][q][reg 0..3][lane]  (C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg).
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+template <int PPW, int IPT>
+__global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ rec, const double* __restrict__ fbuf, const int* __restrict__ tile_i, const int* __restrict__ tile_j,
+                                              double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int fpc, int FS) {
+  extern __shared__ __align__(16) double lds[];
+  const int n = 12 * C, nfb = Fpad >> 6;
+  const int RS = 6 * FS + 2;
+  double* s_y = lds;                          // [NT*16][RS]
+  double* s_L = lds + (size_t)NT * 16 * RS;   // [FS][34]: L(21) 1/diag(6) z(6) pad
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: keeps the tile bookkeeping out of the exec mask
+  const int nitems = (n + 1) * FS;
+
+  int qi[PPW], rowa[PPW], rowb[PPW];
+  mfma_d4 acc[PPW];
+#pragma unroll
+  for (int k = 0; k < PPW; ++k) {
+    int q = blockIdx.y * (4 * PPW) + wave + 4 * k;
+    qi[k] = q < NP ? q : -1;  // a missing pair still multiplies tile (0,0) -- branch-free MFMA loop -- but is never stored
+    int ti = q < NP ? tile_i[q] : 0, tj = q < NP ? tile_j[q] : 0;
+    rowa[k] = (16 * ti + (lane & 15)) * RS + (lane >> 4);
+    rowb[k] = (16 * tj + (lane & 15)) * RS + (lane >> 4);
+    acc[k] = mfma_d4{0.0, 0.0, 0.0, 0.0};
   }
-  double acc[3][4];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc[r][s] = 0.0;
-  double racc[2] = {0.0, 0.0};  // rhs rows t, t+256 (blockIdx.y == 0 only)
+  for (int i = t; i < (NT * 16 - (n + 1)) * RS; i += 256) s_y[(size_t)(n + 1) * RS + i] = 0.0;  // padding rows stay zero
+
   const int f0 = blockIdx.x * fpc, f1 = min(F, f0 + fpc);
-  for (int fb = f0; fb < f1; fb += B) {
-    const int nb = min(B, f1 - fb);
-    // gather W of nb consecutive frames out of the wave tiles: for one (camera, element) the nb frames are
-    // contiguous doubles, so consecutive threads (b fastest) read contiguous 8*nb-byte runs
-    const int nfb = Fpad >> 6;
-    for (int i = t; i < nb * C * 72; i += 256) {
-      int b = i % nb, ce = i / nb, c = ce / 72, e = ce - c * 72;
-      int f = fb + b;
-      s_y[(size_t)b * n6 + c * 72 + e] = rec[((size_t)c * nfb + (f >> 6)) * (MCBA_REC * 64) + e * 64 + (f & 63)];
-    }
-    for (int i = t; i < nb * 27; i += 256) {
-      int b = i / 27, k = i - b * 27;
-      s_f[b * 34 + (k < 21 ? k : k + 6)] = fbuf[(size_t)(fb + b) * MCBA_FB + k];  // L -> [0,21), z -> [27,33)
-    }
-    __syncthreads();
-    if (t < nb * 6) {
-      int b = t / 6, k = t - b * 6;
-      s_f[b * 34 + 21 + k] = 1.0 / s_f[b * 34 + k * (k + 1) / 2 + k];
-    }
-    __syncthreads();
-    for (int i = t; i < nb * n; i += 256) {  // Y rows in place: L y = w
-      int b = i / n;
-      double* w = s_y + (size_t)i * 6;
-      const double* Lp = s_f + b * 34;
-      double wr[6], yr[6];
+  double wreg[IPT][6];
+  double lreg[2];  // FS*27 <= 512 values of (L, z) per stage, two per thread
+
+  auto prefetch = [&](int fb) {  // issue every global load of one stage; nothing waits here
 #pragma unroll
-      for (int k = 0; k < 6; k += 2) { double2 v = *reinterpret_cast<const double2*>(w + k); wr[k] = v.x; wr[k + 1] = v.y; }
-      fwd6(Lp, Lp + 21, wr, yr);
+    for (int it = 0; it < IPT; ++it) {
+      int i = t + 256 * it;
+      int row = i / FS, b = i - row * FS, f = fb + b;
+      if (i < nitems && row < n) {
+        int c = row / 12, lr = row - 12 * c;
+        const double* w = rec + ((size_t)c * nfb + (f >> 6)) * (MCBA_REC * 64) + (size_t)(6 * lr) * 64 + (f & 63);
 #pragma unroll
-      for (int k = 0; k < 6; k += 2) *reinterpret_cast<double2*>(w + k) = make_double2(yr[k], yr[k + 1]);
-    }
-    __syncthreads();
-    if (active) {
-      for (int b = 0; b < nb; ++b) {
-        const double* ya = s_y + (size_t)b * n6 + ra * 6;
-        const double* yb = s_y + (size_t)b * n6 + rb * 6;
-        double a[3][6], bb[4][6];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int k = 0; k < 6; k += 2) { double2 v = *reinterpret_cast<const double2*>(ya + 6 * r + k); a[r][k] = v.x; a[r][k + 1] = v.y; }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int k = 0; k < 6; k += 2) { double2 v = *reinterpret_cast<const double2*>(yb + 6 * s + k); bb[s][k] = v.x; bb[s][k + 1] = v.y; }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc[r][s] += a[r][k] * bb[s][k];
+        for (int k = 0; k < 6; ++k) wreg[it][k] = w[k * 64];
       }
     }
-    if (blockIdx.y == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int row = t + 256 * j;
+    for (int j = 0; j < 2; ++j) {
+      int i = t + 256 * j;
+      int b = i / 27, k = i - b * 27, f = fb + b;
+      lreg[j] = (i < FS * 27 && f < F) ? fbuf[(size_t)f * MCBA_FB + k] : 0.0;
+    }
+  };
+
+  prefetch(f0);
+  for (int fb = f0; fb < f1; fb += FS) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int i = t + 256 * j;
+      if (i < FS * 27) {
+        int b = i / 27, k = i - b * 27;
+        s_L[b * 34 + (k < 21 ? k : k + 6)] = lreg[j];  // L -> [0,21), z -> [27,33)
+      }
+    }
+    __syncthreads();
+    if (t < FS * 6) {
+      int b = t / 6, k = t - b * 6;
+      double d = s_L[b * 34 + k * (k + 1) / 2 + k];
+      s_L[b * 34 + 21 + k] = d != 0.0 ? 1.0 / d : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+      int i = t + 256 * it;
+      if (i < nitems) {
+        int row = i / FS, b = i - row * FS;
+        double* dst = s_y + (size_t)row * RS + b * 6;
+        const double* Lp = s_L + b * 34;
         if (row < n) {
-          for (int b = 0; b < nb; ++b) {
-            const double* yr = s_y + (size_t)b * n6 + row * 6;
-            const double* z = s_f + b * 34 + 27;
+          double yr[6];
+          fwd6(Lp, Lp + 21, wreg[it], yr);
+          bool live = fb + b < F;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) racc[j] += yr[k] * z[k];
-          }
+          for (int k = 0; k < 6; ++k) dst[k] = live ? yr[k] : 0.0;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) dst[k] = Lp[27 + k];  // z_f (zero for padding frames)
         }
       }
     }
     __syncthreads();
+    if (fb + FS < f1) prefetch(fb + FS);  // flies while the matrix cores work
+    // matrix-core phase: K = 6 FS in steps of 4 (6 FS / 4 is even for every FS we use).  Operands of step ks+1 are
+    // read from LDS while the PPW independent MFMAs of step ks issue back to back (64 cycles each on one SIMD).
+    const int nks = (6 * FS) / 4;
+    double a0[PPW], b0[PPW], a1[PPW], b1[PPW];
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) { a0[k] = s_y[rowa[k]]; b0[k] = s_y[rowb[k]]; }
+    for (int ks = 0; ks < nks; ks += 2) {
+#pragma unroll
+      for (int k = 0; k < PPW; ++k) { a1[k] = s_y[rowa[k] + 4 * ks + 4]; b1[k] = s_y[rowb[k] + 4 * ks + 4]; }
+#pragma unroll
+      for (int k = 0; k < PPW; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], b0[k], acc[k], 0, 0, 0);
+      if (ks + 2 < nks) {
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) { a0[k] = s_y[rowa[k] + 4 * ks + 8]; b0[k] = s_y[rowb[k] + 4 * ks + 8]; }
+      }
+#pragma unroll
+      for (int k = 0; k < PPW; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[k], b1[k], acc[k], 0, 0, 0);
+    }
+    __syncthreads();
   }
-  if (active) {
-    int tt = t % 12;
-    double* o = spart + ((size_t)blockIdx.x * npairs + q) * 144 + (3 * (tt / 3)) * 12 + 4 * (tt % 3);
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int s = 0; s < 4; s += 2) *reinterpret_cast<double2*>(o + 12 * r + s) = make_double2(acc[r][s], acc[r][s + 1]);
-  }
-  if (blockIdx.y == 0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int row = t + 256 * j;
-      if (row < n) rpart[(size_t)blockIdx.x * n + row] = racc[j];
+  for (int k = 0; k < PPW; ++k) {
+    if (qi[k] >= 0) {
+      double* o = spart + ((size_t)blockIdx.x * NP + qi[k]) * 256 + lane;
+      o[0] = acc[k][0]; o[64] = acc[k][1]; o[128] = acc[k][2]; o[192] = acc[k][3];
     }
   }
 }
@@ -490,13 +514,22 @@ __device__ __forceinline__ double strided_max16(const double* __restrict__ p, si
   return s;
 }
 
-__global__ __launch_bounds__(256) void k_reduce_system(const double* __restrict__ gpart, const double* __restrict__ spart, const double* __restrict__ rpart, const double* __restrict__ fpart,
-                                                       double* __restrict__ red, int C, int nfb, int G, int npairs, int nfblocks, int rank_slot) {
+__device__ __forceinline__ size_t spart_index(int row, int col, int NT) {
+  // element (row, col) of sum Yx Yx^T inside partial g = 0: tiles are stored for ti <= tj only (symmetric)
+  int ti = row >> 4, tj = col >> 4, r = row & 15, c = col & 15;
+  if (ti > tj) { int x = ti; ti = tj; tj = x; x = r; r = c; c = x; }
+  int q = ti * NT - (ti * (ti - 1)) / 2 + (tj - ti);
+  return ((size_t)q * 4 + (r >> 2)) * 64 + c + 16 * (r & 3);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_system(const double* __restrict__ gpart, const double* __restrict__ spart, const double* __restrict__ fpart,
+                                                       double* __restrict__ red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot) {
   const int n = 12 * C;
   const int nsys = n * n + 3 * n + 16;
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int l = threadIdx.x & 15;
   if (i >= nsys) return;  // whole 16-lane groups leave together
+  const size_t gstride = (size_t)NP * 256;
   double out;
   if (i < n * n) {
     int row = i / n, col = i % n;
@@ -506,17 +539,14 @@ __global__ __launch_bounds__(256) void k_reduce_system(const double* __restrict_
       int a = li <= lj ? li : lj, b = li <= lj ? lj : li;
       s = strided_sum16(gpart + (size_t)ci * nfb * MCBA_GP + tri12(a, b), MCBA_GP, nfb, l);
     }
-    int pa = ci <= cj ? ci : cj, pb = ci <= cj ? cj : ci;
-    int q = pa * C - (pa * (pa - 1)) / 2 + (pb - pa);
-    int loc = ci <= cj ? li * 12 + lj : lj * 12 + li;
-    double y = strided_sum16(spart + (size_t)q * 144 + loc, (size_t)npairs * 144, G, l);
+    double y = strided_sum16(spart + spart_index(row, col, NT), gstride, G, l);
     out = s - y;
   } else {
     int j = i - n * n;
-    if (j < n) {  // rhs = sum Y z - g_c
+    if (j < n) {  // rhs = sum Y z - g_c   (z is row n of Yx)
       int c = j / 12, lc = j % 12;
       double s = strided_sum16(gpart + (size_t)c * nfb * MCBA_GP + 78 + lc, MCBA_GP, nfb, l);
-      double y = strided_sum16(rpart + j, (size_t)n, G, l);
+      double y = strided_sum16(spart + spart_index(j, n, NT), gstride, G, l);
       out = y - s;
     } else if (j < 2 * n) {  // diag U
       int jj = j - n, c = jj / 12, lc = jj % 12;
@@ -583,21 +613,30 @@ __global__ __launch_bounds__(64) void k_backsub(const double* __restrict__ rec, 
   if (threadIdx.x == 63) { bpart[3 * blockIdx.x] = a; bpart[3 * blockIdx.x + 1] = b; bpart[3 * blockIdx.x + 2] = cc; }
 }
 
-// trial scalars: [cost, pred_f, dn2_f, xn2_f, n_residuals, 0, 0, 0].  One block of 512 threads:
-// wavefront w produces scalar w; its 64 lanes stride over the partials, then a fixed xor tree.
-__global__ __launch_bounds__(512) void k_sum_trial(const double* __restrict__ cpart, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out) {
+// trial scalars: [cost, pred_f, dn2_f, xn2_f, n_residuals, 0, 0, 0].  One block of 512 threads: wavefront w
+// produces scalar w; its lanes stride over the partials with 8 loads in flight each, then a fixed DPP tree.
+// Cost partials come either from k_cost (stride 2: cost, n_residuals) or from k_gram's per-wave sums
+// (stride MCBA_GP, entries 90 / 91) when the trial point was linearised speculatively.
+__global__ __launch_bounds__(512) void k_sum_trial(const double* __restrict__ cpart, int cstride, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out) {
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const double* p = nullptr;
   int stride = 1, count = 0;
-  if (w == 0) { p = cpart; stride = 2; count = ncp; }
+  if (w == 0) { p = cpart; stride = cstride; count = ncp; }
   else if (w >= 1 && w <= 3 && bpart) { p = bpart + (w - 1); stride = 3; count = nbp; }
-  else if (w == 4) { p = cpart + 1; stride = 2; count = ncp; }
-  double s0 = 0.0, s1 = 0.0;
-  int k = l;
-  for (; k + 64 < count; k += 128) { s0 += p[(size_t)k * stride]; s1 += p[(size_t)(k + 64) * stride]; }
-  if (k < count) s0 += p[(size_t)k * stride];
-  double s = wave_sum(s0 + s1);
-  if (l == 0) out[w] = s;
+  else if (w == 4) { p = cpart + 1; stride = cstride; count = ncp; }
+  double s = 0.0;
+  for (int base = 0; base < count; base += 512) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int idx = base + l + 64 * k;
+      v[k] = idx < count ? p[(size_t)idx * stride] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+  }
+  s = wave_sum63(s);
+  if (l == 63) out[w] = s;
 }
 
 // ---------------------------------------------------------------- k_jacobian: materialised residual Jacobian blocks
@@ -704,27 +743,39 @@ void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, 
   }
 }
 
+size_t syrk_lds_bytes(int C, int FS) {
+  int NT = (12 * C + 1 + 15) / 16;
+  return ((size_t)NT * 16 * (6 * FS + 2) + (size_t)FS * 34) * sizeof(double);
+}
+
+#define SYRK_IPT 5  // (12C+1)*FS <= 256*SYRK_IPT is guaranteed by the choice of FS in mcba_create
+
 void launch_frame_factor(hipStream_t st, const double* rec, double* fbuf, double* fpart, int C, int F, int Fpad, double lambda) {
-  k_frame_factor<<<dim3((F + 255) / 256), dim3(256), 0, st>>>(rec, fbuf, fpart, C, F, Fpad, lambda);
+  k_frame_factor<<<dim3(Fpad / 64), dim3(64), 0, st>>>(rec, fbuf, fpart, C, F, Fpad, lambda);
 }
 
-void launch_syrk(hipStream_t st, const double* rec, const double* fbuf, const int* pair_ci, const int* pair_cj, double* spart, double* rpart, int C, int F, int Fpad, int npairs, int G, int fpc, int B) {
-  int npg = (npairs + 20) / 21;
-  size_t lds = (size_t)B * (12 * C * 6 + 34) * sizeof(double);
-  k_syrk<<<dim3(G, npg), dim3(256), lds, st>>>(rec, fbuf, pair_ci, pair_cj, spart, rpart, C, F, Fpad, npairs, fpc, B);
+void launch_syrk(hipStream_t st, const double* rec, const double* fbuf, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw) {
+  size_t lds = syrk_lds_bytes(C, FS);
+  if (ppw <= 4) {
+    k_syrk<4, SYRK_IPT><<<dim3(G, (NP + 15) / 16), dim3(256), lds, st>>>(rec, fbuf, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);
+  } else {
+    k_syrk<16, SYRK_IPT><<<dim3(G, (NP + 63) / 64), dim3(256), lds, st>>>(rec, fbuf, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);
+  }
 }
 
-void launch_reduce_system(hipStream_t st, const double* gpart, const double* spart, const double* rpart, const double* fpart, double* red, int C, int nfb, int G, int npairs, int nfblocks, int rank_slot) {
+int syrk_items_per_thread() { return SYRK_IPT; }
+
+void launch_reduce_system(hipStream_t st, const double* gpart, const double* spart, const double* fpart, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot) {
   int n = 12 * C, nsys = n * n + 3 * n + 16;
-  k_reduce_system<<<dim3((nsys * 16 + 255) / 256), dim3(256), 0, st>>>(gpart, spart, rpart, fpart, red, C, nfb, G, npairs, nfblocks, rank_slot);
+  k_reduce_system<<<dim3((nsys * 16 + 255) / 256), dim3(256), 0, st>>>(gpart, spart, fpart, red, C, nfb, G, NT, NP, nfblocks, rank_slot);
 }
 
 void launch_backsub(hipStream_t st, const double* rec, const double* fbuf, const double* dc, const double* xs, double* xd, double* bpart, int C, int F, int Fpad, double lambda) {
   k_backsub<<<dim3(Fpad / 64), dim3(64), 0, st>>>(rec, fbuf, dc, xs, xd, bpart, C, F, Fpad, lambda);
 }
 
-void launch_sum_trial(hipStream_t st, const double* cpart, int ncp, const double* bpart, int nbp, double* out) {
-  k_sum_trial<<<dim3(1), dim3(512), 0, st>>>(cpart, ncp, bpart, nbp, out);
+void launch_sum_trial(hipStream_t st, const double* cpart, int cstride, int ncp, const double* bpart, int nbp, double* out) {
+  k_sum_trial<<<dim3(1), dim3(512), 0, st>>>(cpart, cstride, ncp, bpart, nbp, out);
 }
 
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust) {
@@ -733,7 +784,9 @@ void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs
 }
 
 int syrk_set_lds_limit(size_t bytes) {
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  int a = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk<4, SYRK_IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  int b = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk<16, SYRK_IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return a ? a : b;
 }
 
 }  // namespace mcba

@@ -39,6 +39,8 @@ SYMBOLS = [
     ("mcba_bind_reduce_buffer", ctypes.c_int, [_h, ctypes.c_void_p]),
     ("mcba_get_reduced", ctypes.c_int, [_h, _dp]),
     ("mcba_step", ctypes.c_int, [_h, _dp, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
+    ("mcba_step_linearize", ctypes.c_int, [_h, _dp, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
+    ("mcba_accept_linearization", ctypes.c_int, [_h]),
     ("mcba_get_trial", ctypes.c_int, [_h, _dp]),
     ("mcba_get_frame_gradient", ctypes.c_int, [_h, _dp]),
     ("mcba_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
@@ -187,6 +189,14 @@ class Problem:
     def step(self, delta_cam, lam, src, dst):
         d = _f64(delta_cam)
         self._chk(self.lib.mcba_step(self.handle, _p(d), float(lam), src, dst))
+
+    def step_linearize(self, delta_cam, lam, src, dst):
+        """Back-substitute, then linearise x[dst] speculatively (its cost becomes trial scalar 0)."""
+        d = _f64(delta_cam)
+        self._chk(self.lib.mcba_step_linearize(self.handle, _p(d), float(lam), src, dst))
+
+    def accept_linearization(self):
+        self._chk(self.lib.mcba_accept_linearization(self.handle))
 
     def get_trial(self):
         self._chk(self.lib.mcba_get_trial(self.handle, _p(self._trial)))

@@ -85,7 +85,7 @@ class LevenbergMarquardt:
     One `iterate()` = one LM iteration: (re)build the reduced system for the current damping, solve it on the
     host, back-substitute, evaluate the trial cost, accept or reject, and re-linearise at the accepted point."""
 
-    def __init__(self, problem, comm=None, free_cam_mask=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, lam0=1e-4, lam_min=1e-12, lam_max=1e12):
+    def __init__(self, problem, comm=None, free_cam_mask=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, lam0=1e-4, lam_min=1e-12, lam_max=1e12, speculative=True):
         self.p = problem
         self.comm = comm or SingleProcess()
         n = problem.n
@@ -93,6 +93,9 @@ class LevenbergMarquardt:
         self.all_free = bool(self.free.all())
         self.ftol, self.xtol, self.gtol = ftol, xtol, gtol
         self.lam0, self.lam_min, self.lam_max = float(lam0), lam_min, lam_max
+        # speculative: every trial point is linearised right away (k_gram also yields its cost), so an accepted
+        # step needs one pass over the observations instead of two; a rejected step wastes the extra arithmetic.
+        self.speculative = bool(speculative)
 
     # ------------------------------------------------------------------ set-up
     def start(self, x0):
@@ -127,7 +130,8 @@ class LevenbergMarquardt:
     # ------------------------------------------------------------------ one iteration
     def iterate(self, always_linearize=False):
         """Returns None to continue or a scipy-style status (1 gtol, 2 ftol, 3 xtol, 4 both).
-        always_linearize: re-linearise even after a rejected step (bench: identical work every step)."""
+        always_linearize: (non-speculative mode) re-linearise even after a rejected step, so that every step
+        does identical work; in speculative mode every step linearises its trial point anyway."""
         p, red = self.p, self.red
         self.steps += 1
         if self.g_inf < self.gtol:
@@ -148,7 +152,11 @@ class LevenbergMarquardt:
         status = None
         accepted = False
         if dc is not None:
-            p.step(dc, lam, self.cur, 1 - self.cur)
+            if self.speculative:
+                p.step_linearize(dc, lam, self.cur, 1 - self.cur)
+                self.njev += 1
+            else:
+                p.step(dc, lam, self.cur, 1 - self.cur)
             self.comm.all_reduce_trial(p)
             t = p.get_trial()
             self.nfev += 1
@@ -177,7 +185,9 @@ class LevenbergMarquardt:
             self.nu *= 2
             if self.lam >= self.lam_max and status is None:
                 status = 3
-        if accepted or always_linearize:
+        if accepted and self.speculative:
+            p.accept_linearization()
+        elif accepted or (always_linearize and not self.speculative):
             p.linearize(self.cur)
             self.njev += 1
         self._refresh_system()
@@ -193,10 +203,10 @@ class LevenbergMarquardt:
         )
 
 
-def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=1e-4, max_iterations=None):
+def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=1e-4, max_iterations=None, speculative=True):
     """Minimise the robust reprojection cost from x0 (this shard's flat vector, a7 layout of SURVEY.md).
     `fun` / `jac` / `grad` of the OptimizeResult are attached by api.bundle_adjust."""
-    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0)
+    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative)
     if max_nfev is None:
         max_nfev = 100 * np.size(x0)  # trf.py:437-438
     lm.start(x0)

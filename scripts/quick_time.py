@@ -22,7 +22,7 @@ for mode in modes:
         prob.build_reduced(1e-3)
         red = prob.get_reduced()
         dc = np.linalg.solve(red["S0"] + 1e-3 * np.diag(red["diagU"]), red["rhs"])
-        prob.step(dc, 1e-3, 0, 1)
+        prob.step_linearize(dc, 1e-3, 0, 1)
         t = prob.get_trial()
         if it == 1:
             prob.profile_read()

@@ -75,6 +75,14 @@ class OracleProblem:
         t[3] = np.sum(xs[self.n :] ** 2)
         t[4] = f.size
 
+    def step_linearize(self, dc, lam, src, dst):
+        self.step(dc, lam, src, dst)
+        self.calls["linearize"] += 1
+        self.lin_trial = orc.normal_equations(self.x[dst], self.uvs, self.obj, self.loss, self.f_scale)
+
+    def accept_linearization(self):
+        self.lin = self.lin_trial
+
     def get_trial(self):
         return self._red[self.nsys :].copy()
 
