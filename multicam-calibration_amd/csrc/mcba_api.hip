@@ -39,7 +39,7 @@ struct mcba_handle {
   double *jac = nullptr, *res = nullptr;
   int *tile_i = nullptr, *tile_j = nullptr;
   int NT = 0, NP = 0, G = 0, fpc = 0, FS = 0, ppw = 4, nfblocks = 0, nbblocks = 0, nch = 1;
-  int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD
+  int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD (few frames)
   size_t nx = 0, nsys = 0;
   double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
   // profiling
@@ -136,7 +136,10 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   }
   h->nfblocks = h->Fpad / 64;
   h->nbblocks = h->Fpad / 64;
-  if (const char* e = getenv("MCBA_GRAM_SPLIT")) h->gram_split = atoi(e) != 0;  // tuning knob, see DESIGN.md
+  // fused k_gram needs >= ~1 wavefront per SIMD (1024) to fill the chip; with fewer (camera, frame-block) pairs the
+  // split-role variant doubles the number of wavefronts.  MCBA_GRAM_SPLIT=0/1 overrides (tuning knob).
+  h->gram_split = C * h->nfb < 768;
+  if (const char* e = getenv("MCBA_GRAM_SPLIT")) h->gram_split = atoi(e) != 0;
   // k_cost: split the board points so that ~4 waves per SIMD (1024 SIMDs) are in flight
   h->nch = std::max(1, std::min(std::min(8, N / 8), (4096 + C * h->nfb - 1) / (C * h->nfb)));
   int rc;

@@ -14,6 +14,7 @@
 //   k_jacobian          one wavefront per (camera, frame), one lane per board point; rows transposed through
 //                       LDS so the 288 B/observation Jacobian blocks leave as coalesced 16 B/lane stores.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "mcba_math.h"
 #include "mcba_kernels.h"
@@ -120,28 +121,49 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
   if (DO_B) gram_zero(gb);
   double cost = 0.0;
   bool any = false;
+  // Observation loads run PF points ahead of their use; the ring is indexed statically by unrolling the loop PF times.
+  // (Measured: depth 1, 2 and 4 perform the same -- the loop is FP64-issue bound, not latency bound.)
+  constexpr int PF = 2;
   const double2* op = obs_t + (size_t)c * N * Fpad + f;
-  double2 o_next = op[0];
-  double xn0 = obj[0], xn1 = obj[1], xn2 = obj[2];  // wave-uniform (scalar) loads, prefetched one point ahead
-  for (int p = 0; p < N; ++p) {
-    double2 o2 = o_next;
-    double Xo[3] = {xn0, xn1, xn2};
-    if (p + 1 < N) {
-      o_next = op[(size_t)(p + 1) * Fpad];
-      xn0 = obj[3 * p + 3]; xn1 = obj[3 * p + 4]; xn2 = obj[3 * p + 5];
-    }
+  double2 ring[PF];
+#pragma unroll
+  for (int j = 0; j < PF; ++j) ring[j] = op[(size_t)min(j, N - 1) * Fpad];
+  auto point = [&](double2 o2, int p) {
+    double Xo[3] = {obj[3 * p], obj[3 * p + 1], obj[3 * p + 2]};  // wave-uniform scalar loads
     bool vu = is_num(o2.x), vv = is_num(o2.y);
     if (vu || vv) {
       any = true;
-      ObsRows o;
-      obs_rows_t<DO_B>(K, pc, Xo, o);
+      ObsCommon q;
+      obs_common(K, pc, Xo, q);
       double wu2, wv2, gu, gv;
-      obs_weights<LOSS>(o2.x - o.up, vu, fs2, ifs2, cost, wu2, gu);
-      obs_weights<LOSS>(o2.y - o.vp, vv, fs2, ifs2, cost, wv2, gv);
-      if (DO_A) gram_add(ga, o, wu2, wv2, gu, gv);
-      if (DO_B) gram_add(gb, o, wu2, wv2, gu, gv);
+      obs_weights<LOSS>(o2.x - q.up, vu, fs2, ifs2, cost, wu2, gu);
+      obs_weights<LOSS>(o2.y - q.vp, vv, fs2, ifs2, cost, wv2, gv);
+      {  // u row, completely, before the v row exists: one [A|P] row live at a time
+        double E[6];
+        obs_row<0>(pc, Xo, q, E);
+        if (DO_A) gram_add_row<0>(ga, E, wu2, gu);
+        if (DO_B) { double l4 = q.fa * q.s; gram_add_row<0>(gb, E, wu2, gu, q.a * q.d, l4, l4 * q.s); }
+      }
+      {
+        double E[6];
+        obs_row<1>(pc, Xo, q, E);
+        if (DO_A) gram_add_row<1>(ga, E, wv2, gv);
+        if (DO_B) { double l4 = q.fb * q.s; gram_add_row<1>(gb, E, wv2, gv, q.b * q.d, l4, l4 * q.s); }
+      }
+    }
+  };
+  int p = 0;
+  for (; p + PF <= N; p += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      double2 o2 = ring[j];
+      ring[j] = op[(size_t)min(p + j + PF, N - 1) * Fpad];
+      point(o2, p + j);
     }
   }
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (p + j < N) point(ring[j], p + j);
 
   // ---- expand once per (c,f): this role's part of W, V, g_f (record) and of U, g_c (reduced over the wave)
   ChainConst ch;
@@ -154,19 +176,23 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     for (int i = 0; i < 9; ++i) Jrc[i] = uni(s_cam.Jr[i]);
     make_chain_const(Rc, Jrc, Rf, Jrf, pz + 3, ch);
   }
-  // records are wave tiles rec[camera][frame block][k = 0..99][lane]: every store below is 512 contiguous bytes
-  double* r = rec + ((size_t)c * nfb + fb) * (MCBA_REC * 64) + lane;
+  // records are wave tiles rec[camera][frame block][k/2 = 0..49][lane][2]: every store below is one 1 KiB dwordx4 row
+  double2* r2 = reinterpret_cast<double2*>(rec + ((size_t)c * nfb + fb) * (MCBA_REC * 64)) + lane;
   double* gp = gpart + ((size_t)c * nfb + fb) * MCBA_GP;
   const bool writer = lane == 63;
   if constexpr (DO_A) {
     double U[78], gc[12], W[72], V[21], gf[6];
     gram_expand(ga, ch, U, gc, W, V, gf);
+    {
 #pragma unroll
-    for (int i = 36; i < 72; ++i) r[i * 64] = W[i];
+      for (int i = 36; i < 72; i += 2) r2[(i >> 1) * 64] = make_double2(W[i], W[i + 1]);
 #pragma unroll
-    for (int i = 0; i < 21; ++i) r[(72 + i) * 64] = V[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) r[(93 + i) * 64] = gf[i];
+      for (int i = 0; i < 20; i += 2) r2[(36 + (i >> 1)) * 64] = make_double2(V[i], V[i + 1]);
+      r2[46 * 64] = make_double2(V[20], gf[0]);
+      r2[47 * 64] = make_double2(gf[1], gf[2]);
+      r2[48 * 64] = make_double2(gf[3], gf[4]);
+      r2[49 * 64] = make_double2(gf[5], 0.0);
+    }
 #pragma unroll
     for (int a = 6; a < 12; ++a)
 #pragma unroll
@@ -186,8 +212,10 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
   if constexpr (DO_B) {
     double U[78], gc[12], W[72];
     gram_expand(gb, ch, U, gc, W);
+    {
 #pragma unroll
-    for (int i = 0; i < 36; ++i) r[i * 64] = W[i];
+      for (int i = 0; i < 36; i += 2) r2[(i >> 1) * 64] = make_double2(W[i], W[i + 1]);
+    }
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -267,10 +295,11 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
   }
   double cost = 0.0, nres = 0.0;
   const double2* op = obs_t + (size_t)c * N * Fpad + f;
-  double2 o_next = op[(size_t)p0 * Fpad];
-  for (int p = p0; p < p1; ++p) {
-    double2 o2 = o_next;
-    if (p + 1 < p1) o_next = op[(size_t)(p + 1) * Fpad];
+  constexpr int PF = 4;  // loads run PF points ahead of their use (see k_gram)
+  double2 ring[PF];
+#pragma unroll
+  for (int j = 0; j < PF; ++j) ring[j] = op[(size_t)min(p0 + j, p1 - 1) * Fpad];
+  auto point = [&](double2 o2, int p) {
     bool vu = is_num(o2.x), vv = is_num(o2.y);
     double ru = 0.0, rv = 0.0;
     if (vu || vv) {
@@ -289,7 +318,19 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
       // (C,F,N,2) order of the reference's residual vector before NaN removal
       *reinterpret_cast<double2*>(res + (((size_t)c * F + f) * N + p) * 2) = make_double2(vu ? ru : 0.0, vv ? rv : 0.0);
     }
+  };
+  int p = p0;
+  for (; p + PF <= p1; p += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      double2 o2 = ring[j];
+      ring[j] = op[(size_t)min(p + j + PF, p1 - 1) * Fpad];
+      point(o2, p + j);
+    }
   }
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (p + j < p1) point(ring[j], p + j);
   double cs = wave_sum(cost), ns = wave_sum(nres);
   size_t o = 2 * (((size_t)c * nfb + fb) * nch + ch);
   if (lane == 0) { cpart[o] = cs; cpart[o + 1] = ns; }
@@ -313,9 +354,9 @@ __global__ __launch_bounds__(64) void k_frame_factor(const double* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int cc = min(c0 + j, C - 1);  // clamped duplicate loads are ignored below
-      const double* r = rec + ((size_t)cc * nfb + blockIdx.x) * (MCBA_REC * 64) + 72 * 64 + threadIdx.x;
+      const double2* r2 = reinterpret_cast<const double2*>(rec + ((size_t)cc * nfb + blockIdx.x) * (MCBA_REC * 64)) + 36 * 64 + threadIdx.x;
 #pragma unroll
-      for (int k = 0; k < 27; ++k) t[j][k] = r[k * 64];
+      for (int k = 0; k < 14; ++k) { double2 v = r2[k * 64]; t[j][2 * k] = v.x; if (2 * k + 1 < 27) t[j][2 * k + 1] = v.y; }
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -406,9 +447,9 @@ __global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ rec, co
       int row = i / FS, b = i - row * FS, f = fb + b;
       if (i < nitems && row < n) {
         int c = row / 12, lr = row - 12 * c;
-        const double* w = rec + ((size_t)c * nfb + (f >> 6)) * (MCBA_REC * 64) + (size_t)(6 * lr) * 64 + (f & 63);
+        const double2* w2 = reinterpret_cast<const double2*>(rec + ((size_t)c * nfb + (f >> 6)) * (MCBA_REC * 64)) + (size_t)(3 * lr) * 64 + (f & 63);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) wreg[it][k] = w[k * 64];
+        for (int k = 0; k < 3; ++k) { double2 v = w2[k * 64]; wreg[it][2 * k] = v.x; wreg[it][2 * k + 1] = v.y; }
       }
     }
 #pragma unroll
@@ -566,7 +607,7 @@ __global__ __launch_bounds__(256) void k_reduce_system(const double* __restrict_
 }
 
 // ---------------------------------------------------------------- k_backsub: frame steps + trial parameters
-// lane = frame.  t = g_f + W_f^T d_c with W read from the wave tiles (each load = 64 consecutive frames, 512 B),
+// lane = frame.  t = g_f + W_f^T d_c with W read from the wave tiles (each load = 64 consecutive frames, 1 KiB),
 // d_f = -(L L^T)^-1 t with the Cholesky factor k_frame_factor left in fbuf, x_dst = x_src + d.
 // Per-block partials of  sum d^T(lambda D d - g_f),  sum |d_f|^2,  sum |x_f|^2.
 __global__ __launch_bounds__(64) void k_backsub(const double* __restrict__ rec, const double* __restrict__ fbuf, const double* __restrict__ dc, const double* __restrict__ xs,
@@ -579,15 +620,15 @@ __global__ __launch_bounds__(64) void k_backsub(const double* __restrict__ rec, 
   if (f < F) {
     double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int c = 0; c < C; ++c) {
-      const double* w = rec + ((size_t)c * nfb + blockIdx.x) * (MCBA_REC * 64) + threadIdx.x;
+      const double2* w2 = reinterpret_cast<const double2*>(rec + ((size_t)c * nfb + blockIdx.x) * (MCBA_REC * 64)) + threadIdx.x;
 #pragma unroll 4
       for (int lr = 0; lr < 12; ++lr) {
         double d = dc[12 * c + lr];  // wave-uniform: scalar load
-        double v[6];
+        double2 v[3];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = w[(6 * lr + k) * 64];
+        for (int k = 0; k < 3; ++k) v[k] = w2[(3 * lr + k) * 64];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) t[k] = fma(v[k], d, t[k]);
+        for (int k = 0; k < 3; ++k) { t[2 * k] = fma(v[k].x, d, t[2 * k]); t[2 * k + 1] = fma(v[k].y, d, t[2 * k + 1]); }
       }
     }
     const double* fbp = fbuf + (size_t)f * MCBA_FB;

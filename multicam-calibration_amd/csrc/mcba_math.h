@@ -311,6 +311,42 @@ MCBA_HD void obs_rows_t(const Intr& K, const PairConst& pc, const double Xo[3], 
 }
 MCBA_HD void obs_rows(const Intr& K, const PairConst& pc, const double Xo[3], ObsRows& o) { obs_rows_t<true>(K, pc, Xo, o); }
 
+// ---- row-sequential form used by k_gram: the quantities both rows share, then ONE row (u or v) at a time, so that
+// only one 6-vector [A|P] row (plus its weighted copy) is live while the 87 accumulators are updated.
+struct ObsCommon {
+  double a, b, s, d, dp2, abdp, izx, izy, fa, fb, up, vp;
+};
+MCBA_HD void obs_common(const Intr& K, const PairConst& pc, const double Xo[3], ObsCommon& q) {
+  double x = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], fma(pc.Rcf[2], Xo[2], pc.tcf[0])));
+  double y = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], fma(pc.Rcf[5], Xo[2], pc.tcf[1])));
+  double z = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], fma(pc.Rcf[8], Xo[2], pc.tcf[2])));
+  double iz = fast_rcp(z);
+  q.a = x * iz; q.b = y * iz;
+  q.s = fma(q.a, q.a, q.b * q.b);
+  q.d = fma(q.s, fma(K.k2, q.s, K.k1), 1.0);
+  q.dp2 = 2.0 * fma(2.0 * K.k2, q.s, K.k1);
+  q.abdp = (q.a * q.b) * q.dp2;
+  q.izx = K.fx * iz; q.izy = K.fy * iz;
+  q.fa = K.fx * q.a; q.fb = K.fy * q.b;
+  q.up = fma(q.fa, q.d, K.cx);
+  q.vp = fma(q.fb, q.d, K.cy);
+}
+// ROW 0 = u, 1 = v.  E[0..2] = A row, E[3..5] = P row.
+template <int ROW>
+MCBA_HD void obs_row(const PairConst& pc, const double Xo[3], const ObsCommon& q, double E[6]) {
+  double p0, p1;
+  if (ROW == 0) { p0 = fma(q.a * q.a, q.dp2, q.d) * q.izx; p1 = q.abdp * q.izx; }
+  else { p0 = q.abdp * q.izy; p1 = fma(q.b * q.b, q.dp2, q.d) * q.izy; }
+  double p2 = -fma(p0, q.a, p1 * q.b);
+  E[3] = p0; E[4] = p1; E[5] = p2;
+  double b0 = fma(p0, pc.Rcf[0], fma(p1, pc.Rcf[3], p2 * pc.Rcf[6]));
+  double b1 = fma(p0, pc.Rcf[1], fma(p1, pc.Rcf[4], p2 * pc.Rcf[7]));
+  double b2 = fma(p0, pc.Rcf[2], fma(p1, pc.Rcf[5], p2 * pc.Rcf[8]));
+  E[0] = fma(Xo[1], b2, -(Xo[2] * b1));
+  E[1] = fma(Xo[2], b0, -(Xo[0] * b2));
+  E[2] = fma(Xo[0], b1, -(Xo[1] * b0));
+}
+
 // ---------------------------------------------------------------- local Gram accumulators of one (c,f)
 // The 12x12 Gram matrix of the local rows L = [L_I | A | P] is accumulated by TWO independent roles (two
 // wavefronts in k_gram, so each keeps its accumulators in VGPRs with room for a second wave per SIMD):
@@ -415,6 +451,50 @@ MCBA_HD void gram_add(GramB& g, const ObsRows& o, double wu2, double wv2, double
   g.hi[4] -= o.l4v * gv;
   g.hi[5] -= o.l5u * gu;
   g.hi[5] -= o.l5v * gv;
+}
+
+// One row at a time (ROW 0 = u, 1 = v): w2 = curvature weight, gr = rho' * residual of that scalar.
+template <int ROW>
+MCBA_HD void gram_add_row(GramA& g, const double E[6], double w2, double gr) {
+  double Ew[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) Ew[j] = w2 * E[j];
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) { g.ee[k] += Ew[i] * E[j]; ++k; }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) g.he[j] -= E[j] * gr;
+}
+// lf = a d (u) or b d (v);  l4 = fx a s (u) or fy b s (v);  l5 = l4 s
+template <int ROW>
+MCBA_HD void gram_add_row(GramB& g, const double E[6], double w2, double gr, double lf, double l4, double l5) {
+  double Ew[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) Ew[j] = w2 * E[j];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    g.ie[6 * ROW + j] += lf * Ew[j];
+    g.ie[12 + 6 * ROW + j] += Ew[j];
+    g.ie[24 + j] += l4 * Ew[j];
+    g.ie[30 + j] += l5 * Ew[j];
+  }
+  double wf = w2 * lf, w4 = w2 * l4, w5 = w2 * l5;
+  g.ii[4 * ROW + 0] += wf * lf;   // (0,0) | (1,1)
+  g.ii[4 * ROW + 1] += wf;        // (0,2) | (1,3)
+  g.ii[4 * ROW + 2] += wf * l4;   // (0,4) | (1,4)
+  g.ii[4 * ROW + 3] += wf * l5;   // (0,5) | (1,5)
+  g.ii[8 + 3 * ROW] += w2;        // (2,2) | (3,3)
+  g.ii[9 + 3 * ROW] += w4;        // (2,4) | (3,4)
+  g.ii[10 + 3 * ROW] += w5;       // (2,5) | (3,5)
+  g.ii[14] += w4 * l4;
+  g.ii[15] += w4 * l5;
+  g.ii[16] += w5 * l5;
+  g.hi[ROW] -= lf * gr;
+  g.hi[2 + ROW] -= gr;
+  g.hi[4] -= l4 * gr;
+  g.hi[5] -= l5 * gr;
 }
 
 // ---------------------------------------------------------------- expansion of the local Gram matrix (once per (c,f))

@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, ".")
 import multicam_calibration_amd as m
 
-for (C, F, rows, cols) in [(6, 10000, 6, 9), (6, 10000, 3, 9), (6, 10000, 12, 9), (6, 10000, 1, 2), (6, 2560, 6, 9), (6, 40000, 6, 9)]:
+for (C, F, rows, cols) in [(6, 10000, 6, 9), (6, 10000, 3, 9), (6, 10000, 1, 2), (6, 10000, 12, 9), (6, 40000, 6, 9), (6, 40000, 1, 2)]:
     p = m.synth.make_problem(C, F, rows=rows, cols=cols, seed=0)
     x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
     out = []

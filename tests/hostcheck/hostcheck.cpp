@@ -53,13 +53,17 @@ void hc_normal_eq(int C, int F, int N, const double* uvs, const double* obj, con
         const double* o2 = uvs + (((size_t)c * F + f) * N + p) * 2;
         bool vu = o2[0] == o2[0], vv = o2[1] == o2[1];
         if (!(vu || vv)) continue;
-        ObsRows o;
-        obs_rows(K, pc, obj + 3 * p, o);
-        double wu2, wv2, gu, gv;
-        weights_dyn(loss, o2[0] - o.up, vu, fs2, ifs2, ga.cost, wu2, gu);
-        weights_dyn(loss, o2[1] - o.vp, vv, fs2, ifs2, ga.cost, wv2, gv);
-        gram_add(ga, o, wu2, wv2, gu, gv);
-        gram_add(gb, o, wu2, wv2, gu, gv);
+        ObsCommon q;
+        obs_common(K, pc, obj + 3 * p, q);
+        double wu2, wv2, gu, gv, E[6];
+        weights_dyn(loss, o2[0] - q.up, vu, fs2, ifs2, ga.cost, wu2, gu);
+        weights_dyn(loss, o2[1] - q.vp, vv, fs2, ifs2, ga.cost, wv2, gv);
+        obs_row<0>(pc, obj + 3 * p, q, E);
+        gram_add_row<0>(ga, E, wu2, gu);
+        gram_add_row<0>(gb, E, wu2, gu, q.a * q.d, q.fa * q.s, q.fa * q.s * q.s);
+        obs_row<1>(pc, obj + 3 * p, q, E);
+        gram_add_row<1>(ga, E, wv2, gv);
+        gram_add_row<1>(gb, E, wv2, gv, q.b * q.d, q.fb * q.s, q.fb * q.s * q.s);
       }
       ChainConst ch;
       make_chain_const(cc.R, cc.Jr, Rf, Jrf, pose + 3, ch);
