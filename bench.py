@@ -9,12 +9,13 @@ intrinsics + distortion + extrinsics + poses, soft-L1 loss, synthetic board dete
 (multicam_calibration_amd.synth, seed 0) -- PER GPU.  Frames are the sharding axis (weak scaling:
 every rank owns 10 000 frames of one rig; the reduced camera system is all-reduced once per solve).
 
-A "step" is ONE complete Levenberg-Marquardt iteration on the rank's shard: linearise (k_gram),
-Schur-reduce (k_schur_frames, k_syrk, k_reduce_system), [all-reduce], host Cholesky of the 72x72
-reduced system, back-substitution + trial cost (k_backsub, k_cost, k_sum_trial), [all-reduce],
-accept/reject.  Every step re-linearises, also after a rejected one (never less work than a real
-iteration).  `value` = steps x n_gpus / time, i.e. LM iterations/sec in units of one 6x10kx54
-problem: at N = 1 it is exactly BASELINE's "LM iterations/sec" on config 3.
+A "step" is ONE complete Levenberg-Marquardt iteration on the rank's shard: host Cholesky of the 72x72
+reduced camera system, back-substitution (k_backsub), residuals + analytic Jacobian blocks + normal
+equations of the trial point in one pass over the observations (k_gram; its cost decides accept/reject),
+k_sum_trial, [all-reduce], Schur reduction of the accepted linearisation (k_frame_factor, k_syrk,
+k_reduce_system), [all-reduce].  Every step linearises its trial point, accepted or not (never less work
+than a real iteration).  `value` = steps x n_gpus / time, i.e. LM iterations/sec in units of one
+6x10kx54 problem: at N = 1 it is exactly BASELINE's "LM iterations/sec" on config 3.
 
 Extra objects on the same line: `roofline` (dominant kernel of the timed region, HIP-event timed on
 the launch stream), `jacobian_eval` (BASELINE's second figure: ms per materialised Jacobian-eval,

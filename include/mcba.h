@@ -114,6 +114,11 @@ int mcba_step(mcba_handle* h, const double* delta_cam, double lambda, int src_sl
 int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, int src_slot, int dst_slot);
 int mcba_accept_linearization(mcba_handle* h);
 int mcba_get_trial(mcba_handle* h, double* host8);
+/* Convenience for the single-GPU loop (one ABI crossing instead of two):
+ *   mcba_reduce_fetch     = mcba_build_reduced + mcba_get_reduced
+ *   mcba_step_fetch       = mcba_step (linearize == 0) or mcba_step_linearize (linearize != 0) + mcba_get_trial */
+int mcba_reduce_fetch(mcba_handle* h, double lambda, int rank_slot, double* host);
+int mcba_step_fetch(mcba_handle* h, const double* delta_cam, double lambda, int src_slot, int dst_slot, int linearize, double* host8);
 /* Frame part of the gradient J^T f of the last mcba_build_reduced(): (F,6) doubles, host.
  * (The camera part is the g_c block of the reduce buffer.)  Feeds OptimizeResult.grad (trf.py:557-560). */
 int mcba_get_frame_gradient(mcba_handle* h, double* host);

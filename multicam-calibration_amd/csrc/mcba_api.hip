@@ -454,6 +454,18 @@ int mcba_get_trial(mcba_handle* h, double* host8) {
   return fetch_trial(h, host8);
 }
 
+int mcba_reduce_fetch(mcba_handle* h, double lambda, int rank_slot, double* host) {
+  int rc = mcba_build_reduced(h, lambda, rank_slot);
+  if (rc) return rc;
+  return mcba_get_reduced(h, host);
+}
+
+int mcba_step_fetch(mcba_handle* h, const double* delta_cam, double lambda, int src, int dst, int linearize, double* host8) {
+  int rc = linearize ? mcba_step_linearize(h, delta_cam, lambda, src, dst) : mcba_step(h, delta_cam, lambda, src, dst);
+  if (rc) return rc;
+  return mcba_get_trial(h, host8);
+}
+
 int mcba_get_frame_gradient(mcba_handle* h, double* host) {
   if (!h || !host) return fail(MCBA_ERR_ARG, "mcba_get_frame_gradient: bad argument");
   if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_get_frame_gradient: call mcba_build_reduced first");

@@ -42,6 +42,8 @@ SYMBOLS = [
     ("mcba_step_linearize", ctypes.c_int, [_h, _dp, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
     ("mcba_accept_linearization", ctypes.c_int, [_h]),
     ("mcba_get_trial", ctypes.c_int, [_h, _dp]),
+    ("mcba_reduce_fetch", ctypes.c_int, [_h, ctypes.c_double, ctypes.c_int, _dp]),
+    ("mcba_step_fetch", ctypes.c_int, [_h, _dp, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp]),
     ("mcba_get_frame_gradient", ctypes.c_int, [_h, _dp]),
     ("mcba_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_profile_read", ctypes.c_int, [_h, _dp, _ip, ctypes.c_int, _ip]),
@@ -110,6 +112,10 @@ class Problem:
         self.nsys = self.n * self.n + 3 * self.n + 16
         self._red = np.empty(self.nsys)
         self._trial = np.empty(8)
+        self._red_p, self._trial_p = _p(self._red), _p(self._trial)
+        self._red_views = self.split_reduced(self._red)
+        self._dc = np.empty(self.n)
+        self._dc_p = _p(self._dc)
 
     def _chk(self, rc):
         if rc != OK:
@@ -185,6 +191,22 @@ class Problem:
     def split_reduced(self, r):
         n = self.n
         return dict(S0=r[: n * n].reshape(n, n), rhs=r[n * n : n * n + n], diagU=r[n * n + n : n * n + 2 * n], gc=r[n * n + 2 * n : n * n + 3 * n], scal=r[n * n + 3 * n : n * n + 3 * n + 16])
+
+    def reduce_fetch(self, lam, rank_slot=0):
+        """build_reduced + get_reduced in one ABI crossing.  The returned arrays are VIEWS of a buffer that the
+        next call overwrites (the LM driver adds its damping in place)."""
+        rc = self.lib.mcba_reduce_fetch(self.handle, lam, rank_slot, self._red_p)
+        if rc:
+            self._chk(rc)
+        return self._red_views
+
+    def step_fetch(self, delta_cam, lam, src, dst, linearize):
+        """step / step_linearize + get_trial in one ABI crossing; returns a view of the 8 trial scalars."""
+        self._dc[:] = delta_cam
+        rc = self.lib.mcba_step_fetch(self.handle, self._dc_p, lam, src, dst, 1 if linearize else 0, self._trial_p)
+        if rc:
+            self._chk(rc)
+        return self._trial
 
     def step(self, delta_cam, lam, src, dst):
         d = _f64(delta_cam)

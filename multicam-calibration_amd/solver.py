@@ -12,7 +12,7 @@ rescaling as scipy/optimize/_lsq/common.py:720-731), same termination tests and 
 only sees the (12C)^2 + 3*12C + 16 doubles of the reduced system and 8 trial scalars per step.
 """
 import numpy as np
-import scipy.linalg as sla
+from scipy.linalg import lapack
 from scipy.optimize import OptimizeResult
 
 TERMINATION_MESSAGES = {
@@ -70,13 +70,12 @@ class TorchDistributed:
 
 
 def _solve_spd(S, rhs):
-    """S symmetric positive definite -> step, or None if the Cholesky factorisation fails."""
-    try:
-        c, low = sla.cho_factor(S, lower=True, check_finite=False)
-    except (sla.LinAlgError, ValueError):
+    """S symmetric positive definite -> step, or None if the Cholesky factorisation fails.
+    LAPACK dposv straight on the buffer (S is symmetric, so its C-order memory is a valid Fortran matrix)."""
+    _, d, info = lapack.dposv(S.T, rhs, lower=0, overwrite_a=1, overwrite_b=0)
+    if info != 0 or not np.isfinite(d).all():
         return None
-    d = sla.cho_solve((c, low), rhs, check_finite=False)
-    return d if np.all(np.isfinite(d)) else None
+    return d
 
 
 class LevenbergMarquardt:
@@ -119,9 +118,12 @@ class LevenbergMarquardt:
 
     def _refresh_system(self):
         p = self.p
-        p.build_reduced(self.lam, self.comm.rank % 12)
-        self.comm.all_reduce_system(p)
-        red = p.get_reduced()
+        if self.comm.world == 1 and hasattr(p, "reduce_fetch"):
+            red = p.reduce_fetch(self.lam, 0)
+        else:
+            p.build_reduced(self.lam, self.comm.rank % 12)
+            self.comm.all_reduce_system(p)
+            red = p.get_reduced()
         self.red = red
         self.cost = float(red["scal"][0])
         gc = red["gc"]
@@ -137,15 +139,17 @@ class LevenbergMarquardt:
         if self.g_inf < self.gtol:
             return 1
         lam = self.lam
-        Dc = np.where(red["diagU"] > 0, red["diagU"], 1.0)
-        S = red["S0"] + np.diag(lam * Dc)
+        diagU = red["diagU"]
+        Dc = np.where(diagU > 0, diagU, 1.0)
+        S = red["S0"]  # damped in place: the buffer is rebuilt by the next _refresh_system anyway
+        S.flat[:: p.n + 1] += lam * Dc
         rhs = red["rhs"]
         dc = None
         if red["scal"][2] == 0:  # every frame block factorised
             if self.all_free:
                 dc = _solve_spd(S, rhs)
             else:
-                dfree = _solve_spd(S[np.ix_(self.free, self.free)], rhs[self.free])
+                dfree = _solve_spd(np.ascontiguousarray(S[np.ix_(self.free, self.free)]), rhs[self.free])
                 if dfree is not None:
                     dc = np.zeros(p.n)
                     dc[self.free] = dfree
@@ -153,12 +157,16 @@ class LevenbergMarquardt:
         accepted = False
         if dc is not None:
             if self.speculative:
-                p.step_linearize(dc, lam, self.cur, 1 - self.cur)
                 self.njev += 1
+            if self.comm.world == 1 and hasattr(p, "step_fetch"):
+                t = p.step_fetch(dc, lam, self.cur, 1 - self.cur, self.speculative)
             else:
-                p.step(dc, lam, self.cur, 1 - self.cur)
-            self.comm.all_reduce_trial(p)
-            t = p.get_trial()
+                if self.speculative:
+                    p.step_linearize(dc, lam, self.cur, 1 - self.cur)
+                else:
+                    p.step(dc, lam, self.cur, 1 - self.cur)
+                self.comm.all_reduce_trial(p)
+                t = p.get_trial()
             self.nfev += 1
             cost_new = float(t[0])
             pred = 0.5 * (float(t[1]) + float(dc @ (lam * Dc * dc - red["gc"])))
