@@ -139,7 +139,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    prob.profile_enable(True)
+    # HIP events on the launch stream bracket ONLY the dominant kernel inside the timed region (bracketing all
+    # six kernels of a step costs ~60 us of host time per step); the per-kernel table comes from an untimed pass.
+    DOMINANT = "k_gram"
+    prob.profile_enable(True, only=[DOMINANT])
     prob.profile_read()
     barrier()
     t0 = time.perf_counter()
@@ -147,7 +150,12 @@ def main():
         lm.iterate(always_linearize=True)
     barrier()
     dt = time.perf_counter() - t0
+    prof_timed = prob.profile_read()
+    prob.profile_enable(True)
+    for _ in range(min(args.steps, 50)):
+        lm.iterate(always_linearize=True)
     prof = prob.profile_read()
+    prof[DOMINANT] = prof_timed[DOMINANT]
     prob.profile_enable(False)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -168,7 +176,8 @@ def main():
 
     if rank == 0:
         kern = {k: (ms, n) for k, (ms, n) in prof.items() if n}
-        dom = max(kern, key=lambda k: kern[k][0])
+        dom = max(kern, key=lambda k: kern[k][0] / kern[k][1])
+        assert dom == DOMINANT, f"dominant kernel changed: {dom}"
         dom_ms = kern[dom][0] / kern[dom][1]
         dom_bytes = algorithmic_bytes(dom, C, F, N)
         traffic = None

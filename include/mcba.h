@@ -124,7 +124,9 @@ int mcba_step_fetch(mcba_handle* h, const double* delta_cam, double lambda, int 
 int mcba_get_frame_gradient(mcba_handle* h, double* host);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
-/* When enabled every kernel launch is bracketed by hipEvents on the handle's stream. */
+/* When enabled kernel launches are bracketed by hipEvents on the handle's stream.  `on` = 0: off; 1: every
+ * kernel; otherwise a bit mask over the kernels in mcba_profile_names() order, shifted left by one
+ * (bit k+1 selects kernel k) -- e.g. time only the dominant kernel inside a measured region. */
 int mcba_profile_enable(mcba_handle* h, int on);
 /* Drains the recorded events.  names: '\n'-separated kernel names in the order of ms[] / calls[]. */
 int mcba_profile_read(mcba_handle* h, double* ms_total, int* calls, int capacity, int* n_kernels);

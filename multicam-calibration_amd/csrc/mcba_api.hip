@@ -44,6 +44,7 @@ struct mcba_handle {
   double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
   // profiling
   bool prof = false;
+  unsigned prof_mask = ~0u;
   std::vector<EvRec> evs;
   std::vector<hipEvent_t> pool;
 };
@@ -70,11 +71,12 @@ hipEvent_t get_event(mcba_handle* h) {
 
 struct Scope {  // brackets one launch with events when profiling
   mcba_handle* h; int kid; hipEvent_t a{}, b{};
-  Scope(mcba_handle* h_, int k) : h(h_), kid(k) {
-    if (h->prof) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
+  bool on;
+  Scope(mcba_handle* h_, int k) : h(h_), kid(k), on(h_->prof && ((h_->prof_mask >> k) & 1u)) {
+    if (on) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
   }
   ~Scope() {
-    if (h->prof) { (void)hipEventRecord(b, h->stream); h->evs.push_back({kid, a, b}); }
+    if (on) { (void)hipEventRecord(b, h->stream); h->evs.push_back({kid, a, b}); }
   }
 };
 
@@ -477,6 +479,7 @@ int mcba_get_frame_gradient(mcba_handle* h, double* host) {
 int mcba_profile_enable(mcba_handle* h, int on) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
   h->prof = on != 0;
+  h->prof_mask = (on == 0 || on == 1) ? ~0u : ((unsigned)on >> 1);
   return MCBA_OK;
 }
 

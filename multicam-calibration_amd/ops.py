@@ -239,8 +239,15 @@ class Problem:
     def synchronize(self):
         self._chk(self.lib.mcba_synchronize(self.handle))
 
-    def profile_enable(self, on=True):
-        self._chk(self.lib.mcba_profile_enable(self.handle, int(on)))
+    def profile_enable(self, on=True, only=None):
+        """on=True: time every kernel; only=[names]: time just those (cheaper inside a measured region)."""
+        flag = int(bool(on))
+        if on and only:
+            names = self.lib.mcba_profile_names().decode().split("\n")
+            flag = 0
+            for k in only:
+                flag |= 1 << (names.index(k) + 1)
+        self._chk(self.lib.mcba_profile_enable(self.handle, flag))
 
     def profile_read(self):
         """{kernel name: (total ms, calls)} since the last read."""
