@@ -90,6 +90,10 @@ def cpu_baseline(sample_frames=120, max_nfev=8):
 
 
 def main():
+    # Libraries (RCCL prints a version banner) may write to stdout: keep fd 1 for the ONE JSON line only.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -109,10 +113,12 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
     comm = None
-    if world > 1:
+    force_dist = os.environ.get("MCBA_BENCH_FORCE_DIST") == "1"  # exercise the RCCL plumbing with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
         comm = m.solver.TorchDistributed()
@@ -125,7 +131,7 @@ def main():
     p = m.synth.make_problem(C, F, rows=ROWS, cols=COLS, seed=0, frame_seed=rank if world > 1 else None)
     x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
     prob = m.ops.Problem(p["uvs"], p["obj"], device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    if world > 1:
+    if comm is not None:
         prob.enable_collective(torch.device(f"cuda:{local_rank}"))
 
     lm = m.solver.LevenbergMarquardt(prob, comm, ftol=0.0, xtol=0.0, gtol=0.0)
@@ -221,7 +227,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"]["reference_measured_in_survey_container"] = {"value": 0.0098, "unit": "it/s", "ms_per_jacobian_eval": 68679, "source": "BASELINE.md section 2 (the reference itself, 6x10kx54)"}
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     prob.close()
     if dist is not None:
         dist.barrier()

@@ -118,7 +118,7 @@ class LevenbergMarquardt:
 
     def _refresh_system(self):
         p = self.p
-        if self.comm.world == 1 and hasattr(p, "reduce_fetch"):
+        if isinstance(self.comm, SingleProcess) and hasattr(p, "reduce_fetch"):
             red = p.reduce_fetch(self.lam, 0)
         else:
             p.build_reduced(self.lam, self.comm.rank % 12)
@@ -158,7 +158,7 @@ class LevenbergMarquardt:
         if dc is not None:
             if self.speculative:
                 self.njev += 1
-            if self.comm.world == 1 and hasattr(p, "step_fetch"):
+            if isinstance(self.comm, SingleProcess) and hasattr(p, "step_fetch"):
                 t = p.step_fetch(dc, lam, self.cur, 1 - self.cur, self.speculative)
             else:
                 if self.speculative:
