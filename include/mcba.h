@@ -97,7 +97,7 @@ int mcba_linearize(mcba_handle* h, int slot);
  *                         4..15 per-rank slots: max |g_f| of THIS shard goes to slot 4+rank_slot, others 0
  * so that one all-reduce(SUM) of the whole buffer over the frame shards gives the global system. */
 int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot);
-size_t mcba_reduced_size(const mcba_handle* h);          /* doubles in the reduce buffer (+ trial scalars) */
+size_t mcba_reduced_size(const mcba_handle* h);          /* doubles in the reduce buffer: system + 8 trial scalars + 16 LM state */
 /* Let the caller own the reduce buffer (device pointer, mcba_reduced_size() doubles), e.g. a torch
  * tensor handed to torch.distributed.all_reduce (RCCL).  NULL restores the internal buffer. */
 int mcba_bind_reduce_buffer(mcba_handle* h, double* device_ptr);
@@ -119,6 +119,27 @@ int mcba_get_trial(mcba_handle* h, double* host8);
  *   mcba_step_fetch       = mcba_step (linearize == 0) or mcba_step_linearize (linearize != 0) + mcba_get_trial */
 int mcba_reduce_fetch(mcba_handle* h, double lambda, int rank_slot, double* host);
 int mcba_step_fetch(mcba_handle* h, const double* delta_cam, double lambda, int src_slot, int dst_slot, int linearize, double* host8);
+/* ---- device-resident LM iteration: ONE host synchronisation per iteration ----------------------------
+ * The reduce buffer carries, behind the system (n*n+3n+16) and the 8 trial scalars, MCBA_LM_STATE = 16 doubles:
+ *   0 cost  1 lambda  2 nu  3 sel (index of the current parameter slot AND linearisation buffer)  4 accepted
+ *   5 cost_new  6 predicted reduction  7 ratio  8 step norm  9 x norm  10 actual reduction  11..15 reserved.
+ * mcba_lm_set_state uploads it (after mcba_linearize(slot = sel) + mcba_build_reduced);
+ * mcba_lm_trial            : back-substitute delta_cam from the current point, linearise the trial point
+ *                            (other slot / buffer), sum its cost  -> trial scalars;  [all-reduce them when sharded]
+ * mcba_lm_decide_reduce    : accept/reject + Nielsen damping update ON THE GPU (same rule as the host driver),
+ *                            then Schur-reduce whichever linearisation is now current with the new lambda;
+ *                            pred_cam = d_c^T(lambda D_c d_c - g_c), dcn2 = |d_c|^2, xcn2 = |x_c|^2 from the host solve;
+ *                            [all-reduce the system when sharded]
+ * mcba_lm_fetch            : D2H of system + trial scalars + state (mcba_reduced_size() doubles) and synchronise;
+ * mcba_lm_iterate          : the three above in one call (single GPU);
+ * mcba_lm_rebuild          : Schur-reduce again with the state's lambda (after the host changed it with set_state). */
+#define MCBA_LM_STATE 16
+int mcba_lm_set_state(mcba_handle* h, const double* state16);
+int mcba_lm_trial(mcba_handle* h, const double* delta_cam);
+int mcba_lm_decide_reduce(mcba_handle* h, double pred_cam, double dcn2, double xcn2, double lam_min, double lam_max, int rank_slot);
+int mcba_lm_rebuild(mcba_handle* h, int rank_slot);
+int mcba_lm_fetch(mcba_handle* h, double* host);
+int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, double dcn2, double xcn2, double lam_min, double lam_max, double* host);
 /* Frame part of the gradient J^T f of the last mcba_build_reduced(): (F,6) doubles, host.
  * (The camera part is the g_c block of the reduce buffer.)  Feeds OptimizeResult.grad (trf.py:557-560). */
 int mcba_get_frame_gradient(mcba_handle* h, double* host);

@@ -15,8 +15,8 @@ namespace {
 
 thread_local std::string g_err;
 
-enum KernelId { K_TRANSPOSE = 0, K_GRAM, K_COST, K_FRAME_FACTOR, K_SYRK, K_REDUCE, K_BACKSUB, K_SUM_TRIAL, K_JACOBIAN, K_COUNT };
-const char* kKernelNames = "k_transpose_obs\nk_gram\nk_cost\nk_frame_factor\nk_syrk\nk_reduce_system\nk_backsub\nk_sum_trial\nk_jacobian";
+enum KernelId { K_TRANSPOSE = 0, K_GRAM, K_COST, K_FRAME_FACTOR, K_SYRK, K_REDUCE, K_BACKSUB, K_SUM_TRIAL, K_JACOBIAN, K_DECIDE, K_COUNT };
+const char* kKernelNames = "k_transpose_obs\nk_gram\nk_cost\nk_frame_factor\nk_syrk\nk_reduce_system\nk_backsub\nk_sum_trial\nk_jacobian\nk_decide";
 
 struct EvRec { int kid; hipEvent_t a, b; };
 
@@ -34,7 +34,7 @@ struct mcba_handle {
   double *rec2[2] = {nullptr, nullptr}, *gpart2[2] = {nullptr, nullptr}, *fbuf = nullptr, *fpart = nullptr;
   int lin = 0;          // which of the two linearisation buffers holds the accepted point
   bool have_spec = false;  // the other one holds a speculative linearisation of the last trial point
-  double *spart = nullptr, *cpart = nullptr, *bpart = nullptr, *dc = nullptr;
+  double *spart = nullptr, *cpart = nullptr, *bpart = nullptr;
   double *red_own = nullptr, *red = nullptr;
   double *jac = nullptr, *res = nullptr;
   int *tile_i = nullptr, *tile_j = nullptr;
@@ -79,6 +79,9 @@ struct Scope {  // brackets one launch with events when profiling
     if (on) { (void)hipEventRecord(b, h->stream); h->evs.push_back({kid, a, b}); }
   }
 };
+
+mcba::Sel host_sel(int idx, double lam = 0.0) { return mcba::Sel{nullptr, idx, lam}; }
+mcba::Sel dev_sel(const mcba_handle* h, int flip) { return mcba::Sel{h->red + h->nsys + 8, flip, 0.0}; }  // LM state lives behind the trial scalars
 
 int check_launch() {
   hipError_t e = hipGetLastError();
@@ -160,8 +163,7 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   DA(spart, (size_t)h->G * h->NP * 256);
   DA(cpart, (size_t)2 * C * h->nfb * h->nch);
   DA(bpart, (size_t)3 * h->nbblocks);
-  DA(dc, (size_t)h->n);
-  DA(red_own, h->nsys + 8);
+  DA(red_own, h->nsys + 8 + MCBA_LMS);
   DA(tile_i, (size_t)h->NP);
   DA(tile_j, (size_t)h->NP);
 #undef DA
@@ -170,7 +172,7 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   for (int a = 0; a < h->NT; ++a) for (int b = a; b < h->NT; ++b) { ci.push_back(a); cj.push_back(b); }
   HIPCHK(hipMemcpy(h->tile_i, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->tile_j, cj.data(), cj.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pinned), (h->nsys + 8 + h->n) * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pinned), (h->nsys + 8 + MCBA_LMS + h->n) * sizeof(double), hipHostMallocDefault));
   size_t lds = mcba::syrk_lds_bytes(C, h->FS);
   if (lds > 64 * 1024) {
     if (mcba::syrk_set_lds_limit(lds) != 0) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_syrk"); }
@@ -183,7 +185,7 @@ int mcba_destroy(mcba_handle* h) {
   if (!h) return MCBA_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  double* bufs[] = {h->obs_t, h->obs_raw, h->obj, h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->fbuf, h->fpart, h->spart, h->cpart, h->bpart, h->dc, h->red_own, h->jac, h->res};
+  double* bufs[] = {h->obs_t, h->obs_raw, h->obj, h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->fbuf, h->fpart, h->spart, h->cpart, h->bpart, h->red_own, h->jac, h->res};
   for (double* p : bufs) if (p) (void)hipFree(p);
   if (h->tile_i) (void)hipFree(h->tile_i);
   if (h->tile_j) (void)hipFree(h->tile_j);
@@ -267,7 +269,7 @@ static int run_cost(mcba_handle* h, int slot, double* res_dev, const double* bpa
   if (rc) return rc;
   {
     Scope sc(h, K_SUM_TRIAL);
-    mcba::launch_sum_trial(h->stream, h->cpart, 2, h->C * h->nfb * h->nch, bpart, nbp, h->red + h->nsys);
+    mcba::launch_sum_trial(h->stream, host_sel(0), h->cpart, h->cpart, 2, h->C * h->nfb * h->nch, bpart, nbp, h->red + h->nsys, mcba::DecideArgs{0, 0.0, 0.0, 0.0, 0.0, 0.0, nullptr});
   }
   return check_launch();
 }
@@ -348,7 +350,7 @@ int mcba_linearize(mcba_handle* h, int slot) {
   HIPCHK(hipSetDevice(h->device));
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->rec2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split);
   }
   int rc = check_launch();
   if (rc) return rc;
@@ -365,24 +367,24 @@ int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot) {
   int rc;
   {
     Scope sc(h, K_FRAME_FACTOR);
-    mcba::launch_frame_factor(h->stream, h->rec2[h->lin], h->fbuf, h->fpart, h->C, h->F, h->Fpad, lambda);
+    mcba::launch_frame_factor(h->stream, host_sel(h->lin, lambda), h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->C, h->F, h->Fpad);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, h->rec2[h->lin], h->fbuf, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
+    mcba::launch_syrk(h->stream, host_sel(h->lin), h->rec2[0], h->rec2[1], h->fbuf, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_REDUCE);
-    mcba::launch_reduce_system(h->stream, h->gpart2[h->lin], h->spart, h->fpart, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
+    mcba::launch_reduce_system(h->stream, host_sel(h->lin), h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
   }
   if ((rc = check_launch())) return rc;
   h->have_red = true;
   return MCBA_OK;
 }
 
-size_t mcba_reduced_size(const mcba_handle* h) { return h ? h->nsys + 8 : 0; }
+size_t mcba_reduced_size(const mcba_handle* h) { return h ? h->nsys + 8 + MCBA_LMS : 0; }
 
 int mcba_bind_reduce_buffer(mcba_handle* h, double* p) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
@@ -401,12 +403,12 @@ int mcba_get_reduced(mcba_handle* h, double* host) {
 }
 
 static int step_common(mcba_handle* h, const double* delta_cam, double lambda, int src, int dst) {
-  double* stage = h->pinned + h->nsys + 8;
-  memcpy(stage, delta_cam, h->n * sizeof(double));
-  HIPCHK(hipMemcpyAsync(h->dc, stage, h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  mcba::CamStep cs;
+  memcpy(cs.v, delta_cam, h->n * sizeof(double));
   {
     Scope sc(h, K_BACKSUB);
-    mcba::launch_backsub(h->stream, h->rec2[h->lin], h->fbuf, h->dc, h->x[src], h->x[dst], h->bpart, h->C, h->F, h->Fpad, lambda);
+    // host-selected: 'current' operands are passed in position 0, the destination slot in position 1
+    mcba::launch_backsub(h->stream, host_sel(0, lambda), h->rec2[h->lin], h->rec2[h->lin], h->fbuf, cs, h->x[src], h->x[dst], h->bpart, h->C, h->F, h->Fpad);
   }
   return check_launch();
 }
@@ -430,12 +432,12 @@ int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, 
   const int alt = 1 - h->lin;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[dst], h->rec2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_SUM_TRIAL);
-    mcba::launch_sum_trial(h->stream, h->gpart2[alt] + 90, MCBA_GP, h->C * h->nfb, h->bpart, h->nbblocks, h->red + h->nsys);
+    mcba::launch_sum_trial(h->stream, host_sel(0), h->gpart2[alt] + 90, h->gpart2[alt] + 90, MCBA_GP, h->C * h->nfb, h->bpart, h->nbblocks, h->red + h->nsys, mcba::DecideArgs{0, 0.0, 0.0, 0.0, 0.0, 0.0, nullptr});
   }
   if ((rc = check_launch())) return rc;
   h->have_spec = true;
@@ -466,6 +468,117 @@ int mcba_step_fetch(mcba_handle* h, const double* delta_cam, double lambda, int 
   int rc = linearize ? mcba_step_linearize(h, delta_cam, lambda, src, dst) : mcba_step(h, delta_cam, lambda, src, dst);
   if (rc) return rc;
   return mcba_get_trial(h, host8);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Device-resident LM iteration: the accept/reject decision and the damping update happen on the GPU (k_decide), so
+// backsub -> gram(trial) -> sum -> decide -> frame_factor -> syrk -> reduce is ONE stream-ordered chain.
+// Convention while it is in use: parameter slot i and linearisation buffer i belong together; state[3] = current i.
+int mcba_lm_set_state(mcba_handle* h, const double* state16) {
+  if (!h || !state16) return fail(MCBA_ERR_ARG, "mcba_lm_set_state: bad argument");
+  int sel = (int)state16[3];
+  if (sel != 0 && sel != 1) return fail(MCBA_ERR_ARG, "mcba_lm_set_state: state[3] must be 0 or 1");
+  HIPCHK(hipSetDevice(h->device));
+  double* stage = h->pinned + h->nsys + 8;
+  memcpy(stage, state16, MCBA_LMS * sizeof(double));
+  HIPCHK(hipMemcpyAsync(h->red + h->nsys + 8, stage, MCBA_LMS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (sel != h->lin) {
+    // the accepted linearisation must live in buffer `sel`: swap the buffer pointers instead of copying 48 MB
+    std::swap(h->rec2[0], h->rec2[1]);
+    std::swap(h->gpart2[0], h->gpart2[1]);
+    h->lin = sel;
+  }
+  return MCBA_OK;
+}
+
+static int lm_trial_impl(mcba_handle* h, const double* delta_cam, const mcba::DecideArgs& da) {
+  if (!h || !delta_cam) return fail(MCBA_ERR_ARG, "mcba_lm_trial: bad argument");
+  if (!h->have_lin) return fail(MCBA_ERR_ARG, "mcba_lm_trial: no linearisation");
+  HIPCHK(hipSetDevice(h->device));
+  mcba::CamStep cs;
+  memcpy(cs.v, delta_cam, h->n * sizeof(double));
+  int rc;
+  {
+    Scope sc(h, K_BACKSUB);
+    mcba::launch_backsub(h->stream, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, cs, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad);
+  }
+  if ((rc = check_launch())) return rc;
+  {
+    Scope sc(h, K_GRAM);  // trial point = the OTHER slot / buffer
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split);
+  }
+  if ((rc = check_launch())) return rc;
+  {
+    Scope sc(h, K_SUM_TRIAL);
+    mcba::launch_sum_trial(h->stream, dev_sel(h, 1), h->gpart2[0] + 90, h->gpart2[1] + 90, MCBA_GP, h->C * h->nfb, h->bpart, h->nbblocks, h->red + h->nsys, da);
+  }
+  return check_launch();
+}
+
+int mcba_lm_trial(mcba_handle* h, const double* delta_cam) {
+  return lm_trial_impl(h, delta_cam, mcba::DecideArgs{0, 0.0, 0.0, 0.0, 0.0, 0.0, nullptr});
+}
+
+static int lm_reduce_chain(mcba_handle* h, int rank_slot) {
+  int rc;
+  {
+    Scope sc(h, K_FRAME_FACTOR);
+    mcba::launch_frame_factor(h->stream, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->C, h->F, h->Fpad);
+  }
+  if ((rc = check_launch())) return rc;
+  {
+    Scope sc(h, K_SYRK);
+    mcba::launch_syrk(h->stream, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
+  }
+  if ((rc = check_launch())) return rc;
+  {
+    Scope sc(h, K_REDUCE);
+    mcba::launch_reduce_system(h->stream, dev_sel(h, 0), h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
+  }
+  if ((rc = check_launch())) return rc;
+  h->have_red = true;
+  return MCBA_OK;
+}
+
+int mcba_lm_decide_reduce(mcba_handle* h, double pred_cam, double dcn2, double xcn2, double lam_min, double lam_max, int rank_slot) {
+  if (!h || rank_slot < 0 || rank_slot > 11) return fail(MCBA_ERR_ARG, "mcba_lm_decide_reduce: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  {
+    Scope sc(h, K_DECIDE);
+    mcba::launch_decide(h->stream, h->red + h->nsys, mcba::DecideArgs{1, pred_cam, dcn2, xcn2, lam_min, lam_max, h->red + h->nsys + 8});
+  }
+  int rc = check_launch();
+  if (rc) return rc;
+  return lm_reduce_chain(h, rank_slot);
+}
+
+int mcba_lm_rebuild(mcba_handle* h, int rank_slot) {
+  if (!h || rank_slot < 0 || rank_slot > 11) return fail(MCBA_ERR_ARG, "mcba_lm_rebuild: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  return lm_reduce_chain(h, rank_slot);
+}
+
+int mcba_lm_fetch(mcba_handle* h, double* host) {
+  if (!h || !host) return fail(MCBA_ERR_ARG, "mcba_lm_fetch: bad argument");
+  size_t cnt = h->nsys + 8 + MCBA_LMS;
+  HIPCHK(hipMemcpyAsync(h->pinned, h->red, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  memcpy(host, h->pinned, cnt * sizeof(double));
+  int sel = (int)host[h->nsys + 8 + 3];
+  if (sel == 0 || sel == 1) h->lin = sel;  // keep the host-selected entry points consistent with the device state
+  h->have_spec = false;
+  return MCBA_OK;
+}
+
+int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, double dcn2, double xcn2, double lam_min, double lam_max, double* host) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  // single rank: the decision rides on k_sum_trial (no separate launch, nothing to all-reduce in between)
+  int rc = lm_trial_impl(h, delta_cam, mcba::DecideArgs{1, pred_cam, dcn2, xcn2, lam_min, lam_max, h->red + h->nsys + 8});
+  if (rc) return rc;
+  rc = lm_reduce_chain(h, 0);
+  if (rc) return rc;
+  return mcba_lm_fetch(h, host);
 }
 
 int mcba_get_frame_gradient(mcba_handle* h, double* host) {

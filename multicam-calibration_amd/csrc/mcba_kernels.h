@@ -7,17 +7,39 @@
 #define MCBA_GP 92    // per gram wavefront partial: U 78 | g_c 12 | cost | n_pairs_with_data
 #define MCBA_FB 40    // per frame: L 21 | z 6 | g_f 6 | D_f 6 | pad
 
+#define MCBA_LMS 16   // device LM state: cost, lambda, nu, sel, accepted, cost_new, pred, ratio, step_norm, x_norm, ...
+
 namespace mcba {
+// Double-buffered operands (parameter slots, linearisation records) and the damping are chosen either from host
+// values (lms == nullptr: idx / lam as given) or from the device-resident LM state (idx is XORed with state[3],
+// lam = state[1]) -- so a whole LM iteration can be enqueued without knowing whether its trial step is accepted.
+// Camera step handed to k_backsub through the kernel-argument segment (no H2D copy): 12 x C doubles, C <= 40.
+struct CamStep {
+  double v[480];
+};
+
+struct Sel {
+  const double* lms;
+  int idx;
+  double lam;
+};
+// decide != 0: k_sum_trial / k_decide apply the accept/reject + damping update to the LM state (lms)
+struct DecideArgs {
+  int decide;
+  double pred_cam, dcn2, xcn2, lam_min, lam_max;
+  double* lms;
+};
 void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int C, int F, int N, int Fpad);
-void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* rec, double* gpart, int C, int N, int Fpad, int split);
+void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split);
 void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch);
 size_t syrk_lds_bytes(int C, int FS);
-void launch_frame_factor(hipStream_t st, const double* rec, double* fbuf, double* fpart, int C, int F, int Fpad, double lambda);
-void launch_syrk(hipStream_t st, const double* rec, const double* fbuf, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw);
+void launch_frame_factor(hipStream_t st, Sel s, const double* rec0, const double* rec1, double* fbuf, double* fpart, int C, int F, int Fpad);
+void launch_syrk(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw);
 int syrk_items_per_thread();
-void launch_reduce_system(hipStream_t st, const double* gpart, const double* spart, const double* fpart, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot);
-void launch_backsub(hipStream_t st, const double* rec, const double* fbuf, const double* dc, const double* xs, double* xd, double* bpart, int C, int F, int Fpad, double lambda);
-void launch_sum_trial(hipStream_t st, const double* cpart, int cstride, int ncp, const double* bpart, int nbp, double* out);
+void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot);
+void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad);
+void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int ncp, const double* bpart, int nbp, double* out, DecideArgs da);
+void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);
 int syrk_set_lds_limit(size_t bytes);
 }  // namespace mcba

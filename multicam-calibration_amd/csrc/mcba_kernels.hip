@@ -61,6 +61,8 @@ __device__ __forceinline__ double uni(double v) {
   return u.d;
 }
 __device__ __forceinline__ bool is_num(double v) { return v == v; }
+__device__ __forceinline__ int sel_index(const Sel& s) { return s.lms ? ((static_cast<int>(s.lms[3]) ^ s.idx) & 1) : s.idx; }
+__device__ __forceinline__ double sel_lambda(const Sel& s) { return s.lms ? s.lms[1] : s.lam; }
 
 template <int LOSS>
 __device__ __forceinline__ void obs_weights(double r, bool valid, double fs2, double ifs2, double& cost, double& w2, double& g) {
@@ -233,8 +235,12 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 
 // Split roles: grid.z = 2, <= 256 VGPRs, two waves per SIMD.
 template <int LOSS>
-__global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
-                                                       double* __restrict__ rec, double* __restrict__ gpart, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+__global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
+                                                       double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+  const int sidx = sel_index(sl);
+  const double* __restrict__ x = sidx ? x1 : x0;
+  double* __restrict__ rec = sidx ? rec1 : rec0;
+  double* __restrict__ gpart = sidx ? gp1 : gp0;
   __shared__ CamConst s_cam;
   const int c = blockIdx.y;
   if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
@@ -248,8 +254,12 @@ __global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict
 
 // Both roles in one lane: grid.z = 1, one wave per SIMD (all 87 accumulators + temporaries in the 512-register file).
 template <int LOSS>
-__global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
-                                                 double* __restrict__ rec, double* __restrict__ gpart, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+__global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
+                                                 double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+  const int sidx = sel_index(sl);
+  const double* __restrict__ x = sidx ? x1 : x0;
+  double* __restrict__ rec = sidx ? rec1 : rec0;
+  double* __restrict__ gpart = sidx ? gp1 : gp0;
   __shared__ CamConst s_cam;  // camera intrinsics + pose (R, t, Jr) staged once per workgroup
   const int c = blockIdx.y;
   if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
@@ -340,7 +350,9 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
 // lane = frame.  V_f = sum_c V_cf; D_f = diag(V_f) (Marquardt); L L^T = V_f + lambda D_f; z = L^-1 g_f.
 // fbuf[f] = {L(21), z(6), g_f(6), D_f(6), pad}.  Per-block partials: max |g_f|, #failed factorisations.
 // The V_cf / g_cf reads are coalesced tile rows; three cameras (81 loads) are in flight per lane at a time.
-__global__ __launch_bounds__(64) void k_frame_factor(const double* __restrict__ rec, double* __restrict__ fbuf, double* __restrict__ fpart, int C, int F, int Fpad, double lambda) {
+__global__ __launch_bounds__(64) void k_frame_factor(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, double* __restrict__ fbuf, double* __restrict__ fpart, int C, int F, int Fpad) {
+  const double* __restrict__ rec = sel_index(sl) ? rec1 : rec0;
+  const double lambda = sel_lambda(sl);
   const int f = blockIdx.x * 64 + threadIdx.x;
   const int nfb = Fpad >> 6;
   double gmax = 0.0, nfail = 0.0;
@@ -412,8 +424,9 @@ __global__ __launch_bounds__(64) void k_frame_factor(const double* __restrict__ 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 template <int PPW, int IPT>
-__global__ __launch_bounds__(256) void k_syrk(const double* __restrict__ rec, const double* __restrict__ fbuf, const int* __restrict__ tile_i, const int* __restrict__ tile_j,
-                                              double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int fpc, int FS) {
+__global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const int* __restrict__ tile_i,
+                                              const int* __restrict__ tile_j, double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int fpc, int FS) {
+  const double* __restrict__ rec = sel_index(sl) ? rec1 : rec0;
   extern __shared__ __align__(16) double lds[];
   const int n = 12 * C, nfb = Fpad >> 6;
   const int RS = 6 * FS + 2;
@@ -563,8 +576,9 @@ __device__ __forceinline__ size_t spart_index(int row, int col, int NT) {
   return ((size_t)q * 4 + (r >> 2)) * 64 + c + 16 * (r & 3);
 }
 
-__global__ __launch_bounds__(256) void k_reduce_system(const double* __restrict__ gpart, const double* __restrict__ spart, const double* __restrict__ fpart,
+__global__ __launch_bounds__(256) void k_reduce_system(Sel sl, const double* __restrict__ gp0, const double* __restrict__ gp1, const double* __restrict__ spart, const double* __restrict__ fpart,
                                                        double* __restrict__ red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot) {
+  const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
   const int n = 12 * C;
   const int nsys = n * n + 3 * n + 16;
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -610,12 +624,17 @@ __global__ __launch_bounds__(256) void k_reduce_system(const double* __restrict_
 // lane = frame.  t = g_f + W_f^T d_c with W read from the wave tiles (each load = 64 consecutive frames, 1 KiB),
 // d_f = -(L L^T)^-1 t with the Cholesky factor k_frame_factor left in fbuf, x_dst = x_src + d.
 // Per-block partials of  sum d^T(lambda D d - g_f),  sum |d_f|^2,  sum |x_f|^2.
-__global__ __launch_bounds__(64) void k_backsub(const double* __restrict__ rec, const double* __restrict__ fbuf, const double* __restrict__ dc, const double* __restrict__ xs,
-                                                double* __restrict__ xd, double* __restrict__ bpart, int C, int F, int Fpad, double lambda) {
+__global__ __launch_bounds__(64) void k_backsub(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const CamStep dcs,
+                                                double* __restrict__ x0, double* __restrict__ x1, double* __restrict__ bpart, int C, int F, int Fpad) {
+  const int sidx = sel_index(sl);  // current slot / linearisation; the trial goes to the other slot
+  const double* __restrict__ rec = sidx ? rec1 : rec0;
+  const double* __restrict__ xs = sidx ? x1 : x0;
+  double* __restrict__ xd = sidx ? x0 : x1;
+  const double lambda = sel_lambda(sl);
   const int n = 12 * C, nfb = Fpad >> 6;
   const int f = blockIdx.x * 64 + threadIdx.x;
   if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < n; i += 64) xd[i] = xs[i] + dc[i];
+    for (int i = threadIdx.x; i < n; i += 64) xd[i] = xs[i] + dcs.v[i];
   double pred = 0.0, dn2 = 0.0, xn2 = 0.0;
   if (f < F) {
     double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -623,7 +642,7 @@ __global__ __launch_bounds__(64) void k_backsub(const double* __restrict__ rec, 
       const double2* w2 = reinterpret_cast<const double2*>(rec + ((size_t)c * nfb + blockIdx.x) * (MCBA_REC * 64)) + threadIdx.x;
 #pragma unroll 4
       for (int lr = 0; lr < 12; ++lr) {
-        double d = dc[12 * c + lr];  // wave-uniform: scalar load
+        double d = dcs.v[12 * c + lr];  // wave-uniform: scalar load from the kernel-argument segment
         double2 v[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[k] = w2[(3 * lr + k) * 64];
@@ -658,7 +677,39 @@ __global__ __launch_bounds__(64) void k_backsub(const double* __restrict__ rec, 
 // produces scalar w; its lanes stride over the partials with 8 loads in flight each, then a fixed DPP tree.
 // Cost partials come either from k_cost (stride 2: cost, n_residuals) or from k_gram's per-wave sums
 // (stride MCBA_GP, entries 90 / 91) when the trial point was linearised speculatively.
-__global__ __launch_bounds__(512) void k_sum_trial(const double* __restrict__ cpart, int cstride, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out) {
+// state (lms): 0 cost  1 lambda  2 nu  3 sel (current slot / linearisation)  4 accepted  5 cost_new  6 pred  7 ratio
+//        8 step_norm  9 x_norm  10 dF.   pred_cam = d_c^T (lam D_c d_c - g_c), dcn2 = |d_c|^2, xcn2 = |x_c|^2 come from
+// the host (it solved the camera system).  Nielsen's update on acceptance, doubling growth on rejection -- identical
+// to solver.LevenbergMarquardt.iterate.
+__device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs& da) {
+  double* lms = da.lms;
+  double cost = lms[0], lam = lms[1], nu = lms[2];
+  int sel = static_cast<int>(lms[3]);
+  double cost_new = trial8[0];
+  double pred = 0.5 * (trial8[1] + da.pred_cam);
+  bool ok = isfinite(cost_new) && pred > 0.0;
+  double ratio = ok ? (cost - cost_new) / pred : -1.0;
+  double dF = cost - cost_new;
+  bool accepted = ratio > 0.0 && dF >= 0.0;
+  if (accepted) {
+    double t = 2.0 * ratio - 1.0;
+    double fac = fmax(1.0 / 3.0, 1.0 - t * t * t);
+    lam = fmax(lam * fac, da.lam_min);
+    nu = 2.0;
+    sel ^= 1;
+    cost = cost_new;
+  } else {
+    lam = fmin(lam * nu, da.lam_max);
+    nu *= 2.0;
+  }
+  lms[0] = cost; lms[1] = lam; lms[2] = nu; lms[3] = sel; lms[4] = accepted ? 1.0 : 0.0;
+  lms[5] = cost_new; lms[6] = pred; lms[7] = ratio;
+  lms[8] = sqrt(trial8[2] + da.dcn2); lms[9] = sqrt(trial8[3] + da.xcn2); lms[10] = dF;
+}
+
+__global__ __launch_bounds__(512) void k_sum_trial(Sel sl, const double* __restrict__ cp0, const double* __restrict__ cp1, int cstride, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out, DecideArgs da) {
+  const double* __restrict__ cpart = sel_index(sl) ? cp1 : cp0;
+  __shared__ double s_out[8];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const double* p = nullptr;
   int stride = 1, count = 0;
@@ -677,7 +728,16 @@ __global__ __launch_bounds__(512) void k_sum_trial(const double* __restrict__ cp
     for (int k = 0; k < 8; ++k) s += v[k];
   }
   s = wave_sum63(s);
-  if (l == 63) out[w] = s;
+  if (l == 63) { out[w] = s; s_out[w] = s; }
+  if (da.decide) {  // single-rank runs: the accept/reject decision rides on the same launch
+    __syncthreads();
+    if (threadIdx.x == 0) lm_decide(s_out, da);
+  }
+}
+
+// stand-alone decision (frame-sharded runs: the trial scalars are all-reduced between k_sum_trial and this)
+__global__ void k_decide(const double* __restrict__ trial8, DecideArgs da) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) lm_decide(trial8, da);
 }
 
 // ---------------------------------------------------------------- k_jacobian: materialised residual Jacobian blocks
@@ -760,16 +820,16 @@ void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int 
   k_transpose_obs<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(raw), reinterpret_cast<double2*>(obs_t), C, F, N, Fpad);
 }
 
-void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* rec, double* gpart, int C, int N, int Fpad, int split) {
+void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split) {
   int nfb = Fpad / 64;
   dim3 block(256);
   double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
   if (split) {
     dim3 grid((nfb + 3) / 4, C, 2);
-    DISPATCH_LOSS(loss, (k_gram_split<L><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, rec, gpart, C, N, Fpad, nfb, fs2, ifs2)));
+    DISPATCH_LOSS(loss, (k_gram_split<L><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fs2, ifs2)));
   } else {
     dim3 grid((nfb + 3) / 4, C, 1);
-    DISPATCH_LOSS(loss, (k_gram<L><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, rec, gpart, C, N, Fpad, nfb, fs2, ifs2)));
+    DISPATCH_LOSS(loss, (k_gram<L><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fs2, ifs2)));
   }
 }
 
@@ -791,32 +851,36 @@ size_t syrk_lds_bytes(int C, int FS) {
 
 #define SYRK_IPT 5  // (12C+1)*FS <= 256*SYRK_IPT is guaranteed by the choice of FS in mcba_create
 
-void launch_frame_factor(hipStream_t st, const double* rec, double* fbuf, double* fpart, int C, int F, int Fpad, double lambda) {
-  k_frame_factor<<<dim3(Fpad / 64), dim3(64), 0, st>>>(rec, fbuf, fpart, C, F, Fpad, lambda);
+void launch_frame_factor(hipStream_t st, Sel s, const double* rec0, const double* rec1, double* fbuf, double* fpart, int C, int F, int Fpad) {
+  k_frame_factor<<<dim3(Fpad / 64), dim3(64), 0, st>>>(s, rec0, rec1, fbuf, fpart, C, F, Fpad);
 }
 
-void launch_syrk(hipStream_t st, const double* rec, const double* fbuf, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw) {
+void launch_syrk(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw) {
   size_t lds = syrk_lds_bytes(C, FS);
   if (ppw <= 4) {
-    k_syrk<4, SYRK_IPT><<<dim3(G, (NP + 15) / 16), dim3(256), lds, st>>>(rec, fbuf, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);
+    k_syrk<4, SYRK_IPT><<<dim3(G, (NP + 15) / 16), dim3(256), lds, st>>>(s, rec0, rec1, fbuf, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);
   } else {
-    k_syrk<16, SYRK_IPT><<<dim3(G, (NP + 63) / 64), dim3(256), lds, st>>>(rec, fbuf, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);
+    k_syrk<16, SYRK_IPT><<<dim3(G, (NP + 63) / 64), dim3(256), lds, st>>>(s, rec0, rec1, fbuf, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);
   }
 }
 
 int syrk_items_per_thread() { return SYRK_IPT; }
 
-void launch_reduce_system(hipStream_t st, const double* gpart, const double* spart, const double* fpart, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot) {
+void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot) {
   int n = 12 * C, nsys = n * n + 3 * n + 16;
-  k_reduce_system<<<dim3((nsys * 16 + 255) / 256), dim3(256), 0, st>>>(gpart, spart, fpart, red, C, nfb, G, NT, NP, nfblocks, rank_slot);
+  k_reduce_system<<<dim3((nsys * 16 + 255) / 256), dim3(256), 0, st>>>(s, gp0, gp1, spart, fpart, red, C, nfb, G, NT, NP, nfblocks, rank_slot);
 }
 
-void launch_backsub(hipStream_t st, const double* rec, const double* fbuf, const double* dc, const double* xs, double* xd, double* bpart, int C, int F, int Fpad, double lambda) {
-  k_backsub<<<dim3(Fpad / 64), dim3(64), 0, st>>>(rec, fbuf, dc, xs, xd, bpart, C, F, Fpad, lambda);
+void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {
+  k_backsub<<<dim3(Fpad / 64), dim3(64), 0, st>>>(s, rec0, rec1, fbuf, dc, x0, x1, bpart, C, F, Fpad);
 }
 
-void launch_sum_trial(hipStream_t st, const double* cpart, int cstride, int ncp, const double* bpart, int nbp, double* out) {
-  k_sum_trial<<<dim3(1), dim3(512), 0, st>>>(cpart, cstride, ncp, bpart, nbp, out);
+void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int ncp, const double* bpart, int nbp, double* out, DecideArgs da) {
+  k_sum_trial<<<dim3(1), dim3(512), 0, st>>>(s, cp0, cp1, cstride, ncp, bpart, nbp, out, da);
+}
+
+void launch_decide(hipStream_t st, const double* trial8, DecideArgs da) {
+  k_decide<<<dim3(1), dim3(64), 0, st>>>(trial8, da);
 }
 
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust) {

@@ -44,6 +44,12 @@ SYMBOLS = [
     ("mcba_get_trial", ctypes.c_int, [_h, _dp]),
     ("mcba_reduce_fetch", ctypes.c_int, [_h, ctypes.c_double, ctypes.c_int, _dp]),
     ("mcba_step_fetch", ctypes.c_int, [_h, _dp, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp]),
+    ("mcba_lm_set_state", ctypes.c_int, [_h, _dp]),
+    ("mcba_lm_trial", ctypes.c_int, [_h, _dp]),
+    ("mcba_lm_decide_reduce", ctypes.c_int, [_h, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int]),
+    ("mcba_lm_rebuild", ctypes.c_int, [_h, ctypes.c_int]),
+    ("mcba_lm_fetch", ctypes.c_int, [_h, _dp]),
+    ("mcba_lm_iterate", ctypes.c_int, [_h, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp]),
     ("mcba_get_frame_gradient", ctypes.c_int, [_h, _dp]),
     ("mcba_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_profile_read", ctypes.c_int, [_h, _dp, _ip, ctypes.c_int, _ip]),
@@ -110,9 +116,11 @@ class Problem:
         self._chk(self.lib.mcba_upload_observations(self.handle, _p(uvs), _p(objpoints)))
         self.set_loss(loss, f_scale)
         self.nsys = self.n * self.n + 3 * self.n + 16
-        self._red = np.empty(self.nsys)
-        self._trial = np.empty(8)
-        self._red_p, self._trial_p = _p(self._red), _p(self._trial)
+        self._all = np.zeros(self.nsys + 8 + 16)         # system | trial scalars | LM state, as the device lays them out
+        self._red = self._all[: self.nsys]
+        self._trial = self._all[self.nsys : self.nsys + 8]
+        self._state = self._all[self.nsys + 8 :]
+        self._all_p, self._red_p, self._trial_p = _p(self._all), _p(self._red), _p(self._trial)
         self._red_views = self.split_reduced(self._red)
         self._dc = np.empty(self.n)
         self._dc_p = _p(self._dc)
@@ -223,6 +231,35 @@ class Problem:
     def get_trial(self):
         self._chk(self.lib.mcba_get_trial(self.handle, _p(self._trial)))
         return self._trial.copy()
+
+    # ---- device-resident LM iteration (one host synchronisation per iteration)
+    def lm_set_state(self, cost, lam, nu, sel):
+        st = np.zeros(16)
+        st[:4] = cost, lam, nu, sel
+        self._chk(self.lib.mcba_lm_set_state(self.handle, _p(st)))
+
+    def lm_iterate(self, delta_cam, pred_cam, dcn2, xcn2, lam_min, lam_max):
+        """backsub -> linearise trial -> decide (GPU) -> Schur-reduce -> fetch.  Returns (system views, trial, state):
+        views of buffers that the next call overwrites."""
+        self._dc[:] = delta_cam
+        rc = self.lib.mcba_lm_iterate(self.handle, self._dc_p, pred_cam, dcn2, xcn2, lam_min, lam_max, self._all_p)
+        if rc:
+            self._chk(rc)
+        return self._red_views, self._trial, self._state
+
+    def lm_trial(self, delta_cam):
+        self._dc[:] = delta_cam
+        self._chk(self.lib.mcba_lm_trial(self.handle, self._dc_p))
+
+    def lm_decide_reduce(self, pred_cam, dcn2, xcn2, lam_min, lam_max, rank_slot=0):
+        self._chk(self.lib.mcba_lm_decide_reduce(self.handle, pred_cam, dcn2, xcn2, lam_min, lam_max, int(rank_slot)))
+
+    def lm_rebuild(self, rank_slot=0):
+        self._chk(self.lib.mcba_lm_rebuild(self.handle, int(rank_slot)))
+
+    def lm_fetch(self):
+        self._chk(self.lib.mcba_lm_fetch(self.handle, self._all_p))
+        return self._red_views, self._trial, self._state
 
     def frame_gradient(self):
         g = np.empty((self.F, 6))

@@ -95,6 +95,9 @@ class LevenbergMarquardt:
         # speculative: every trial point is linearised right away (k_gram also yields its cost), so an accepted
         # step needs one pass over the observations instead of two; a rejected step wastes the extra arithmetic.
         self.speculative = bool(speculative)
+        # device_decide: accept/reject and the damping update run on the GPU (k_decide) so that one LM iteration is a
+        # single stream-ordered chain with ONE host synchronisation; needs a backend with lm_iterate (libmcba).
+        self.device_decide = self.speculative and hasattr(problem, "lm_iterate")
 
     # ------------------------------------------------------------------ set-up
     def start(self, x0):
@@ -115,6 +118,8 @@ class LevenbergMarquardt:
         self._refresh_system()
         if not np.isfinite(self.cost):
             raise ValueError("Residuals are not finite in the initial point.")
+        if self.device_decide:
+            self.p.lm_set_state(self.cost, self.lam, self.nu, self.cur)
 
     def _refresh_system(self):
         p = self.p
@@ -129,6 +134,77 @@ class LevenbergMarquardt:
         gc = red["gc"]
         self.g_inf = max(float(np.abs(gc[self.free]).max()) if self.free.any() else 0.0, float(red["scal"][4:16].max()))
 
+    def _adopt(self, red):
+        self.red = red
+        self.cost = float(red["scal"][0])
+        self.g_inf = max(float(np.abs(red["gc"][self.free]).max()) if self.free.any() else 0.0, float(red["scal"][4:16].max()))
+
+    def _solve_cameras(self, red, lam):
+        diagU = red["diagU"]
+        Dc = np.where(diagU > 0, diagU, 1.0)
+        S = red["S0"]  # damped in place: the buffer is rebuilt before it is used again
+        S.flat[:: self.p.n + 1] += lam * Dc
+        if red["scal"][2] != 0:  # a frame block failed to factorise
+            return None, Dc
+        if self.all_free:
+            return _solve_spd(S, red["rhs"]), Dc
+        dfree = _solve_spd(np.ascontiguousarray(S[np.ix_(self.free, self.free)]), red["rhs"][self.free])
+        if dfree is None:
+            return None, Dc
+        dc = np.zeros(self.p.n)
+        dc[self.free] = dfree
+        return dc, Dc
+
+    def _iterate_device(self):
+        """One LM iteration with the decision on the GPU: a single host synchronisation (the fetch)."""
+        p, red, comm = self.p, self.red, self.comm
+        lam = self.lam
+        dc, Dc = self._solve_cameras(red, lam)
+        distributed = not isinstance(comm, SingleProcess)
+        if dc is None:  # more damping, rebuild the reduced system on the GPU
+            self.lam = min(lam * self.nu, self.lam_max)
+            self.nu *= 2
+            p.lm_set_state(self.cost, self.lam, self.nu, self.cur)
+            p.lm_rebuild(comm.rank % 12)
+            if distributed:
+                comm.all_reduce_system(p)
+            new_red, _, _ = p.lm_fetch()
+            self._adopt(new_red)
+            self.accepted = False
+            return 3 if self.lam >= self.lam_max else None
+        pred_cam = float(dc @ (lam * Dc * dc - red["gc"]))
+        dcn2, xcn2 = float(dc @ dc), float(self.x_cam @ self.x_cam)
+        cost_before = self.cost
+        if distributed:
+            p.lm_trial(dc)
+            comm.all_reduce_trial(p)
+            p.lm_decide_reduce(pred_cam, dcn2, xcn2, self.lam_min, self.lam_max, comm.rank % 12)
+            comm.all_reduce_system(p)
+            new_red, t, st = p.lm_fetch()
+        else:
+            new_red, t, st = p.lm_iterate(dc, pred_cam, dcn2, xcn2, self.lam_min, self.lam_max)
+        self.nfev += 1
+        self.njev += 1
+        accepted = st[4] > 0
+        cost_new, pred, ratio, step_norm, x_norm, dF = float(st[5]), float(st[6]), float(st[7]), float(st[8]), float(st[9]), float(st[10])
+        self.history.append((self.nfev, cost_before, cost_new, pred, ratio, lam, step_norm))
+        ftol_ok = dF < self.ftol * cost_before and ratio > 0.25
+        xtol_ok = step_norm < self.xtol * (self.xtol + x_norm)
+        status = 4 if (ftol_ok and xtol_ok) else 2 if ftol_ok else 3 if xtol_ok else None
+        if accepted:
+            self.cur = int(st[3])
+            self.x_cam = self.x_cam + dc
+            self.actual_reduction, self.step_norm = dF, step_norm
+            self.iteration += 1
+        elif status == 2:
+            status = None
+        self.lam, self.nu = float(st[1]), float(st[2])
+        if not accepted and self.lam >= self.lam_max and status is None:
+            status = 3
+        self._adopt(new_red)
+        self.accepted = bool(accepted)
+        return status
+
     # ------------------------------------------------------------------ one iteration
     def iterate(self, always_linearize=False):
         """Returns None to continue or a scipy-style status (1 gtol, 2 ftol, 3 xtol, 4 both).
@@ -138,6 +214,8 @@ class LevenbergMarquardt:
         self.steps += 1
         if self.g_inf < self.gtol:
             return 1
+        if self.device_decide:
+            return self._iterate_device()
         lam = self.lam
         diagU = red["diagU"]
         Dc = np.where(diagU > 0, diagU, 1.0)
