@@ -164,6 +164,71 @@ def test_reduced_system_and_step_vs_oracle(mc, kw, loss):
     prob.close()
 
 
+def test_config5_shapes_24_cameras_200_points(mc):
+    """BASELINE configs[4] shapes at a CPU-checkable frame count: 24 cameras (289-row Schur operand, 19x19 MFMA tiles,
+    PPW = 16 path), 200 board points (four 64-point chunks per wavefront in k_jacobian), ragged frame count."""
+    p = mc.synth.make_problem(24, 70, rows=10, cols=20, seed=31, missing=0.2)
+    C, F, N = p["uvs"].shape[:3]
+    x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = mc.ops.Problem(p["uvs"], p["obj"])
+    prob.set_params(0, x)
+    cost, nres = prob.cost(0)
+    f = orc.residuals(x, p["uvs"], p["obj"])
+    assert nres == f.size and abs(cost - orc.robust_cost(f)) <= 1e-12 * cost
+    prob.linearize(0)
+    lam = 1e-2
+    prob.build_reduced(lam)
+    red = prob.get_reduced()
+    U, gc, V, gf, W, cost0 = orc.normal_equations(x, p["uvs"], p["obj"])
+    Df2 = np.stack([np.diag(V[k]) for k in range(F)])
+    S, rhs = orc.schur_reduce(U, gc, V, gf, W, lam, np.zeros((C, 12)), Df2)
+    assert np.abs(red["S0"] - S).max() <= 1e-10 * np.abs(S).max()
+    assert np.abs(red["rhs"] - rhs).max() <= 1e-10 * np.abs(rhs).max()
+    assert abs(red["scal"][0] - cost0) <= 1e-12 * cost0
+    Dc2 = np.concatenate([np.diag(U[c]) for c in range(C)])
+    dc = np.linalg.solve(S + lam * np.diag(Dc2), rhs)
+    df = orc.back_substitute(dc, V, gf, W, lam, Df2)
+    prob.step_linearize(dc, lam, 0, 1)
+    t = prob.get_trial()
+    want = x + np.concatenate([dc, df.ravel()])
+    x1 = prob.get_params(1)
+    assert np.abs(x1 - want).max() <= 1e-8 * np.abs(df).max() + 1e-13 * np.abs(x).max()
+    assert abs(t[0] - orc.robust_cost(orc.residuals(want, p["uvs"], p["obj"]))) <= 1e-9 * t[0]
+    # materialised Jacobian, 200 points per (camera, frame)
+    prob.jacobian_eval(0, robust_scaled=False)
+    jac, res = prob.jacobian_download()
+    Jc, Jf = orc.jacobian_blocks(x, C, p["obj"])
+    mask = ~np.isnan(p["uvs"])
+    want_j = -np.concatenate([Jc, Jf], -1)
+    assert np.abs(jac[mask] - want_j[mask]).max() <= 1e-11 * np.abs(want_j).max()
+    assert np.all(jac[~mask] == 0)
+    prob.close()
+    # and the full solver on it (device-resident LM state, 288x288 reduced system on the host)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res_ = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=1e-12, verbose=0, return_jac=False)
+    assert res_.success and res_.cost < 0.05 * cost
+    fin = orc.residuals(res_.x, p["uvs"][:, use], p["obj"])
+    assert abs(orc.robust_cost(fin) - res_.cost) <= 1e-10 * res_.cost
+
+
+def test_config2_fixed_intrinsics_matches_oracle_driver(mc):
+    """BASELINE configs[1]: intrinsics held fixed (extrinsics + poses only).  The reference has no such entry point
+    (SURVEY 8c-8): the oracle is the same LM driver over the CPU test double with the same free mask."""
+    from fake_problem import OracleProblem
+
+    p = mc.synth.make_problem(3, 40, seed=32)
+    x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    free = np.tile(np.r_[np.zeros(6, bool), np.ones(6, bool)], 3)
+    ref = mc.solver.lm_solve(OracleProblem(p["uvs"], p["obj"]), x0, ftol=0.0, xtol=1e-12, gtol=1e-9, free_cam_mask=free, max_nfev=100)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, fix_intrinsics=True, ftol=0.0, xtol=1e-12, gtol=1e-9, verbose=0, max_nfev=100)
+    assert abs(res.cost - ref.cost) <= 1e-10 * ref.cost
+    pa, pb = orc.predict_from_x(res.x, 3, p["obj"]), orc.predict_from_x(ref.x, 3, p["obj"])
+    assert np.abs(pa - pb).max() < 1e-6
+    np.testing.assert_array_equal(res.x[:36].reshape(3, 12)[:, :6], x0[:36].reshape(3, 12)[:, :6])
+    assert np.all(res.grad[:36].reshape(3, 12)[:, :6] == 0)
+
+
 # ------------------------------------------------------------------ converged solution vs the reference driven to a tight optimum
 def _compare_to_tight(mc, z, x, C, tol):
     ext, intr, poses = orc.deserialize_params(x, C)
