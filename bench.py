@@ -34,6 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+# scripts/micro/write_bw.hip on the gpurun MI355X (1 GiB, 16 B/lane): streaming write 4.5-5.9 TB/s, copy 4.8-5.5, read 6.2-6.6
+HBM_MEASURED_WRITE_GBS = 5930.0
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (AMD datasheet; 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
 
 C, F_PER_GPU, ROWS, COLS = 6, 10000, 6, 9
@@ -186,11 +188,13 @@ def main():
         assert dom == DOMINANT, f"dominant kernel changed: {dom}"
         dom_ms = kern[dom][0] / kern[dom][1]
         dom_bytes = algorithmic_bytes(dom, C, F, N)
-        traffic = None
+        traffic = jtraffic = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_file):
+        if os.path.exists(pmc_file) and F == F_PER_GPU:  # PMC passes were collected at the default shard size
             with open(pmc_file) as fh:
-                traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(fh)
+            traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
+            jtraffic = pmc.get("k_jacobian", {}).get("hbm_bytes_per_launch")
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
         roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_us": dom_ms * 1e3, "algorithmic_bytes_per_launch": dom_bytes}
@@ -219,7 +223,8 @@ def main():
             "ms_per_jacobian_eval": ms_jac,
             "roofline": roofline,
             "jacobian_eval": {"kernel": "k_jacobian", "ms": ms_jac, "roofline": {"bound": "hbm", "achieved": jach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jach / HBM_PEAK_GBS,
-                              "traffic": None, "algorithmic_bytes_per_launch": jb}},
+                              "traffic": jtraffic, "algorithmic_bytes_per_launch": jb,
+                              "frac_of_measured_write_ceiling": jach / HBM_MEASURED_WRITE_GBS}},
             "kernels_us": {k: round(1e3 * ms / n, 3) for k, (ms, n) in kern.items()},
             "kernel_calls": {k: n for k, (ms, n) in kern.items()},
             "lm": {"cost_start": cost0, "cost_end": lm.cost, "accepted": lm.iteration, "steps_total": lm.steps, "lambda": lm.lam},

@@ -1,4 +1,5 @@
-// mcba_kernels.hip -- gfx950 kernels of the bundle-adjustment hot path (FP64, no MFMA: HBM/VALU bound).
+// mcba_kernels.hip -- gfx950 kernels of the bundle-adjustment hot path (FP64; the per-observation kernels are VALU/HBM
+// bound, the Schur SYRK runs on the FP64 matrix cores).
 //
 // Work decomposition:
 //   k_gram / k_cost     one LANE per (camera c, frame f): lanes of a wavefront are 64 consecutive frames of
