@@ -119,6 +119,18 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
 
     uvs = np.ascontiguousarray(all_calib_uvs[:, use_frames])
     x0 = serialize_params(all_extrinsics, all_intrinsics, calib_poses[use_frames])
+    if use_frames.size == 0:
+        # nothing to fit: scipy's least_squares on an empty residual vector returns x0 with status 1 (gtol) after one
+        # evaluation (what the reference then returns: bundle_adjustment.py:307-327)
+        from scipy.optimize import OptimizeResult
+
+        result = OptimizeResult(x=x0, cost=0.0, fun=np.empty(0), jac=sp.csr_matrix((0, x0.size)), grad=np.zeros(x0.size), optimality=0.0,
+                                active_mask=np.zeros(x0.size), nfev=1, njev=1, status=1, message=solver.TERMINATION_MESSAGES[1], success=True)
+        if kw["verbose"] >= 1:
+            print(result.message)
+            print("Function evaluations 1, initial cost 0.0000e+00, final cost 0.0000e+00, first-order optimality 0.00e+00.")
+        ext, intr, poses = deserialize_params(x0, n_cameras)
+        return ext, intr, poses, use_frames, result
     prob = ops.Problem(uvs, calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0))
     free = None
     if fix_intrinsics:
