@@ -58,12 +58,12 @@ def jacobian_structure(all_calib_uvs):
     return idx.ravel(), np.arange(m + 1, dtype=np.int64) * 18, (m, 12 * C + 6 * F), mask
 
 
-def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device=0):
+def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device=0, backend=None):
     """The reference's pre-filter (bundle_adjustment.py:265-296); the reprojection pass runs on the GPU."""
     use_frames = np.nonzero((~np.isnan(all_calib_uvs).any((-1, -2))).sum(0) > 1)[0]
     sub = all_calib_uvs[:, use_frames]
     if use_frames.size:
-        prob = ops.Problem(sub, calib_objpoints, device=device)
+        prob = (backend or ops.Problem)(sub, calib_objpoints, device=device)
         prob.set_params(0, serialize_params(all_extrinsics, all_intrinsics, np.asarray(calib_poses)[use_frames]))
         res = prob.residuals(0)
         prob.close()
@@ -89,10 +89,25 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
 
     Parameters and return value are those of the reference `multicam_calibration.bundle_adjust`.
     Extra keyword arguments (defaults preserve reference behaviour):
-      device=0             HIP device ordinal
+      device=0             HIP device ordinal (distributed: defaults to LOCAL_RANK)
       fix_intrinsics=False hold fx fy cx cy k1 k2 of every camera (BASELINE config 2); extrinsics + poses only
       return_jac=True      attach the robust-rescaled CSR Jacobian as `result.jac` (18 nnz/row; 1.4 GB at 6x10k x54)
+      distributed=False    one process per GPU under torch.distributed (an initialised process group, backend nccl =
+                           RCCL): the frames chosen by rank 0 are sharded contiguously over the ranks, every LM iteration
+                           all-reduces the reduced camera system, and every rank returns the full 5-tuple (poses
+                           all-gathered).  `result.fun` / `result.jac` then cover the calling rank's shard only.
     """
+    distributed = opt_kwargs.pop("distributed", False)
+    backend = opt_kwargs.pop("_backend", None)  # test hook: a drop-in for ops.Problem (tests/fake_problem.py)
+    rank, world, dist = 0, 1, None
+    if distributed:
+        import os
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            raise RuntimeError("distributed=True needs an initialised torch.distributed process group (launch with torchrun)")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        opt_kwargs.setdefault("device", int(os.environ.get("LOCAL_RANK", rank)))
     device = opt_kwargs.pop("device", 0)
     fix_intrinsics = opt_kwargs.pop("fix_intrinsics", False)
     return_jac = opt_kwargs.pop("return_jac", True)
@@ -103,7 +118,13 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     calib_poses = np.asarray(calib_poses, dtype=np.float64)
     n_cameras = all_calib_uvs.shape[0]
 
-    use_frames = select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device)
+    if not distributed:
+        use_frames = select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device, backend)
+    else:
+        # rank 0 owns the reference's frame selection (its printed line and its use of the global numpy RNG)
+        box = [select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device, backend) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        use_frames = box[0]
 
     kw = dict(verbose=2, x_scale="jac", ftol=1e-4, method="trf", loss="soft_l1")
     kw.update(opt_kwargs)
@@ -117,6 +138,11 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     if unknown:
         raise TypeError(f"unsupported least_squares keyword(s) for the GPU solver: {sorted(unknown)}")
 
+    all_use = use_frames
+    if distributed:
+        if use_frames.size < world:
+            raise ValueError(f"{use_frames.size} usable frames cannot be sharded over {world} ranks")
+        use_frames = np.array_split(all_use, world)[rank]  # contiguous shard of the selection, in selection order
     uvs = np.ascontiguousarray(all_calib_uvs[:, use_frames])
     x0 = serialize_params(all_extrinsics, all_intrinsics, calib_poses[use_frames])
     if use_frames.size == 0:
@@ -131,18 +157,27 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             print("Function evaluations 1, initial cost 0.0000e+00, final cost 0.0000e+00, first-order optimality 0.00e+00.")
         ext, intr, poses = deserialize_params(x0, n_cameras)
         return ext, intr, poses, use_frames, result
-    prob = ops.Problem(uvs, calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0))
+    prob = (backend or ops.Problem)(uvs, calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0))
+    comm = None
+    if distributed:
+        import torch
+
+        prob.enable_collective(torch.device(f"cuda:{device}") if backend is None else "cpu")
+        comm = solver.TorchDistributed()
+        return_jac = False if backend is not None else return_jac
     free = None
     if fix_intrinsics:
         free = np.tile(np.r_[np.zeros(6, bool), np.ones(6, bool)], n_cameras)
     tol = lambda name, default: default if kw.get(name, default) is None else kw.get(name, default)
     result = solver.lm_solve(prob, x0, ftol=tol("ftol", 1e-4), xtol=tol("xtol", 1e-8), gtol=tol("gtol", 1e-8),
-                             max_nfev=kw.get("max_nfev"), verbose=kw["verbose"], free_cam_mask=free, **lm_kwargs)
+                             max_nfev=kw.get("max_nfev"), verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, **lm_kwargs)
 
     # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560)
     slot = result.lm["slot"]
     idx, indptr, shape, mask = jacobian_structure(uvs)
-    if return_jac:
+    if backend is not None:  # test double: no materialised Jacobian kernel
+        result.fun = prob.residuals(slot)[mask]
+    elif return_jac:
         prob.jacobian_eval(slot, robust_scaled=kw["loss"] != "linear")
         jac, res = prob.jacobian_download()
         result.jac = sp.csr_matrix((jac[mask].ravel(), idx, indptr), shape=shape)
@@ -154,11 +189,19 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     grad = np.concatenate([red["gc"], prob.frame_gradient().ravel()])
     if free is not None:
         grad[: 12 * n_cameras][~free] = 0.0
+    if distributed:
+        # assemble the global vectors: cameras are identical on every rank, poses / frame gradients are gathered
+        parts = [None] * world
+        dist.all_gather_object(parts, (result.x[12 * n_cameras:], grad[12 * n_cameras:]))
+        result.x = np.concatenate([result.x[: 12 * n_cameras]] + [p[0] for p in parts])
+        grad = np.concatenate([grad[: 12 * n_cameras]] + [p[1] for p in parts])
+        result.active_mask = np.zeros_like(result.x)
+        result.optimality = float(np.abs(grad).max())
     result.grad = grad
     prob.close()
 
     adjusted_extrinsics, adjusted_intrinsics, adjusted_calib_poses = deserialize_params(result.x, n_cameras)
-    return adjusted_extrinsics, adjusted_intrinsics, adjusted_calib_poses, use_frames, result
+    return adjusted_extrinsics, adjusted_intrinsics, adjusted_calib_poses, all_use, result
 
 
 # BASELINE.json's north star calls the entry point `bundle_adjustment()`; the reference function is `bundle_adjust`.

@@ -9,7 +9,7 @@ from oracle import ba_oracle as orc
 
 
 class OracleProblem:
-    def __init__(self, uvs, objpoints, loss="soft_l1", f_scale=1.0):
+    def __init__(self, uvs, objpoints, loss="soft_l1", f_scale=1.0, device=None):
         self.uvs, self.obj = np.asarray(uvs, float), np.asarray(objpoints, float)
         self.C, self.F, self.N = self.uvs.shape[:3]
         self.n = 12 * self.C
@@ -82,6 +82,13 @@ class OracleProblem:
 
     def accept_linearization(self):
         self.lin = self.lin_trial
+
+    def residuals(self, slot):
+        r = self.uvs - orc.predict_from_x(self.x[slot], self.C, self.obj)
+        return np.where(np.isnan(self.uvs), 0.0, r)
+
+    def close(self):
+        pass
 
     def get_trial(self):
         return self._red[self.nsys :].copy()

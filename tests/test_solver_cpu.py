@@ -140,3 +140,53 @@ def test_two_rank_frame_sharding_matches_single_process(tmp_path):
     assert np.abs(pred_a - pred_b).max() < 1e-6   # same minimiser (gauge aside): predictions agree
     cam_a, cam_b = x_sh[:36].reshape(3, 12), ref.x[:36].reshape(3, 12)
     assert (np.abs(cam_a[:, :6] - cam_b[:, :6]) / np.abs(cam_b[:, :6])).max() < 1e-6
+
+
+# ------------------------------------------------------------------ bundle_adjust(distributed=True), world_size 2 over gloo
+def _ba_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import contextlib
+    import io
+
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    p = synth.make_problem(3, 41, seed=9, missing=0.15, outlier_frames=3)   # 41: ragged shards
+    np.random.seed(100 + rank)   # different global RNG state per rank: only rank 0's may matter
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        e, it, ps, use, res = api.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=30,
+                                                 ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, distributed=True, _backend=OracleProblem)
+    np.savez(os.path.join(out_dir, f"ba{rank}.npz"), ext=e, poses=ps, use=use, x=res.x, cost=res.cost, grad=res.grad, printed=np.array(buf.getvalue()),
+             K=np.stack([k for k, _ in it]), dist=np.stack([d for _, d in it]))
+    dist.destroy_process_group()
+
+
+def test_bundle_adjust_distributed_two_ranks(tmp_path):
+    import contextlib
+    import io
+
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_ba_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "ba0.npz"), np.load(tmp_path / "ba1.npz")
+    # every rank returns the same full result; only rank 0 printed the reference's "Excluding ..." line
+    for k in ("ext", "poses", "use", "x", "K", "dist", "grad"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    assert float(r0["cost"]) == float(r1["cost"])
+    assert str(r0["printed"]).startswith("Excluding ") and str(r1["printed"]) == ""
+    assert r0["use"].shape == (30,) and r0["poses"].shape == (30, 6) and r0["x"].shape == (36 + 180,)
+    # the same call in one process with rank 0's RNG state selects the same frames and reaches the same optimum
+    p = synth.make_problem(3, 41, seed=9, missing=0.15, outlier_frames=3)
+    np.random.seed(100)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = api.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=30,
+                                                 ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, _backend=OracleProblem)
+    np.testing.assert_array_equal(use, r0["use"])
+    assert abs(res.cost - float(r0["cost"])) <= 1e-10 * res.cost
+    pa = orc.predict_from_x(r0["x"], 3, p["obj"])
+    pb = orc.predict_from_x(res.x, 3, p["obj"])
+    assert np.abs(pa - pb).max() < 1e-6
+    assert np.abs(r0["grad"]).max() < 1e-5
