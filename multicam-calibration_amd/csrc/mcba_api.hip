@@ -269,7 +269,7 @@ static int run_cost(mcba_handle* h, int slot, double* res_dev, const double* bpa
   if (rc) return rc;
   {
     Scope sc(h, K_SUM_TRIAL);
-    mcba::launch_sum_trial(h->stream, host_sel(0), h->cpart, h->cpart, 2, h->C * h->nfb * h->nch, bpart, nbp, h->red + h->nsys, mcba::DecideArgs{0, 0.0, 0.0, 0.0, 0.0, 0.0, nullptr});
+    mcba::launch_sum_trial(h->stream, host_sel(0), h->cpart, h->cpart, 2, h->C * h->nfb * h->nch, 0, h->C * h->nfb * h->nch, bpart, nbp, h->red + h->nsys, mcba::DecideArgs{0, 0.0, 0.0, 0.0, 0.0, 0.0, nullptr});
   }
   return check_launch();
 }
@@ -377,7 +377,7 @@ int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot) {
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_REDUCE);
-    mcba::launch_reduce_system(h->stream, host_sel(h->lin), h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
+    mcba::launch_reduce_system(h->stream, host_sel(h->lin), h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
   }
   if ((rc = check_launch())) return rc;
   h->have_red = true;
@@ -437,7 +437,7 @@ int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, 
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_SUM_TRIAL);
-    mcba::launch_sum_trial(h->stream, host_sel(0), h->gpart2[alt] + 90, h->gpart2[alt] + 90, MCBA_GP, h->C * h->nfb, h->bpart, h->nbblocks, h->red + h->nsys, mcba::DecideArgs{0, 0.0, 0.0, 0.0, 0.0, 0.0, nullptr});
+    mcba::launch_sum_trial(h->stream, host_sel(0), h->gpart2[alt] + (size_t)90 * h->nfb, h->gpart2[alt] + (size_t)90 * h->nfb, 1, h->nfb, (size_t)MCBA_GP * h->nfb, h->C * h->nfb, h->bpart, h->nbblocks, h->red + h->nsys, mcba::DecideArgs{0, 0.0, 0.0, 0.0, 0.0, 0.0, nullptr});
   }
   if ((rc = check_launch())) return rc;
   h->have_spec = true;
@@ -511,7 +511,7 @@ static int lm_trial_impl(mcba_handle* h, const double* delta_cam, const mcba::De
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_SUM_TRIAL);
-    mcba::launch_sum_trial(h->stream, dev_sel(h, 1), h->gpart2[0] + 90, h->gpart2[1] + 90, MCBA_GP, h->C * h->nfb, h->bpart, h->nbblocks, h->red + h->nsys, da);
+    mcba::launch_sum_trial(h->stream, dev_sel(h, 1), h->gpart2[0] + (size_t)90 * h->nfb, h->gpart2[1] + (size_t)90 * h->nfb, 1, h->nfb, (size_t)MCBA_GP * h->nfb, h->C * h->nfb, h->bpart, h->nbblocks, h->red + h->nsys, da);
   }
   return check_launch();
 }
@@ -534,7 +534,7 @@ static int lm_reduce_chain(mcba_handle* h, int rank_slot) {
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_REDUCE);
-    mcba::launch_reduce_system(h->stream, dev_sel(h, 0), h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
+    mcba::launch_reduce_system(h->stream, dev_sel(h, 0), h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
   }
   if ((rc = check_launch())) return rc;
   h->have_red = true;

@@ -4,7 +4,7 @@
 #include <stddef.h>
 
 #define MCBA_REC 100  // per (frame, camera) record: W 72 | V 21 | g_f 6 | pad
-#define MCBA_GP 92    // per gram wavefront partial: U 78 | g_c 12 | cost | n_pairs_with_data
+#define MCBA_GP 92    // k_gram per-wavefront sums, stored [camera][k][frame block]: k = U 78 | g_c 12 | cost | pairs with data
 #define MCBA_FB 40    // per frame: L 21 | z 6 | g_f 6 | D_f 6 | pad
 
 #define MCBA_LMS 16   // device LM state: cost, lambda, nu, sel, accepted, cost_new, pred, ratio, step_norm, x_norm, ...
@@ -36,9 +36,9 @@ size_t syrk_lds_bytes(int C, int FS);
 void launch_frame_factor(hipStream_t st, Sel s, const double* rec0, const double* rec1, double* fbuf, double* fpart, int C, int F, int Fpad);
 void launch_syrk(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw);
 int syrk_items_per_thread();
-void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot);
+void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot);
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad);
-void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int ncp, const double* bpart, int nbp, double* out, DecideArgs da);
+void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da);
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);
 int syrk_set_lds_limit(size_t bytes);

@@ -181,7 +181,8 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
   }
   // records are wave tiles rec[camera][frame block][k/2 = 0..49][lane][2]: every store below is one 1 KiB dwordx4 row
   double2* r2 = reinterpret_cast<double2*>(rec + ((size_t)c * nfb + fb) * (MCBA_REC * 64)) + lane;
-  double* gp = gpart + ((size_t)c * nfb + fb) * MCBA_GP;
+  // per-wavefront sums, stored [camera][k = 0..91][frame block] so that the second stage reads contiguous runs
+  double* gp = gpart + (size_t)c * MCBA_GP * nfb + fb;
   const bool writer = lane == 63;
   if constexpr (DO_A) {
     double U[78], gc[12], W[72], V[21], gf[6];
@@ -201,16 +202,16 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #pragma unroll
       for (int b = a; b < 12; ++b) {
         double sm = wave_sum63(U[tri12(a, b)]);
-        if (writer) gp[tri12(a, b)] = sm;
+        if (writer) gp[(size_t)tri12(a, b) * nfb] = sm;
       }
 #pragma unroll
     for (int a = 6; a < 12; ++a) {
       double sm = wave_sum63(gc[a]);
-      if (writer) gp[78 + a] = sm;
+      if (writer) gp[(size_t)(78 + a) * nfb] = sm;
     }
     double cs = wave_sum63(cost);
     double nv = wave_sum63(any ? 1.0 : 0.0);
-    if (writer) { gp[90] = cs; gp[91] = nv; }
+    if (writer) { gp[(size_t)90 * nfb] = cs; gp[(size_t)91 * nfb] = nv; }
   }
   if constexpr (DO_B) {
     double U[78], gc[12], W[72];
@@ -224,12 +225,12 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #pragma unroll
       for (int b = a; b < 12; ++b) {
         double sm = wave_sum63(U[tri12(a, b)]);
-        if (writer) gp[tri12(a, b)] = sm;
+        if (writer) gp[(size_t)tri12(a, b) * nfb] = sm;
       }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       double sm = wave_sum63(gc[a]);
-      if (writer) gp[78 + a] = sm;
+      if (writer) gp[(size_t)(78 + a) * nfb] = sm;
     }
   }
 }
@@ -542,83 +543,109 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
 }
 
 // ---------------------------------------------------------------- k_reduce_system: fixed-order second stage
-// 16 lanes per output double of the reduce buffer (layout in include/mcba.h): lane l sums partials
-// l, l+16, l+32, ... (independent loads in flight), then a 4-step xor tree -- a fixed summation order,
-// so the result is bit-reproducible run to run (no FP64 atomics anywhere).
-__device__ __forceinline__ double strided_sum16(const double* __restrict__ p, size_t stride, int count, int l) {
+// Sums the per-workgroup partials of k_syrk and the per-wavefront partials of k_gram into the reduce buffer (layout in
+// include/mcba.h) with coalesced reads and a FIXED summation order (bit-reproducible; no FP64 atomics anywhere).
+//   blocks [0, 4 NP): one per (tile pair q, accumulator register reg) = 64 elements that are 512 contiguous bytes in
+//       every k_syrk partial.  Wave s of 16 sums partials g = s, s+16, ... (all loads in flight), LDS, then wave 0 adds
+//       the 16 slices in order.  Elements that fall on a camera's diagonal block also need U_c (and column 12C needs
+//       g_c): those sums over the frame blocks are contiguous runs of gpart[camera][k][frame block] -- one wavefront
+//       task each, four per wave.  Off-diagonal tiles are mirrored on write.
+//   blocks [4 NP, ...): diag(U), g_c and the 16 scalars, one wavefront task per output.
+__device__ __forceinline__ double run_sum(const double* __restrict__ p, int count, int lane) {  // sum of a contiguous run, result in lane 63
   double s = 0.0;
   for (int base = 0; base < count; base += 256) {
-    double v[16];
+    double v[4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {  // 16 independent loads in flight per lane
-      int idx = base + l + 16 * k;
-      v[k] = idx < count ? p[(size_t)idx * stride] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s += v[k];
+    for (int k = 0; k < 4; ++k) { int i = base + lane + 64 * k; v[k] = i < count ? p[i] : 0.0; }
+    s += (v[0] + v[1]) + (v[2] + v[3]);
   }
-#pragma unroll
-  for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-  return s;
-}
-__device__ __forceinline__ double strided_max16(const double* __restrict__ p, size_t stride, int count, int l) {
-  double s = 0.0;
-  for (int k = l; k < count; k += 16) s = fmax(s, p[(size_t)k * stride]);
-#pragma unroll
-  for (int off = 8; off >= 1; off >>= 1) s = fmax(s, __shfl_xor(s, off, 64));
-  return s;
+  return wave_sum63(s);
 }
 
-__device__ __forceinline__ size_t spart_index(int row, int col, int NT) {
-  // element (row, col) of sum Yx Yx^T inside partial g = 0: tiles are stored for ti <= tj only (symmetric)
-  int ti = row >> 4, tj = col >> 4, r = row & 15, c = col & 15;
-  if (ti > tj) { int x = ti; ti = tj; tj = x; x = r; r = c; c = x; }
-  int q = ti * NT - (ti * (ti - 1)) / 2 + (tj - ti);
-  return ((size_t)q * 4 + (r >> 2)) * 64 + c + 16 * (r & 3);
-}
-
-__global__ __launch_bounds__(256) void k_reduce_system(Sel sl, const double* __restrict__ gp0, const double* __restrict__ gp1, const double* __restrict__ spart, const double* __restrict__ fpart,
-                                                       double* __restrict__ red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot) {
+__global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __restrict__ gp0, const double* __restrict__ gp1, const double* __restrict__ spart, const double* __restrict__ fpart,
+                                                        const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ red, int C, int nfb, int G, int NT, int NP,
+                                                        int nfblocks, int rank_slot) {
   const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
   const int n = 12 * C;
-  const int nsys = n * n + 3 * n + 16;
-  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int l = threadIdx.x & 15;
-  if (i >= nsys) return;  // whole 16-lane groups leave together
-  const size_t gstride = (size_t)NP * 256;
-  double out;
-  if (i < n * n) {
-    int row = i / n, col = i % n;
-    int ci = row / 12, cj = col / 12, li = row % 12, lj = col % 12;
-    double s = 0.0;
-    if (ci == cj) {
-      int a = li <= lj ? li : lj, b = li <= lj ? lj : li;
-      s = strided_sum16(gpart + (size_t)ci * nfb * MCBA_GP + tri12(a, b), MCBA_GP, nfb, l);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ double s_part[16][64];
+  __shared__ double s_u[64];
+  const size_t camstride = (size_t)MCBA_GP * nfb;
+  if ((int)blockIdx.x < 4 * NP) {
+    const int q = blockIdx.x >> 2, reg = blockIdx.x & 3;
+    const int ti = tile_i[q], tj = tile_j[q];
+    {  // ---- slice sums of the k_syrk partials
+      const double* p = spart + (size_t)q * 256 + reg * 64 + lane;
+      const size_t gs = (size_t)NP * 256;
+      double s = 0.0;
+      for (int base = 0; base < G; base += 128) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { int g = base + wave + 16 * k; v[k] = g < G ? p[(size_t)g * gs] : 0.0; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+      }
+      s_part[wave][lane] = s;
     }
-    double y = strided_sum16(spart + spart_index(row, col, NT), gstride, G, l);
-    out = s - y;
-  } else {
-    int j = i - n * n;
-    if (j < n) {  // rhs = sum Y z - g_c   (z is row n of Yx)
-      int c = j / 12, lc = j % 12;
-      double s = strided_sum16(gpart + (size_t)c * nfb * MCBA_GP + 78 + lc, MCBA_GP, nfb, l);
-      double y = strided_sum16(spart + spart_index(j, n, NT), gstride, G, l);
-      out = y - s;
-    } else if (j < 2 * n) {  // diag U
-      int jj = j - n, c = jj / 12, lc = jj % 12;
-      out = strided_sum16(gpart + (size_t)c * nfb * MCBA_GP + tri12(lc, lc), MCBA_GP, nfb, l);
-    } else if (j < 3 * n) {  // g_c
-      int jj = j - 2 * n, c = jj / 12, lc = jj % 12;
-      out = strided_sum16(gpart + (size_t)c * nfb * MCBA_GP + 78 + lc, MCBA_GP, nfb, l);
-    } else {
-      int jj = j - 3 * n;
-      out = 0.0;
-      if (jj == 0 || jj == 1) out = strided_sum16(gpart + 90 + jj, MCBA_GP, C * nfb, l);  // cost, (camera,frame) pairs with data
-      else if (jj == 2) out = strided_sum16(fpart + 1, 2, nfblocks, l);
-      else if (jj == 4 + rank_slot) out = strided_max16(fpart, 2, nfblocks, l);
+    // ---- U_c / g_c terms of the elements that need them: element e = wave + 16 j, one wavefront task each
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = wave + 16 * j;
+      const int row = 16 * ti + (e >> 4) + 4 * reg, col = 16 * tj + (e & 15);
+      double u = 0.0;
+      if (row < n && col < n && row / 12 == col / 12) {
+        int cam = row / 12, li = row - 12 * cam, lj = col - 12 * cam;
+        int a = li <= lj ? li : lj, b = li <= lj ? lj : li;
+        u = run_sum(gpart + cam * camstride + (size_t)tri12(a, b) * nfb, nfb, lane);
+      } else if (col == n && row < n) {
+        int cam = row / 12, li = row - 12 * cam;
+        u = run_sum(gpart + cam * camstride + (size_t)(78 + li) * nfb, nfb, lane);
+      }
+      if (lane == 63) s_u[e] = u;
     }
+    __syncthreads();
+    if (wave == 0) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v += s_part[k][lane];
+      const int row = 16 * ti + (lane >> 4) + 4 * reg, col = 16 * tj + (lane & 15);
+      if (row < n && col < n) {
+        double out = s_u[lane] - v;  // S0 = blockdiag(U) - sum Y Y^T
+        red[(size_t)row * n + col] = out;
+        if (ti != tj) red[(size_t)col * n + row] = out;
+      } else if (col == n && row < n) {
+        red[(size_t)n * n + row] = v - s_u[lane];  // rhs = sum Y z - g_c
+      }
+    }
+    return;
   }
-  if (l == 0) red[i] = out;
+  // ---- diag(U), g_c, scalars: task id per wavefront
+  const int task = ((int)blockIdx.x - 4 * NP) * 16 + wave;
+  double* tail = red + (size_t)n * n + n;
+  if (task < n) {  // diag U
+    int cam = task / 12, l = task - 12 * cam;
+    double v = run_sum(gpart + cam * camstride + (size_t)tri12(l, l) * nfb, nfb, lane);
+    if (lane == 63) tail[task] = v;
+  } else if (task < 2 * n) {  // g_c
+    int jj = task - n, cam = jj / 12, l = jj - 12 * cam;
+    double v = run_sum(gpart + cam * camstride + (size_t)(78 + l) * nfb, nfb, lane);
+    if (lane == 63) tail[n + jj] = v;
+  } else if (task < 2 * n + 16) {
+    int jj = task - 2 * n;
+    double v = 0.0;
+    if (jj == 0 || jj == 1) {  // cost, (camera, frame) pairs with data: cameras in order, frame blocks inside
+      for (int cam = 0; cam < C; ++cam) v += run_sum(gpart + cam * camstride + (size_t)(90 + jj) * nfb, nfb, lane);
+    } else if (jj == 2) {
+      double a = 0.0;
+      for (int k = lane; k < nfblocks; k += 64) a += fpart[2 * k + 1];
+      v = wave_sum63(a);
+    } else if (jj == 4 + rank_slot) {
+      double a = 0.0;
+      for (int k = lane; k < nfblocks; k += 64) a = fmax(a, fpart[2 * k]);
+      v = wave_max(a);
+    }
+    if (lane == 63) tail[2 * n + jj] = v;
+  }
 }
 
 // ---------------------------------------------------------------- k_backsub: frame steps + trial parameters
@@ -691,8 +718,12 @@ __device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs
   bool ok = isfinite(cost_new) && pred > 0.0;
   double ratio = ok ? (cost - cost_new) / pred : -1.0;
   double dF = cost - cost_new;
-  bool accepted = ratio > 0.0 && dF >= 0.0;
+  // round-off guard: near the optimum the last Gauss-Newton corrections change the cost by less than FP64 resolves
+  // (|dF| ~ EPS * F * sqrt(m)); such a step is neutral, not bad -- accept it with the damping unchanged
+  bool neutral = isfinite(cost_new) && pred >= 0.0 && fabs(dF) <= 32.0 * MCBA_EPS * fabs(cost);
+  bool accepted = (ratio > 0.0 && dF >= 0.0) || neutral;
   if (accepted) {
+    if (!(ratio > 0.0 && dF >= 0.0)) ratio = 0.5;  // neutral: factor 1 in Nielsen's rule
     double t = 2.0 * ratio - 1.0;
     double fac = fmax(1.0 / 3.0, 1.0 - t * t * t);
     lam = fmax(lam * fac, da.lam_min);
@@ -708,22 +739,26 @@ __device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs
   lms[8] = sqrt(trial8[2] + da.dcn2); lms[9] = sqrt(trial8[3] + da.xcn2); lms[10] = dF;
 }
 
-__global__ __launch_bounds__(512) void k_sum_trial(Sel sl, const double* __restrict__ cp0, const double* __restrict__ cp1, int cstride, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out, DecideArgs da) {
+// Cost partials: element idx of `ncp` lives at (idx / cinner) * couter + (idx % cinner) * cstride  (k_cost: cinner = ncp,
+// cstride = 2; k_gram: per camera a contiguous run of nfb values, cinner = nfb, couter = 92 nfb, cstride = 1).
+__global__ __launch_bounds__(512) void k_sum_trial(Sel sl, const double* __restrict__ cp0, const double* __restrict__ cp1, int cstride, int cinner, size_t couter, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out, DecideArgs da) {
   const double* __restrict__ cpart = sel_index(sl) ? cp1 : cp0;
   __shared__ double s_out[8];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const double* p = nullptr;
-  int stride = 1, count = 0;
-  if (w == 0) { p = cpart; stride = cstride; count = ncp; }
+  int stride = 1, count = 0, inner = 1 << 30;
+  size_t outer = 0;
+  if (w == 0) { p = cpart; stride = cstride; count = ncp; inner = cinner; outer = couter; }
   else if (w >= 1 && w <= 3 && bpart) { p = bpart + (w - 1); stride = 3; count = nbp; }
-  else if (w == 4) { p = cpart + 1; stride = cstride; count = ncp; }
+  else if (w == 4) { p = cpart + (cstride == 2 ? 1 : (size_t)cinner); stride = cstride; count = ncp; inner = cinner; outer = couter; }  // n_residuals / pairs with data
   double s = 0.0;
   for (int base = 0; base < count; base += 512) {
     double v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       int idx = base + l + 64 * k;
-      v[k] = idx < count ? p[(size_t)idx * stride] : 0.0;
+      int hi = idx / inner, lo = idx - hi * inner;
+      v[k] = idx < count ? p[(size_t)hi * outer + (size_t)lo * stride] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += v[k];
@@ -867,17 +902,18 @@ void launch_syrk(hipStream_t st, Sel s, const double* rec0, const double* rec1, 
 
 int syrk_items_per_thread() { return SYRK_IPT; }
 
-void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot) {
-  int n = 12 * C, nsys = n * n + 3 * n + 16;
-  k_reduce_system<<<dim3((nsys * 16 + 255) / 256), dim3(256), 0, st>>>(s, gp0, gp1, spart, fpart, red, C, nfb, G, NT, NP, nfblocks, rank_slot);
+void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot) {
+  int n = 12 * C;
+  int tail_blocks = (2 * n + 16 + 15) / 16;
+  k_reduce_system<<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot);
 }
 
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {
   k_backsub<<<dim3(Fpad / 64), dim3(64), 0, st>>>(s, rec0, rec1, fbuf, dc, x0, x1, bpart, C, F, Fpad);
 }
 
-void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int ncp, const double* bpart, int nbp, double* out, DecideArgs da) {
-  k_sum_trial<<<dim3(1), dim3(512), 0, st>>>(s, cp0, cp1, cstride, ncp, bpart, nbp, out, da);
+void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da) {
+  k_sum_trial<<<dim3(1), dim3(512), 0, st>>>(s, cp0, cp1, cstride, cinner, couter, ncp, bpart, nbp, out, da);
 }
 
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da) {

@@ -15,6 +15,8 @@ import numpy as np
 from scipy.linalg import lapack
 from scipy.optimize import OptimizeResult
 
+EPS = np.finfo(float).eps
+
 TERMINATION_MESSAGES = {
     -1: "Improper input parameters status returned from `leastsq`",
     0: "The maximum number of function evaluations is exceeded.",
@@ -188,7 +190,7 @@ class LevenbergMarquardt:
         accepted = st[4] > 0
         cost_new, pred, ratio, step_norm, x_norm, dF = float(st[5]), float(st[6]), float(st[7]), float(st[8]), float(st[9]), float(st[10])
         self.history.append((self.nfev, cost_before, cost_new, pred, ratio, lam, step_norm))
-        ftol_ok = dF < self.ftol * cost_before and ratio > 0.25
+        ftol_ok = max(dF, 0.0) < self.ftol * cost_before and ratio > 0.25  # (a neutral step has dF ~ -EPS F: counts as 0)
         xtol_ok = step_norm < self.xtol * (self.xtol + x_norm)
         status = 4 if (ftol_ok and xtol_ok) else 2 if ftol_ok else 3 if xtol_ok else None
         if accepted:
@@ -253,10 +255,14 @@ class LevenbergMarquardt:
             ratio = (self.cost - cost_new) / pred if (np.isfinite(cost_new) and pred > 0) else -1.0
             dF = self.cost - cost_new
             self.history.append((self.nfev, self.cost, cost_new, pred, ratio, lam, step_norm))
-            ftol_ok = dF < self.ftol * self.cost and ratio > 0.25
+            ftol_ok = max(dF, 0.0) < self.ftol * self.cost and ratio > 0.25  # (a neutral step has dF ~ -EPS F: counts as 0)
             xtol_ok = step_norm < self.xtol * (self.xtol + x_norm)
             status = 4 if (ftol_ok and xtol_ok) else 2 if ftol_ok else 3 if xtol_ok else None
-            accepted = ratio > 0 and dF >= 0
+            # round-off guard (same rule as k_decide): |dF| below FP64 resolution of the cost = neutral step, accepted
+            neutral = bool(np.isfinite(cost_new) and pred >= 0 and abs(dF) <= 32 * EPS * abs(self.cost))
+            accepted = (ratio > 0 and dF >= 0) or neutral
+            if accepted and not (ratio > 0 and dF >= 0):
+                ratio = 0.5
             if accepted:
                 self.cur = 1 - self.cur
                 self.x_cam = self.x_cam + dc

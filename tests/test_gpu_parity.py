@@ -261,7 +261,7 @@ def test_solution_matches_tight_reference_optimum(mc, golden, tag, kwargs):
     golden_acc = (np.abs(c0 - c1) / np.abs(c0)).max()
     assert golden_acc < 5e-7
     with contextlib.redirect_stdout(io.StringIO()):
-        e, i, p_, use, res = mc.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=None, ftol=1e-15, xtol=1e-15, gtol=1e-9, verbose=0, max_nfev=200, **kwargs)
+        e, i, p_, use, res = mc.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=None, ftol=0.0, xtol=1e-12, gtol=1e-10, verbose=0, max_nfev=200, **kwargs)
     np.testing.assert_array_equal(use, z["s0_use"])
     assert abs(res.cost - float(z["s0_cost"])) <= 1e-10 * res.cost
     _compare_to_tight(mc, z, res.x, C, 1e-6)
