@@ -123,7 +123,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-        comm = m.solver.TorchDistributed()
+        comm = "pending"
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -134,7 +134,7 @@ def main():
     x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
     prob = m.ops.Problem(p["uvs"], p["obj"], device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
     if comm is not None:
-        prob.enable_collective(torch.device(f"cuda:{local_rank}"))
+        comm = m.solver.make_comm(prob, torch.device(f"cuda:{local_rank}"))  # direct RCCL, else torch.distributed
 
     lm = m.solver.LevenbergMarquardt(prob, comm, ftol=0.0, xtol=0.0, gtol=0.0)
     lm.start(x0)
@@ -219,7 +219,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"bundle adjustment, {C} cameras x {F} frames/GPU x {N} points, intrinsics+distortion+extrinsics+poses free, soft_l1 (BASELINE configs[2])",
-                       "frames_total": F * world, "parallelism": f"frames sharded over {world} GPU(s), all-reduce of the {12 * C}x{12 * C} reduced camera system"},
+                       "frames_total": F * world, "parallelism": f"frames sharded over {world} GPU(s), all-reduce of the {12 * C}x{12 * C} reduced camera system",
+                       "collectives": type(comm).__name__ if comm is not None else "none"},
             "ms_per_jacobian_eval": ms_jac,
             "roofline": roofline,
             "jacobian_eval": {"kernel": "k_jacobian", "ms": ms_jac, "roofline": {"bound": "hbm", "achieved": jach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jach / HBM_PEAK_GBS,

@@ -140,6 +140,15 @@ int mcba_lm_decide_reduce(mcba_handle* h, double pred_cam, double dcn2, double x
 int mcba_lm_rebuild(mcba_handle* h, int rank_slot);
 int mcba_lm_fetch(mcba_handle* h, double* host);
 int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, double dcn2, double xcn2, double lam_min, double lam_max, double* host);
+/* ---- direct RCCL (optional; frame-sharded runs) ------------------------------------------------------------
+ * The library dlopen()s the RCCL already loaded in the process (torch's) -- it is not linked against it.
+ * Rank 0 calls mcba_comm_unique_id (128 bytes), the caller broadcasts them (e.g. torch.distributed), every rank
+ * calls mcba_comm_init; mcba_comm_allreduce then enqueues ncclAllReduce(SUM, f64, in place) on `count` doubles of the
+ * reduce buffer starting at `offset`, on the handle's stream (no host synchronisation, no Python dispatch). */
+int mcba_comm_unique_id(unsigned char* out128);
+int mcba_comm_init(mcba_handle* h, const unsigned char* id128, int rank, int world);
+int mcba_comm_allreduce(mcba_handle* h, size_t offset, size_t count);
+int mcba_comm_destroy(mcba_handle* h);
 /* Frame part of the gradient J^T f of the last mcba_build_reduced(): (F,6) doubles, host.
  * (The camera part is the g_c block of the reduce buffer.)  Feeds OptimizeResult.grad (trf.py:557-560). */
 int mcba_get_frame_gradient(mcba_handle* h, double* host);

@@ -108,6 +108,10 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             raise RuntimeError("distributed=True needs an initialised torch.distributed process group (launch with torchrun)")
         rank, world = dist.get_rank(), dist.get_world_size()
         opt_kwargs.setdefault("device", int(os.environ.get("LOCAL_RANK", rank)))
+        if backend is None:
+            import torch
+
+            torch.cuda.set_device(opt_kwargs["device"])  # object collectives of the nccl backend use the current device
     device = opt_kwargs.pop("device", 0)
     fix_intrinsics = opt_kwargs.pop("fix_intrinsics", False)
     return_jac = opt_kwargs.pop("return_jac", True)
@@ -162,8 +166,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     if distributed:
         import torch
 
-        prob.enable_collective(torch.device(f"cuda:{device}") if backend is None else "cpu")
-        comm = solver.TorchDistributed()
+        comm = solver.make_comm(prob, torch.device(f"cuda:{device}") if backend is None else "cpu")
         return_jac = False if backend is not None else return_jac
     free = None
     if fix_intrinsics:

@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> multicam-calibration_amd/libmcba.so (cross-compiles without a GPU)."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", LIB, "-ldl"] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

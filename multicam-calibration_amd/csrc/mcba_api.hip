@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <string>
 #include <vector>
 
@@ -42,6 +44,7 @@ struct mcba_handle {
   int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD (few frames)
   size_t nx = 0, nsys = 0;
   double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
+  ncclComm_t comm = nullptr;  // direct RCCL communicator (optional)
   // profiling
   bool prof = false;
   unsigned prof_mask = ~0u;
@@ -97,6 +100,38 @@ int dalloc(T** p, size_t count) {
 }
 
 }  // namespace
+
+// RCCL entry points resolved at run time from the copy already loaded in the process (torch's librccl.so)
+struct RcclApi {
+  bool ok = false;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int load_rccl() {
+  if (g_rccl.ok) return MCBA_OK;
+  void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return fail(MCBA_ERR_ARG, "RCCL library not found (dlopen librccl.so)");
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+  g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+  g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) return fail(MCBA_ERR_ARG, "RCCL symbols missing");
+  g_rccl.ok = true;
+  return MCBA_OK;
+}
+static int rccl_fail(const char* what, ncclResult_t r) {
+  g_err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+  return MCBA_ERR_HIP;
+}
 
 extern "C" {
 
@@ -185,6 +220,7 @@ int mcba_destroy(mcba_handle* h) {
   if (!h) return MCBA_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl.ok) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   double* bufs[] = {h->obs_t, h->obs_raw, h->obj, h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->fbuf, h->fpart, h->spart, h->cpart, h->bpart, h->red_own, h->jac, h->res};
   for (double* p : bufs) if (p) (void)hipFree(p);
   if (h->tile_i) (void)hipFree(h->tile_i);
@@ -579,6 +615,46 @@ int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, do
   rc = lm_reduce_chain(h, 0);
   if (rc) return rc;
   return mcba_lm_fetch(h, host);
+}
+
+int mcba_comm_unique_id(unsigned char* out128) {
+  if (!out128) return fail(MCBA_ERR_ARG, "mcba_comm_unique_id: NULL");
+  int rc = load_rccl();
+  if (rc) return rc;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
+  memcpy(out128, &id, 128);
+  return MCBA_OK;
+}
+
+int mcba_comm_init(mcba_handle* h, const unsigned char* id128, int rank, int world) {
+  if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return fail(MCBA_ERR_ARG, "mcba_comm_init: bad argument");
+  int rc = load_rccl();
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(h->device));
+  if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclResult_t r = g_rccl.CommInitRank(&h->comm, world, id, rank);
+  if (r != ncclSuccess) { h->comm = nullptr; return rccl_fail("ncclCommInitRank", r); }
+  return MCBA_OK;
+}
+
+int mcba_comm_allreduce(mcba_handle* h, size_t offset, size_t count) {
+  if (!h || !h->comm) return fail(MCBA_ERR_ARG, "mcba_comm_allreduce: no communicator (call mcba_comm_init)");
+  if (offset + count > h->nsys + 8 + MCBA_LMS) return fail(MCBA_ERR_ARG, "mcba_comm_allreduce: range outside the reduce buffer");
+  ncclResult_t r = g_rccl.AllReduce(h->red + offset, h->red + offset, count, ncclDouble, ncclSum, h->comm, h->stream);
+  if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+  return MCBA_OK;
+}
+
+int mcba_comm_destroy(mcba_handle* h) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  if (h->comm && g_rccl.ok) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); }
+  h->comm = nullptr;
+  return MCBA_OK;
 }
 
 int mcba_get_frame_gradient(mcba_handle* h, double* host) {

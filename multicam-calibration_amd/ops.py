@@ -50,6 +50,10 @@ SYMBOLS = [
     ("mcba_lm_rebuild", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_lm_fetch", ctypes.c_int, [_h, _dp]),
     ("mcba_lm_iterate", ctypes.c_int, [_h, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp]),
+    ("mcba_comm_unique_id", ctypes.c_int, [ctypes.c_char_p]),
+    ("mcba_comm_init", ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
+    ("mcba_comm_allreduce", ctypes.c_int, [_h, ctypes.c_size_t, ctypes.c_size_t]),
+    ("mcba_comm_destroy", ctypes.c_int, [_h]),
     ("mcba_get_frame_gradient", ctypes.c_int, [_h, _dp]),
     ("mcba_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_profile_read", ctypes.c_int, [_h, _dp, _ip, ctypes.c_int, _ip]),
@@ -260,6 +264,27 @@ class Problem:
     def lm_fetch(self):
         self._chk(self.lib.mcba_lm_fetch(self.handle, self._all_p))
         return self._red_views, self._trial, self._state
+
+    # ---- direct RCCL on the library's own reduce buffer (frame-sharded runs)
+    def comm_init_from_torch(self, group=None):
+        """Create an RCCL communicator over the ranks of an initialised torch.distributed group: rank 0 draws the
+        unique id, torch.distributed broadcasts it.  Raises on failure (the caller may fall back to torch collectives)."""
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            self._chk(self.lib.mcba_comm_unique_id(buf))
+            box[0] = buf.raw
+        dist.broadcast_object_list(box, src=0, group=group)
+        self._chk(self.lib.mcba_comm_init(self.handle, box[0], rank, world))
+        return rank, world
+
+    def comm_allreduce(self, offset, count):
+        rc = self.lib.mcba_comm_allreduce(self.handle, offset, count)
+        if rc:
+            self._chk(rc)
 
     def frame_gradient(self):
         g = np.empty((self.F, 6))

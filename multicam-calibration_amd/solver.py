@@ -71,6 +71,36 @@ class TorchDistributed:
         self.dist.all_reduce(problem.reduce_tensor[problem.nsys : problem.nsys + 8], group=self.group)
 
 
+class DirectRCCL:
+    """Same two collectives as TorchDistributed, but enqueued by libmcba itself with ncclAllReduce on its own reduce
+    buffer (ops.Problem.comm_init_from_torch): no torch tensor, no Python collective dispatch (~25 us each)."""
+
+    def __init__(self, problem, group=None):
+        self.rank, self.world = problem.comm_init_from_torch(group)
+
+    def all_reduce_system(self, problem):
+        problem.comm_allreduce(0, problem.nsys)
+
+    def all_reduce_trial(self, problem):
+        problem.comm_allreduce(problem.nsys, 8)
+
+
+def make_comm(problem, device, group=None, direct=None):
+    """Collective backend for a frame-sharded solve: direct RCCL if it can be set up (MCBA_DIRECT_RCCL=0 disables),
+    otherwise torch.distributed on a tensor that aliases the reduce buffer."""
+    import os
+
+    if direct is None:
+        direct = os.environ.get("MCBA_DIRECT_RCCL", "1") != "0"
+    if direct and hasattr(problem, "comm_init_from_torch"):
+        try:
+            return DirectRCCL(problem, group)
+        except Exception as e:  # noqa: BLE001 -- any failure: use the torch path
+            print(f"[mcba] direct RCCL unavailable ({e}); using torch.distributed collectives", flush=True)
+    problem.enable_collective(device)
+    return TorchDistributed(group)
+
+
 def _solve_spd(S, rhs):
     """S symmetric positive definite -> step, or None if the Cholesky factorisation fails.
     LAPACK dposv straight on the buffer (S is symmetric, so its C-order memory is a valid Fortran matrix)."""
