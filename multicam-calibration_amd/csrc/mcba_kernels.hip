@@ -129,10 +129,14 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
   constexpr int PF = 2;
   const double2* op = obs_t + (size_t)c * N * Fpad + f;
   double2 ring[PF];
+  double xring[PF][3];  // board points travel with the ring: wave-uniform scalar loads issued PF points ahead as well
 #pragma unroll
-  for (int j = 0; j < PF; ++j) ring[j] = op[(size_t)min(j, N - 1) * Fpad];
-  auto point = [&](double2 o2, int p) {
-    double Xo[3] = {obj[3 * p], obj[3 * p + 1], obj[3 * p + 2]};  // wave-uniform scalar loads
+  for (int j = 0; j < PF; ++j) {
+    const int pj = min(j, N - 1);
+    ring[j] = op[(size_t)pj * Fpad];
+    xring[j][0] = obj[3 * pj]; xring[j][1] = obj[3 * pj + 1]; xring[j][2] = obj[3 * pj + 2];
+  }
+  auto point = [&](double2 o2, const double Xo[3]) {
     bool vu = is_num(o2.x), vv = is_num(o2.y);
     if (vu || vv) {
       any = true;
@@ -160,13 +164,16 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       double2 o2 = ring[j];
-      ring[j] = op[(size_t)min(p + j + PF, N - 1) * Fpad];
-      point(o2, p + j);
+      double Xo[3] = {xring[j][0], xring[j][1], xring[j][2]};
+      const int pn = min(p + j + PF, N - 1);
+      ring[j] = op[(size_t)pn * Fpad];
+      xring[j][0] = obj[3 * pn]; xring[j][1] = obj[3 * pn + 1]; xring[j][2] = obj[3 * pn + 2];
+      point(o2, Xo);
     }
   }
 #pragma unroll
   for (int j = 0; j < PF; ++j)
-    if (p + j < N) point(ring[j], p + j);
+    if (p + j < N) point(ring[j], xring[j]);
 
   // ---- expand once per (c,f): this role's part of W, V, g_f (record) and of U, g_c (reduced over the wave)
   ChainConst ch;

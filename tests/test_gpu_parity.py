@@ -310,6 +310,29 @@ def test_default_tolerance_run_reaches_reference_cost(mc, golden):
     assert "Iteration" in out and "Optimality" in out and "termination condition is satisfied" in out
 
 
+def test_default_run_6x1000_vs_reference(mc, golden):
+    """The UNMODIFIED reference's default bundle_adjust() on 6 cameras x 1000 frames x 54 points took 101.5 s on the CPU
+    (tests/golden/make_golden_large.py: 9 TRF iterations, nfev 15, ftol stop).  Same inputs (regenerated from the seed),
+    same defaults here: same frames, a cost at least as low, predictions within the reference's own stopping slack."""
+    z = golden("default_run_6x1000.npz")
+    p = mc.synth.make_problem(6, 1000, seed=0, perturb_seed=1)
+    assert abs(float(z["uvs_checksum"]) - np.nansum(p["uvs"])) <= 1e-9 * abs(float(z["uvs_checksum"]))  # same inputs
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, return_jac=False)
+    np.testing.assert_array_equal(use, z["use"])
+    assert res.status in (1, 2, 3, 4)
+    assert res.cost <= float(z["cost"]) * (1 + 1e-6)
+    assert res.cost >= 0.999 * float(z["cost"])          # and not a different problem
+    pa = orc.predict_from_x(res.x, 6, p["obj"])
+    pb = orc.predict_from_x(z["x"], 6, p["obj"])
+    assert np.abs(pa - pb).max() < 0.2                    # px; the reference stopped at ftol = 1e-4, far from the optimum
+    # run to the optimum: strictly below the reference's early-stop cost, and stationary
+    with contextlib.redirect_stdout(io.StringIO()):
+        e2, it2, ps2, use2, res2 = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, return_jac=False,
+                                                     ftol=0.0, xtol=1e-12, gtol=1e-8, verbose=0)
+    assert res2.cost < float(z["cost"]) and res2.optimality < 1e-3
+
+
 def test_fix_intrinsics(mc):
     p = mc.synth.make_problem(3, 40, seed=26)
     with contextlib.redirect_stdout(io.StringIO()):
