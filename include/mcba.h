@@ -93,7 +93,7 @@ int mcba_linearize(mcba_handle* h, int slot);
  *   [0,n*n)      S0  = blockdiag(U_c) - sum_f W_f (V_f + lambda D_f)^-1 W_f^T      (undamped camera block)
  *   [n*n,+n)     rhs = -g_c + sum_f W_f (V_f + lambda D_f)^-1 g_f
  *   [..,+n)      diag(U)          [..,+n)  g_c
- *   [..,+16)     scalars: 0 cost, 1 n_residuals, 2 n_cholesky_failures, 3 reserved,
+ *   [..,+16)     scalars: 0 cost, 1 number of (camera, frame) pairs with data, 2 n_cholesky_failures, 3 reserved,
  *                         4..15 per-rank slots: max |g_f| of THIS shard goes to slot 4+rank_slot, others 0
  * so that one all-reduce(SUM) of the whole buffer over the frame shards gives the global system. */
 int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot);
@@ -126,7 +126,8 @@ int mcba_step_fetch(mcba_handle* h, const double* delta_cam, double lambda, int 
  * mcba_lm_set_state uploads it (after mcba_linearize(slot = sel) + mcba_build_reduced);
  * mcba_lm_trial            : back-substitute delta_cam from the current point, linearise the trial point
  *                            (other slot / buffer), sum its cost  -> trial scalars;  [all-reduce them when sharded]
- * mcba_lm_decide_reduce    : accept/reject + Nielsen damping update ON THE GPU (same rule as the host driver),
+ * mcba_lm_decide_reduce    : accept/reject (with a round-off guard for |dF| <= 32 EPS F) + Nielsen damping update ON THE
+ *                            GPU (same rule as the host driver, solver.py),
  *                            then Schur-reduce whichever linearisation is now current with the new lambda;
  *                            pred_cam = d_c^T(lambda D_c d_c - g_c), dcn2 = |d_c|^2, xcn2 = |x_c|^2 from the host solve;
  *                            [all-reduce the system when sharded]
