@@ -120,9 +120,10 @@ int mcba_get_trial(mcba_handle* h, double* host8);
 int mcba_reduce_fetch(mcba_handle* h, double lambda, int rank_slot, double* host);
 int mcba_step_fetch(mcba_handle* h, const double* delta_cam, double lambda, int src_slot, int dst_slot, int linearize, double* host8);
 /* ---- device-resident LM iteration: ONE host synchronisation per iteration ----------------------------
- * The reduce buffer carries, behind the system (n*n+3n+16) and the 8 trial scalars, MCBA_LM_STATE = 16 doubles:
+ * The reduce buffer carries, behind the system (n*n+3n+16) and the 8 trial scalars, MCBA_LM_STATE = 32 doubles:
  *   0 cost  1 lambda  2 nu  3 sel (index of the current parameter slot AND linearisation buffer)  4 accepted
- *   5 cost_new  6 predicted reduction  7 ratio  8 step norm  9 x norm  10 actual reduction  11..15 reserved.
+ *   5 cost_new  6 predicted reduction  7 ratio  8 step norm  9 x norm  10 actual reduction;
+ *   11..24 belong to the device-resident solve below (0 for the host-solve entry points), 25..31 reserved.
  * mcba_lm_set_state uploads it (after mcba_linearize(slot = sel) + mcba_build_reduced);
  * mcba_lm_trial            : back-substitute delta_cam from the current point, linearise the trial point
  *                            (other slot / buffer), sum its cost  -> trial scalars;  [all-reduce them when sharded]
@@ -134,13 +135,42 @@ int mcba_step_fetch(mcba_handle* h, const double* delta_cam, double lambda, int 
  * mcba_lm_fetch            : D2H of system + trial scalars + state (mcba_reduced_size() doubles) and synchronise;
  * mcba_lm_iterate          : the three above in one call (single GPU);
  * mcba_lm_rebuild          : Schur-reduce again with the state's lambda (after the host changed it with set_state). */
-#define MCBA_LM_STATE 16
-int mcba_lm_set_state(mcba_handle* h, const double* state16);
+#define MCBA_LM_STATE 32
+int mcba_lm_set_state(mcba_handle* h, const double* state);
 int mcba_lm_trial(mcba_handle* h, const double* delta_cam);
 int mcba_lm_decide_reduce(mcba_handle* h, double pred_cam, double dcn2, double xcn2, double lam_min, double lam_max, int rank_slot);
 int mcba_lm_rebuild(mcba_handle* h, int rank_slot);
 int mcba_lm_fetch(mcba_handle* h, double* host);
 int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, double dcn2, double xcn2, double lam_min, double lam_max, double* host);
+/* ---- device-resident LM loop: NO host synchronisation per iteration --------------------------------------------
+ * The reduced camera system is factorised and solved on the GPU as well (k_solve_cam: blocked FP64 Cholesky on
+ * v_mfma_f64_16x16x4, one workgroup), the ftol / xtol / gtol tests of scipy (least_squares.py / trf.py:529-551) run
+ * there, and the host only enqueues "ticks" and reads the state each tick posts to a host-mapped ring of 16 slots.
+ *   state 11 pred_cam  12 |d_c|^2  13 |x_c|^2  14 skip (reduced solve failed: next tick only re-damps)  15 done (0 or
+ *   the scipy status 1..4)  16 first-order optimality  17 trial evaluations  18 accepted steps  19 pending verdict
+ *   20 lambda of the last trial  21 cost before it  22 ticks that did work  23 solve info (0 ok, 1 not positive
+ *   definite, 2 a frame block failed)  24 last tick was a rebuild  31 (ring slots) sequence number.
+ * mcba_lm_auto_config : tolerances, damping bounds, optional mask (n bytes, 1 = camera parameter held fixed);
+ * mcba_lm_auto_solve  : optimality + termination verdict + solve of the system in the reduce buffer -> camera step on
+ *                       the device, state posted to ring slot seq % 16 with sequence number `seq` (>= 1);
+ *                       call once after mcba_build_reduced + mcba_lm_set_state, then once per tick;
+ * mcba_lm_auto_trial  : back-substitute that step, linearise the trial point, sum its cost; decide != 0: accept/reject on
+ *                       the same launch (single GPU);  [sharded: decide = 0, all-reduce the 8 trial scalars]
+ * mcba_lm_auto_reduce : [decide != 0: the stand-alone decision kernel, sharded runs] + Schur reduction of the now
+ *                       current linearisation;  [sharded: all-reduce the system];
+ * mcba_lm_auto_tick   : trial + reduce + solve in one call, with the two all-reduces issued by the library itself when a
+ *                       direct RCCL communicator is attached (mcba_comm_init);
+ * mcba_lm_auto_wait   : spin on the ring slot until tick `seq` has posted (falls back to a stream synchronisation after
+ *                       50 ms) and copy its MCBA_LM_STATE doubles.  At most 15 ticks may be outstanding.
+ * After termination (state 15 != 0) the kernels of later ticks return at once; such ticks still post their slot. */
+int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, double lam_min, double lam_max, const unsigned char* fixed_mask);
+int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq);
+int mcba_lm_auto_trial(mcba_handle* h, int decide);
+int mcba_lm_auto_reduce(mcba_handle* h, int decide, int rank_slot);
+int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot);
+int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state);
+/* The camera step (12C doubles) the last mcba_lm_auto_solve left on the device; synchronises. */
+int mcba_get_cam_step(mcba_handle* h, double* host);
 /* ---- direct RCCL (optional; frame-sharded runs) ------------------------------------------------------------
  * The library dlopen()s the RCCL already loaded in the process (torch's) -- it is not linked against it.
  * Rank 0 calls mcba_comm_unique_id (128 bytes), the caller broadcasts them (e.g. torch.distributed), every rank

@@ -115,7 +115,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     device = opt_kwargs.pop("device", 0)
     fix_intrinsics = opt_kwargs.pop("fix_intrinsics", False)
     return_jac = opt_kwargs.pop("return_jac", True)
-    lm_kwargs = {k: opt_kwargs.pop(k) for k in ("lam0",) if k in opt_kwargs}
+    lm_kwargs = {k: opt_kwargs.pop(k) for k in ("lam0", "reduced_solver") if k in opt_kwargs}
 
     all_calib_uvs = np.asarray(all_calib_uvs, dtype=np.float64)
     calib_objpoints = np.asarray(calib_objpoints, dtype=np.float64)

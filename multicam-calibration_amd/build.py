@@ -7,7 +7,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmcba.so")
-SOURCES = ["mcba_kernels.hip", "mcba_api.hip"]
+SOURCES = ["mcba_kernels.hip", "mcba_solve.hip", "mcba_api.hip"]
 DEPS = SOURCES + ["mcba_math.h", "mcba_kernels.h", os.path.join("..", "..", "include", "mcba.h")]
 
 
@@ -29,7 +29,8 @@ def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> multicam-calibration_amd/libmcba.so (cross-compiles without a GPU)."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", LIB, "-ldl"] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("MCBA_HIPCC_FLAGS", "").split()  # development only (e.g. -DMCBA_SOLVE_TIMING, -save-temps)
+    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", LIB, "-ldl"] + extra + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

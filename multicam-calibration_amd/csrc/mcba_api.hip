@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <string>
@@ -17,8 +19,9 @@ namespace {
 
 thread_local std::string g_err;
 
-enum KernelId { K_TRANSPOSE = 0, K_GRAM, K_COST, K_FRAME_FACTOR, K_SYRK, K_REDUCE, K_BACKSUB, K_SUM_TRIAL, K_JACOBIAN, K_DECIDE, K_COUNT };
-const char* kKernelNames = "k_transpose_obs\nk_gram\nk_cost\nk_frame_factor\nk_syrk\nk_reduce_system\nk_backsub\nk_sum_trial\nk_jacobian\nk_decide";
+enum KernelId { K_TRANSPOSE = 0, K_GRAM, K_COST, K_FRAME_FACTOR, K_SYRK, K_REDUCE, K_BACKSUB, K_SUM_TRIAL, K_JACOBIAN, K_DECIDE, K_SOLVE, K_COUNT };
+const char* kKernelNames = "k_transpose_obs\nk_gram\nk_cost\nk_frame_factor\nk_syrk\nk_reduce_system\nk_backsub\nk_sum_trial\nk_jacobian\nk_decide\nk_solve_cam";
+constexpr int kRing = 16;  // host-mapped LM state slots (device-resident loop): the host may run at most kRing - 1 ticks ahead
 
 struct EvRec { int kid; hipEvent_t a, b; };
 
@@ -45,6 +48,14 @@ struct mcba_handle {
   size_t nx = 0, nsys = 0;
   double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
   ncclComm_t comm = nullptr;  // direct RCCL communicator (optional)
+  // device-resident LM loop (mcba_lm_auto_*)
+  double *dcbuf = nullptr, *swork = nullptr;
+  unsigned char* fixed = nullptr;
+  bool have_fixed = false, auto_ready = false;
+  double* ring = nullptr;      // kRing x MCBA_LMS doubles, host-coherent pinned memory the GPU writes directly
+  double* ring_dev = nullptr;  // the same memory as the device sees it
+  int npad = 0, solve_lds = 0;
+  double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8, lam_min = 1e-12, lam_max = 1e12;
   // profiling
   bool prof = false;
   unsigned prof_mask = ~0u;
@@ -201,7 +212,20 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   DA(red_own, h->nsys + 8 + MCBA_LMS);
   DA(tile_i, (size_t)h->NP);
   DA(tile_j, (size_t)h->NP);
+  h->npad = 16 * h->NT;
+  h->solve_lds = mcba::solve_fits_lds(h->npad);
+  DA(dcbuf, (size_t)h->n);
+  DA(swork, h->solve_lds ? 16 : (size_t)h->npad * h->npad);
+  DA(fixed, (size_t)h->n);
 #undef DA
+  if (mcba::solve_set_lds_limit(h->npad, h->solve_lds) != 0) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_solve_cam"); }
+  {
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h->ring), (size_t)kRing * MCBA_LMS * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostMalloc(reinterpret_cast<void**>(&h->ring), (size_t)kRing * MCBA_LMS * sizeof(double), hipHostMallocDefault); }
+    if (e != hipSuccess) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "cannot allocate the host-mapped LM state ring"); }
+    memset(h->ring, 0, (size_t)kRing * MCBA_LMS * sizeof(double));
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&h->ring_dev), h->ring, 0) != hipSuccess) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "hipHostGetDevicePointer failed for the LM state ring"); }
+  }
   h->red = h->red_own;
   std::vector<int> ci, cj;
   for (int a = 0; a < h->NT; ++a) for (int b = a; b < h->NT; ++b) { ci.push_back(a); cj.push_back(b); }
@@ -226,6 +250,10 @@ int mcba_destroy(mcba_handle* h) {
   if (h->tile_i) (void)hipFree(h->tile_i);
   if (h->tile_j) (void)hipFree(h->tile_j);
   if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->ring) (void)hipHostFree(h->ring);
+  if (h->dcbuf) (void)hipFree(h->dcbuf);
+  if (h->swork) (void)hipFree(h->swork);
+  if (h->fixed) (void)hipFree(h->fixed);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->pool) (void)hipEventDestroy(e);
   delete h;
@@ -510,13 +538,13 @@ int mcba_step_fetch(mcba_handle* h, const double* delta_cam, double lambda, int 
 // Device-resident LM iteration: the accept/reject decision and the damping update happen on the GPU (k_decide), so
 // backsub -> gram(trial) -> sum -> decide -> frame_factor -> syrk -> reduce is ONE stream-ordered chain.
 // Convention while it is in use: parameter slot i and linearisation buffer i belong together; state[3] = current i.
-int mcba_lm_set_state(mcba_handle* h, const double* state16) {
-  if (!h || !state16) return fail(MCBA_ERR_ARG, "mcba_lm_set_state: bad argument");
-  int sel = (int)state16[3];
+int mcba_lm_set_state(mcba_handle* h, const double* state) {
+  if (!h || !state) return fail(MCBA_ERR_ARG, "mcba_lm_set_state: bad argument");
+  int sel = (int)state[3];
   if (sel != 0 && sel != 1) return fail(MCBA_ERR_ARG, "mcba_lm_set_state: state[3] must be 0 or 1");
   HIPCHK(hipSetDevice(h->device));
   double* stage = h->pinned + h->nsys + 8;
-  memcpy(stage, state16, MCBA_LMS * sizeof(double));
+  memcpy(stage, state, MCBA_LMS * sizeof(double));
   HIPCHK(hipMemcpyAsync(h->red + h->nsys + 8, stage, MCBA_LMS * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (sel != h->lin) {
@@ -615,6 +643,127 @@ int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, do
   rc = lm_reduce_chain(h, 0);
   if (rc) return rc;
   return mcba_lm_fetch(h, host);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Device-resident LM loop: the reduced camera system is solved on the GPU too (k_solve_cam), the termination tests run
+// there, and the host only enqueues "ticks" and reads the 32-double state each one posts to a host-mapped ring:
+//   tick = k_backsub -> k_gram(trial) -> k_sum_trial [-> all-reduce -> k_decide] -> k_frame_factor -> k_syrk
+//          -> k_reduce_system [-> all-reduce] -> k_solve_cam
+// No host synchronisation inside or between ticks; after termination the remaining ticks return immediately.
+int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, double lam_min, double lam_max, const unsigned char* fixed) {
+  if (!h || !(lam_min > 0.0) || !(lam_max > lam_min)) return fail(MCBA_ERR_ARG, "mcba_lm_auto_config: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  h->ftol = ftol; h->xtol = xtol; h->gtol = gtol; h->lam_min = lam_min; h->lam_max = lam_max;
+  h->have_fixed = fixed != nullptr;
+  if (fixed) {
+    HIPCHK(hipMemcpyAsync(h->fixed, fixed, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  memset(h->ring, 0, (size_t)kRing * MCBA_LMS * sizeof(double));
+  h->auto_ready = true;
+  return MCBA_OK;
+}
+
+int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq) {
+  if (!h || !h->auto_ready || seq == 0) return fail(MCBA_ERR_ARG, "mcba_lm_auto_solve: call mcba_lm_auto_config first; seq >= 1");
+  if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_lm_auto_solve: no reduced system");
+  HIPCHK(hipSetDevice(h->device));
+  mcba::SolveArgs a;
+  a.red = h->red; a.lms = h->red + h->nsys + 8; a.work = h->swork; a.dc = h->dcbuf; a.x0 = h->x[0]; a.x1 = h->x[1];
+  a.fixed = h->have_fixed ? h->fixed : nullptr;
+  a.host_state = h->ring_dev + (size_t)(seq % kRing) * MCBA_LMS;
+  a.seq = (double)seq; a.gtol = h->gtol; a.lam_max = h->lam_max;
+  a.n = h->n; a.npad = h->npad; a.use_lds = h->solve_lds;
+  {
+    Scope sc(h, K_SOLVE);
+    mcba::launch_solve_cam(h->stream, a);
+  }
+  return check_launch();
+}
+
+int mcba_lm_auto_trial(mcba_handle* h, int decide) {
+  if (!h || !h->auto_ready) return fail(MCBA_ERR_ARG, "mcba_lm_auto_trial: call mcba_lm_auto_config first");
+  if (!h->have_lin) return fail(MCBA_ERR_ARG, "mcba_lm_auto_trial: no linearisation");
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  {
+    Scope sc(h, K_BACKSUB);
+    mcba::launch_backsub_dev(h->stream, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->dcbuf, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad);
+  }
+  if ((rc = check_launch())) return rc;
+  {
+    Scope sc(h, K_GRAM);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split);
+  }
+  if ((rc = check_launch())) return rc;
+  {
+    Scope sc(h, K_SUM_TRIAL);
+    mcba::DecideArgs da{decide ? 2 : 0, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, h->red + h->nsys + 8, h->ftol, h->xtol};
+    mcba::launch_sum_trial(h->stream, dev_sel(h, 1), h->gpart2[0] + (size_t)90 * h->nfb, h->gpart2[1] + (size_t)90 * h->nfb, 1, h->nfb, (size_t)MCBA_GP * h->nfb, h->C * h->nfb, h->bpart, h->nbblocks, h->red + h->nsys, da);
+  }
+  return check_launch();
+}
+
+int mcba_lm_auto_reduce(mcba_handle* h, int decide, int rank_slot) {
+  if (!h || !h->auto_ready || rank_slot < 0 || rank_slot > 11) return fail(MCBA_ERR_ARG, "mcba_lm_auto_reduce: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  if (decide) {
+    {
+      Scope sc(h, K_DECIDE);
+      mcba::launch_decide(h->stream, h->red + h->nsys, mcba::DecideArgs{2, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, h->red + h->nsys + 8, h->ftol, h->xtol});
+    }
+    int rc = check_launch();
+    if (rc) return rc;
+  }
+  return lm_reduce_chain(h, rank_slot);
+}
+
+int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  const bool coll = h->comm != nullptr;
+  int rc = mcba_lm_auto_trial(h, coll ? 0 : 1);
+  if (rc) return rc;
+  if (coll && (rc = mcba_comm_allreduce(h, h->nsys, 8))) return rc;
+  if ((rc = mcba_lm_auto_reduce(h, coll ? 1 : 0, rank_slot))) return rc;
+  if (coll && (rc = mcba_comm_allreduce(h, 0, h->nsys))) return rc;
+  return mcba_lm_auto_solve(h, seq);
+}
+
+int mcba_get_cam_step(mcba_handle* h, double* host) {
+  if (!h || !host) return fail(MCBA_ERR_ARG, "mcba_get_cam_step: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(host, h->dcbuf, (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state) {
+  if (!h || !state || !h->auto_ready || seq == 0) return fail(MCBA_ERR_ARG, "mcba_lm_auto_wait: bad argument");
+  volatile double* slot = h->ring + (size_t)(seq % kRing) * MCBA_LMS;
+  const double want = (double)seq;
+  auto t0 = std::chrono::steady_clock::now();
+  bool synced = false;
+  for (unsigned spin = 0;; ++spin) {
+    if (slot[MCBA_LM_SEQ] == want) break;
+    __builtin_ia32_pause();
+    if ((spin & 0xFFF) == 0xFFF && !synced) {
+      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > 0.05) {  // not the fast path any more: block on the stream, then look once more
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        synced = true;
+        if (slot[MCBA_LM_SEQ] != want) return fail(MCBA_ERR_ARG, "mcba_lm_auto_wait: that tick was never enqueued (or the ring slot was overwritten)");
+      }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for (int i = 0; i < MCBA_LMS; ++i) state[i] = slot[i];
+  int sel = (int)state[3];
+  if (sel == 0 || sel == 1) h->lin = sel;
+  h->have_spec = false;
+  return MCBA_OK;
 }
 
 int mcba_comm_unique_id(unsigned char* out128) {

@@ -7,7 +7,24 @@
 #define MCBA_GP 92    // k_gram per-wavefront sums, stored [camera][k][frame block]: k = U 78 | g_c 12 | cost | pairs with data
 #define MCBA_FB 40    // per frame: L 21 | z 6 | g_f 6 | D_f 6 | pad
 
-#define MCBA_LMS 16   // device LM state: cost, lambda, nu, sel, accepted, cost_new, pred, ratio, step_norm, x_norm, ...
+// device LM state (doubles): 0 cost  1 lambda  2 nu  3 sel (current slot / linearisation)  4 accepted  5 cost_new  6 pred
+// 7 ratio  8 step_norm  9 x_norm  10 dF, then the fields of the device-resident solve (k_solve_cam, mcba_solve.hip):
+#define MCBA_LMS 32
+#define MCBA_LM_PRED_CAM 11    // d_c^T (lam D_c d_c - g_c) of the camera step waiting in the dc buffer
+#define MCBA_LM_DCN2 12        // |d_c|^2
+#define MCBA_LM_XCN2 13        // |x_c|^2 at the current point
+#define MCBA_LM_SKIP 14        // 1: the reduced solve failed -> this tick only rebuilds the system with more damping
+#define MCBA_LM_DONE 15        // 0 running, else the scipy status (1 gtol, 2 ftol, 3 xtol, 4 both): every kernel of a tick returns early
+#define MCBA_LM_GINF 16        // first-order optimality at the current point
+#define MCBA_LM_NFEV 17        // trial evaluations so far (the host adds the initial one)
+#define MCBA_LM_NACC 18        // accepted steps
+#define MCBA_LM_PENDING 19     // ftol / xtol verdict of the last decision, applied by the next k_solve_cam
+#define MCBA_LM_LAM_USED 20    // damping of the last trial step
+#define MCBA_LM_COST_BEFORE 21 // cost before the last trial step
+#define MCBA_LM_TICK 22        // ticks that did work
+#define MCBA_LM_SOLVE_INFO 23  // 0 ok, 1 reduced system not positive definite / non-finite step, 2 a frame block failed
+#define MCBA_LM_REBUILD 24     // 1: the last tick was a damping-only rebuild (no trial)
+#define MCBA_LM_SEQ 31         // host ring slots only: sequence number of the tick, written last
 
 namespace mcba {
 // Double-buffered operands (parameter slots, linearisation records) and the damping are chosen either from host
@@ -24,10 +41,27 @@ struct Sel {
   double lam;
 };
 // decide != 0: k_sum_trial / k_decide apply the accept/reject + damping update to the LM state (lms)
+// decide == 2: device-resident solve -- pred_cam / dcn2 / xcn2 come from the LM state (k_solve_cam left them there) and
+// the ftol / xtol tests of solver.LevenbergMarquardt run on the GPU as well (verdict -> state[MCBA_LM_PENDING])
 struct DecideArgs {
   int decide;
   double pred_cam, dcn2, xcn2, lam_min, lam_max;
   double* lms;
+  double ftol, xtol;
+};
+// k_solve_cam (mcba_solve.hip): reduced camera system factorised and solved by one workgroup
+struct SolveArgs {
+  const double* red;         // S0 (n x n) | rhs | diag U | g_c | 16 scalars
+  double* lms;               // device LM state
+  double* work;              // npad x npad scratch (used when the factor does not fit LDS)
+  double* dc;                // n doubles: the camera step
+  const double* x0;          // parameter slots (camera block first)
+  const double* x1;
+  const unsigned char* fixed;  // n flags (1 = parameter held fixed) or nullptr
+  double* host_state;        // host-mapped ring slot of MCBA_LMS doubles, or nullptr
+  double seq;
+  double gtol, lam_max;
+  int n, npad, use_lds;
 };
 void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int C, int F, int N, int Fpad);
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split);
@@ -38,6 +72,11 @@ void launch_syrk(hipStream_t st, Sel s, const double* rec0, const double* rec1, 
 int syrk_items_per_thread();
 void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot);
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad);
+void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const double* dc_dev, double* x0, double* x1, double* bpart, int C, int F, int Fpad);
+size_t solve_lds_bytes(int npad, int use_lds);
+int solve_fits_lds(int npad);
+int solve_set_lds_limit(int npad, int use_lds);
+void launch_solve_cam(hipStream_t st, const SolveArgs& a);
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da);
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);

@@ -64,6 +64,13 @@ __device__ __forceinline__ double uni(double v) {
 __device__ __forceinline__ bool is_num(double v) { return v == v; }
 __device__ __forceinline__ int sel_index(const Sel& s) { return s.lms ? ((static_cast<int>(s.lms[3]) ^ s.idx) & 1) : s.idx; }
 __device__ __forceinline__ double sel_lambda(const Sel& s) { return s.lms ? s.lms[1] : s.lam; }
+// device-resident LM loop: after termination every kernel of a tick returns at once; a tick that follows a failed
+// reduced solve skips its trial kernels (`trial` = true) and only rebuilds the system with the raised damping
+__device__ __forceinline__ bool sel_active(const Sel& s, bool trial) {
+  if (!s.lms) return true;
+  if (s.lms[MCBA_LM_DONE] != 0.0) return false;
+  return !(trial && s.lms[MCBA_LM_SKIP] != 0.0);
+}
 
 template <int LOSS>
 __device__ __forceinline__ void obs_weights(double r, bool valid, double fs2, double ifs2, double& cost, double& w2, double& g) {
@@ -246,6 +253,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 template <int LOSS>
 __global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
                                                        double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+  if (!sel_active(sl, true)) return;
   const int sidx = sel_index(sl);
   const double* __restrict__ x = sidx ? x1 : x0;
   double* __restrict__ rec = sidx ? rec1 : rec0;
@@ -265,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict
 template <int LOSS>
 __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
                                                  double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+  if (!sel_active(sl, true)) return;
   const int sidx = sel_index(sl);
   const double* __restrict__ x = sidx ? x1 : x0;
   double* __restrict__ rec = sidx ? rec1 : rec0;
@@ -360,6 +369,7 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
 // fbuf[f] = {L(21), z(6), g_f(6), D_f(6), pad}.  Per-block partials: max |g_f|, #failed factorisations.
 // The V_cf / g_cf reads are coalesced tile rows; three cameras (81 loads) are in flight per lane at a time.
 __global__ __launch_bounds__(64) void k_frame_factor(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, double* __restrict__ fbuf, double* __restrict__ fpart, int C, int F, int Fpad) {
+  if (!sel_active(sl, false)) return;
   const double* __restrict__ rec = sel_index(sl) ? rec1 : rec0;
   const double lambda = sel_lambda(sl);
   const int f = blockIdx.x * 64 + threadIdx.x;
@@ -435,6 +445,7 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 template <int PPW, int IPT>
 __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const int* __restrict__ tile_i,
                                               const int* __restrict__ tile_j, double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int fpc, int FS) {
+  if (!sel_active(sl, false)) return;
   const double* __restrict__ rec = sel_index(sl) ? rec1 : rec0;
   extern __shared__ __align__(16) double lds[];
   const int n = 12 * C, nfb = Fpad >> 6;
@@ -572,6 +583,7 @@ __device__ __forceinline__ double run_sum(const double* __restrict__ p, int coun
 __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __restrict__ gp0, const double* __restrict__ gp1, const double* __restrict__ spart, const double* __restrict__ fpart,
                                                         const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ red, int C, int nfb, int G, int NT, int NP,
                                                         int nfblocks, int rank_slot) {
+  if (!sel_active(sl, false)) return;
   const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
   const int n = 12 * C;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -659,8 +671,15 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
 // lane = frame.  t = g_f + W_f^T d_c with W read from the wave tiles (each load = 64 consecutive frames, 1 KiB),
 // d_f = -(L L^T)^-1 t with the Cholesky factor k_frame_factor left in fbuf, x_dst = x_src + d.
 // Per-block partials of  sum d^T(lambda D d - g_f),  sum |d_f|^2,  sum |x_f|^2.
-__global__ __launch_bounds__(64) void k_backsub(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const CamStep dcs,
+// DcSrc: the camera step either rides in the kernel-argument segment (CamStep, host solve) or sits in device memory
+// where k_solve_cam left it (DevStep); both are wave-uniform scalar loads.
+struct DevStep {
+  const double* __restrict__ v;
+};
+template <class DcSrc>
+__global__ __launch_bounds__(64) void k_backsub(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const DcSrc dcs,
                                                 double* __restrict__ x0, double* __restrict__ x1, double* __restrict__ bpart, int C, int F, int Fpad) {
+  if (!sel_active(sl, true)) return;
   const int sidx = sel_index(sl);  // current slot / linearisation; the trial goes to the other slot
   const double* __restrict__ rec = sidx ? rec1 : rec0;
   const double* __restrict__ xs = sidx ? x1 : x0;
@@ -719,9 +738,13 @@ __global__ __launch_bounds__(64) void k_backsub(Sel sl, const double* __restrict
 __device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs& da) {
   double* lms = da.lms;
   double cost = lms[0], lam = lms[1], nu = lms[2];
+  const bool dev = da.decide == 2;  // camera-step scalars left in the state by k_solve_cam
+  const double pred_cam = dev ? lms[MCBA_LM_PRED_CAM] : da.pred_cam;
+  const double dcn2 = dev ? lms[MCBA_LM_DCN2] : da.dcn2, xcn2 = dev ? lms[MCBA_LM_XCN2] : da.xcn2;
+  const double cost_before = cost, lam_used = lam;
   int sel = static_cast<int>(lms[3]);
   double cost_new = trial8[0];
-  double pred = 0.5 * (trial8[1] + da.pred_cam);
+  double pred = 0.5 * (trial8[1] + pred_cam);
   bool ok = isfinite(cost_new) && pred > 0.0;
   double ratio = ok ? (cost - cost_new) / pred : -1.0;
   double dF = cost - cost_new;
@@ -741,14 +764,37 @@ __device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs
     lam = fmin(lam * nu, da.lam_max);
     nu *= 2.0;
   }
+  const double step_norm = sqrt(trial8[2] + dcn2), x_norm = sqrt(trial8[3] + xcn2);
   lms[0] = cost; lms[1] = lam; lms[2] = nu; lms[3] = sel; lms[4] = accepted ? 1.0 : 0.0;
   lms[5] = cost_new; lms[6] = pred; lms[7] = ratio;
-  lms[8] = sqrt(trial8[2] + da.dcn2); lms[9] = sqrt(trial8[3] + da.xcn2); lms[10] = dF;
+  lms[8] = step_norm; lms[9] = x_norm; lms[10] = dF;
+  if (dev) {  // termination tests of solver.LevenbergMarquardt._iterate_device, verdict applied by the next k_solve_cam
+    const bool ftol_ok = fmax(dF, 0.0) < da.ftol * cost_before && ratio > 0.25;
+    const bool xtol_ok = step_norm < da.xtol * (da.xtol + x_norm);
+    double status = (ftol_ok && xtol_ok) ? 4.0 : ftol_ok ? 2.0 : xtol_ok ? 3.0 : 0.0;
+    if (!accepted && status == 2.0) status = 0.0;  // ftol needs an accepted step
+    if (!accepted && lam >= da.lam_max && status == 0.0) status = 3.0;
+    lms[MCBA_LM_PENDING] = status;
+    lms[MCBA_LM_NFEV] += 1.0;
+    lms[MCBA_LM_NACC] += accepted ? 1.0 : 0.0;
+    lms[MCBA_LM_LAM_USED] = lam_used;
+    lms[MCBA_LM_COST_BEFORE] = cost_before;
+    lms[MCBA_LM_REBUILD] = 0.0;
+  }
+}
+// a tick that only rebuilds the system (the reduced solve failed): no trial, nothing accepted
+__device__ __forceinline__ void lm_mark_rebuild(double* lms) {
+  lms[4] = 0.0;
+  lms[MCBA_LM_REBUILD] = 1.0;
 }
 
 // Cost partials: element idx of `ncp` lives at (idx / cinner) * couter + (idx % cinner) * cstride  (k_cost: cinner = ncp,
 // cstride = 2; k_gram: per camera a contiguous run of nfb values, cinner = nfb, couter = 92 nfb, cstride = 1).
 __global__ __launch_bounds__(512) void k_sum_trial(Sel sl, const double* __restrict__ cp0, const double* __restrict__ cp1, int cstride, int cinner, size_t couter, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out, DecideArgs da) {
+  if (!sel_active(sl, true)) {
+    if (da.decide && threadIdx.x == 0 && sl.lms[MCBA_LM_DONE] == 0.0) lm_mark_rebuild(da.lms);
+    return;
+  }
   const double* __restrict__ cpart = sel_index(sl) ? cp1 : cp0;
   __shared__ double s_out[8];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -780,7 +826,9 @@ __global__ __launch_bounds__(512) void k_sum_trial(Sel sl, const double* __restr
 
 // stand-alone decision (frame-sharded runs: the trial scalars are all-reduced between k_sum_trial and this)
 __global__ void k_decide(const double* __restrict__ trial8, DecideArgs da) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) lm_decide(trial8, da);
+  if (threadIdx.x != 0 || blockIdx.x != 0 || da.lms[MCBA_LM_DONE] != 0.0) return;
+  if (da.lms[MCBA_LM_SKIP] != 0.0) lm_mark_rebuild(da.lms);
+  else lm_decide(trial8, da);
 }
 
 // ---------------------------------------------------------------- k_jacobian: materialised residual Jacobian blocks
@@ -916,7 +964,10 @@ void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double
 }
 
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {
-  k_backsub<<<dim3(Fpad / 64), dim3(64), 0, st>>>(s, rec0, rec1, fbuf, dc, x0, x1, bpart, C, F, Fpad);
+  k_backsub<CamStep><<<dim3(Fpad / 64), dim3(64), 0, st>>>(s, rec0, rec1, fbuf, dc, x0, x1, bpart, C, F, Fpad);
+}
+void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const double* dc_dev, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {
+  k_backsub<DevStep><<<dim3(Fpad / 64), dim3(64), 0, st>>>(s, rec0, rec1, fbuf, DevStep{dc_dev}, x0, x1, bpart, C, F, Fpad);
 }
 
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da) {

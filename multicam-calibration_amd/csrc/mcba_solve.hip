@@ -1,0 +1,428 @@
+// mcba_solve.hip -- the reduced camera system solved ON THE GPU (BASELINE.json config 5: "on-GPU Schur solve").
+//
+// One workgroup factorises  S(lambda) = S0 + lambda diag(D_c)  (n = 12 C <= 480, FP64) and produces the camera step
+// d_c = S^-1 rhs that k_backsub consumes straight from device memory, so that a Levenberg-Marquardt iteration needs
+// no host round trip at all (solver.py `reduced_solver="device"`).  It replaces the host LAPACK call of
+// solver._solve_spd, which itself stands where the reference calls LSMR (scipy/optimize/_lsq/trf.py:479-480).
+//
+// Algorithm: left-looking blocked Cholesky, block 16, of the matrix augmented with the right-hand side as ROW n
+//            [ S   . ]        L y = rhs falls out of the factorisation as row n of the factor (no forward sweep)
+//            [ rhs 1 ]
+//   per block column k:   panel  = A[16k:, 16k:16k+16] - L[16k:, :16k] L[16k:16k+16, :16k]^T     v_mfma_f64_16x16x4, one
+//                                                                                               wave per 16-row tile
+//                         diagonal 16x16 block factorised by wavefront 0 in registers (v_readlane broadcasts)
+//                         rows below: one thread per row, triangular solve against the LDS copy of the block
+//   backward sweep L^T d = y block by block (diagonal blocks kept in LDS, the rest read row-wise = coalesced).
+// The factor lives in LDS when (16 ceil((n+1)/16))^2 doubles fit (<= 9 cameras), otherwise in an L2-resident scratch.
+// The same launch evaluates first-order optimality, applies the pending termination verdict of k_decide, handles a
+// failed factorisation (more damping, trial skipped) and posts the LM state to a host-mapped ring slot.
+#include "mcba_kernels.h"
+#include "mcba_math.h"
+
+namespace mcba {
+
+typedef double solve_d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double lane_bcast(double v, int lane) {  // `lane` wave-uniform
+  union { double d; int i[2]; } a, b;
+  a.d = v;
+  b.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
+  b.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
+  return b.d;
+}
+
+// 1/sqrt(a): hardware estimate + ONE third-order step  y (1 + e/2 + 3 e^2/8), e = 1 - a y^2  (estimate good to > 2^-20
+// -> full FP64); shorter dependent chain than two Newton steps -- it sits on the critical path of every pivot
+__device__ __forceinline__ double rsqrt_cubic(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  double e = fma(-a * y, y, 1.0);
+  double q = e * fma(0.375, e, 0.5);
+  return fma(y, q, y);
+}
+
+template <int NTHREADS>
+__device__ __forceinline__ double block_reduce(double v, bool take_max, double* s_red) {  // result to every thread
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    double o = __shfl_xor(v, off, 64);
+    v = take_max ? fmax(v, o) : v + o;
+  }
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  double r = s_red[0];
+  for (int w = 1; w < NTHREADS / 64; ++w) r = take_max ? fmax(r, s_red[w]) : r + s_red[w];
+  return r;
+}
+
+// four values at once (sum or max), result to every thread: one pair of barriers instead of four
+template <int NTHREADS>
+__device__ __forceinline__ void block_reduce4(double (&v)[4], bool take_max, double* s_red) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double o = __shfl_xor(v[c], off, 64);
+      v[c] = take_max ? fmax(v[c], o) : v[c] + o;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s_red[c * 16 + wave] = v[c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double r = s_red[c * 16];
+    for (int w = 1; w < NTHREADS / 64; ++w) r = take_max ? fmax(r, s_red[c * 16 + w]) : r + s_red[c * 16 + w];
+    v[c] = r;
+  }
+}
+
+// LM state (LDS copy `st`) -> device state and the host-mapped ring slot; the sequence number goes last, after a
+// system-scope fence, so that a host that sees it also sees the rest.  Called by every thread of the block.
+__device__ __forceinline__ void post_state(const SolveArgs& a, const double* st, bool write_back) {
+  const int tid = threadIdx.x;
+  if (tid < MCBA_LMS - 1) {
+    const double v = st[tid];
+    if (write_back) a.lms[tid] = v;
+    if (a.host_state) a.host_state[tid] = v;
+  }
+  if (!a.host_state) return;
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    *reinterpret_cast<volatile double*>(a.host_state + MCBA_LMS - 1) = a.seq;
+    __threadfence_system();
+  }
+}
+
+#ifdef MCBA_SOLVE_TIMING
+#define STAMP(k) do { if (tid == 0) lst[25 + (k)] = (double)(clock64() - t_begin); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+// Staging of the reduce buffer: thread (rr, cc) = (tid / 16, tid % 16) owns the elements (rr + RS a, cc + 16 b) --
+// all index arithmetic is incremental, every load is unconditional (clamped address) so none of them waits for another.
+// kStage x kStage elements per thread cover npad <= 16 kStage with 256 threads.
+constexpr int kStage = 7;
+
+template <int NTHREADS, bool LDSW>
+__global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
+  extern __shared__ double smem[];
+  const int n = a.n, npad = a.npad, nblk = npad >> 4;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr int NW = NTHREADS / 64;
+  constexpr int RS = NTHREADS / 16;                    // rows per staging pass
+  double* panel = smem;                                // npad x 17 : sum_p L[i][p] L[r0+c][p] of the current panel
+  double* diagL = panel + (size_t)npad * 17;           // nblk x 16 x 17 : factorised diagonal blocks
+  double* yv = diagL + (size_t)nblk * 272;             // npad : y, then scratch of the backward sweep
+  double* dv = yv + npad;                              // npad : d
+  double* invd = dv + npad;                            // npad : 1 / L_ii
+  double* damp = invd + npad;                          // npad : lambda * D_c
+  double* s_red = damp + npad;                         // 4 x 16 + 8
+  int* s_flag = reinterpret_cast<int*>(s_red + 64);    // [0] mode
+  double* lst = s_red + 72;                            // MCBA_LMS : the LM state, worked on in LDS
+  double* W = LDSW ? (lst + MCBA_LMS) : a.work;        // npad rows, row-major: the factor L (lower part)
+  const int ldw = LDSW ? npad + 1 : npad;              // odd row stride in LDS: rows land in different banks
+#ifdef MCBA_SOLVE_TIMING
+  const long long t_begin = clock64();
+#endif
+
+  const double* __restrict__ S0 = a.red;               // rhs follows S0: it is "row n" of the same stride-n array
+  const double* __restrict__ diagU = a.red + (size_t)n * n + n;
+  const double* __restrict__ gc = diagU + n;
+  const double* __restrict__ scal = gc + n;
+  const unsigned char* fixed = a.fixed;
+  const int rr = tid >> 4, cc = tid & 15;
+
+  // ---- a dependent global round trip costs ~2 us here (the reduce buffer was written by other XCDs): with the factor
+  // in LDS the whole lower triangle goes in flight before anything else
+  double stage[LDSW ? kStage * kStage : 1];
+  if (LDSW) {
+#pragma unroll
+    for (int ia = 0; ia < kStage; ++ia) {
+      const int i = rr + RS * ia;
+#pragma unroll
+      for (int b = 0; b < kStage; ++b) {
+        const int j = cc + 16 * b;
+        const bool need = i <= n && j < n && j <= i;
+        stage[ia * kStage + b] = S0[need ? i * n + j : 0];
+      }
+    }
+  }
+
+  // ---- LM state -> LDS; first-order optimality of the CURRENT point (the reduced system was built there)
+  if (tid < MCBA_LMS) lst[tid] = a.lms[tid];
+  double gm = 0.0;
+  for (int i = tid; i < npad; i += NTHREADS) {
+    const bool in = i < n, fx = in && fixed && fixed[i];
+    const double du = in ? diagU[i] : 1.0;
+    damp[i] = du > 0.0 ? du : 1.0;  // scaled by lambda below (the state is not in LDS yet)
+    if (in && !fx) gm = fmax(gm, fabs(gc[i]));
+  }
+  if (tid < 12) gm = fmax(gm, scal[4 + tid]);
+  const double frame_fail = scal[2];
+  double red4[4] = {gm, 0.0, 0.0, 0.0};
+  block_reduce4<NTHREADS>(red4, true, s_red);
+  const double g_inf = red4[0];
+  double* lms = lst;
+  if (lms[MCBA_LM_DONE] != 0.0) {  // already terminated: only acknowledge the tick
+    post_state(a, lst, false);
+    return;
+  }
+  if (tid == 0) {
+    int mode = 0;  // 0 solve, 1 terminated, 2 no solve possible (a frame block failed to factorise)
+    lms[MCBA_LM_GINF] = g_inf;
+    lms[MCBA_LM_TICK] += 1.0;
+    const double pending = lms[MCBA_LM_PENDING];
+    if (pending != 0.0) { lms[MCBA_LM_DONE] = pending; mode = 1; }
+    else if (g_inf < a.gtol) { lms[MCBA_LM_DONE] = 1.0; mode = 1; }
+    else if (frame_fail != 0.0) mode = 2;
+    s_flag[0] = mode;
+  }
+  __syncthreads();
+  const int mode = s_flag[0];
+  if (mode == 1) {
+    post_state(a, lst, true);
+    return;
+  }
+  STAMP(0);
+  const double lambda = lms[1];
+  const int sel = static_cast<int>(lms[3]) & 1;
+  const double* xc = sel ? a.x1 : a.x0;
+
+  if (mode == 0) {
+    // ---- augmented, damped matrix -> W (lower triangle; the strictly upper part is never read as data):
+    //   rows < n: S0 + lambda D_c on the diagonal,  row n: the right-hand side, 1 on the diagonal,  rows > n: identity
+    for (int i = tid; i < npad; i += NTHREADS) damp[i] *= lambda;
+    __syncthreads();
+    if (LDSW) {
+#pragma unroll
+      for (int ia = 0; ia < kStage; ++ia) {
+        const int i = rr + RS * ia;
+#pragma unroll
+        for (int b = 0; b < kStage; ++b) {
+          const int j = cc + 16 * b;
+          if (i <= n && j < n && j <= i) W[i * ldw + j] = stage[ia * kStage + b] + ((i == j) ? damp[i] : 0.0);
+        }
+      }
+    } else {
+      for (int i0 = 0; i0 <= n; i0 += RS) {
+        const int i = i0 + rr;
+        for (int j0 = 0; j0 < n && j0 <= i0 + RS - 1; j0 += 16 * 8) {  // 8 loads in flight
+          double v[8];
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const int j = j0 + cc + 16 * b;
+            v[b] = S0[(i <= n && j < n && j <= i) ? (size_t)i * n + j : 0];
+          }
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const int j = j0 + cc + 16 * b;
+            if (i <= n && j < n && j <= i) W[(size_t)i * ldw + j] = v[b] + ((i == j) ? damp[i] : 0.0);
+          }
+        }
+      }
+    }
+    for (int e = n * npad + n + tid; e < npad * npad; e += NTHREADS) {  // W[n][n] = 1 and the identity rows of the padding
+      const int i = e / npad, j = e - i * npad;
+      if (j <= i && (i > n || j == n)) W[(size_t)i * ldw + j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (fixed) {  // parameters held fixed: identity row and column, zero right-hand side (uniform branch, rare path)
+      for (int e = tid; e < (n + 1) * npad; e += NTHREADS) {
+        const int i = e / npad, j = e - i * npad;
+        if (j < n && j <= i && ((i < n && fixed[i]) || fixed[j])) W[(size_t)i * ldw + j] = (i == j) ? 1.0 : 0.0;
+      }
+      __syncthreads();
+    }
+    // Row lanes: lanes 0..15 of EVERY wavefront hold the 16 rows of the diagonal block (redundantly -- their finished
+    // entries are what v_readlane broadcasts), lanes 16..63 hold 48 further rows of the panel each.
+    const int q = lane < 16 ? lane : 16 + 48 * wave + (lane - 16);  // row inside the panel
+    STAMP(1);
+#ifdef MCBA_SOLVE_TIMING
+    long long acc_t[3] = {0, 0, 0}, tl = clock64();
+#define LAP(i) do { long long tn = clock64(); acc_t[i] += tn - tl; tl = tn; } while (0)
+#else
+#define LAP(i) do { } while (0)
+#endif
+    // ---- factorisation
+    for (int k = 0; k < nblk; ++k) {
+      const int r0 = 16 * k, ntile = nblk - k;
+      if (k > 0) {
+        for (int t = wave; t < ntile; t += NW) {  // panel update, one 16x16 tile per wavefront pass
+          const int R = r0 + 16 * t;
+          solve_d4 acc = {0.0, 0.0, 0.0, 0.0};
+          const double* pa = W + (size_t)(R + (lane & 15)) * ldw + (lane >> 4);
+          const double* pb = W + (size_t)(r0 + (lane & 15)) * ldw + (lane >> 4);
+          for (int p = 0; p < r0; p += 16) {  // r0 is a multiple of 16: four operand pairs in flight
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = pa[p + 4 * u]; bv[u] = pb[p + 4 * u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) panel[(16 * t + 4 * reg + (lane >> 4)) * 17 + (lane & 15)] = acc[reg];
+        }
+        __syncthreads();
+      }
+      LAP(0);
+      if (wave == 0 || 16 + 48 * wave < 16 * ntile) {  // wavefronts whose rows are all past the end sit this panel out
+        const bool rv = q < 16 * ntile;
+        double r[16];
+        {
+          const double* wsrc = W + (size_t)(r0 + (rv ? q : 0)) * ldw + r0;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) r[c] = wsrc[c];
+          if (k > 0) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) r[c] -= panel[(rv ? q : 0) * 17 + c];
+          }
+        }
+        double myinv = 1.0;
+        // left-looking: column j of every row is finished at step j; L[r0+j][q'] (q' < j) is lane j's finished r[q'].
+        // A non-positive pivot turns into NaN / inf here and surfaces as a non-finite step below.
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int qq = 0; qq < j; ++qq) {
+            const double ljq = lane_bcast(r[qq], j);
+            if (qq & 1) s1 = fma(r[qq], ljq, s1); else s0 = fma(r[qq], ljq, s0);
+          }
+          r[j] -= s0 + s1;
+          double pj = lane_bcast(r[j], j);
+          if (r0 + j == n) pj = 1.0;  // right-hand-side row: not a pivot
+          const double inv = rsqrt_cubic(pj);
+          r[j] *= inv;
+          myinv = lane == j ? inv : myinv;
+        }
+        if (rv && (lane >= 16 || wave == 0)) {
+          double* wr = W + (size_t)(r0 + q) * ldw + r0;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) wr[c] = r[c];
+        }
+        if (wave == 0 && lane < 16) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) diagL[k * 272 + lane * 17 + c] = r[c];
+          invd[r0 + lane] = myinv;
+        }
+      }
+      __syncthreads();
+      LAP(1);
+    }
+#ifdef MCBA_SOLVE_TIMING
+    if (tid == 0) { lst[30] = (double)acc_t[0]; lst[29] = (double)acc_t[1]; }
+#endif
+
+    STAMP(2);
+    // ---- backward sweep  L^T d = y,  y = row n of the factor
+    for (int j = tid; j < npad; j += NTHREADS) yv[j] = j < n ? W[(size_t)n * ldw + j] : 0.0;
+    __syncthreads();
+    for (int k = nblk - 1; k >= 0; --k) {
+      const int r0 = 16 * k;
+      if (wave == 0) {
+        const int row = lane & 15;
+        double y = yv[r0 + row];
+        const double iv = invd[r0 + row];
+        double col[16];  // col[l] = L[l][row]
+#pragma unroll
+        for (int l = 0; l < 16; ++l) col[l] = diagL[k * 272 + l * 17 + row];
+#pragma unroll
+        for (int l = 15; l >= 0; --l) {
+          const double dl = lane_bcast(y * iv, l);
+          if (row == l) y = dl;
+          else if (row < l) y = fma(-col[l], dl, y);
+        }
+        if (lane < 16) dv[r0 + row] = (r0 + row < n) ? y : 0.0;
+      }
+      __syncthreads();
+      for (int j = tid; j < r0; j += NTHREADS) {
+        double s = yv[j];
+        const double* wc = W + (size_t)r0 * ldw + j;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s = fma(-wc[(size_t)t * ldw], dv[r0 + t], s);
+        yv[j] = s;
+      }
+      __syncthreads();
+    }
+  }
+
+  STAMP(3);
+  // ---- step scalars, failure handling, state
+  double sums[4] = {0.0, 0.0, 0.0, 0.0};  // pred_cam, |d_c|^2, |x_c|^2, non-finite entries
+  if (mode == 0) {
+    for (int i = tid; i < n; i += NTHREADS) {
+      const double d = dv[i], xv = xc[i];
+      a.dc[i] = d;
+      sums[3] += (fabs(d) < 1e300) ? 0.0 : 1.0;
+      sums[0] += d * (damp[i] * d - gc[i]);
+      sums[1] += d * d;
+      sums[2] += xv * xv;
+    }
+  }
+  block_reduce4<NTHREADS>(sums, false, s_red);
+  if (tid == 0) {
+    const bool failed = mode == 2 || sums[3] != 0.0 || !(fabs(sums[0]) < 1e300);
+    lms[MCBA_LM_SOLVE_INFO] = mode == 2 ? 2.0 : failed ? 1.0 : 0.0;
+    if (failed) {  // more damping; the next tick rebuilds the reduced system without a trial step
+      const double lam = fmin(lambda * lms[2], a.lam_max);
+      lms[1] = lam;
+      lms[2] *= 2.0;
+      lms[MCBA_LM_SKIP] = 1.0;
+      if (lam >= a.lam_max) lms[MCBA_LM_DONE] = 3.0;
+    } else {
+      lms[MCBA_LM_SKIP] = 0.0;
+      lms[MCBA_LM_PRED_CAM] = sums[0];
+      lms[MCBA_LM_DCN2] = sums[1];
+      lms[MCBA_LM_XCN2] = sums[2];
+    }
+  }
+  __syncthreads();
+  post_state(a, lst, true);
+}
+
+// rows a launch can hold: 16 diagonal rows + 48 per wavefront
+int solve_threads(int npad) { return npad <= 16 + 4 * 48 ? 256 : npad <= 16 + 8 * 48 ? 512 : 1024; }
+
+size_t solve_lds_bytes(int npad, int use_lds) {
+  size_t d = (size_t)npad * 17 + (size_t)(npad / 16) * 272 + 4 * (size_t)npad + 72 + MCBA_LMS;
+  if (use_lds) d += (size_t)npad * (npad + 1);
+  return d * sizeof(double);
+}
+
+// the factor fits LDS (and the register staging of the 256-thread variant covers it)
+int solve_fits_lds(int npad) { return npad <= 16 * kStage && solve_lds_bytes(npad, 1) <= 150 * 1024; }
+
+static const void* solve_kernel(int npad, int use_lds) {
+  if (use_lds) return reinterpret_cast<const void*>(&k_solve_cam<256, true>);
+  switch (solve_threads(npad)) {
+    case 256: return reinterpret_cast<const void*>(&k_solve_cam<256, false>);
+    case 512: return reinterpret_cast<const void*>(&k_solve_cam<512, false>);
+    default: return reinterpret_cast<const void*>(&k_solve_cam<1024, false>);
+  }
+}
+
+int solve_set_lds_limit(int npad, int use_lds) {
+  size_t bytes = solve_lds_bytes(npad, use_lds);
+  if (bytes <= 64 * 1024) return 0;
+  return hipFuncSetAttribute(solve_kernel(npad, use_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : 1;
+}
+
+void launch_solve_cam(hipStream_t st, const SolveArgs& a) {
+  size_t lds = solve_lds_bytes(a.npad, a.use_lds);
+  if (a.use_lds) { hipLaunchKernelGGL((k_solve_cam<256, true>), dim3(1), dim3(256), lds, st, a); return; }
+  switch (solve_threads(a.npad)) {
+    case 256: hipLaunchKernelGGL((k_solve_cam<256, false>), dim3(1), dim3(256), lds, st, a); break;
+    case 512: hipLaunchKernelGGL((k_solve_cam<512, false>), dim3(1), dim3(512), lds, st, a); break;
+    default: hipLaunchKernelGGL((k_solve_cam<1024, false>), dim3(1), dim3(1024), lds, st, a);
+  }
+}
+
+}  // namespace mcba

@@ -50,6 +50,13 @@ SYMBOLS = [
     ("mcba_lm_rebuild", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_lm_fetch", ctypes.c_int, [_h, _dp]),
     ("mcba_lm_iterate", ctypes.c_int, [_h, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp]),
+    ("mcba_lm_auto_config", ctypes.c_int, [_h, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_char_p]),
+    ("mcba_lm_auto_solve", ctypes.c_int, [_h, ctypes.c_ulonglong]),
+    ("mcba_lm_auto_trial", ctypes.c_int, [_h, ctypes.c_int]),
+    ("mcba_lm_auto_reduce", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int]),
+    ("mcba_lm_auto_tick", ctypes.c_int, [_h, ctypes.c_ulonglong, ctypes.c_int]),
+    ("mcba_lm_auto_wait", ctypes.c_int, [_h, ctypes.c_ulonglong, _dp]),
+    ("mcba_get_cam_step", ctypes.c_int, [_h, _dp]),
     ("mcba_comm_unique_id", ctypes.c_int, [ctypes.c_char_p]),
     ("mcba_comm_init", ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     ("mcba_comm_allreduce", ctypes.c_int, [_h, ctypes.c_size_t, ctypes.c_size_t]),
@@ -60,6 +67,8 @@ SYMBOLS = [
     ("mcba_profile_names", ctypes.c_char_p, []),
     ("mcba_synchronize", ctypes.c_int, [_h]),
 ]
+
+LM_STATE = 32  # MCBA_LM_STATE of include/mcba.h
 
 _lib = None
 
@@ -120,7 +129,7 @@ class Problem:
         self._chk(self.lib.mcba_upload_observations(self.handle, _p(uvs), _p(objpoints)))
         self.set_loss(loss, f_scale)
         self.nsys = self.n * self.n + 3 * self.n + 16
-        self._all = np.zeros(self.nsys + 8 + 16)         # system | trial scalars | LM state, as the device lays them out
+        self._all = np.zeros(self.nsys + 8 + LM_STATE)   # system | trial scalars | LM state, as the device lays them out
         self._red = self._all[: self.nsys]
         self._trial = self._all[self.nsys : self.nsys + 8]
         self._state = self._all[self.nsys + 8 :]
@@ -238,7 +247,7 @@ class Problem:
 
     # ---- device-resident LM iteration (one host synchronisation per iteration)
     def lm_set_state(self, cost, lam, nu, sel):
-        st = np.zeros(16)
+        st = np.zeros(LM_STATE)
         st[:4] = cost, lam, nu, sel
         self._chk(self.lib.mcba_lm_set_state(self.handle, _p(st)))
 
@@ -264,6 +273,47 @@ class Problem:
     def lm_fetch(self):
         self._chk(self.lib.mcba_lm_fetch(self.handle, self._all_p))
         return self._red_views, self._trial, self._state
+
+    # ---- device-resident LM loop (reduced system solved on the GPU, no host synchronisation per iteration)
+    AUTO_RING = 16
+
+    def lm_auto_config(self, ftol, xtol, gtol, lam_min, lam_max, fixed_mask=None):
+        m = None if fixed_mask is None else np.ascontiguousarray(fixed_mask, dtype=np.uint8).tobytes()
+        self._chk(self.lib.mcba_lm_auto_config(self.handle, ftol, xtol, gtol, lam_min, lam_max, m))
+        self._auto_state = np.zeros(LM_STATE)
+        self._auto_state_p = _p(self._auto_state)
+
+    def lm_auto_solve(self, seq):
+        rc = self.lib.mcba_lm_auto_solve(self.handle, seq)
+        if rc:
+            self._chk(rc)
+
+    def lm_auto_trial(self, decide):
+        rc = self.lib.mcba_lm_auto_trial(self.handle, int(decide))
+        if rc:
+            self._chk(rc)
+
+    def lm_auto_reduce(self, decide, rank_slot=0):
+        rc = self.lib.mcba_lm_auto_reduce(self.handle, int(decide), int(rank_slot))
+        if rc:
+            self._chk(rc)
+
+    def lm_auto_tick(self, seq, rank_slot=0):
+        rc = self.lib.mcba_lm_auto_tick(self.handle, seq, int(rank_slot))
+        if rc:
+            self._chk(rc)
+
+    def lm_auto_wait(self, seq):
+        """State (LM_STATE doubles, a buffer the next call overwrites) that tick `seq` posted."""
+        rc = self.lib.mcba_lm_auto_wait(self.handle, seq, self._auto_state_p)
+        if rc:
+            self._chk(rc)
+        return self._auto_state
+
+    def cam_step(self):
+        d = np.empty(self.n)
+        self._chk(self.lib.mcba_get_cam_step(self.handle, _p(d)))
+        return d
 
     # ---- direct RCCL on the library's own reduce buffer (frame-sharded runs)
     def comm_init_from_torch(self, group=None):

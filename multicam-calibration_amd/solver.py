@@ -116,7 +116,8 @@ class LevenbergMarquardt:
     One `iterate()` = one LM iteration: (re)build the reduced system for the current damping, solve it on the
     host, back-substitute, evaluate the trial cost, accept or reject, and re-linearise at the accepted point."""
 
-    def __init__(self, problem, comm=None, free_cam_mask=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, lam0=1e-4, lam_min=1e-12, lam_max=1e12, speculative=True):
+    def __init__(self, problem, comm=None, free_cam_mask=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, lam0=1e-4, lam_min=1e-12, lam_max=1e12, speculative=True,
+                 reduced_solver=None, depth=2):
         self.p = problem
         self.comm = comm or SingleProcess()
         n = problem.n
@@ -130,6 +131,20 @@ class LevenbergMarquardt:
         # device_decide: accept/reject and the damping update run on the GPU (k_decide) so that one LM iteration is a
         # single stream-ordered chain with ONE host synchronisation; needs a backend with lm_iterate (libmcba).
         self.device_decide = self.speculative and hasattr(problem, "lm_iterate")
+        # device_solve: the reduced camera system is factorised on the GPU as well (k_solve_cam) and the termination
+        # tests run there; the host enqueues `depth` iterations ahead and never synchronises inside the loop.
+        # reduced_solver = "host" keeps the LAPACK solve above (one synchronisation per iteration); MCBA_REDUCED_SOLVER
+        # overrides the default.
+        if reduced_solver is None:
+            import os
+
+            reduced_solver = os.environ.get("MCBA_REDUCED_SOLVER", "device")
+        if reduced_solver not in ("device", "host"):
+            raise ValueError("reduced_solver must be 'device' or 'host'")
+        self.device_solve = self.device_decide and reduced_solver == "device" and hasattr(problem, "lm_auto_tick")
+        self.depth = max(1, min(int(depth), 12))
+        self.max_nfev = None
+        self.max_steps = None
 
     # ------------------------------------------------------------------ set-up
     def start(self, x0):
@@ -152,6 +167,63 @@ class LevenbergMarquardt:
             raise ValueError("Residuals are not finite in the initial point.")
         if self.device_decide:
             self.p.lm_set_state(self.cost, self.lam, self.nu, self.cur)
+        if self.device_solve:
+            p = self.p
+            p.synchronize()  # no tick of an earlier run may still be posting into the ring
+            p.lm_auto_config(self.ftol, self.xtol, self.gtol, self.lam_min, self.lam_max, None if self.all_free else ~self.free)
+            self.issued = self.retired = 1  # sequence number 1 = the solve of the initial system
+            p.lm_auto_solve(1)
+            st = p.lm_auto_wait(1)
+            self.g_inf = float(st[16])
+            self._status0 = int(st[15]) or None
+
+    def _issue_tick(self):
+        p, comm = self.p, self.comm
+        self.issued += 1
+        slot = comm.rank % 12
+        if isinstance(comm, TorchDistributed):  # torch issues the collectives, on the stream the library launches on
+            p.lm_auto_trial(0)
+            comm.all_reduce_trial(p)
+            p.lm_auto_reduce(1, slot)
+            comm.all_reduce_system(p)
+            p.lm_auto_solve(self.issued)
+        else:  # single GPU, or direct RCCL: the library enqueues the whole tick
+            p.lm_auto_tick(self.issued, slot)
+
+    def _iterate_auto(self):
+        """One LM iteration of the device-resident loop: top up the ticks in flight, then retire the oldest one."""
+        if self._status0 is not None:
+            return self._status0
+        while self.issued - self.retired < self.depth:
+            inflight = self.issued - self.retired
+            if self.max_nfev is not None and self.nfev + inflight >= self.max_nfev:
+                break
+            if self.max_steps is not None and self.issued - 1 >= self.max_steps:
+                break
+            self._issue_tick()
+        if self.issued == self.retired:
+            return 0
+        self.retired += 1
+        st = self.p.lm_auto_wait(self.retired)
+        done = int(st[15])
+        if st[24] != 0:  # the reduced solve had failed: this tick only re-damped and rebuilt the system
+            self.lam, self.nu = float(st[1]), float(st[2])
+            self.g_inf = float(st[16])
+            self.accepted = False
+            return done or None
+        cost_before, lam_used = float(st[21]), float(st[20])
+        accepted = st[4] > 0
+        cost_new, pred, ratio, step_norm, dF = float(st[5]), float(st[6]), float(st[7]), float(st[8]), float(st[10])
+        self.nfev = 1 + int(st[17])
+        self.njev = self.nfev
+        self.history.append((self.nfev, cost_before, cost_new, pred, ratio, lam_used, step_norm))
+        self.cost, self.lam, self.nu, self.cur = float(st[0]), float(st[1]), float(st[2]), int(st[3])
+        self.g_inf = float(st[16])
+        self.iteration = int(st[18])
+        if accepted:
+            self.actual_reduction, self.step_norm = dF, step_norm
+        self.accepted = bool(accepted)
+        return done or None
 
     def _refresh_system(self):
         p = self.p
@@ -244,6 +316,8 @@ class LevenbergMarquardt:
         does identical work; in speculative mode every step linearises its trial point anyway."""
         p, red = self.p, self.red
         self.steps += 1
+        if self.device_solve:
+            return self._iterate_auto()
         if self.g_inf < self.gtol:
             return 1
         if self.device_decide:
@@ -325,12 +399,14 @@ class LevenbergMarquardt:
         )
 
 
-def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=1e-4, max_iterations=None, speculative=True):
+def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=1e-4, max_iterations=None, speculative=True,
+             reduced_solver=None):
     """Minimise the robust reprojection cost from x0 (this shard's flat vector, a7 layout of SURVEY.md).
     `fun` / `jac` / `grad` of the OptimizeResult are attached by api.bundle_adjust."""
-    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative)
+    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative, reduced_solver=reduced_solver)
     if max_nfev is None:
         max_nfev = 100 * np.size(x0)  # trf.py:437-438
+    lm.max_nfev, lm.max_steps = max_nfev, max_iterations
     lm.start(x0)
     cost0 = lm.cost
     if verbose == 2:

@@ -1,0 +1,27 @@
+"""k_solve_cam phase stamps (build with MCBA_HIPCC_FLAGS=-DMCBA_SOLVE_TIMING) and launch time."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import multicam_calibration_amd as m
+
+for C in [int(a) for a in sys.argv[1:]] or [6, 24]:
+    p = m.synth.make_problem(C, 256, seed=0)
+    x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = m.ops.Problem(p["uvs"], p["obj"])
+    prob.set_params(0, x0)
+    prob.linearize(0)
+    prob.build_reduced(1e-3)
+    red = prob.get_reduced()
+    prob.lm_set_state(float(red["scal"][0]), 1e-3, 2.0, 0)
+    prob.lm_auto_config(0.0, 0.0, 0.0, 1e-12, 1e12, None)
+    prob.profile_enable(True)
+    for s in range(1, 12):
+        prob.lm_auto_solve(s)
+        st = prob.lm_auto_wait(s).copy()
+    prof = prob.profile_read()
+    ms, n = prof["k_solve_cam"]
+    print("C=%d n=%d: k_solve_cam %.2f us avg; stamps (cycles): %s" % (C, 12 * C, 1e3 * ms / n, np.array2string(st[25:31], precision=6)))
+    prob.close()

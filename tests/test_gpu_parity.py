@@ -386,3 +386,83 @@ def test_full_size_properties(mc):
     for k in ("S0", "rhs", "diagU", "gc"):
         assert np.abs(acc[k] - full[k]).max() <= 1e-11 * np.abs(full[k]).max(), k
     assert abs(acc["scal"][0] - full["scal"][0]) <= 1e-12 * full["scal"][0]
+
+
+# ------------------------------------------------------------------ reduced camera system solved on the GPU (k_solve_cam)
+@pytest.mark.parametrize("C,fixed", [(2, False), (6, False), (6, True), (7, False), (10, False), (24, False)])
+def test_device_reduced_solve_matches_lapack(mc, C, fixed):
+    """k_solve_cam (blocked FP64 Cholesky, one workgroup) against LAPACK on the SAME reduced system.
+    C = 2, 6, 7: factor in LDS (npad 32 / 80 / 96); C = 10: 256 threads, factor in the L2 scratch (npad 128);
+    C = 24: 1024 threads (npad 304, BASELINE configs[4]).  `fixed`: intrinsics held fixed (configs[1])."""
+    import scipy.linalg as sla
+
+    p = mc.synth.make_problem(C, 40, seed=60 + C, missing=0.1)
+    x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    n = 12 * C
+    prob = mc.ops.Problem(p["uvs"], p["obj"])
+    prob.set_params(0, x)
+    prob.linearize(0)
+    lam = 2e-3
+    prob.build_reduced(lam, rank_slot=0)
+    red = prob.get_reduced()
+    red = {k: v.copy() for k, v in red.items()}
+    prob.lm_set_state(float(red["scal"][0]), lam, 2.0, 0)
+    mask = np.tile(np.r_[np.ones(6, bool), np.zeros(6, bool)], C) if fixed else None
+    prob.lm_auto_config(1e-8, 1e-8, 1e-8, 1e-12, 1e12, mask)
+    prob.lm_auto_solve(1)
+    st = prob.lm_auto_wait(1).copy()
+    d_dev = prob.cam_step()
+
+    Dc = np.where(red["diagU"] > 0, red["diagU"], 1.0)
+    S = red["S0"] + lam * np.diag(Dc)
+    free = np.ones(n, bool) if mask is None else ~mask
+    d_ref = np.zeros(n)
+    d_ref[free] = sla.cho_solve(sla.cho_factor(S[np.ix_(free, free)]), red["rhs"][free])
+    assert st[31] == 1 and st[15] == 0 and st[14] == 0 and st[23] == 0 and st[22] == 1
+    assert np.all(d_dev[~free] == 0.0)
+    # backward error of the device solution, and agreement with LAPACK at the conditioning of S (~1e6..1e9)
+    r = S[np.ix_(free, free)] @ d_dev[free] - red["rhs"][free]
+    assert np.abs(r).max() <= 1e-11 * (np.abs(S).max() * np.abs(d_dev).max() + np.abs(red["rhs"]).max())
+    assert np.abs(d_dev - d_ref).max() <= 1e-7 * np.abs(d_ref).max()
+    pred_cam = float(d_ref @ (lam * Dc * d_ref - red["gc"]))
+    assert abs(st[11] - pred_cam) <= 1e-6 * abs(pred_cam)
+    assert abs(st[12] - d_ref @ d_ref) <= 1e-6 * (d_ref @ d_ref)
+    assert abs(st[13] - x[:n] @ x[:n]) <= 1e-13 * (x[:n] @ x[:n])
+    g_inf = max(np.abs(red["gc"][free]).max(), red["scal"][4:16].max())
+    assert abs(st[16] - g_inf) <= 1e-14 * g_inf
+    prob.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(fix_intrinsics=True), dict(loss="huber", f_scale=1.0)])
+def test_device_loop_equals_host_solve_loop(mc, kw):
+    """The device-resident LM loop (reduced solve + termination tests on the GPU, host two ticks ahead) and the
+    host-solve loop (LAPACK, one synchronisation per iteration) walk the same iterates."""
+    p = mc.synth.make_problem(4, 90, seed=71, missing=0.15, scalar_nans=7)
+    out = {}
+    for mode in ("device", "host"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            e, i, po, use, res = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=1e-10, xtol=1e-10, gtol=1e-10,
+                                                  verbose=0, reduced_solver=mode, return_jac=False, **kw)
+        out[mode] = res
+    a, b = out["device"], out["host"]
+    assert a.status > 0 and b.status > 0
+    assert abs(a.cost - b.cost) <= 1e-10 * b.cost
+    assert a.status == b.status
+    assert a.nfev == b.nfev and a.lm["iterations"] == b.lm["iterations"]
+    assert np.abs(a.x - b.x).max() <= 1e-8 * np.abs(b.x).max()
+    assert abs(a.optimality - b.optimality) <= 0.1 * b.optimality + 1e-9   # round-off level of a gradient that started at ~1e6
+    ha, hb = np.array(a.lm["history"]), np.array(b.lm["history"])
+    np.testing.assert_allclose(ha[:, 1:3], hb[:, 1:3], rtol=1e-10)   # cost before / after every trial step
+
+
+def test_device_loop_max_nfev_and_verbose(mc, capsys):
+    p = mc.synth.make_problem(3, 40, seed=72)
+    e, i, po, use, res = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=0.0, xtol=0.0, gtol=0.0, verbose=2, max_nfev=7,
+                                          return_jac=False)
+    assert res.status == 0 and res.nfev == 7
+    txt = capsys.readouterr().out
+    assert "The maximum number of function evaluations is exceeded." in txt
+    with contextlib.redirect_stdout(io.StringIO()):
+        e2, i2, po2, use2, res2 = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=0.0, xtol=0.0, gtol=0.0, verbose=0, max_nfev=7,
+                                                   return_jac=False, reduced_solver="host")
+    assert res2.nfev == 7 and abs(res.cost - res2.cost) <= 1e-12 * res2.cost
