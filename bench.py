@@ -150,14 +150,18 @@ def main():
     # HIP events on the launch stream bracket ONLY the dominant kernel inside the timed region (bracketing all
     # six kernels of a step costs ~60 us of host time per step); the per-kernel table comes from an untimed pass.
     DOMINANT = "k_gram"
-    prob.profile_enable(True, only=[DOMINANT])
+    prob.profile_enable(True, only=[DOMINANT], stride=8)  # every 8th launch: the event records must not pace the stream
     prob.profile_read()
     barrier()
+    nfev0 = lm.nfev
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lm.iterate(always_linearize=True)
+        status = lm.iterate(always_linearize=True)
+        assert status is None, f"the LM loop stopped inside the timed region (status {status})"
     barrier()
     dt = time.perf_counter() - t0
+    # every timed step must have evaluated (and linearised) a trial point: no terminated / skipped iterations
+    assert lm.nfev - nfev0 == args.steps, f"{lm.nfev - nfev0} trial evaluations in {args.steps} timed steps"
     prof_timed = prob.profile_read()
     prob.profile_enable(True)
     for _ in range(min(args.steps, 50)):
@@ -220,7 +224,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"bundle adjustment, {C} cameras x {F} frames/GPU x {N} points, intrinsics+distortion+extrinsics+poses free, soft_l1 (BASELINE configs[2])",
                        "frames_total": F * world, "parallelism": f"frames sharded over {world} GPU(s), all-reduce of the {12 * C}x{12 * C} reduced camera system",
-                       "collectives": type(comm).__name__ if comm is not None else "none"},
+                       "collectives": type(comm).__name__ if comm is not None else "none",
+                       "reduced_solver": "device (k_solve_cam), host two iterations ahead, no synchronisation per iteration" if lm.device_solve else "host (LAPACK), one synchronisation per iteration"},
             "ms_per_jacobian_eval": ms_jac,
             "roofline": roofline,
             "jacobian_eval": {"kernel": "k_jacobian", "ms": ms_jac, "roofline": {"bound": "hbm", "achieved": jach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jach / HBM_PEAK_GBS,

@@ -189,6 +189,9 @@ int mcba_get_frame_gradient(mcba_handle* h, double* host);
  * kernel; otherwise a bit mask over the kernels in mcba_profile_names() order, shifted left by one
  * (bit k+1 selects kernel k) -- e.g. time only the dominant kernel inside a measured region. */
 int mcba_profile_enable(mcba_handle* h, int on);
+/* Bracket only every `stride`-th launch of each selected kernel (event records put barrier packets on the stream:
+ * sampling keeps a measured region undisturbed).  Reset to 1 by mcba_profile_enable. */
+int mcba_profile_stride(mcba_handle* h, int stride);
 /* Drains the recorded events.  names: '\n'-separated kernel names in the order of ms[] / calls[]. */
 int mcba_profile_read(mcba_handle* h, double* ms_total, int* calls, int capacity, int* n_kernels);
 const char* mcba_profile_names(void);

@@ -59,6 +59,8 @@ struct mcba_handle {
   // profiling
   bool prof = false;
   unsigned prof_mask = ~0u;
+  int prof_stride = 1;             // bracket every prof_stride-th launch of a selected kernel
+  unsigned prof_count[32] = {};
   std::vector<EvRec> evs;
   std::vector<hipEvent_t> pool;
 };
@@ -86,7 +88,7 @@ hipEvent_t get_event(mcba_handle* h) {
 struct Scope {  // brackets one launch with events when profiling
   mcba_handle* h; int kid; hipEvent_t a{}, b{};
   bool on;
-  Scope(mcba_handle* h_, int k) : h(h_), kid(k), on(h_->prof && ((h_->prof_mask >> k) & 1u)) {
+  Scope(mcba_handle* h_, int k) : h(h_), kid(k), on(h_->prof && ((h_->prof_mask >> k) & 1u) && (h_->prof_count[k]++ % (unsigned)h_->prof_stride) == 0) {
     if (on) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
   }
   ~Scope() {
@@ -818,6 +820,13 @@ int mcba_profile_enable(mcba_handle* h, int on) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
   h->prof = on != 0;
   h->prof_mask = (on == 0 || on == 1) ? ~0u : ((unsigned)on >> 1);
+  h->prof_stride = 1;
+  return MCBA_OK;
+}
+
+int mcba_profile_stride(mcba_handle* h, int stride) {
+  if (!h || stride < 1) return fail(MCBA_ERR_ARG, "mcba_profile_stride: stride >= 1 required");
+  h->prof_stride = stride;
   return MCBA_OK;
 }
 

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "mcba_math.h"
+#include <algorithm>
 #include "mcba_kernels.h"
 
 namespace mcba {
@@ -676,9 +677,12 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
 struct DevStep {
   const double* __restrict__ v;
 };
+// Workgroup = 64 frames x BW wavefronts: wavefront w accumulates W_cf^T d_c for the cameras c = w, w + BW, ... (each
+// load = 64 consecutive frames, 1 KiB), the partial 6-vectors meet in LDS, wavefront 0 finishes the frame solve.
+constexpr int kBacksubWaves = 8;
 template <class DcSrc>
-__global__ __launch_bounds__(64) void k_backsub(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const DcSrc dcs,
-                                                double* __restrict__ x0, double* __restrict__ x1, double* __restrict__ bpart, int C, int F, int Fpad) {
+__global__ __launch_bounds__(64 * kBacksubWaves) void k_backsub(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const DcSrc dcs,
+                                                                double* __restrict__ x0, double* __restrict__ x1, double* __restrict__ bpart, int C, int F, int Fpad) {
   if (!sel_active(sl, true)) return;
   const int sidx = sel_index(sl);  // current slot / linearisation; the trial goes to the other slot
   const double* __restrict__ rec = sidx ? rec1 : rec0;
@@ -686,30 +690,49 @@ __global__ __launch_bounds__(64) void k_backsub(Sel sl, const double* __restrict
   double* __restrict__ xd = sidx ? x0 : x1;
   const double lambda = sel_lambda(sl);
   const int n = 12 * C, nfb = Fpad >> 6;
-  const int f = blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int f = blockIdx.x * 64 + lane;
+  __shared__ double s_t[kBacksubWaves][6][64];
   if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < n; i += 64) xd[i] = xs[i] + dcs.v[i];
-  double pred = 0.0, dn2 = 0.0, xn2 = 0.0;
-  if (f < F) {
-    double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int c = 0; c < C; ++c) {
-      const double2* w2 = reinterpret_cast<const double2*>(rec + ((size_t)c * nfb + blockIdx.x) * (MCBA_REC * 64)) + threadIdx.x;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) xd[i] = xs[i] + dcs.v[i];
+  double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int c = wave; c < C; c += nw) {
+    const double2* w2 = reinterpret_cast<const double2*>(rec + ((size_t)c * nfb + blockIdx.x) * (MCBA_REC * 64)) + lane;
 #pragma unroll 4
-      for (int lr = 0; lr < 12; ++lr) {
-        double d = dcs.v[12 * c + lr];  // wave-uniform: scalar load from the kernel-argument segment
-        double2 v[3];
+    for (int lr = 0; lr < 12; ++lr) {
+      double d = dcs.v[12 * c + lr];  // wave-uniform: scalar load
+      double2 v[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) v[k] = w2[(3 * lr + k) * 64];
+      for (int k = 0; k < 3; ++k) v[k] = w2[(3 * lr + k) * 64];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { t[2 * k] = fma(v[k].x, d, t[2 * k]); t[2 * k + 1] = fma(v[k].y, d, t[2 * k + 1]); }
-      }
+      for (int k = 0; k < 3; ++k) { t[2 * k] = fma(v[k].x, d, t[2 * k]); t[2 * k + 1] = fma(v[k].y, d, t[2 * k + 1]); }
     }
+  }
+  // frame data of wavefront 0 in flight while the partial sums meet
+  double Lp[21], gf[6], D[6];
+  const bool fin = wave == 0 && f < F;
+  if (fin) {
     const double* fbp = fbuf + (size_t)f * MCBA_FB;
-    double Lp[21], id[6], gf[6], D[6], y[6], dl[6];
 #pragma unroll
     for (int k = 0; k < 21; ++k) Lp[k] = fbp[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { gf[k] = fbp[27 + k]; D[k] = fbp[33 + k]; id[k] = 1.0 / Lp[k * (k + 1) / 2 + k]; t[k] += gf[k]; }
+    for (int k = 0; k < 6; ++k) { gf[k] = fbp[27 + k]; D[k] = fbp[33 + k]; }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s_t[wave][k][lane] = t[k];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  for (int w = 1; w < nw; ++w) {  // fixed order: bit-reproducible
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] += s_t[w][k][lane];
+  }
+  double pred = 0.0, dn2 = 0.0, xn2 = 0.0;
+  if (fin) {
+    double id[6], y[6], dl[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { id[k] = 1.0 / Lp[k * (k + 1) / 2 + k]; t[k] += gf[k]; }
     fwd6(Lp, id, t, y);
     bwd6(Lp, id, y, dl);
     const double* xf = xs + n + 6 * (size_t)f;
@@ -724,7 +747,7 @@ __global__ __launch_bounds__(64) void k_backsub(Sel sl, const double* __restrict
     }
   }
   double a = wave_sum63(pred), b = wave_sum63(dn2), cc = wave_sum63(xn2);
-  if (threadIdx.x == 63) { bpart[3 * blockIdx.x] = a; bpart[3 * blockIdx.x + 1] = b; bpart[3 * blockIdx.x + 2] = cc; }
+  if (lane == 63) { bpart[3 * blockIdx.x] = a; bpart[3 * blockIdx.x + 1] = b; bpart[3 * blockIdx.x + 2] = cc; }
 }
 
 // trial scalars: [cost, pred_f, dn2_f, xn2_f, n_residuals, 0, 0, 0].  One block of 512 threads: wavefront w
@@ -964,10 +987,10 @@ void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double
 }
 
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {
-  k_backsub<CamStep><<<dim3(Fpad / 64), dim3(64), 0, st>>>(s, rec0, rec1, fbuf, dc, x0, x1, bpart, C, F, Fpad);
+  k_backsub<CamStep><<<dim3(Fpad / 64), dim3(64 * std::min(C, kBacksubWaves)), 0, st>>>(s, rec0, rec1, fbuf, dc, x0, x1, bpart, C, F, Fpad);
 }
 void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const double* dc_dev, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {
-  k_backsub<DevStep><<<dim3(Fpad / 64), dim3(64), 0, st>>>(s, rec0, rec1, fbuf, DevStep{dc_dev}, x0, x1, bpart, C, F, Fpad);
+  k_backsub<DevStep><<<dim3(Fpad / 64), dim3(64 * std::min(C, kBacksubWaves)), 0, st>>>(s, rec0, rec1, fbuf, DevStep{dc_dev}, x0, x1, bpart, C, F, Fpad);
 }
 
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da) {

@@ -63,6 +63,7 @@ SYMBOLS = [
     ("mcba_comm_destroy", ctypes.c_int, [_h]),
     ("mcba_get_frame_gradient", ctypes.c_int, [_h, _dp]),
     ("mcba_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
+    ("mcba_profile_stride", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_profile_read", ctypes.c_int, [_h, _dp, _ip, ctypes.c_int, _ip]),
     ("mcba_profile_names", ctypes.c_char_p, []),
     ("mcba_synchronize", ctypes.c_int, [_h]),
@@ -351,8 +352,9 @@ class Problem:
     def synchronize(self):
         self._chk(self.lib.mcba_synchronize(self.handle))
 
-    def profile_enable(self, on=True, only=None):
-        """on=True: time every kernel; only=[names]: time just those (cheaper inside a measured region)."""
+    def profile_enable(self, on=True, only=None, stride=1):
+        """on=True: time every kernel; only=[names]: time just those; stride=k: bracket every k-th launch only
+        (event records cost barrier packets on the stream: sample inside a measured region)."""
         flag = int(bool(on))
         if on and only:
             names = self.lib.mcba_profile_names().decode().split("\n")
@@ -360,6 +362,8 @@ class Problem:
             for k in only:
                 flag |= 1 << (names.index(k) + 1)
         self._chk(self.lib.mcba_profile_enable(self.handle, flag))
+        if on and stride > 1:
+            self._chk(self.lib.mcba_profile_stride(self.handle, int(stride)))
 
     def profile_read(self):
         """{kernel name: (total ms, calls)} since the last read."""
