@@ -191,7 +191,12 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   h->nbblocks = h->Fpad / 64;
   // fused k_gram needs >= ~1 wavefront per SIMD (1024) to fill the chip; with fewer (camera, frame-block) pairs the
   // split-role variant doubles the number of wavefronts.  MCBA_GRAM_SPLIT=0/1 overrides (tuning knob).
-  h->gram_split = C * h->nfb < 768;
+  // Beyond one round (1024 wavefront slots) a small second round costs the fused variant a full pass; the split roles
+  // share SIMDs and fill the tail better (measured 6 x 12500 x 54: 102 us split vs 132 us fused; equal at 1.84 and 2.3 rounds).
+  {
+    const int items = C * h->nfb;
+    h->gram_split = items < 768 || (items > 1024 && items <= 1536);
+  }
   if (const char* e = getenv("MCBA_GRAM_SPLIT")) h->gram_split = atoi(e) != 0;
   // k_cost: split the board points so that ~4 waves per SIMD (1024 SIMDs) are in flight
   h->nch = std::max(1, std::min(std::min(8, N / 8), (4096 + C * h->nfb - 1) / (C * h->nfb)));

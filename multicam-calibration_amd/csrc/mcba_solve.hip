@@ -95,8 +95,7 @@ __device__ __forceinline__ void post_state(const SolveArgs& a, const double* st,
   __threadfence_system();
   __syncthreads();
   if (tid == 0) {
-    *reinterpret_cast<volatile double*>(a.host_state + MCBA_LMS - 1) = a.seq;
-    __threadfence_system();
+    *reinterpret_cast<volatile double*>(a.host_state + MCBA_LMS - 1) = a.seq;  // (the end of the kernel releases it)
   }
 }
 
@@ -108,19 +107,19 @@ __device__ __forceinline__ void post_state(const SolveArgs& a, const double* st,
 
 // Staging of the reduce buffer: thread (rr, cc) = (tid / 16, tid % 16) owns the elements (rr + RS a, cc + 16 b) --
 // all index arithmetic is incremental, every load is unconditional (clamped address) so none of them waits for another.
-// kStage x kStage elements per thread cover npad <= 16 kStage with 256 threads.
-constexpr int kStage = 7;
+// KS x KS elements per thread cover npad <= 16 KS with 256 threads (KS = 5: up to 6 cameras, KS = 7: up to 9).
+constexpr int kStageMax = 7;
 
-template <int NTHREADS, bool LDSW>
+template <int NTHREADS, bool LDSW, int KS>
 __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
+  constexpr int kStage = KS;
   extern __shared__ double smem[];
   const int n = a.n, npad = a.npad, nblk = npad >> 4;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   constexpr int NW = NTHREADS / 64;
   constexpr int RS = NTHREADS / 16;                    // rows per staging pass
   double* panel = smem;                                // npad x 17 : sum_p L[i][p] L[r0+c][p] of the current panel
-  double* diagL = panel + (size_t)npad * 17;           // nblk x 16 x 17 : factorised diagonal blocks
-  double* yv = diagL + (size_t)nblk * 272;             // npad : y, then scratch of the backward sweep
+  double* yv = panel + (size_t)npad * 17;              // npad : y, then scratch of the backward sweep
   double* dv = yv + npad;                              // npad : d
   double* invd = dv + npad;                            // npad : 1 / L_ii
   double* damp = invd + npad;                          // npad : lambda * D_c
@@ -129,6 +128,8 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
   double* lst = s_red + 72;                            // MCBA_LMS : the LM state, worked on in LDS
   double* W = LDSW ? (lst + MCBA_LMS) : a.work;        // npad rows, row-major: the factor L (lower part)
   const int ldw = LDSW ? npad + 1 : npad;              // odd row stride in LDS: rows land in different banks
+  double* Bs = lst + MCBA_LMS;                         // !LDSW: 16 x bst, the panel's own rows of L (the MFMA B operand)
+  const int bst = npad + 2;                            // bst / 2 odd: conflict-free 16-byte LDS reads
 #ifdef MCBA_SOLVE_TIMING
   const long long t_begin = clock64();
 #endif
@@ -255,20 +256,65 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
     for (int k = 0; k < nblk; ++k) {
       const int r0 = 16 * k, ntile = nblk - k;
       if (k > 0) {
-        for (int t = wave; t < ntile; t += NW) {  // panel update, one 16x16 tile per wavefront pass
-          const int R = r0 + 16 * t;
-          solve_d4 acc = {0.0, 0.0, 0.0, 0.0};
-          const double* pa = W + (size_t)(R + (lane & 15)) * ldw + (lane >> 4);
-          const double* pb = W + (size_t)(r0 + (lane & 15)) * ldw + (lane >> 4);
-          for (int p = 0; p < r0; p += 16) {  // r0 is a multiple of 16: four operand pairs in flight
-            double av[4], bv[4];
+        if (LDSW) {
+          for (int t = wave; t < ntile; t += NW) {  // panel update, one 16x16 tile per wavefront pass
+            const int R = r0 + 16 * t;
+            solve_d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const double* pa = W + (size_t)(R + (lane & 15)) * ldw + (lane >> 4);
+            const double* pb = W + (size_t)(r0 + (lane & 15)) * ldw + (lane >> 4);
+            for (int p = 0; p < r0; p += 16) {  // r0 is a multiple of 16: four operand pairs in flight
+              double av[4], bv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { av[u] = pa[p + 4 * u]; bv[u] = pb[p + 4 * u]; }
+              for (int u = 0; u < 4; ++u) { av[u] = pa[p + 4 * u]; bv[u] = pb[p + 4 * u]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+              for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) panel[(16 * t + 4 * reg + (lane >> 4)) * 17 + (lane & 15)] = acc[reg];
           }
+        } else {
+          // factor in (L2-resident) global memory: a dependent load costs ~1-2k cycles, so the panel's own 16 rows -- the
+          // B operand of every tile -- are staged in LDS once, and each wavefront streams its A rows 32 B per lane
+          // (lane (i, kk) owns K indices P + 4 kk .. + 3 of a 16-wide chunk: any K order is fine as long as A and B agree)
+          for (int e = tid; e < 4 * r0; e += NTHREADS) {  // 16 rows x r0 / 4 double4
+            const int row = e / (r0 >> 2), c4 = e - row * (r0 >> 2);
+            const solve_d4 v = *reinterpret_cast<const solve_d4*>(W + (size_t)(r0 + row) * ldw + 4 * c4);
+            *reinterpret_cast<solve_d4*>(Bs + row * bst + 4 * c4) = v;
+          }
+          __syncthreads();
+          constexpr int CH = 6;  // chunks of 16 K indices per work item; the next item's A rows load while this one computes
+          const int ngrp = (r0 + 16 * CH - 1) / (16 * CH);
+          const int nitems = ((ntile - wave + NW - 1) / NW) * ngrp;
+          const double* pb = Bs + (lane & 15) * bst + 4 * (lane >> 4);
+          solve_d4 cur[CH], nxt[CH];
+          auto load_item = [&](int it, solve_d4 (&dst)[CH]) {
+            const int tl = it / ngrp, p = (it - tl * ngrp) * 16 * CH;
+            const double* pa = W + (size_t)(r0 + 16 * (wave + NW * tl) + (lane & 15)) * ldw + 4 * (lane >> 4);
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) panel[(16 * t + 4 * reg + (lane >> 4)) * 17 + (lane & 15)] = acc[reg];
+            for (int u = 0; u < CH; ++u) dst[u] = *reinterpret_cast<const solve_d4*>(pa + min(p + 16 * u, r0 - 16));
+          };
+          if (nitems > 0) load_item(0, cur);
+          solve_d4 acc = {0.0, 0.0, 0.0, 0.0};
+          for (int it = 0; it < nitems; ++it) {
+            if (it + 1 < nitems) load_item(it + 1, nxt);
+            const int tl = it / ngrp, g = it - tl * ngrp, p = g * 16 * CH;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+              if (p + 16 * u < r0) {
+                const solve_d4 bv = *reinterpret_cast<const solve_d4*>(pb + p + 16 * u);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u][c], bv[c], acc, 0, 0, 0);
+              }
+            }
+            if (g == ngrp - 1) {
+              const int t = wave + NW * tl;
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) panel[(16 * t + 4 * reg + (lane >> 4)) * 17 + (lane & 15)] = acc[reg];
+              acc = solve_d4{0.0, 0.0, 0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) cur[u] = nxt[u];
+          }
         }
         __syncthreads();
       }
@@ -308,11 +354,7 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
 #pragma unroll
           for (int c = 0; c < 16; ++c) wr[c] = r[c];
         }
-        if (wave == 0 && lane < 16) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) diagL[k * 272 + lane * 17 + c] = r[c];
-          invd[r0 + lane] = myinv;
-        }
+        if (wave == 0 && lane < 16) invd[r0 + lane] = myinv;
       }
       __syncthreads();
       LAP(1);
@@ -325,15 +367,28 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
     // ---- backward sweep  L^T d = y,  y = row n of the factor
     for (int j = tid; j < npad; j += NTHREADS) yv[j] = j < n ? W[(size_t)n * ldw + j] : 0.0;
     __syncthreads();
+    // Every step's loads are issued at its top: the off-diagonal rows it needs after the barrier, and (wavefront 0) the
+    // diagonal block of the NEXT step -- both are in flight while wavefront 0 does the 16 sequential pivots.
+    double col[16];   // wavefront 0: col[l] = L[r0 + l][r0 + row] of the block being solved
+    {
+      const int r0 = 16 * (nblk - 1);
+#pragma unroll
+      for (int l = 0; l < 16; ++l) col[l] = W[(size_t)(r0 + l) * ldw + r0 + (lane & 15)];
+    }
     for (int k = nblk - 1; k >= 0; --k) {
       const int r0 = 16 * k;
+      double wcur[16];  // wcur[t] = L[r0 + t][j] for this thread's column j = tid (first pass over j)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) wcur[t] = W[(size_t)(r0 + t) * ldw + min(tid, npad - 1)];
       if (wave == 0) {
         const int row = lane & 15;
+        double cnx[16];
+        if (k > 0) {
+#pragma unroll
+          for (int l = 0; l < 16; ++l) cnx[l] = W[(size_t)(r0 - 16 + l) * ldw + r0 - 16 + row];
+        }
         double y = yv[r0 + row];
         const double iv = invd[r0 + row];
-        double col[16];  // col[l] = L[l][row]
-#pragma unroll
-        for (int l = 0; l < 16; ++l) col[l] = diagL[k * 272 + l * 17 + row];
 #pragma unroll
         for (int l = 15; l >= 0; --l) {
           const double dl = lane_bcast(y * iv, l);
@@ -341,13 +396,22 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
           else if (row < l) y = fma(-col[l], dl, y);
         }
         if (lane < 16) dv[r0 + row] = (r0 + row < n) ? y : 0.0;
+        if (k > 0) {
+#pragma unroll
+          for (int l = 0; l < 16; ++l) col[l] = cnx[l];
+        }
       }
       __syncthreads();
       for (int j = tid; j < r0; j += NTHREADS) {
         double s = yv[j];
-        const double* wc = W + (size_t)r0 * ldw + j;
+        if (j == tid) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) s = fma(-wc[(size_t)t * ldw], dv[r0 + t], s);
+          for (int t = 0; t < 16; ++t) s = fma(-wcur[t], dv[r0 + t], s);
+        } else {
+          const double* wc = W + (size_t)r0 * ldw + j;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) s = fma(-wc[(size_t)t * ldw], dv[r0 + t], s);
+        }
         yv[j] = s;
       }
       __syncthreads();
@@ -392,20 +456,20 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
 int solve_threads(int npad) { return npad <= 16 + 4 * 48 ? 256 : npad <= 16 + 8 * 48 ? 512 : 1024; }
 
 size_t solve_lds_bytes(int npad, int use_lds) {
-  size_t d = (size_t)npad * 17 + (size_t)(npad / 16) * 272 + 4 * (size_t)npad + 72 + MCBA_LMS;
-  if (use_lds) d += (size_t)npad * (npad + 1);
+  size_t d = (size_t)npad * 17 + 4 * (size_t)npad + 72 + MCBA_LMS;
+  d += use_lds ? (size_t)npad * (npad + 1) : (size_t)16 * (npad + 2);
   return d * sizeof(double);
 }
 
 // the factor fits LDS (and the register staging of the 256-thread variant covers it)
-int solve_fits_lds(int npad) { return npad <= 16 * kStage && solve_lds_bytes(npad, 1) <= 150 * 1024; }
+int solve_fits_lds(int npad) { return npad <= 16 * kStageMax && solve_lds_bytes(npad, 1) <= 150 * 1024; }
 
 static const void* solve_kernel(int npad, int use_lds) {
-  if (use_lds) return reinterpret_cast<const void*>(&k_solve_cam<256, true>);
+  if (use_lds) return npad <= 80 ? reinterpret_cast<const void*>(&k_solve_cam<256, true, 5>) : reinterpret_cast<const void*>(&k_solve_cam<256, true, kStageMax>);
   switch (solve_threads(npad)) {
-    case 256: return reinterpret_cast<const void*>(&k_solve_cam<256, false>);
-    case 512: return reinterpret_cast<const void*>(&k_solve_cam<512, false>);
-    default: return reinterpret_cast<const void*>(&k_solve_cam<1024, false>);
+    case 256: return reinterpret_cast<const void*>(&k_solve_cam<256, false, 1>);
+    case 512: return reinterpret_cast<const void*>(&k_solve_cam<512, false, 1>);
+    default: return reinterpret_cast<const void*>(&k_solve_cam<1024, false, 1>);
   }
 }
 
@@ -417,11 +481,15 @@ int solve_set_lds_limit(int npad, int use_lds) {
 
 void launch_solve_cam(hipStream_t st, const SolveArgs& a) {
   size_t lds = solve_lds_bytes(a.npad, a.use_lds);
-  if (a.use_lds) { hipLaunchKernelGGL((k_solve_cam<256, true>), dim3(1), dim3(256), lds, st, a); return; }
+  if (a.use_lds) {
+    if (a.npad <= 80) hipLaunchKernelGGL((k_solve_cam<256, true, 5>), dim3(1), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_solve_cam<256, true, kStageMax>), dim3(1), dim3(256), lds, st, a);
+    return;
+  }
   switch (solve_threads(a.npad)) {
-    case 256: hipLaunchKernelGGL((k_solve_cam<256, false>), dim3(1), dim3(256), lds, st, a); break;
-    case 512: hipLaunchKernelGGL((k_solve_cam<512, false>), dim3(1), dim3(512), lds, st, a); break;
-    default: hipLaunchKernelGGL((k_solve_cam<1024, false>), dim3(1), dim3(1024), lds, st, a);
+    case 256: hipLaunchKernelGGL((k_solve_cam<256, false, 1>), dim3(1), dim3(256), lds, st, a); break;
+    case 512: hipLaunchKernelGGL((k_solve_cam<512, false, 1>), dim3(1), dim3(512), lds, st, a); break;
+    default: hipLaunchKernelGGL((k_solve_cam<1024, false, 1>), dim3(1), dim3(1024), lds, st, a);
   }
 }
 
