@@ -110,6 +110,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MCBA_BENCH_SHARE_GPU") == "1":  # rehearsal of N > 1 ranks on a one-GPU box (all ranks on device 0)
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")

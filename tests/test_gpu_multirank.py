@@ -1,0 +1,96 @@
+"""Two ranks on ONE MI355X (both on cuda:0, gloo rendezvous): the frame-sharded device-resident LM loop end to end
+through libmcba.so -- trial kernels -> all-reduce of the trial scalars -> decision kernel -> Schur reduction ->
+all-reduce of the reduced system -> k_solve_cam -- against the single-process run on the same data.
+RCCL refuses two ranks on one device, so the collectives here are host-staged gloo all-reduces of the very same
+buffers; the RCCL plumbing itself is exercised by the single-rank `nccl` runs of bench.py (MCBA_BENCH_FORCE_DIST=1)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem(m):
+    return m.synth.make_problem(4, 150, seed=31, missing=0.1, scalar_nans=5)   # 150 frames: ragged 64-frame blocks per shard
+
+
+def _worker(rank, world, port, out_dir, mode):
+    sys.path.insert(0, ROOT)
+    import contextlib
+    import io
+
+    import torch
+    import torch.distributed as dist
+
+    import multicam_calibration_amd as m
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+
+    class HostStaged(m.solver.TorchDistributed):
+        """all-reduce of slices of the library's reduce buffer through the host (gloo)"""
+
+        def _ar(self, t):
+            c = t.cpu()
+            dist.all_reduce(c)
+            t.copy_(c)
+
+        def all_reduce_system(self, problem):
+            self._ar(problem.reduce_tensor[: problem.nsys])
+
+        def all_reduce_trial(self, problem):
+            self._ar(problem.reduce_tensor[problem.nsys : problem.nsys + 8])
+
+    real_make_comm = m.solver.make_comm
+
+    def make_comm(problem, device, group=None, direct=None):
+        problem.enable_collective(device)
+        return HostStaged(group)
+
+    m.solver.make_comm = make_comm
+    p = _problem(m)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, device=0,
+                                              ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, distributed=True, return_jac=False, reduced_solver=mode)
+    m.solver.make_comm = real_make_comm
+    np.savez(os.path.join(out_dir, f"{mode}{rank}.npz"), x=res.x, cost=res.cost, nfev=res.nfev, status=res.status, use=use, grad=res.grad)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["device", "host"])
+def test_two_ranks_one_gpu_match_single_process(tmp_path, mode):
+    import contextlib
+    import io
+
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / f"{mode}0.npz"), np.load(tmp_path / f"{mode}1.npz")
+    # every rank took the same decisions and returns the same full result
+    assert int(r0["nfev"]) == int(r1["nfev"]) and int(r0["status"]) == int(r1["status"]) and int(r0["status"]) > 0
+    assert float(r0["cost"]) == float(r1["cost"])
+    np.testing.assert_array_equal(r0["x"], r1["x"])
+    np.testing.assert_array_equal(r0["use"], r1["use"])
+
+    import multicam_calibration_amd as m
+
+    p = _problem(m)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None,
+                                              ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, return_jac=False, reduced_solver=mode)
+    np.testing.assert_array_equal(use, r0["use"])
+    assert abs(res.cost - float(r0["cost"])) <= 1e-10 * res.cost
+    C = 4
+    cam_a, cam_b = r0["x"][: 12 * C].reshape(C, 12), res.x[: 12 * C].reshape(C, 12)
+    assert (np.abs(cam_a[:, :6] - cam_b[:, :6]) / np.abs(cam_b[:, :6])).max() < 1e-6   # intrinsics + distortion: gauge-free
+    assert np.abs(r0["grad"]).max() <= 10 * max(res.optimality, 1e-6)   # the sharded run is as stationary as the single-process one
