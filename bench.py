@@ -157,12 +157,16 @@ def main():
     barrier()
     nfev0 = lm.nfev
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    ticks = 0
+    while lm.nfev - nfev0 < args.steps:
+        # a step = an LM iteration that evaluated (and linearised) a trial point.  Frame-sharded runs with one collective
+        # per iteration occasionally need an extra rebuild-only pass (mispredicted damping): it is timed, not counted.
         status = lm.iterate(always_linearize=True)
+        ticks += 1
         assert status is None, f"the LM loop stopped inside the timed region (status {status})"
+        assert ticks <= 2 * args.steps, "too many rebuild-only passes"
     barrier()
     dt = time.perf_counter() - t0
-    # every timed step must have evaluated (and linearised) a trial point: no terminated / skipped iterations
     assert lm.nfev - nfev0 == args.steps, f"{lm.nfev - nfev0} trial evaluations in {args.steps} timed steps"
     prof_timed = prob.profile_read()
     prob.profile_enable(True)
@@ -235,7 +239,8 @@ def main():
                               "frac_of_measured_write_ceiling": jach / HBM_MEASURED_WRITE_GBS}},
             "kernels_us": {k: round(1e3 * ms / n, 3) for k, (ms, n) in kern.items()},
             "kernel_calls": {k: n for k, (ms, n) in kern.items()},
-            "lm": {"cost_start": cost0, "cost_end": lm.cost, "accepted": lm.iteration, "steps_total": lm.steps, "lambda": lm.lam},
+            "lm": {"cost_start": cost0, "cost_end": lm.cost, "accepted": lm.iteration, "steps_total": lm.steps, "lambda": lm.lam,
+                   "passes_in_timed_region": ticks, "rebuild_only_passes_total": getattr(lm, "rebuilds", 0)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

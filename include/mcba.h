@@ -153,18 +153,24 @@ int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, do
  * mcba_lm_auto_config : tolerances, damping bounds, optional mask (n bytes, 1 = camera parameter held fixed);
  * mcba_lm_auto_solve  : optimality + termination verdict + solve of the system in the reduce buffer -> camera step on
  *                       the device, state posted to ring slot seq % 16 with sequence number `seq` (>= 1);
- *                       call once after mcba_build_reduced + mcba_lm_set_state, then once per tick;
+ *                       call once after mcba_build_reduced + mcba_lm_set_state (decide = 0), then once per tick;
  * mcba_lm_auto_trial  : back-substitute that step, linearise the trial point, sum its cost; decide != 0: accept/reject on
  *                       the same launch (single GPU);  [sharded: decide = 0, all-reduce the 8 trial scalars]
- * mcba_lm_auto_reduce : [decide != 0: the stand-alone decision kernel, sharded runs] + Schur reduction of the now
- *                       current linearisation;  [sharded: all-reduce the system];
- * mcba_lm_auto_tick   : trial + reduce + solve in one call, with the two all-reduces issued by the library itself when a
- *                       direct RCCL communicator is attached (mcba_comm_init);
+ * mcba_lm_auto_reduce : decide = 0: Schur reduction of the current linearisation (the decision has been taken);
+ *                       decide = 1: the stand-alone decision kernel first (sharded runs with TWO collectives: trial scalars,
+ *                       then the system);  decide = 2: SPECULATIVE reduction (sharded runs with ONE collective): the trial
+ *                       linearisation is reduced before the decision is known, on the prediction "accepted, lambda' =
+ *                       max(lambda / 3, lambda_min)"; the caller all-reduces [system | trial scalars] in one go
+ *                       (offset 0, n*n + 3n + 16 + 8 doubles) and calls mcba_lm_auto_solve(seq, decide = 1), which takes
+ *                       the decision and, if the prediction does not hold (rejected step, or another damping), marks the
+ *                       next tick as a rebuild-only tick instead of solving;
+ * mcba_lm_auto_tick   : trial + reduce + solve in one call; with a direct RCCL communicator attached (mcba_comm_init) the
+ *                       library issues the collective(s) itself -- one per tick (speculative), or two with MCBA_SPECULATE=0;
  * mcba_lm_auto_wait   : spin on the ring slot until tick `seq` has posted (falls back to a stream synchronisation after
  *                       50 ms) and copy its MCBA_LM_STATE doubles.  At most 15 ticks may be outstanding.
  * After termination (state 15 != 0) the kernels of later ticks return at once; such ticks still post their slot. */
 int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, double lam_min, double lam_max, const unsigned char* fixed_mask);
-int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq);
+int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq, int decide);
 int mcba_lm_auto_trial(mcba_handle* h, int decide);
 int mcba_lm_auto_reduce(mcba_handle* h, int decide, int rank_slot);
 int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot);

@@ -52,6 +52,7 @@ struct mcba_handle {
   double *dcbuf = nullptr, *swork = nullptr;
   unsigned char* fixed = nullptr;
   bool have_fixed = false, auto_ready = false;
+  bool speculate = true;       // frame-sharded ticks: one collective (speculative Schur reduction) instead of two
   double* ring = nullptr;      // kRing x MCBA_LMS doubles, host-coherent pinned memory the GPU writes directly
   double* ring_dev = nullptr;  // the same memory as the device sees it
   int npad = 0, solve_lds = 0;
@@ -96,8 +97,9 @@ struct Scope {  // brackets one launch with events when profiling
   }
 };
 
-mcba::Sel host_sel(int idx, double lam = 0.0) { return mcba::Sel{nullptr, idx, lam}; }
-mcba::Sel dev_sel(const mcba_handle* h, int flip) { return mcba::Sel{h->red + h->nsys + 8, flip, 0.0}; }  // LM state lives behind the trial scalars
+mcba::Sel host_sel(int idx, double lam = 0.0) { return mcba::Sel{nullptr, idx, lam, 0}; }
+mcba::Sel dev_sel(const mcba_handle* h, int flip) { return mcba::Sel{h->red + h->nsys + 8, flip, 0.0, 0}; }  // LM state lives behind the trial scalars
+mcba::Sel spec_sel(const mcba_handle* h) { return mcba::Sel{h->red + h->nsys + 8, 0, h->lam_min, 1}; }
 
 int check_launch() {
   hipError_t e = hipGetLastError();
@@ -591,21 +593,22 @@ int mcba_lm_trial(mcba_handle* h, const double* delta_cam) {
   return lm_trial_impl(h, delta_cam, mcba::DecideArgs{0, 0.0, 0.0, 0.0, 0.0, 0.0, nullptr});
 }
 
-static int lm_reduce_chain(mcba_handle* h, int rank_slot) {
+static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false) {
   int rc;
+  const mcba::Sel sl = spec ? spec_sel(h) : dev_sel(h, 0);
   {
     Scope sc(h, K_FRAME_FACTOR);
-    mcba::launch_frame_factor(h->stream, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->C, h->F, h->Fpad);
+    mcba::launch_frame_factor(h->stream, sl, h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->C, h->F, h->Fpad);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
+    mcba::launch_syrk(h->stream, sl, h->rec2[0], h->rec2[1], h->fbuf, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_REDUCE);
-    mcba::launch_reduce_system(h->stream, dev_sel(h, 0), h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
+    mcba::launch_reduce_system(h->stream, sl, h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
   }
   if ((rc = check_launch())) return rc;
   h->have_red = true;
@@ -670,10 +673,11 @@ int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, d
   }
   memset(h->ring, 0, (size_t)kRing * MCBA_LMS * sizeof(double));
   h->auto_ready = true;
+  if (const char* e = getenv("MCBA_SPECULATE")) h->speculate = atoi(e) != 0;
   return MCBA_OK;
 }
 
-int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq) {
+int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq, int decide) {
   if (!h || !h->auto_ready || seq == 0) return fail(MCBA_ERR_ARG, "mcba_lm_auto_solve: call mcba_lm_auto_config first; seq >= 1");
   if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_lm_auto_solve: no reduced system");
   HIPCHK(hipSetDevice(h->device));
@@ -683,6 +687,7 @@ int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq) {
   a.host_state = h->ring_dev + (size_t)(seq % kRing) * MCBA_LMS;
   a.seq = (double)seq; a.gtol = h->gtol; a.lam_max = h->lam_max;
   a.n = h->n; a.npad = h->npad; a.use_lds = h->solve_lds;
+  a.decide = decide ? 1 : 0; a.lam_min = h->lam_min; a.ftol = h->ftol; a.xtol = h->xtol;
   {
     Scope sc(h, K_SOLVE);
     mcba::launch_solve_cam(h->stream, a);
@@ -714,9 +719,9 @@ int mcba_lm_auto_trial(mcba_handle* h, int decide) {
 }
 
 int mcba_lm_auto_reduce(mcba_handle* h, int decide, int rank_slot) {
-  if (!h || !h->auto_ready || rank_slot < 0 || rank_slot > 11) return fail(MCBA_ERR_ARG, "mcba_lm_auto_reduce: bad argument");
+  if (!h || !h->auto_ready || rank_slot < 0 || rank_slot > 11 || decide < 0 || decide > 2) return fail(MCBA_ERR_ARG, "mcba_lm_auto_reduce: bad argument");
   HIPCHK(hipSetDevice(h->device));
-  if (decide) {
+  if (decide == 1) {
     {
       Scope sc(h, K_DECIDE);
       mcba::launch_decide(h->stream, h->red + h->nsys, mcba::DecideArgs{2, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, h->red + h->nsys + 8, h->ftol, h->xtol});
@@ -724,18 +729,29 @@ int mcba_lm_auto_reduce(mcba_handle* h, int decide, int rank_slot) {
     int rc = check_launch();
     if (rc) return rc;
   }
-  return lm_reduce_chain(h, rank_slot);
+  return lm_reduce_chain(h, rank_slot, decide == 2);
 }
 
 int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
   const bool coll = h->comm != nullptr;
-  int rc = mcba_lm_auto_trial(h, coll ? 0 : 1);
-  if (rc) return rc;
-  if (coll && (rc = mcba_comm_allreduce(h, h->nsys, 8))) return rc;
-  if ((rc = mcba_lm_auto_reduce(h, coll ? 1 : 0, rank_slot))) return rc;
-  if (coll && (rc = mcba_comm_allreduce(h, 0, h->nsys))) return rc;
-  return mcba_lm_auto_solve(h, seq);
+  int rc;
+  if (!coll) {  // one GPU: the decision rides on k_sum_trial
+    if ((rc = mcba_lm_auto_trial(h, 1))) return rc;
+    if ((rc = mcba_lm_auto_reduce(h, 0, rank_slot))) return rc;
+    return mcba_lm_auto_solve(h, seq, 0);
+  }
+  if (h->speculate) {  // ONE collective: speculative reduction, [system | trial scalars] all-reduced together, decision in k_solve_cam
+    if ((rc = mcba_lm_auto_trial(h, 0))) return rc;
+    if ((rc = mcba_lm_auto_reduce(h, 2, rank_slot))) return rc;
+    if ((rc = mcba_comm_allreduce(h, 0, h->nsys + 8))) return rc;
+    return mcba_lm_auto_solve(h, seq, 1);
+  }
+  if ((rc = mcba_lm_auto_trial(h, 0))) return rc;
+  if ((rc = mcba_comm_allreduce(h, h->nsys, 8))) return rc;
+  if ((rc = mcba_lm_auto_reduce(h, 1, rank_slot))) return rc;
+  if ((rc = mcba_comm_allreduce(h, 0, h->nsys))) return rc;
+  return mcba_lm_auto_solve(h, seq, 0);
 }
 
 int mcba_get_cam_step(mcba_handle* h, double* host) {

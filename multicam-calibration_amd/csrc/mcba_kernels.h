@@ -38,7 +38,8 @@ struct CamStep {
 struct Sel {
   const double* lms;
   int idx;
-  double lam;
+  double lam;   // host value of the damping (lms == nullptr); lambda_min when spec != 0
+  int spec;     // speculative Schur reduction of the trial linearisation (see sel_spec in mcba_kernels.hip)
 };
 // decide != 0: k_sum_trial / k_decide apply the accept/reject + damping update to the LM state (lms)
 // decide == 2: device-resident solve -- pred_cam / dcn2 / xcn2 come from the LM state (k_solve_cam left them there) and
@@ -62,6 +63,10 @@ struct SolveArgs {
   double seq;
   double gtol, lam_max;
   int n, npad, use_lds;
+  // decide != 0 (frame-sharded ticks with one collective): the all-reduced trial scalars sit behind the system and the
+  // accept/reject decision is taken HERE, then checked against the prediction the speculative Schur reduction was built on
+  int decide;
+  double lam_min, ftol, xtol;
 };
 void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int C, int F, int N, int Fpad);
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split);

@@ -20,6 +20,7 @@
 #include "mcba_math.h"
 #include <algorithm>
 #include "mcba_kernels.h"
+#include "mcba_lm.h"
 
 namespace mcba {
 
@@ -63,8 +64,12 @@ __device__ __forceinline__ double uni(double v) {
   return u.d;
 }
 __device__ __forceinline__ bool is_num(double v) { return v == v; }
-__device__ __forceinline__ int sel_index(const Sel& s) { return s.lms ? ((static_cast<int>(s.lms[3]) ^ s.idx) & 1) : s.idx; }
-__device__ __forceinline__ double sel_lambda(const Sel& s) { return s.lms ? s.lms[1] : s.lam; }
+// spec (frame-sharded ticks with ONE collective): the Schur reduction runs BEFORE the decision is known, on the
+// prediction "trial step accepted, lambda' = max(lambda / 3, lambda_min)" -- except in a rebuild tick (state[SKIP] != 0),
+// which reduces the current linearisation with the state's own damping.  k_solve_cam checks the prediction afterwards.
+__device__ __forceinline__ bool sel_spec(const Sel& s) { return s.spec && s.lms[MCBA_LM_SKIP] == 0.0; }
+__device__ __forceinline__ int sel_index(const Sel& s) { return s.lms ? ((static_cast<int>(s.lms[3]) ^ s.idx ^ (sel_spec(s) ? 1 : 0)) & 1) : s.idx; }
+__device__ __forceinline__ double sel_lambda(const Sel& s) { return s.lms ? (sel_spec(s) ? lm_spec_lambda(s.lms[1], s.lam) : s.lms[1]) : s.lam; }
 // device-resident LM loop: after termination every kernel of a tick returns at once; a tick that follows a failed
 // reduced solve skips its trial kernels (`trial` = true) and only rebuilds the system with the raised damping
 __device__ __forceinline__ bool sel_active(const Sel& s, bool trial) {
@@ -758,59 +763,6 @@ __global__ __launch_bounds__(64 * kBacksubWaves) void k_backsub(Sel sl, const do
 //        8 step_norm  9 x_norm  10 dF.   pred_cam = d_c^T (lam D_c d_c - g_c), dcn2 = |d_c|^2, xcn2 = |x_c|^2 come from
 // the host (it solved the camera system).  Nielsen's update on acceptance, doubling growth on rejection -- identical
 // to solver.LevenbergMarquardt.iterate.
-__device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs& da) {
-  double* lms = da.lms;
-  double cost = lms[0], lam = lms[1], nu = lms[2];
-  const bool dev = da.decide == 2;  // camera-step scalars left in the state by k_solve_cam
-  const double pred_cam = dev ? lms[MCBA_LM_PRED_CAM] : da.pred_cam;
-  const double dcn2 = dev ? lms[MCBA_LM_DCN2] : da.dcn2, xcn2 = dev ? lms[MCBA_LM_XCN2] : da.xcn2;
-  const double cost_before = cost, lam_used = lam;
-  int sel = static_cast<int>(lms[3]);
-  double cost_new = trial8[0];
-  double pred = 0.5 * (trial8[1] + pred_cam);
-  bool ok = isfinite(cost_new) && pred > 0.0;
-  double ratio = ok ? (cost - cost_new) / pred : -1.0;
-  double dF = cost - cost_new;
-  // round-off guard: near the optimum the last Gauss-Newton corrections change the cost by less than FP64 resolves
-  // (|dF| ~ EPS * F * sqrt(m)); such a step is neutral, not bad -- accept it with the damping unchanged
-  bool neutral = isfinite(cost_new) && pred >= 0.0 && fabs(dF) <= 32.0 * MCBA_EPS * fabs(cost);
-  bool accepted = (ratio > 0.0 && dF >= 0.0) || neutral;
-  if (accepted) {
-    if (!(ratio > 0.0 && dF >= 0.0)) ratio = 0.5;  // neutral: factor 1 in Nielsen's rule
-    double t = 2.0 * ratio - 1.0;
-    double fac = fmax(1.0 / 3.0, 1.0 - t * t * t);
-    lam = fmax(lam * fac, da.lam_min);
-    nu = 2.0;
-    sel ^= 1;
-    cost = cost_new;
-  } else {
-    lam = fmin(lam * nu, da.lam_max);
-    nu *= 2.0;
-  }
-  const double step_norm = sqrt(trial8[2] + dcn2), x_norm = sqrt(trial8[3] + xcn2);
-  lms[0] = cost; lms[1] = lam; lms[2] = nu; lms[3] = sel; lms[4] = accepted ? 1.0 : 0.0;
-  lms[5] = cost_new; lms[6] = pred; lms[7] = ratio;
-  lms[8] = step_norm; lms[9] = x_norm; lms[10] = dF;
-  if (dev) {  // termination tests of solver.LevenbergMarquardt._iterate_device, verdict applied by the next k_solve_cam
-    const bool ftol_ok = fmax(dF, 0.0) < da.ftol * cost_before && ratio > 0.25;
-    const bool xtol_ok = step_norm < da.xtol * (da.xtol + x_norm);
-    double status = (ftol_ok && xtol_ok) ? 4.0 : ftol_ok ? 2.0 : xtol_ok ? 3.0 : 0.0;
-    if (!accepted && status == 2.0) status = 0.0;  // ftol needs an accepted step
-    if (!accepted && lam >= da.lam_max && status == 0.0) status = 3.0;
-    lms[MCBA_LM_PENDING] = status;
-    lms[MCBA_LM_NFEV] += 1.0;
-    lms[MCBA_LM_NACC] += accepted ? 1.0 : 0.0;
-    lms[MCBA_LM_LAM_USED] = lam_used;
-    lms[MCBA_LM_COST_BEFORE] = cost_before;
-    lms[MCBA_LM_REBUILD] = 0.0;
-  }
-}
-// a tick that only rebuilds the system (the reduced solve failed): no trial, nothing accepted
-__device__ __forceinline__ void lm_mark_rebuild(double* lms) {
-  lms[4] = 0.0;
-  lms[MCBA_LM_REBUILD] = 1.0;
-}
-
 // Cost partials: element idx of `ncp` lives at (idx / cinner) * couter + (idx % cinner) * cstride  (k_cost: cinner = ncp,
 // cstride = 2; k_gram: per camera a contiguous run of nfb values, cinner = nfb, couter = 92 nfb, cstride = 1).
 __global__ __launch_bounds__(512) void k_sum_trial(Sel sl, const double* __restrict__ cp0, const double* __restrict__ cp1, int cstride, int cinner, size_t couter, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out, DecideArgs da) {

@@ -1,0 +1,70 @@
+// mcba_lm.h -- the accept/reject decision of the device-resident LM loop (shared by k_sum_trial / k_decide in
+// mcba_kernels.hip and k_solve_cam in mcba_solve.hip).  Device code only.
+#pragma once
+#include "mcba_kernels.h"
+#include "mcba_math.h"
+
+namespace mcba {
+
+// damping a speculative Schur reduction assumes for the accepted trial point: Nielsen's factor at its floor of 1/3
+// (ratio >= 0.937, the usual case while converging).  Must be the very expression lm_decide evaluates.
+__device__ __forceinline__ double lm_spec_lambda(double lam, double lam_min) { return fmax(lam * (1.0 / 3.0), lam_min); }
+
+// state (lms): 0 cost  1 lambda  2 nu  3 sel (current slot / linearisation)  4 accepted  5 cost_new  6 pred  7 ratio
+//        8 step_norm  9 x_norm  10 dF.   pred_cam = d_c^T (lam D_c d_c - g_c), dcn2 = |d_c|^2, xcn2 = |x_c|^2 come from
+// whoever solved the camera system (host: DecideArgs; k_solve_cam: the state).  Nielsen's update on acceptance, doubling
+// growth on rejection -- identical to solver.LevenbergMarquardt.iterate.
+__device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs& da) {
+  double* lms = da.lms;
+  double cost = lms[0], lam = lms[1], nu = lms[2];
+  const bool dev = da.decide == 2;  // camera-step scalars left in the state by k_solve_cam
+  const double pred_cam = dev ? lms[MCBA_LM_PRED_CAM] : da.pred_cam;
+  const double dcn2 = dev ? lms[MCBA_LM_DCN2] : da.dcn2, xcn2 = dev ? lms[MCBA_LM_XCN2] : da.xcn2;
+  const double cost_before = cost, lam_used = lam;
+  int sel = static_cast<int>(lms[3]);
+  double cost_new = trial8[0];
+  double pred = 0.5 * (trial8[1] + pred_cam);
+  bool ok = isfinite(cost_new) && pred > 0.0;
+  double ratio = ok ? (cost - cost_new) / pred : -1.0;
+  double dF = cost - cost_new;
+  // round-off guard: near the optimum the last Gauss-Newton corrections change the cost by less than FP64 resolves
+  // (|dF| ~ EPS * F * sqrt(m)); such a step is neutral, not bad -- accept it with the damping unchanged
+  bool neutral = isfinite(cost_new) && pred >= 0.0 && fabs(dF) <= 32.0 * MCBA_EPS * fabs(cost);
+  bool accepted = (ratio > 0.0 && dF >= 0.0) || neutral;
+  if (accepted) {
+    if (!(ratio > 0.0 && dF >= 0.0)) ratio = 0.5;  // neutral: factor 1 in Nielsen's rule
+    double t = 2.0 * ratio - 1.0;
+    double fac = fmax(1.0 / 3.0, 1.0 - t * t * t);
+    lam = fmax(lam * fac, da.lam_min);
+    nu = 2.0;
+    sel ^= 1;
+    cost = cost_new;
+  } else {
+    lam = fmin(lam * nu, da.lam_max);
+    nu *= 2.0;
+  }
+  const double step_norm = sqrt(trial8[2] + dcn2), x_norm = sqrt(trial8[3] + xcn2);
+  lms[0] = cost; lms[1] = lam; lms[2] = nu; lms[3] = sel; lms[4] = accepted ? 1.0 : 0.0;
+  lms[5] = cost_new; lms[6] = pred; lms[7] = ratio;
+  lms[8] = step_norm; lms[9] = x_norm; lms[10] = dF;
+  if (dev) {  // termination tests of solver.LevenbergMarquardt._iterate_device, verdict applied by the next k_solve_cam
+    const bool ftol_ok = fmax(dF, 0.0) < da.ftol * cost_before && ratio > 0.25;
+    const bool xtol_ok = step_norm < da.xtol * (da.xtol + x_norm);
+    double status = (ftol_ok && xtol_ok) ? 4.0 : ftol_ok ? 2.0 : xtol_ok ? 3.0 : 0.0;
+    if (!accepted && status == 2.0) status = 0.0;  // ftol needs an accepted step
+    if (!accepted && lam >= da.lam_max && status == 0.0) status = 3.0;
+    lms[MCBA_LM_PENDING] = status;
+    lms[MCBA_LM_NFEV] += 1.0;
+    lms[MCBA_LM_NACC] += accepted ? 1.0 : 0.0;
+    lms[MCBA_LM_LAM_USED] = lam_used;
+    lms[MCBA_LM_COST_BEFORE] = cost_before;
+    lms[MCBA_LM_REBUILD] = 0.0;
+  }
+}
+// a tick that only rebuilds the system (the reduced solve failed): no trial, nothing accepted
+__device__ __forceinline__ void lm_mark_rebuild(double* lms) {
+  lms[4] = 0.0;
+  lms[MCBA_LM_REBUILD] = 1.0;
+}
+
+}  // namespace mcba

@@ -17,6 +17,7 @@
 // The same launch evaluates first-order optimality, applies the pending termination verdict of k_decide, handles a
 // failed factorisation (more damping, trial skipped) and posts the LM state to a host-mapped ring slot.
 #include "mcba_kernels.h"
+#include "mcba_lm.h"
 #include "mcba_math.h"
 
 namespace mcba {
@@ -177,18 +178,32 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
     return;
   }
   if (tid == 0) {
-    int mode = 0;  // 0 solve, 1 terminated, 2 no solve possible (a frame block failed to factorise)
-    lms[MCBA_LM_GINF] = g_inf;
+    int mode = 0;  // 0 solve, 1 terminated, 2 no solve possible (a frame block failed to factorise), 3 mispredicted
     lms[MCBA_LM_TICK] += 1.0;
-    const double pending = lms[MCBA_LM_PENDING];
-    if (pending != 0.0) { lms[MCBA_LM_DONE] = pending; mode = 1; }
-    else if (g_inf < a.gtol) { lms[MCBA_LM_DONE] = 1.0; mode = 1; }
-    else if (frame_fail != 0.0) mode = 2;
+    if (a.decide) {  // one-collective ticks: the decision is taken here, on the all-reduced trial scalars
+      if (lms[MCBA_LM_SKIP] != 0.0) lm_mark_rebuild(lms);  // this tick only rebuilt the system (no trial)
+      else {
+        const double lam_spec = lm_spec_lambda(lms[1], a.lam_min);  // what the Schur reduction before us assumed
+        lm_decide(a.red + (size_t)n * n + 3 * n + 16, DecideArgs{2, 0.0, 0.0, 0.0, a.lam_min, a.lam_max, lms, a.ftol, a.xtol});
+        if (!(lms[4] != 0.0 && lms[1] == lam_spec)) {  // rejected, or accepted with another damping: the system in the
+          lms[MCBA_LM_SKIP] = 1.0;                     // buffer is not the one to solve -> the next tick rebuilds it
+          lms[MCBA_LM_SOLVE_INFO] = 3.0;
+          mode = 3;
+        }
+      }
+    }
+    if (mode == 0) {
+      lms[MCBA_LM_GINF] = g_inf;
+      const double pending = lms[MCBA_LM_PENDING];
+      if (pending != 0.0) { lms[MCBA_LM_DONE] = pending; mode = 1; }
+      else if (g_inf < a.gtol) { lms[MCBA_LM_DONE] = 1.0; mode = 1; }
+      else if (frame_fail != 0.0) mode = 2;
+    }
     s_flag[0] = mode;
   }
   __syncthreads();
   const int mode = s_flag[0];
-  if (mode == 1) {
+  if (mode == 1 || mode == 3) {
     post_state(a, lst, true);
     return;
   }

@@ -51,7 +51,7 @@ SYMBOLS = [
     ("mcba_lm_fetch", ctypes.c_int, [_h, _dp]),
     ("mcba_lm_iterate", ctypes.c_int, [_h, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp]),
     ("mcba_lm_auto_config", ctypes.c_int, [_h, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_char_p]),
-    ("mcba_lm_auto_solve", ctypes.c_int, [_h, ctypes.c_ulonglong]),
+    ("mcba_lm_auto_solve", ctypes.c_int, [_h, ctypes.c_ulonglong, ctypes.c_int]),
     ("mcba_lm_auto_trial", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_lm_auto_reduce", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int]),
     ("mcba_lm_auto_tick", ctypes.c_int, [_h, ctypes.c_ulonglong, ctypes.c_int]),
@@ -284,8 +284,8 @@ class Problem:
         self._auto_state = np.zeros(LM_STATE)
         self._auto_state_p = _p(self._auto_state)
 
-    def lm_auto_solve(self, seq):
-        rc = self.lib.mcba_lm_auto_solve(self.handle, seq)
+    def lm_auto_solve(self, seq, decide=0):
+        rc = self.lib.mcba_lm_auto_solve(self.handle, seq, int(decide))
         if rc:
             self._chk(rc)
 

@@ -70,6 +70,10 @@ class TorchDistributed:
     def all_reduce_trial(self, problem):
         self.dist.all_reduce(problem.reduce_tensor[problem.nsys : problem.nsys + 8], group=self.group)
 
+    def all_reduce_tick(self, problem):
+        """[system | trial scalars] in one collective (speculative ticks of the device-resident loop)."""
+        self.dist.all_reduce(problem.reduce_tensor[: problem.nsys + 8], group=self.group)
+
 
 class DirectRCCL:
     """Same two collectives as TorchDistributed, but enqueued by libmcba itself with ncclAllReduce on its own reduce
@@ -143,6 +147,9 @@ class LevenbergMarquardt:
             raise ValueError("reduced_solver must be 'device' or 'host'")
         self.device_solve = self.device_decide and reduced_solver == "device" and hasattr(problem, "lm_auto_tick")
         self.depth = max(1, min(int(depth), 12))
+        import os as _os
+
+        self.speculate = _os.environ.get("MCBA_SPECULATE", "1") != "0"  # frame-sharded ticks: one collective instead of two
         self.max_nfev = None
         self.max_steps = None
 
@@ -156,6 +163,7 @@ class LevenbergMarquardt:
         self.nfev, self.njev = 1, 1
         self.lam, self.nu = self.lam0, 2.0
         self.iteration, self.steps = 0, 0
+        self.rebuilds = 0
         self.cost = None
         self.step_norm = None
         self.actual_reduction = None
@@ -183,10 +191,15 @@ class LevenbergMarquardt:
         slot = comm.rank % 12
         if isinstance(comm, TorchDistributed):  # torch issues the collectives, on the stream the library launches on
             p.lm_auto_trial(0)
-            comm.all_reduce_trial(p)
-            p.lm_auto_reduce(1, slot)
-            comm.all_reduce_system(p)
-            p.lm_auto_solve(self.issued)
+            if self.speculate:  # ONE collective per tick: speculative Schur reduction, decision inside k_solve_cam
+                p.lm_auto_reduce(2, slot)
+                comm.all_reduce_tick(p)
+                p.lm_auto_solve(self.issued, 1)
+            else:
+                comm.all_reduce_trial(p)
+                p.lm_auto_reduce(1, slot)
+                comm.all_reduce_system(p)
+                p.lm_auto_solve(self.issued, 0)
         else:  # single GPU, or direct RCCL: the library enqueues the whole tick
             p.lm_auto_tick(self.issued, slot)
 
@@ -206,7 +219,8 @@ class LevenbergMarquardt:
         self.retired += 1
         st = self.p.lm_auto_wait(self.retired)
         done = int(st[15])
-        if st[24] != 0:  # the reduced solve had failed: this tick only re-damped and rebuilt the system
+        if st[24] != 0:  # a rebuild-only tick (the reduced solve had failed, or a speculative reduction was mispredicted)
+            self.rebuilds += 1
             self.lam, self.nu = float(st[1]), float(st[2])
             self.g_inf = float(st[16])
             self.accepted = False
@@ -395,7 +409,7 @@ class LevenbergMarquardt:
         return OptimizeResult(
             x=x, cost=self.cost, optimality=self.g_inf, nfev=self.nfev, njev=self.njev, status=status, message=TERMINATION_MESSAGES[status],
             success=status > 0, active_mask=np.zeros_like(x),
-            lm=dict(iterations=self.iteration, steps=self.steps, lam=self.lam, slot=self.cur, history=self.history),
+            lm=dict(iterations=self.iteration, steps=self.steps, lam=self.lam, slot=self.cur, history=self.history, rebuilds=getattr(self, "rebuilds", 0)),
         )
 
 

@@ -26,6 +26,12 @@ def _problem(m):
 
 def _worker(rank, world, port, out_dir, mode):
     sys.path.insert(0, ROOT)
+    if mode == "device2":  # two collectives per tick instead of the speculative single one
+        os.environ["MCBA_SPECULATE"] = "0"
+        mode = "device"
+        tag = "device2"
+    else:
+        tag = mode
     import contextlib
     import io
 
@@ -50,6 +56,9 @@ def _worker(rank, world, port, out_dir, mode):
         def all_reduce_trial(self, problem):
             self._ar(problem.reduce_tensor[problem.nsys : problem.nsys + 8])
 
+        def all_reduce_tick(self, problem):
+            self._ar(problem.reduce_tensor[: problem.nsys + 8])
+
     real_make_comm = m.solver.make_comm
 
     def make_comm(problem, device, group=None, direct=None):
@@ -62,11 +71,12 @@ def _worker(rank, world, port, out_dir, mode):
         e, it, ps, use, res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, device=0,
                                               ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, distributed=True, return_jac=False, reduced_solver=mode)
     m.solver.make_comm = real_make_comm
-    np.savez(os.path.join(out_dir, f"{mode}{rank}.npz"), x=res.x, cost=res.cost, nfev=res.nfev, status=res.status, use=use, grad=res.grad)
+    np.savez(os.path.join(out_dir, f"{tag}{rank}.npz"), x=res.x, cost=res.cost, nfev=res.nfev, status=res.status, use=use, grad=res.grad,
+             rebuilds=res.lm["rebuilds"], steps=res.lm["steps"])
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["device", "host"])
+@pytest.mark.parametrize("mode", ["device", "device2", "host"])
 def test_two_ranks_one_gpu_match_single_process(tmp_path, mode):
     import contextlib
     import io
@@ -76,6 +86,11 @@ def test_two_ranks_one_gpu_match_single_process(tmp_path, mode):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / f"{mode}0.npz"), np.load(tmp_path / f"{mode}1.npz")
+    if mode == "device":  # speculative ticks: mispredictions cost rebuild ticks (here: the rejected first steps), never correctness
+        assert int(r0["rebuilds"]) >= 1 and int(r0["steps"]) == int(r0["nfev"]) - 1 + int(r0["rebuilds"])
+    else:
+        assert int(r0["rebuilds"]) == 0
+    mode = "device" if mode == "device2" else mode
     # every rank took the same decisions and returns the same full result
     assert int(r0["nfev"]) == int(r1["nfev"]) and int(r0["status"]) == int(r1["status"]) and int(r0["status"]) > 0
     assert float(r0["cost"]) == float(r1["cost"])
