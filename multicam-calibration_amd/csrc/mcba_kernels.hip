@@ -22,6 +22,10 @@
 #include "mcba_kernels.h"
 #include "mcba_lm.h"
 
+#ifndef MCBA_GRAM_PIPE
+#define MCBA_GRAM_PIPE 1
+#endif
+
 namespace mcba {
 
 // ---------------------------------------------------------------- small device helpers
@@ -172,6 +176,70 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       }
     }
   };
+  if constexpr (ROLE == 2 && MCBA_GRAM_PIPE) {
+    // Software-pipelined, branch-free point loop (fused variant, one wavefront per SIMD): the projection of point p + 1 --
+    // a serial chain (rotate, reciprocal, distortion polynomial) -- is issued next to the 180 independent accumulator
+    // updates of point p, which is what fills the FP64 pipe when no second wavefront is there to do it.  Lanes without
+    // an observation project a harmless point and add exact zeros.
+    constexpr int RD = 4;  // observation ring: points p .. p + 3 resident
+    double2 r4[RD];
+    double x4[RD][3];
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+      const int pj = min(j, N - 1);
+      r4[j] = op[(size_t)pj * Fpad];
+      x4[j][0] = obj[3 * pj]; x4[j][1] = obj[3 * pj + 1]; x4[j][2] = obj[3 * pj + 2];
+    }
+    ObsCommon qc;
+    obs_common<true>(K, pc, x4[0], qc, is_num(r4[0].x) || is_num(r4[0].y));
+    auto accumulate = [&](double2 o2, const double Xo[3], const ObsCommon& q) {
+      const bool vu = is_num(o2.x), vv = is_num(o2.y);
+      any = any || vu || vv;
+      double wu2, wv2, gu, gv;
+      obs_weights<LOSS>(o2.x - q.up, vu, fs2, ifs2, cost, wu2, gu);
+      obs_weights<LOSS>(o2.y - q.vp, vv, fs2, ifs2, cost, wv2, gv);
+      {
+        double E[6];
+        obs_row<0>(pc, Xo, q, E);
+        gram_add_row<0>(ga, E, wu2, gu);
+        double l4 = q.fa * q.s;
+        gram_add_row<0>(gb, E, wu2, gu, q.a * q.d, l4, l4 * q.s);
+      }
+      {
+        double E[6];
+        obs_row<1>(pc, Xo, q, E);
+        gram_add_row<1>(ga, E, wv2, gv);
+        double l4 = q.fb * q.s;
+        gram_add_row<1>(gb, E, wv2, gv, q.b * q.d, l4, l4 * q.s);
+      }
+    };
+    int p = 0;
+    for (; p + RD <= N; p += RD) {
+#pragma unroll
+      for (int j = 0; j < RD; ++j) {
+        const int jn = (j + 1) % RD;
+        ObsCommon qn;
+        obs_common<true>(K, pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));  // point p + j + 1 (clamped duplicate at the very end)
+        const double2 o2 = r4[j];
+        const double Xo[3] = {x4[j][0], x4[j][1], x4[j][2]};
+        const int pn = min(p + j + RD, N - 1);
+        r4[j] = op[(size_t)pn * Fpad];
+        x4[j][0] = obj[3 * pn]; x4[j][1] = obj[3 * pn + 1]; x4[j][2] = obj[3 * pn + 2];
+        accumulate(o2, Xo, qc);
+        qc = qn;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {  // remainder (N not a multiple of 4): same rotation of the ring, no refill
+      if (p + j < N) {
+        const int jn = (j + 1) % RD;
+        ObsCommon qn;
+        obs_common<true>(K, pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));
+        accumulate(r4[j], x4[j], qc);
+        qc = qn;
+      }
+    }
+  } else {
   int p = 0;
   for (; p + PF <= N; p += PF) {
 #pragma unroll
@@ -187,6 +255,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #pragma unroll
   for (int j = 0; j < PF; ++j)
     if (p + j < N) point(ring[j], xring[j]);
+  }
 
   // ---- expand once per (c,f): this role's part of W, V, g_f (record) and of U, g_c (reduced over the wave)
   ChainConst ch;

@@ -316,10 +316,14 @@ MCBA_HD void obs_rows(const Intr& K, const PairConst& pc, const double Xo[3], Ob
 struct ObsCommon {
   double a, b, s, d, dp2, abdp, izx, izy, fa, fb, up, vp;
 };
-MCBA_HD void obs_common(const Intr& K, const PairConst& pc, const double Xo[3], ObsCommon& q) {
+// MASKED: lanes without an observation (`ok` false) work on the harmless point (0, 0, 1) instead of their own, so that a
+// branch-free caller can weight their rows with 0 without ever meeting inf * 0 (padding frames, cameras that look away).
+template <bool MASKED = false>
+MCBA_HD void obs_common(const Intr& K, const PairConst& pc, const double Xo[3], ObsCommon& q, bool ok = true) {
   double x = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], fma(pc.Rcf[2], Xo[2], pc.tcf[0])));
   double y = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], fma(pc.Rcf[5], Xo[2], pc.tcf[1])));
   double z = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], fma(pc.Rcf[8], Xo[2], pc.tcf[2])));
+  if (MASKED) { x = ok ? x : 0.0; y = ok ? y : 0.0; z = ok ? z : 1.0; }
   double iz = fast_rcp(z);
   q.a = x * iz; q.b = y * iz;
   q.s = fma(q.a, q.a, q.b * q.b);
