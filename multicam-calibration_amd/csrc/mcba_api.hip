@@ -179,13 +179,17 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   h->NT = (h->n + 1 + 15) / 16;
   h->NP = h->NT * (h->NT + 1) / 2;
   h->ppw = h->NP <= 64 ? 4 : 16;
-  h->FS = 16;
+  h->FS = 8;  // (measured at 6 x 10k: 8 frames per stage and up to 512 workgroups -- two per CU, one building Y while the
+              //  other is in its MFMA phase -- 24.2 us; 16 frames / 256 workgroups 27.4 us)
+  if (const char* e = getenv("MCBA_SYRK_FS")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) h->FS = v; }  // tuning knob
   while (h->FS > 2 && (mcba::syrk_lds_bytes(C, h->FS) > 96 * 1024 || (h->n + 1) * h->FS > 256 * mcba::syrk_items_per_thread())) h->FS /= 2;
   if ((h->n + 1) * h->FS > 256 * mcba::syrk_items_per_thread()) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for k_syrk's per-thread item budget"); }
   if (mcba::syrk_lds_bytes(C, h->FS) > 160 * 1024) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for the LDS staging of k_syrk"); }
   {
     int nstage = (F + h->FS - 1) / h->FS;
-    int g = std::min(nstage, 256);
+    int gmax = 512;
+    if (const char* e = getenv("MCBA_SYRK_G")) gmax = std::max(1, atoi(e));  // tuning knob
+    int g = std::min(nstage, gmax);
     h->fpc = ((nstage + g - 1) / g) * h->FS;
     h->G = (F + h->fpc - 1) / h->fpc;
   }
@@ -215,7 +219,7 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   DA(gpart2[1], (size_t)C * h->nfb * MCBA_GP);
   DA(fbuf, (size_t)h->Fpad * MCBA_FB);
   DA(fpart, (size_t)2 * h->nfblocks);
-  DA(spart, (size_t)h->G * h->NP * 256);
+  DA(spart, (size_t)h->G * h->NP * 256 + 64);
   DA(cpart, (size_t)2 * C * h->nfb * h->nch);
   DA(bpart, (size_t)3 * h->nbblocks);
   DA(red_own, h->nsys + 8 + MCBA_LMS);
@@ -752,6 +756,12 @@ int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot) {
   if ((rc = mcba_lm_auto_reduce(h, 1, rank_slot))) return rc;
   if ((rc = mcba_comm_allreduce(h, 0, h->nsys))) return rc;
   return mcba_lm_auto_solve(h, seq, 0);
+}
+
+int mcba_debug_syrk_stamps(mcba_handle* h, double* host8) {  // development only (MCBA_SYRK_TIMING builds)
+  if (!h || !host8) return fail(MCBA_ERR_ARG, "bad argument");
+  HIPCHK(hipMemcpy(host8, h->spart + (size_t)h->G * h->NP * 256, 8 * sizeof(double), hipMemcpyDeviceToHost));
+  return MCBA_OK;
 }
 
 int mcba_get_cam_step(mcba_handle* h, double* host) {

@@ -529,7 +529,6 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
   double* s_L = lds + (size_t)NT * 16 * RS;   // [FS][34]: L(21) 1/diag(6) z(6) pad
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: keeps the tile bookkeeping out of the exec mask
-  const int nitems = (n + 1) * FS;
 
   int qi[PPW], rowa[PPW], rowb[PPW];
   mfma_d4 acc[PPW];
@@ -548,12 +547,14 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
   double wreg[IPT][6];
   double lreg[2];  // FS*27 <= 512 values of (L, z) per stage, two per thread
 
+  // thread = (frame b of the stage, row group): its IPT items are rows r0, r0 + 256/FS, ... of the SAME frame, so that
+  // frame's L and 1/diag are read from LDS once per stage instead of once per item
+  const int tb = t % FS, tr0 = t / FS, rstep = 256 / FS;
   auto prefetch = [&](int fb) {  // issue every global load of one stage; nothing waits here
 #pragma unroll
     for (int it = 0; it < IPT; ++it) {
-      int i = t + 256 * it;
-      int row = i / FS, b = i - row * FS, f = fb + b;
-      if (i < nitems && row < n) {
+      int row = tr0 + rstep * it, b = tb, f = fb + b;
+      if (row < n) {
         int c = row / 12, lr = row - 12 * c;
         const double2* w2 = reinterpret_cast<const double2*>(rec + ((size_t)c * nfb + (f >> 6)) * (MCBA_REC * 64)) + (size_t)(3 * lr) * 64 + (f & 63);
 #pragma unroll
@@ -568,6 +569,13 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
     }
   };
 
+#ifdef MCBA_SYRK_TIMING
+  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tl = clock64();
+  const long long tstart = tl;
+#define SLAP(i) do { long long tn = clock64(); tacc[i] += tn - tl; tl = tn; } while (0)
+#else
+#define SLAP(i) do { } while (0)
+#endif
   prefetch(f0);
   for (int fb = f0; fb < f1; fb += FS) {
 #pragma unroll
@@ -585,30 +593,38 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
       s_L[b * 34 + 21 + k] = d != 0.0 ? 1.0 / d : 0.0;
     }
     __syncthreads();
+    SLAP(0);
+    {
+      double Lr[27];
+      const double* Lp = s_L + tb * 34;
 #pragma unroll
-    for (int it = 0; it < IPT; ++it) {
-      int i = t + 256 * it;
-      if (i < nitems) {
-        int row = i / FS, b = i - row * FS;
-        double* dst = s_y + (size_t)row * RS + b * 6;
-        const double* Lp = s_L + b * 34;
-        if (row < n) {
-          double yr[6];
-          fwd6(Lp, Lp + 21, wreg[it], yr);
-          bool live = fb + b < F;
+      for (int k = 0; k < 27; ++k) Lr[k] = Lp[k];
+      const bool live = fb + tb < F;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) dst[k] = live ? yr[k] : 0.0;
-        } else {
+      for (int it = 0; it < IPT; ++it) {
+        const int row = tr0 + rstep * it;
+        if (row <= n) {
+          double* dst = s_y + (size_t)row * RS + tb * 6;
+          if (row < n) {
+            double yr[6];
+            fwd6(Lr, Lr + 21, wreg[it], yr);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) dst[k] = Lp[27 + k];  // z_f (zero for padding frames)
+            for (int k = 0; k < 6; ++k) dst[k] = live ? yr[k] : 0.0;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dst[k] = Lp[27 + k];  // z_f (zero for padding frames)
+          }
         }
       }
     }
     __syncthreads();
+    SLAP(1);
     if (fb + FS < f1) prefetch(fb + FS);  // flies while the matrix cores work
     // matrix-core phase: K = 6 FS in steps of 4 (6 FS / 4 is even for every FS we use).  Operands of step ks+1 are
     // read from LDS while the PPW independent MFMAs of step ks issue back to back (64 cycles each on one SIMD).
     const int nks = (6 * FS) / 4;
+    // (Measured: skipping the LDS read of a fragment that a neighbouring pair already holds -- wave-uniform branches
+    // between the MFMAs -- costs more than the bandwidth it saves: 55k vs 33k cycles for this phase.  Keep it branch-free.)
     double a0[PPW], b0[PPW], a1[PPW], b1[PPW];
 #pragma unroll
     for (int k = 0; k < PPW; ++k) { a0[k] = s_y[rowa[k]]; b0[k] = s_y[rowb[k]]; }
@@ -624,8 +640,17 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
 #pragma unroll
       for (int k = 0; k < PPW; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[k], b1[k], acc[k], 0, 0, 0);
     }
+    SLAP(2);
     __syncthreads();
+    SLAP(3);
   }
+#ifdef MCBA_SYRK_TIMING
+  if (t == 0 && blockIdx.x == 3 && blockIdx.y == 0) {
+    double* dbg = spart + (size_t)gridDim.x * NP * 256;
+    for (int i = 0; i < 4; ++i) dbg[i] = (double)tacc[i];
+    dbg[4] = (double)(clock64() - tstart);
+  }
+#endif
 #pragma unroll
   for (int k = 0; k < PPW; ++k) {
     if (qi[k] >= 0) {
