@@ -190,9 +190,11 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       r4[j] = op[(size_t)pj * Fpad];
       x4[j][0] = obj[3 * pj]; x4[j][1] = obj[3 * pj + 1]; x4[j][2] = obj[3 * pj + 2];
     }
-    ObsCommon qc;
-    obs_common<true>(K, pc, x4[0], qc, is_num(r4[0].x) || is_num(r4[0].y));
-    auto accumulate = [&](double2 o2, const double Xo[3], const ObsCommon& q) {
+    ObsLead qc;
+    obs_lead<true>(pc, x4[0], qc, is_num(r4[0].x) || is_num(r4[0].y));
+    auto accumulate = [&](double2 o2, const double Xo[3], const ObsLead& ql) {
+      ObsCommon q;
+      obs_finish(K, ql, q);
       const bool vu = is_num(o2.x), vv = is_num(o2.y);
       any = any || vu || vv;
       double wu2, wv2, gu, gv;
@@ -218,8 +220,8 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #pragma unroll
       for (int j = 0; j < RD; ++j) {
         const int jn = (j + 1) % RD;
-        ObsCommon qn;
-        obs_common<true>(K, pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));  // point p + j + 1 (clamped duplicate at the very end)
+        ObsLead qn;
+        obs_lead<true>(pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));  // point p + j + 1 (clamped duplicate at the very end)
         const double2 o2 = r4[j];
         const double Xo[3] = {x4[j][0], x4[j][1], x4[j][2]};
         const int pn = min(p + j + RD, N - 1);
@@ -233,8 +235,8 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     for (int j = 0; j < RD; ++j) {  // remainder (N not a multiple of 4): same rotation of the ring, no refill
       if (p + j < N) {
         const int jn = (j + 1) % RD;
-        ObsCommon qn;
-        obs_common<true>(K, pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));
+        ObsLead qn;
+        obs_lead<true>(pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));
         accumulate(r4[j], x4[j], qc);
         qc = qn;
       }

@@ -335,6 +335,31 @@ MCBA_HD void obs_common(const Intr& K, const PairConst& pc, const double Xo[3], 
   q.up = fma(q.fa, q.d, K.cx);
   q.vp = fma(q.fb, q.d, K.cy);
 }
+// The same in two halves for a software-pipelined caller: the serial part (rotate, reciprocal) one point ahead -- only
+// (a, b, 1/z) travel between the stages --, the cheap polynomial part next to the accumulator updates.
+struct ObsLead {
+  double a, b, iz;
+};
+template <bool MASKED = false>
+MCBA_HD void obs_lead(const PairConst& pc, const double Xo[3], ObsLead& l, bool ok = true) {
+  double x = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], fma(pc.Rcf[2], Xo[2], pc.tcf[0])));
+  double y = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], fma(pc.Rcf[5], Xo[2], pc.tcf[1])));
+  double z = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], fma(pc.Rcf[8], Xo[2], pc.tcf[2])));
+  if (MASKED) { x = ok ? x : 0.0; y = ok ? y : 0.0; z = ok ? z : 1.0; }
+  l.iz = fast_rcp(z);
+  l.a = x * l.iz; l.b = y * l.iz;
+}
+MCBA_HD void obs_finish(const Intr& K, const ObsLead& l, ObsCommon& q) {
+  q.a = l.a; q.b = l.b;
+  q.s = fma(q.a, q.a, q.b * q.b);
+  q.d = fma(q.s, fma(K.k2, q.s, K.k1), 1.0);
+  q.dp2 = 2.0 * fma(2.0 * K.k2, q.s, K.k1);
+  q.abdp = (q.a * q.b) * q.dp2;
+  q.izx = K.fx * l.iz; q.izy = K.fy * l.iz;
+  q.fa = K.fx * q.a; q.fb = K.fy * q.b;
+  q.up = fma(q.fa, q.d, K.cx);
+  q.vp = fma(q.fb, q.d, K.cy);
+}
 // ROW 0 = u, 1 = v.  E[0..2] = A row, E[3..5] = P row.
 template <int ROW>
 MCBA_HD void obs_row(const PairConst& pc, const double Xo[3], const ObsCommon& q, double E[6]) {
