@@ -164,13 +164,13 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       obs_weights<LOSS>(o2.y - q.vp, vv, fs2, ifs2, cost, wv2, gv);
       {  // u row, completely, before the v row exists: one [A|P] row live at a time
         double E[6];
-        obs_row<0>(pc, Xo, q, E);
+        obs_row_cam<0>(q, E);
         if (DO_A) gram_add_row<0>(ga, E, wu2, gu);
         if (DO_B) { double l4 = q.fa * q.s; gram_add_row<0>(gb, E, wu2, gu, q.a * q.d, l4, l4 * q.s); }
       }
       {
         double E[6];
-        obs_row<1>(pc, Xo, q, E);
+        obs_row_cam<1>(q, E);
         if (DO_A) gram_add_row<1>(ga, E, wv2, gv);
         if (DO_B) { double l4 = q.fb * q.s; gram_add_row<1>(gb, E, wv2, gv, q.b * q.d, l4, l4 * q.s); }
       }
@@ -202,14 +202,14 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       obs_weights<LOSS>(o2.y - q.vp, vv, fs2, ifs2, cost, wv2, gv);
       {
         double E[6];
-        obs_row<0>(pc, Xo, q, E);
+        obs_row_cam<0>(q, E);
         gram_add_row<0>(ga, E, wu2, gu);
         double l4 = q.fa * q.s;
         gram_add_row<0>(gb, E, wu2, gu, q.a * q.d, l4, l4 * q.s);
       }
       {
         double E[6];
-        obs_row<1>(pc, Xo, q, E);
+        obs_row_cam<1>(q, E);
         gram_add_row<1>(ga, E, wv2, gv);
         double l4 = q.fb * q.s;
         gram_add_row<1>(gb, E, wv2, gv, q.b * q.d, l4, l4 * q.s);
@@ -269,6 +269,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #pragma unroll
     for (int i = 0; i < 9; ++i) Jrc[i] = uni(s_cam.Jr[i]);
     make_chain_const(Rc, Jrc, Rf, Jrf, pz + 3, ch);
+    chain_to_cam_rows(pc.Rcf, ch);  // the point loop accumulated camera-frame rows [A~ | P]
   }
   // records are wave tiles rec[camera][frame block][k/2 = 0..49][lane][2]: every store below is one 1 KiB dwordx4 row
   double2* r2 = reinterpret_cast<double2*>(rec + ((size_t)c * nfb + fb) * (MCBA_REC * 64)) + lane;

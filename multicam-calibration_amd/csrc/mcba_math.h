@@ -315,14 +315,16 @@ MCBA_HD void obs_rows(const Intr& K, const PairConst& pc, const double Xo[3], Ob
 // only one 6-vector [A|P] row (plus its weighted copy) is live while the 87 accumulators are updated.
 struct ObsCommon {
   double a, b, s, d, dp2, abdp, izx, izy, fa, fb, up, vp;
+  double xr[3];  // Rcf X_o: the point in camera-aligned axes, before the translation
 };
 // MASKED: lanes without an observation (`ok` false) work on the harmless point (0, 0, 1) instead of their own, so that a
 // branch-free caller can weight their rows with 0 without ever meeting inf * 0 (padding frames, cameras that look away).
 template <bool MASKED = false>
 MCBA_HD void obs_common(const Intr& K, const PairConst& pc, const double Xo[3], ObsCommon& q, bool ok = true) {
-  double x = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], fma(pc.Rcf[2], Xo[2], pc.tcf[0])));
-  double y = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], fma(pc.Rcf[5], Xo[2], pc.tcf[1])));
-  double z = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], fma(pc.Rcf[8], Xo[2], pc.tcf[2])));
+  q.xr[0] = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], pc.Rcf[2] * Xo[2]));
+  q.xr[1] = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], pc.Rcf[5] * Xo[2]));
+  q.xr[2] = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], pc.Rcf[8] * Xo[2]));
+  double x = q.xr[0] + pc.tcf[0], y = q.xr[1] + pc.tcf[1], z = q.xr[2] + pc.tcf[2];
   if (MASKED) { x = ok ? x : 0.0; y = ok ? y : 0.0; z = ok ? z : 1.0; }
   double iz = fast_rcp(z);
   q.a = x * iz; q.b = y * iz;
@@ -338,18 +340,20 @@ MCBA_HD void obs_common(const Intr& K, const PairConst& pc, const double Xo[3], 
 // The same in two halves for a software-pipelined caller: the serial part (rotate, reciprocal) one point ahead -- only
 // (a, b, 1/z) travel between the stages --, the cheap polynomial part next to the accumulator updates.
 struct ObsLead {
-  double a, b, iz;
+  double a, b, iz, xr[3];
 };
 template <bool MASKED = false>
 MCBA_HD void obs_lead(const PairConst& pc, const double Xo[3], ObsLead& l, bool ok = true) {
-  double x = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], fma(pc.Rcf[2], Xo[2], pc.tcf[0])));
-  double y = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], fma(pc.Rcf[5], Xo[2], pc.tcf[1])));
-  double z = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], fma(pc.Rcf[8], Xo[2], pc.tcf[2])));
+  l.xr[0] = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], pc.Rcf[2] * Xo[2]));
+  l.xr[1] = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], pc.Rcf[5] * Xo[2]));
+  l.xr[2] = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], pc.Rcf[8] * Xo[2]));
+  double x = l.xr[0] + pc.tcf[0], y = l.xr[1] + pc.tcf[1], z = l.xr[2] + pc.tcf[2];
   if (MASKED) { x = ok ? x : 0.0; y = ok ? y : 0.0; z = ok ? z : 1.0; }
   l.iz = fast_rcp(z);
   l.a = x * l.iz; l.b = y * l.iz;
 }
 MCBA_HD void obs_finish(const Intr& K, const ObsLead& l, ObsCommon& q) {
+  q.xr[0] = l.xr[0]; q.xr[1] = l.xr[1]; q.xr[2] = l.xr[2];
   q.a = l.a; q.b = l.b;
   q.s = fma(q.a, q.a, q.b * q.b);
   q.d = fma(q.s, fma(K.k2, q.s, K.k1), 1.0);
@@ -374,6 +378,31 @@ MCBA_HD void obs_row(const PairConst& pc, const double Xo[3], const ObsCommon& q
   E[0] = fma(Xo[1], b2, -(Xo[2] * b1));
   E[1] = fma(Xo[2], b0, -(Xo[0] * b2));
   E[2] = fma(Xo[0], b1, -(Xo[1] * b0));
+}
+
+// Camera-frame variant used by k_gram: with A = X_o x (Rcf^T p) = ((Rcf X_o) x p)^T Rcf, the rows are accumulated as
+// [A~ | P] with A~ = (Rcf X_o) x p -- no product with Rcf per row (9 FMAs and, in k_gram, 18 register-file moves per row
+// saved) -- and the constant factor Rcf is folded ONCE per (camera, frame) into the chain matrices (chain_to_cam_rows).
+template <int ROW>
+MCBA_HD void obs_row_cam(const ObsCommon& q, double E[6]) {
+  double p0, p1;
+  if (ROW == 0) { p0 = fma(q.a * q.a, q.dp2, q.d) * q.izx; p1 = q.abdp * q.izx; }
+  else { p0 = q.abdp * q.izy; p1 = fma(q.b * q.b, q.dp2, q.d) * q.izy; }
+  double p2 = -fma(p0, q.a, p1 * q.b);
+  E[3] = p0; E[4] = p1; E[5] = p2;
+  E[0] = fma(q.xr[1], p2, -(q.xr[2] * p1));
+  E[1] = fma(q.xr[2], p0, -(q.xr[0] * p2));
+  E[2] = fma(q.xr[0], p1, -(q.xr[1] * p0));
+}
+// J_rho = A Pa + P Pb = A~ (Rcf Pa) + P Pb,  J_omega = A Sa = A~ (Rcf Sa)
+MCBA_HD void chain_to_cam_rows(const double* Rcf, ChainConst& ch) {
+  double T[9];
+  mm33(Rcf, ch.Pa, T);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) ch.Pa[i] = T[i];
+  mm33(Rcf, ch.Sa, T);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) ch.Sa[i] = T[i];
 }
 
 // ---------------------------------------------------------------- local Gram accumulators of one (c,f)

@@ -58,15 +58,16 @@ void hc_normal_eq(int C, int F, int N, const double* uvs, const double* obj, con
         double wu2, wv2, gu, gv, E[6];
         weights_dyn(loss, o2[0] - q.up, vu, fs2, ifs2, ga.cost, wu2, gu);
         weights_dyn(loss, o2[1] - q.vp, vv, fs2, ifs2, ga.cost, wv2, gv);
-        obs_row<0>(pc, obj + 3 * p, q, E);
+        obs_row_cam<0>(q, E);
         gram_add_row<0>(ga, E, wu2, gu);
         gram_add_row<0>(gb, E, wu2, gu, q.a * q.d, q.fa * q.s, q.fa * q.s * q.s);
-        obs_row<1>(pc, obj + 3 * p, q, E);
+        obs_row_cam<1>(q, E);
         gram_add_row<1>(ga, E, wv2, gv);
         gram_add_row<1>(gb, E, wv2, gv, q.b * q.d, q.fb * q.s, q.fb * q.s * q.s);
       }
       ChainConst ch;
       make_chain_const(cc.R, cc.Jr, Rf, Jrf, pose + 3, ch);
+      chain_to_cam_rows(pc.Rcf, ch);  // as k_gram: camera-frame rows
       double Ul[78], gcl[12];
       gram_expand(ga, ch, Ul, gcl, W + ((size_t)c * F + f) * 72, V + ((size_t)c * F + f) * 21, gf + ((size_t)c * F + f) * 6);
       gram_expand(gb, ch, Ul, gcl, W + ((size_t)c * F + f) * 72);
