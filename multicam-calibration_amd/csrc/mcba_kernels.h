@@ -5,7 +5,7 @@
 
 #define MCBA_REC 100  // per (frame, camera) record: W 72 | V 21 | g_f 6 | pad
 #define MCBA_GP 92    // k_gram per-wavefront sums, stored [camera][k][frame block]: k = U 78 | g_c 12 | cost | pairs with data
-#define MCBA_FB 40    // per frame: L 21 | z 6 | g_f 6 | D_f 6 | pad
+#define MCBA_FB 40    // per frame: L 21 (diagonal slots hold 1 / L_ii) | z 6 | g_f 6 | D_f 6 | pad
 
 // device LM state (doubles): 0 cost  1 lambda  2 nu  3 sel (current slot / linearisation)  4 accepted  5 cost_new  6 pred
 // 7 ratio  8 step_norm  9 x_norm  10 dF, then the fields of the device-resident solve (k_solve_cam, mcba_solve.hip):

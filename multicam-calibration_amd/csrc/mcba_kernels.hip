@@ -458,17 +458,18 @@ __global__ __launch_bounds__(64) void k_frame_factor(Sel sl, const double* __res
   for (int k = 0; k < 21; ++k) V[k] = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) gf[k] = 0.0;
-  for (int c0 = 0; c0 < C; c0 += 3) {
-    double t[3][27];
+  constexpr int CB = 6;  // cameras per batch: 84 loads in flight (a dependent round trip costs ~2 us, the data next to nothing)
+  for (int c0 = 0; c0 < C; c0 += CB) {
+    double t[CB][27];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < CB; ++j) {
       const int cc = min(c0 + j, C - 1);  // clamped duplicate loads are ignored below
       const double2* r2 = reinterpret_cast<const double2*>(rec + ((size_t)cc * nfb + blockIdx.x) * (MCBA_REC * 64)) + 36 * 64 + threadIdx.x;
 #pragma unroll
       for (int k = 0; k < 14; ++k) { double2 v = r2[k * 64]; t[j][2 * k] = v.x; if (2 * k + 1 < 27) t[j][2 * k + 1] = v.y; }
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < CB; ++j) {
       if (c0 + j < C) {
 #pragma unroll
         for (int k = 0; k < 21; ++k) V[k] += t[j][k];
@@ -486,9 +487,9 @@ __global__ __launch_bounds__(64) void k_frame_factor(Sel sl, const double* __res
       V[tri6(k, k)] = d + lambda * D[k];
     }
     double Lp[21], id[6], z[6];
-    bool ok = chol6(V, Lp);
+    bool ok = chol6i(V, Lp);  // diagonal slots: 1 / L_ii
 #pragma unroll
-    for (int k = 0; k < 6; ++k) id[k] = 1.0 / Lp[k * (k + 1) / 2 + k];
+    for (int k = 0; k < 6; ++k) id[k] = Lp[k * (k + 1) / 2 + k];
     fwd6(Lp, id, gf, z);
     double o[40];
 #pragma unroll
@@ -592,8 +593,7 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
     __syncthreads();
     if (t < FS * 6) {
       int b = t / 6, k = t - b * 6;
-      double d = s_L[b * 34 + k * (k + 1) / 2 + k];
-      s_L[b * 34 + 21 + k] = d != 0.0 ? 1.0 / d : 0.0;
+      s_L[b * 34 + 21 + k] = s_L[b * 34 + k * (k + 1) / 2 + k];  // k_frame_factor stores 1 / L_kk there (0 for padding frames)
     }
     __syncthreads();
     SLAP(0);
@@ -799,15 +799,18 @@ __global__ __launch_bounds__(64 * kBacksubWaves) void k_backsub(Sel sl, const do
     for (int i = threadIdx.x; i < n; i += blockDim.x) xd[i] = xs[i] + dcs.v[i];
   double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int c = wave; c < C; c += nw) {
+    // all 36 loads of the camera's W block in flight at once: a dependent round trip costs ~2 us, the data 0.1 us
     const double2* w2 = reinterpret_cast<const double2*>(rec + ((size_t)c * nfb + blockIdx.x) * (MCBA_REC * 64)) + lane;
-#pragma unroll 4
+    double2 v[36];
+    double d[12];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) v[k] = w2[k * 64];
+#pragma unroll
+    for (int lr = 0; lr < 12; ++lr) d[lr] = dcs.v[12 * c + lr];  // wave-uniform: scalar loads
+#pragma unroll
     for (int lr = 0; lr < 12; ++lr) {
-      double d = dcs.v[12 * c + lr];  // wave-uniform: scalar load
-      double2 v[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) v[k] = w2[(3 * lr + k) * 64];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { t[2 * k] = fma(v[k].x, d, t[2 * k]); t[2 * k + 1] = fma(v[k].y, d, t[2 * k + 1]); }
+      for (int k = 0; k < 3; ++k) { t[2 * k] = fma(v[3 * lr + k].x, d[lr], t[2 * k]); t[2 * k + 1] = fma(v[3 * lr + k].y, d[lr], t[2 * k + 1]); }
     }
   }
   // frame data of wavefront 0 in flight while the partial sums meet
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(64 * kBacksubWaves) void k_backsub(Sel sl, const do
   if (fin) {
     double id[6], y[6], dl[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { id[k] = 1.0 / Lp[k * (k + 1) / 2 + k]; t[k] += gf[k]; }
+    for (int k = 0; k < 6; ++k) { id[k] = Lp[k * (k + 1) / 2 + k]; t[k] += gf[k]; }  // diagonal slots hold 1 / L_kk
     fwd6(Lp, id, t, y);
     bwd6(Lp, id, y, dl);
     const double* xf = xs + n + 6 * (size_t)f;

@@ -694,6 +694,27 @@ MCBA_HD bool chol6(const double* Vt, double* Lp) {
   }
   return ok;
 }
+// The form the kernels store and consume: the DIAGONAL slots of Lp hold 1 / L_ii (what every forward / backward
+// substitution multiplies by), computed with v_rsq_f64 + Newton instead of a square root and fifteen FP64 divisions.
+MCBA_HD bool chol6i(const double* Vt, double* Lp) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double s = Vt[tri6(j, i)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= Lp[i * (i + 1) / 2 + k] * Lp[j * (j + 1) / 2 + k];
+      if (i == j) {
+        if (!(s > 0.0)) { ok = false; s = 1.0; }
+        Lp[i * (i + 1) / 2 + i] = fast_rsqrt(s);
+      } else {
+        Lp[i * (i + 1) / 2 + j] = s * Lp[j * (j + 1) / 2 + j];
+      }
+    }
+  }
+  return ok;
+}
 // y = L^-1 b   (forward substitution), idiag[i] = 1/L_ii
 MCBA_HD void fwd6(const double* Lp, const double* idiag, const double* b, double* y) {
 #pragma unroll

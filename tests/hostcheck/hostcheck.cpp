@@ -112,8 +112,8 @@ void hc_rot(const double* r, double* R, double* Jr) { rot_and_jr(r, R, Jr); }
 // Cholesky solve of a packed 6x6: x = V^-1 b ; returns 1 if positive definite
 int hc_chol_solve(const double* Vt, const double* b, double* x) {
   double Lp[21], id[6], y[6];
-  bool ok = chol6(Vt, Lp);
-  for (int i = 0; i < 6; ++i) id[i] = 1.0 / Lp[i * (i + 1) / 2 + i];
+  bool ok = chol6i(Vt, Lp);  // the form the kernels use: diagonal slots hold 1 / L_ii
+  for (int i = 0; i < 6; ++i) id[i] = Lp[i * (i + 1) / 2 + i];
   fwd6(Lp, id, b, y);
   bwd6(Lp, id, y, x);
   return ok ? 1 : 0;
