@@ -6,12 +6,15 @@
 //                       one camera, the loop runs over the board points.  Observations are stored
 //                       [camera][point][frame] so each iteration's load is one coalesced 1 KiB line group;
 //                       all accumulation (12x12 local Gram matrix) is lane-local -- no shuffles in the loop.
-//                       Camera intrinsics + pose are staged in LDS once per workgroup.
+//                       Camera intrinsics + pose are staged in LDS once per workgroup.  The fused variant's point
+//                       loop is branch-free and software-pipelined; rows are accumulated in camera-aligned axes.
 //   k_frame_factor      one lane per frame: 6x6 Cholesky of the damped frame block, z = L^-1 g_f.
 //   k_syrk              per stage of frames: Y = W L^-T built in LDS, S -= Y Y^T on v_mfma_f64_16x16x4 (the one
 //                       GEMM-shaped step); the next stage's operands are prefetched into registers meanwhile.
 //   k_reduce_system     fixed-order second-stage reduction (deterministic; no FP64 atomics anywhere).
-//   k_backsub           one lane per frame: frame steps, trial parameters, predicted-reduction terms.
+//   k_backsub           64 frames x min(C, 8) wavefronts: frame steps, trial parameters, predicted-reduction terms.
+//   k_sum_trial/k_decide  trial sums, accept/reject + damping update + ftol/xtol on the device LM state (mcba_lm.h).
+//   (mcba_solve.hip)    k_solve_cam: the reduced camera system factorised and solved by one workgroup.
 //   k_jacobian          one wavefront per (camera, frame), one lane per board point; rows transposed through
 //                       LDS so the 288 B/observation Jacobian blocks leave as coalesced 16 B/lane stores.
 #include <hip/hip_runtime.h>

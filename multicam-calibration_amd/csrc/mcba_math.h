@@ -364,22 +364,7 @@ MCBA_HD void obs_finish(const Intr& K, const ObsLead& l, ObsCommon& q) {
   q.up = fma(q.fa, q.d, K.cx);
   q.vp = fma(q.fb, q.d, K.cy);
 }
-// ROW 0 = u, 1 = v.  E[0..2] = A row, E[3..5] = P row.
-template <int ROW>
-MCBA_HD void obs_row(const PairConst& pc, const double Xo[3], const ObsCommon& q, double E[6]) {
-  double p0, p1;
-  if (ROW == 0) { p0 = fma(q.a * q.a, q.dp2, q.d) * q.izx; p1 = q.abdp * q.izx; }
-  else { p0 = q.abdp * q.izy; p1 = fma(q.b * q.b, q.dp2, q.d) * q.izy; }
-  double p2 = -fma(p0, q.a, p1 * q.b);
-  E[3] = p0; E[4] = p1; E[5] = p2;
-  double b0 = fma(p0, pc.Rcf[0], fma(p1, pc.Rcf[3], p2 * pc.Rcf[6]));
-  double b1 = fma(p0, pc.Rcf[1], fma(p1, pc.Rcf[4], p2 * pc.Rcf[7]));
-  double b2 = fma(p0, pc.Rcf[2], fma(p1, pc.Rcf[5], p2 * pc.Rcf[8]));
-  E[0] = fma(Xo[1], b2, -(Xo[2] * b1));
-  E[1] = fma(Xo[2], b0, -(Xo[0] * b2));
-  E[2] = fma(Xo[0], b1, -(Xo[1] * b0));
-}
-
+// ROW 0 = u, 1 = v.  E[0..2] = A~ row, E[3..5] = P row.
 // Camera-frame variant used by k_gram: with A = X_o x (Rcf^T p) = ((Rcf X_o) x p)^T Rcf, the rows are accumulated as
 // [A~ | P] with A~ = (Rcf X_o) x p -- no product with Rcf per row (9 FMAs and, in k_gram, 18 register-file moves per row
 // saved) -- and the constant factor Rcf is folded ONCE per (camera, frame) into the chain matrices (chain_to_cam_rows).
@@ -673,27 +658,8 @@ MCBA_HD void expand_rows(const ObsRows& o, const ChainConst& ch, double* Jcu, do
 }
 
 // ---------------------------------------------------------------- 6x6 SPD helpers for the frame blocks
-// Cholesky of a packed upper-triangle 6x6 (tri6 order) -> L packed lower, row-major by (i>=j): Lp[i(i+1)/2 + j].
-// Returns false if a pivot is not positive.
-MCBA_HD bool chol6(const double* Vt, double* Lp) {
-  bool ok = true;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-#pragma unroll
-    for (int j = 0; j <= i; ++j) {
-      double s = Vt[tri6(j, i)];
-#pragma unroll
-      for (int k = 0; k < j; ++k) s -= Lp[i * (i + 1) / 2 + k] * Lp[j * (j + 1) / 2 + k];
-      if (i == j) {
-        if (!(s > 0.0)) { ok = false; s = 1.0; }
-        Lp[i * (i + 1) / 2 + i] = sqrt(s);
-      } else {
-        Lp[i * (i + 1) / 2 + j] = s / Lp[j * (j + 1) / 2 + j];
-      }
-    }
-  }
-  return ok;
-}
+// Cholesky of a packed upper-triangle 6x6 (tri6 order) -> L packed lower, row-major by (i>=j): Lp[i(i+1)/2 + j];
+// returns false if a pivot is not positive.
 // The form the kernels store and consume: the DIAGONAL slots of Lp hold 1 / L_ii (what every forward / backward
 // substitution multiplies by), computed with v_rsq_f64 + Newton instead of a square root and fifteen FP64 divisions.
 MCBA_HD bool chol6i(const double* Vt, double* Lp) {

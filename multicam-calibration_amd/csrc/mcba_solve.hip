@@ -10,12 +10,17 @@
 //            [ rhs 1 ]
 //   per block column k:   panel  = A[16k:, 16k:16k+16] - L[16k:, :16k] L[16k:16k+16, :16k]^T     v_mfma_f64_16x16x4, one
 //                                                                                               wave per 16-row tile
-//                         diagonal 16x16 block factorised by wavefront 0 in registers (v_readlane broadcasts)
-//                         rows below: one thread per row, triangular solve against the LDS copy of the block
-//   backward sweep L^T d = y block by block (diagonal blocks kept in LDS, the rest read row-wise = coalesced).
-// The factor lives in LDS when (16 ceil((n+1)/16))^2 doubles fit (<= 9 cameras), otherwise in an L2-resident scratch.
-// The same launch evaluates first-order optimality, applies the pending termination verdict of k_decide, handles a
-// failed factorisation (more damping, trial skipped) and posts the LM state to a host-mapped ring slot.
+//                         diagonal block AND the rows below it in ONE instruction stream: lanes 0..15 of every wavefront
+//                         hold the 16 diagonal rows (redundantly), lanes 16..63 hold 48 further panel rows; finished
+//                         entries of the diagonal rows are broadcast with v_readlane (left-looking inside the block), so
+//                         there is no barrier between "factor" and "triangular solve"; pivots: v_rsq_f64 + one cubic step
+//   backward sweep L^T d = y block by block, each step's operands in flight while wavefront 0 does the 16 pivots.
+// The factor lives in LDS (odd row stride) when it fits (<= 9 cameras) -- then the whole lower triangle is put in flight
+// before anything else, because a dependent global round trip costs ~2 us here; otherwise in an L2-resident scratch,
+// with the panel's own rows staged in LDS and the A rows streamed 32 B per lane, one work item ahead.
+// The same launch evaluates first-order optimality, applies the termination verdict (pending from k_sum_trial / k_decide,
+// or taken here on the all-reduced trial scalars: one-collective ticks), handles a failed factorisation (more damping,
+// next tick rebuild-only) and posts the LM state to a host-mapped ring slot.
 #include "mcba_kernels.h"
 #include "mcba_lm.h"
 #include "mcba_math.h"
@@ -39,22 +44,6 @@ __device__ __forceinline__ double rsqrt_cubic(double a) {
   double e = fma(-a * y, y, 1.0);
   double q = e * fma(0.375, e, 0.5);
   return fma(y, q, y);
-}
-
-template <int NTHREADS>
-__device__ __forceinline__ double block_reduce(double v, bool take_max, double* s_red) {  // result to every thread
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    double o = __shfl_xor(v, off, 64);
-    v = take_max ? fmax(v, o) : v + o;
-  }
-  __syncthreads();
-  if (lane == 0) s_red[wave] = v;
-  __syncthreads();
-  double r = s_red[0];
-  for (int w = 1; w < NTHREADS / 64; ++w) r = take_max ? fmax(r, s_red[w]) : r + s_red[w];
-  return r;
 }
 
 // four values at once (sum or max), result to every thread: one pair of barriers instead of four
