@@ -466,3 +466,38 @@ def test_device_loop_max_nfev_and_verbose(mc, capsys):
         e2, i2, po2, use2, res2 = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=0.0, xtol=0.0, gtol=0.0, verbose=0, max_nfev=7,
                                                    return_jac=False, reduced_solver="host")
     assert res2.nfev == 7 and abs(res.cost - res2.cost) <= 1e-12 * res2.cost
+
+
+# ------------------------------------------------------------------ degenerate inputs: same answers as the oracle-driven LM
+@pytest.mark.parametrize("tag", ["blind_camera", "three_frames", "two_point_board", "unseen_frame", "nine_cameras", "ten_cameras"])
+def test_degenerate_inputs_match_oracle_driver(mc, tag):
+    """Edge cases of the domain: a camera that never sees the board, fewer frames than a wavefront, a board
+    with two points (rank-deficient frame blocks: only the damping keeps them solvable), a frame nobody sees, and the two
+    sizes either side of the LDS-resident reduced solve.  Oracle = the same LM driver over the CPU test double."""
+    from fake_problem import OracleProblem
+
+    if tag == "blind_camera":
+        p = mc.synth.make_problem(3, 40, seed=1)
+        p["uvs"][2] = np.nan
+    elif tag == "three_frames":
+        p = mc.synth.make_problem(2, 3, seed=2)
+    elif tag == "two_point_board":
+        p = mc.synth.make_problem(2, 65, seed=3, rows=1, cols=2)
+    elif tag == "unseen_frame":
+        p = mc.synth.make_problem(2, 30, seed=4)
+        p["uvs"][:, 5] = np.nan
+    elif tag == "nine_cameras":
+        p = mc.synth.make_problem(9, 20, seed=6, missing=0.4)
+    else:
+        p = mc.synth.make_problem(10, 20, seed=7, missing=0.4)
+    C = p["uvs"].shape[0]
+    kw = dict(n_frames=None, ftol=1e-10, xtol=1e-10, gtol=1e-8, verbose=0, max_nfev=80)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], return_jac=False, **kw)
+        e2, it2, ps2, use2, ref = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], _backend=OracleProblem, **kw)
+    np.testing.assert_array_equal(use, use2)
+    assert np.isfinite(res.x).all() and res.status > 0 and ref.status > 0
+    assert abs(res.cost - ref.cost) <= 1e-8 * ref.cost
+    seen = ~np.isnan(p["uvs"][:, use])
+    pa, pb = orc.predict_from_x(res.x, C, p["obj"]), orc.predict_from_x(ref.x, C, p["obj"])
+    assert np.abs(pa - pb)[seen].max() < 1e-4   # px: same minimiser wherever the data constrain it
