@@ -764,6 +764,13 @@ int mcba_debug_syrk_stamps(mcba_handle* h, double* host8) {  // development only
   return MCBA_OK;
 }
 
+int mcba_debug_gram_stamps(mcba_handle* h, double* host3) {  // development only (MCBA_GRAM_TIMING builds)
+  if (!h || !host3) return fail(MCBA_ERR_ARG, "bad argument");
+  for (int l = 0; l < 3; ++l)
+    HIPCHK(hipMemcpy(host3 + l, h->rec2[h->lin] + ((size_t)0 * h->nfb + 1) * (MCBA_REC * 64) + (size_t)(49 * 64 + l) * 2 + 1, sizeof(double), hipMemcpyDeviceToHost));
+  return MCBA_OK;
+}
+
 int mcba_get_cam_step(mcba_handle* h, double* host) {
   if (!h || !host) return fail(MCBA_ERR_ARG, "mcba_get_cam_step: bad argument");
   HIPCHK(hipSetDevice(h->device));

@@ -40,12 +40,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Sum over the 64 lanes, result valid in lane 63 only.  DPP moves (pure VALU, no LDS round trip):
 // xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror -> every lane holds its 16-lane row total;
 // row_bcast15 (rows 1,3) and row_bcast31 (rows 2,3) fold the four rows into row 3.
+// v_mov_b32_dpp with an UNDEFINED previous destination (mov_dpp): lanes the move does not write (rows masked out by
+// the two row_bcast steps) hold garbage afterwards -- harmless, because only lane 63 of the final value is used -- and
+// the compiler no longer has to zero the destination before every move (1 100 instructions per k_gram epilogue).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v) {
   union { double d; int i[2]; } a, b;
   a.d = v;
-  b.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, ROW_MASK, 0xF, false);
-  b.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, ROW_MASK, 0xF, false);
+  b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], CTRL, ROW_MASK, 0xF, true);
+  b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], CTRL, ROW_MASK, 0xF, true);
   return v + b.d;
 }
 __device__ __forceinline__ double wave_sum63(double v) {
@@ -119,6 +122,9 @@ template <int LOSS, int ROLE>
 __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
                                           double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
   const int f = fb * 64 + lane;
+#ifdef MCBA_GRAM_TIMING
+  const long long gt0 = clock64();
+#endif
   Intr K;
   K.fx = uni(s_cam.fx); K.fy = uni(s_cam.fy); K.cx = uni(s_cam.cx); K.cy = uni(s_cam.cy); K.k1 = uni(s_cam.k1); K.k2 = uni(s_cam.k2);
   double Rc[9], tc[3];
@@ -179,6 +185,9 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       }
     }
   };
+#ifdef MCBA_GRAM_TIMING
+  const long long gt1 = clock64();
+#endif
   if constexpr (ROLE == 2 && MCBA_GRAM_PIPE) {
     // Software-pipelined, branch-free point loop (fused variant, one wavefront per SIMD): the projection of point p + 1 --
     // a serial chain (rotate, reciprocal, distortion polynomial) -- is issued next to the 180 independent accumulator
@@ -262,6 +271,9 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     if (p + j < N) point(ring[j], xring[j]);
   }
 
+#ifdef MCBA_GRAM_TIMING
+  const long long gt2 = clock64();
+#endif
   // ---- expand once per (c,f): this role's part of W, V, g_f (record) and of U, g_c (reduced over the wave)
   ChainConst ch;
   {
@@ -328,6 +340,13 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       if (writer) gp[(size_t)(78 + a) * nfb] = sm;
     }
   }
+#ifdef MCBA_GRAM_TIMING
+  if (c == 0 && fb == 1 && lane < 3) {
+    const long long gt3 = clock64();
+    const double v = lane == 0 ? (double)(gt1 - gt0) : lane == 1 ? (double)(gt2 - gt1) : (double)(gt3 - gt2);
+    r2[49 * 64].y = v;  // pad slot of the record
+  }
+#endif
 }
 
 // Split roles: grid.z = 2, <= 256 VGPRs, two waves per SIMD.
