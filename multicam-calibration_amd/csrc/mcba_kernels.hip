@@ -540,7 +540,8 @@ __global__ __launch_bounds__(64) void k_frame_factor(Sel sl, const double* __res
 //      then wavefront w accumulates its PPW output tiles (pair q = w + 4k): per K-step of 4 the A operand of tile
 //      row ti is one ds_read_b64 per lane (lane l <- s_y[16 ti + (l & 15)][4 ks + (l >> 4)]); B is the same pattern
 //      of tile row tj (B = Y^T).  The global-load latency hides under the matrix-core phase.
-// Partials: spart[g][q][reg 0..3][lane]  (C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg).
+// Partials: spart[q][reg 0..3][g][lane]  (C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg): the second stage reads
+// each (q, reg) slice as ONE contiguous run of G x 512 B.
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 template <int PPW, int IPT>
@@ -679,8 +680,9 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
 #pragma unroll
   for (int k = 0; k < PPW; ++k) {
     if (qi[k] >= 0) {
-      double* o = spart + ((size_t)blockIdx.x * NP + qi[k]) * 256 + lane;
-      o[0] = acc[k][0]; o[64] = acc[k][1]; o[128] = acc[k][2]; o[192] = acc[k][3];
+      const size_t G = gridDim.x;
+      double* o = spart + ((size_t)(4 * qi[k]) * G + blockIdx.x) * 64 + lane;
+      o[0] = acc[k][0]; o[G * 64] = acc[k][1]; o[2 * G * 64] = acc[k][2]; o[3 * G * 64] = acc[k][3];
     }
   }
 }
@@ -719,8 +721,8 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
     const int q = blockIdx.x >> 2, reg = blockIdx.x & 3;
     const int ti = tile_i[q], tj = tile_j[q];
     {  // ---- slice sums of the k_syrk partials
-      const double* p = spart + (size_t)q * 256 + reg * 64 + lane;
-      const size_t gs = (size_t)NP * 256;
+      const double* p = spart + (size_t)(4 * q + reg) * G * 64 + lane;
+      const size_t gs = 64;
       double s = 0.0;
       for (int base = 0; base < G; base += 128) {
         double v[8];
@@ -777,8 +779,20 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
   } else if (task < 2 * n + 16) {
     int jj = task - 2 * n;
     double v = 0.0;
-    if (jj == 0 || jj == 1) {  // cost, (camera, frame) pairs with data: cameras in order, frame blocks inside
-      for (int cam = 0; cam < C; ++cam) v += run_sum(gpart + cam * camstride + (size_t)(90 + jj) * nfb, nfb, lane);
+    if (jj == 0 || jj == 1) {  // cost, (camera, frame) pairs with data: one pass over all C x nfb per-wavefront sums, 8 loads in
+      double a = 0.0;          // flight per lane (a run_sum per camera would be C dependent round trips of ~2 us each)
+      const int total = C * nfb;
+      for (int base = 0; base < total; base += 512) {
+        double w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = base + lane + 64 * k;
+          const int cam = i / nfb, fbk = i - cam * nfb;
+          w[k] = i < total ? gpart[cam * camstride + (size_t)(90 + jj) * nfb + fbk] : 0.0;
+        }
+        a += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+      }
+      v = wave_sum63(a);
     } else if (jj == 2) {
       double a = 0.0;
       for (int k = lane; k < nfblocks; k += 64) a += fpart[2 * k + 1];
