@@ -109,3 +109,60 @@ def test_two_ranks_one_gpu_match_single_process(tmp_path, mode):
     cam_a, cam_b = r0["x"][: 12 * C].reshape(C, 12), res.x[: 12 * C].reshape(C, 12)
     assert (np.abs(cam_a[:, :6] - cam_b[:, :6]) / np.abs(cam_b[:, :6])).max() < 1e-6   # intrinsics + distortion: gauge-free
     assert np.abs(r0["grad"]).max() <= 10 * max(res.optimality, 1e-6)   # the sharded run is as stationary as the single-process one
+
+
+# ------------------------------------------------------------------ the direct RCCL path (one rank: RCCL needs one device per rank)
+def _rccl_worker(rank, world, port, out_dir, speculate):
+    sys.path.insert(0, ROOT)
+    os.environ["MCBA_SPECULATE"] = "1" if speculate else "0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import contextlib
+    import io
+
+    import torch
+    import torch.distributed as dist
+
+    import multicam_calibration_amd as m
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    p = _problem(m)
+    made = []
+    real_make_comm = m.solver.make_comm
+
+    def make_comm(problem, device, group=None, direct=None):
+        c = real_make_comm(problem, device, group, direct)
+        made.append(type(c).__name__)
+        return c
+
+    m.solver.make_comm = make_comm
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, device=0,
+                                              ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, distributed=True, return_jac=False)
+    np.savez(os.path.join(out_dir, f"rccl{int(speculate)}.npz"), x=res.x, cost=res.cost, nfev=res.nfev, status=res.status, rebuilds=res.lm["rebuilds"], comm=np.array(made[0]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("speculate", [True, False])
+def test_single_rank_direct_rccl_matches_single_process(tmp_path, speculate):
+    """bundle_adjust(distributed=True) over the `nccl` backend with the library's own RCCL communicator (ncclAllReduce
+    enqueued by mcba_lm_auto_tick): one collective per tick (speculative) and two, against the plain single-GPU solve."""
+    import contextlib
+    import io
+
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path), speculate), nprocs=1, join=True)
+    r = np.load(tmp_path / f"rccl{int(speculate)}.npz")
+    assert str(r["comm"]) == "DirectRCCL"
+    assert (int(r["rebuilds"]) >= 1) == speculate
+
+    import multicam_calibration_amd as m
+
+    p = _problem(m)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None,
+                                              ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, return_jac=False)
+    assert int(r["status"]) == res.status and int(r["nfev"]) == res.nfev
+    assert abs(float(r["cost"]) - res.cost) <= 1e-12 * res.cost
+    np.testing.assert_allclose(r["x"], res.x, rtol=0, atol=1e-9 * np.abs(res.x).max())
