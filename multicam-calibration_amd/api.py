@@ -177,7 +177,10 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
 
     # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560)
     slot = result.lm["slot"]
-    idx, indptr, shape, mask = jacobian_structure(uvs)
+    if backend is None and return_jac:
+        idx, indptr, shape, mask = jacobian_structure(uvs)  # CSR indices: 0.25 s of numpy at 6 x 10k x 54 -- only when asked for
+    else:
+        mask = ~np.isnan(uvs)
     if backend is not None:  # test double: no materialised Jacobian kernel
         result.fun = prob.residuals(slot)[mask]
     elif return_jac:
