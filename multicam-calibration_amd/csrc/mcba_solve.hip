@@ -21,6 +21,7 @@
 // The same launch evaluates first-order optimality, applies the termination verdict (pending from k_sum_trial / k_decide,
 // or taken here on the all-reduced trial scalars: one-collective ticks), handles a failed factorisation (more damping,
 // next tick rebuild-only) and posts the LM state to a host-mapped ring slot.
+#include <stdlib.h>
 #include "mcba_kernels.h"
 #include "mcba_lm.h"
 #include "mcba_math.h"
@@ -457,7 +458,11 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
 }
 
 // rows a launch can hold: 16 diagonal rows + 48 per wavefront
-int solve_threads(int npad) { return npad <= 16 + 4 * 48 ? 256 : npad <= 16 + 8 * 48 ? 512 : 1024; }
+int solve_threads(int npad) {
+  int t = npad <= 16 + 4 * 48 ? 256 : npad <= 16 + 8 * 48 ? 512 : 1024;
+  if (const char* e = getenv("MCBA_SOLVE_THREADS")) { int v = atoi(e); if ((v == 512 || v == 1024) && v > t) t = v; }  // tuning knob
+  return t;
+}
 
 size_t solve_lds_bytes(int npad, int use_lds) {
   size_t d = (size_t)npad * 17 + 4 * (size_t)npad + 72 + MCBA_LMS;
