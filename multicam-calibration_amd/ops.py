@@ -319,17 +319,36 @@ class Problem:
     # ---- direct RCCL on the library's own reduce buffer (frame-sharded runs)
     def comm_init_from_torch(self, group=None):
         """Create an RCCL communicator over the ranks of an initialised torch.distributed group: rank 0 draws the
-        unique id, torch.distributed broadcasts it.  Raises on failure (the caller may fall back to torch collectives)."""
+        unique id, torch.distributed broadcasts it.  Every step is agreed on by ALL ranks before the next one (a rank that
+        failed alone would leave the others waiting inside a collective), so the call either succeeds everywhere or raises
+        everywhere -- and the caller may then fall back to torch collectives consistently."""
+        import torch
         import torch.distributed as dist
 
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         box = [None]
         if rank == 0:
-            buf = ctypes.create_string_buffer(128)
-            self._chk(self.lib.mcba_comm_unique_id(buf))
-            box[0] = buf.raw
+            try:
+                buf = ctypes.create_string_buffer(128)
+                self._chk(self.lib.mcba_comm_unique_id(buf))
+                box[0] = buf.raw
+            except Exception as e:  # noqa: BLE001 -- reported to every rank through the broadcast below
+                box[0] = "error: %s" % e
         dist.broadcast_object_list(box, src=0, group=group)
-        self._chk(self.lib.mcba_comm_init(self.handle, box[0], rank, world))
+        if not isinstance(box[0], bytes):
+            raise McbaError(-1, "rank 0 could not draw an RCCL unique id (%s)" % (box[0],))
+        err = None
+        try:
+            self._chk(self.lib.mcba_comm_init(self.handle, box[0], rank, world))
+        except Exception as e:  # noqa: BLE001
+            err = e
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            if err is None:
+                self.lib.mcba_comm_destroy(self.handle)
+            raise McbaError(-1, "RCCL communicator could not be created on every rank (%s)" % (err or "another rank failed"))
         return rank, world
 
     def comm_allreduce(self, offset, count):
