@@ -6,11 +6,15 @@ rescaling as scipy/optimize/_lsq/common.py:720-731), same termination tests and 
 (common.py:705-717), but the step comes from an exact damped Gauss-Newton solve:
 
     linearise (GPU)  ->  Schur complement of the 6x6 frame blocks (GPU)  ->  [all-reduce over frame shards]
-    ->  (12C)^2 reduced camera system solved HERE with LAPACK Cholesky  ->  back-substitution + trial cost (GPU)
+    ->  (12C)^2 reduced camera system: Cholesky on the GPU (k_solve_cam; default) or HERE with LAPACK (reduced_solver="host")
+    ->  back-substitution + trial cost (GPU)
 
-`problem` is an `ops.Problem` (libmcba.so).  Everything per-observation happens on the GPU; this file
-only sees the (12C)^2 + 3*12C + 16 doubles of the reduced system and 8 trial scalars per step.
+`problem` is an `ops.Problem` (libmcba.so).  Everything per-observation happens on the GPU.  In the default,
+device-resident mode this file only enqueues iterations and reads 32 doubles of LM state per iteration; with the host
+solve it sees the (12C)^2 + 3*12C + 16 doubles of the reduced system and 8 trial scalars per step.
 """
+import os
+
 import numpy as np
 from scipy.linalg import lapack
 from scipy.optimize import OptimizeResult
@@ -92,8 +96,6 @@ class DirectRCCL:
 def make_comm(problem, device, group=None, direct=None):
     """Collective backend for a frame-sharded solve: direct RCCL if it can be set up (MCBA_DIRECT_RCCL=0 disables),
     otherwise torch.distributed on a tensor that aliases the reduce buffer."""
-    import os
-
     if direct is None:
         direct = os.environ.get("MCBA_DIRECT_RCCL", "1") != "0"
     if direct and hasattr(problem, "comm_init_from_torch"):
@@ -117,8 +119,13 @@ def _solve_spd(S, rhs):
 class LevenbergMarquardt:
     """State machine: `start(x0)` then `iterate()` until it returns a status.
 
-    One `iterate()` = one LM iteration: (re)build the reduced system for the current damping, solve it on the
-    host, back-substitute, evaluate the trial cost, accept or reject, and re-linearise at the accepted point."""
+    One `iterate()` = one LM iteration (trial step, accept / reject, damping update, reduced system at the accepted point,
+    its solution).  Three drivers, chosen by what the problem backend offers:
+      device-resident (libmcba, default): everything incl. the reduced solve and the termination tests on the GPU; this
+          class enqueues ticks `depth` ahead and reads the state each tick posts (`_iterate_auto`);
+      host solve (`reduced_solver="host"`): LAPACK Cholesky here, decision on the GPU, one synchronisation per iteration
+          (`_iterate_device`);
+      host-driven (`iterate` itself): decision here as well -- what the CPU test double (tests/fake_problem.py) runs."""
 
     def __init__(self, problem, comm=None, free_cam_mask=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, lam0=1e-4, lam_min=1e-12, lam_max=1e12, speculative=True,
                  reduced_solver=None, depth=2):
@@ -140,16 +147,12 @@ class LevenbergMarquardt:
         # reduced_solver = "host" keeps the LAPACK solve above (one synchronisation per iteration); MCBA_REDUCED_SOLVER
         # overrides the default.
         if reduced_solver is None:
-            import os
-
             reduced_solver = os.environ.get("MCBA_REDUCED_SOLVER", "device")
         if reduced_solver not in ("device", "host"):
             raise ValueError("reduced_solver must be 'device' or 'host'")
         self.device_solve = self.device_decide and reduced_solver == "device" and hasattr(problem, "lm_auto_tick")
         self.depth = max(1, min(int(depth), 12))
-        import os as _os
-
-        self.speculate = _os.environ.get("MCBA_SPECULATE", "1") != "0"  # frame-sharded ticks: one collective instead of two
+        self.speculate = os.environ.get("MCBA_SPECULATE", "1") != "0"  # frame-sharded ticks: one collective instead of two
         self.max_nfev = None
         self.max_steps = None
 
