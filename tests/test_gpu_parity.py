@@ -501,3 +501,46 @@ def test_degenerate_inputs_match_oracle_driver(mc, tag):
     seen = ~np.isnan(p["uvs"][:, use])
     pa, pb = orc.predict_from_x(res.x, C, p["obj"]), orc.predict_from_x(ref.x, C, p["obj"])
     assert np.abs(pa - pb)[seen].max() < 1e-4   # px: same minimiser wherever the data constrain it
+
+
+# ------------------------------------------------------------------ full-size (BASELINE configs[2]) properties of the complete solve
+def test_full_size_solve_properties(mc):
+    """6 x 10 000 x 54 through bundle_adjust(): size-independent properties instead of an oracle run.
+    (i) the optimum is a fixed point: restarting from it terminates at once on the same parameters;
+    (ii) permuting the frames permutes the poses and changes nothing else;
+    (iii) relabelling the cameras relabels their parameters (the world frame stays attached to the same physical camera
+          through the gauge-free quantities: intrinsics, cost);
+    (iv) the Jacobian kernel agrees with the solver's own gradient: J^T (rho' f) = grad at the solution."""
+    p = mc.synth.make_problem(6, 10000, seed=0)
+    C, F = 6, 10000
+    kw = dict(n_frames=None, ftol=1e-12, xtol=1e-12, gtol=1e-8, verbose=0, max_nfev=80, return_jac=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], **kw)
+        e1, it1, ps1, use1, res1 = mc.bundle_adjust(p["uvs"], e, it, p["obj"], ps, **kw)
+    assert res.status > 0 and res1.status > 0
+    assert res1.nfev <= 3 and abs(res1.cost - res.cost) <= 1e-13 * res.cost           # (i)
+    assert np.abs(res1.x - res.x).max() <= 1e-9 * np.abs(res.x).max()
+
+    perm = np.random.default_rng(0).permutation(F)                                      # (ii)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e2, it2, ps2, use2, res2 = mc.bundle_adjust(p["uvs"][:, perm], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"][perm], **kw)
+    assert abs(res2.cost - res.cost) <= 1e-10 * res.cost
+    cam, cam2 = res.x[:12 * C].reshape(C, 12), res2.x[:12 * C].reshape(C, 12)
+    assert (np.abs(cam2[:, :6] - cam[:, :6]) / np.abs(cam[:, :6])).max() < 1e-6
+
+    order = np.array([0, 3, 1, 5, 2, 4])                                                # (iii) camera 0 keeps the gauge
+    with contextlib.redirect_stdout(io.StringIO()):
+        e3, it3, ps3, use3, res3 = mc.bundle_adjust(p["uvs"][order], p["extrinsics"][order], [p["intrinsics"][i] for i in order], p["obj"], p["poses"], **kw)
+    assert abs(res3.cost - res.cost) <= 1e-10 * res.cost
+    cam3 = res3.x[:12 * C].reshape(C, 12)
+    assert (np.abs(cam3[:, :6] - cam[order, :6]) / np.abs(cam[order, :6])).max() < 1e-6
+
+    with contextlib.redirect_stdout(io.StringIO()):                                     # (iv)
+        e4, it4, ps4, use4, res4 = mc.bundle_adjust(p["uvs"], e, it, p["obj"], ps, n_frames=None, ftol=1e-12, xtol=1e-12, gtol=1e-8, verbose=0, max_nfev=3, return_jac=True)
+    f = res4.fun                 # scipy semantics: `jac` is the robust-rescaled Jacobian J~ = js * J, `fun` the UNSCALED residual
+    rho1 = orc.loss_rho(f ** 2, "soft_l1")[1]
+    js = orc.robust_scales(f, "soft_l1")[0]
+    g = res4.jac.T @ (rho1 * f / js)   # J~ = js * J  ->  J^T (rho' f) = J~^T (rho' f / js)
+    scale = np.abs(res4.jac).T @ np.abs(rho1 * f / js)
+    assert np.abs(g - res4.grad).max() <= 1e-9 * scale.max()
+    del res4
