@@ -9,7 +9,8 @@
  *               residuals()                       bundle_adjustment.py:66-98
  *               bundle_adjustment_sparsity()      bundle_adjustment.py:101-125  (structure is implicit here)
  *               scipy 2-point FD Jacobian         scipy/optimize/_numdiff.py:628-705 (replaced by analytic blocks)
- *               scipy TRF + LSMR linear algebra   scipy/optimize/_lsq/trf.py:401-560 (replaced by LM + Schur)
+ *               scipy TRF + LSMR linear algebra   scipy/optimize/_lsq/trf.py:401-560 (replaced by LM + Schur, incl. the
+ *                                                 reduced solve and the termination tests: mcba_lm_auto_*)
  *
  * Conventions
  *   - plain C types only; every function returns an int status (0 = MCBA_OK), never throws;
@@ -97,7 +98,7 @@ int mcba_linearize(mcba_handle* h, int slot);
  *                         4..15 per-rank slots: max |g_f| of THIS shard goes to slot 4+rank_slot, others 0
  * so that one all-reduce(SUM) of the whole buffer over the frame shards gives the global system. */
 int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot);
-size_t mcba_reduced_size(const mcba_handle* h);          /* doubles in the reduce buffer: system + 8 trial scalars + 16 LM state */
+size_t mcba_reduced_size(const mcba_handle* h);          /* doubles in the reduce buffer: system + 8 trial scalars + MCBA_LM_STATE */
 /* Let the caller own the reduce buffer (device pointer, mcba_reduced_size() doubles), e.g. a torch
  * tensor handed to torch.distributed.all_reduce (RCCL).  NULL restores the internal buffer. */
 int mcba_bind_reduce_buffer(mcba_handle* h, double* device_ptr);

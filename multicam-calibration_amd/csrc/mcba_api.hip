@@ -150,7 +150,7 @@ static int rccl_fail(const char* what, ncclResult_t r) {
 
 extern "C" {
 
-int mcba_abi_version(void) { return 1; }
+int mcba_abi_version(void) { return 2; }  // 2: 32-double LM state, mcba_lm_auto_*
 const char* mcba_last_error(void) { return g_err.c_str(); }
 const char* mcba_profile_names(void) { return kKernelNames; }
 
