@@ -202,8 +202,11 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   {
     const int items = C * h->nfb;
     h->gram_split = items < 768 || (items > 1024 && items <= 1536);
+    // more than one round with a short last round: fused for the whole rounds + split roles for the tail (mode 2)
+    // (measured 24 x 6250 x 200, 2.3 rounds: 536 us vs 561 us fused, 612 us split; at 1.15 rounds plain split roles win)
+    if (items > 2048 && (items % 1024) > 0 && (items % 1024) <= 512) h->gram_split = 2;
   }
-  if (const char* e = getenv("MCBA_GRAM_SPLIT")) h->gram_split = atoi(e) != 0;
+  if (const char* e = getenv("MCBA_GRAM_SPLIT")) h->gram_split = std::max(0, std::min(2, atoi(e)));  // 0 fused, 1 split roles, 2 fused + split tail
   // k_cost: split the board points so that ~4 waves per SIMD (1024 SIMDs) are in flight
   h->nch = std::max(1, std::min(std::min(8, N / 8), (4096 + C * h->nfb - 1) / (C * h->nfb)));
   int rc;

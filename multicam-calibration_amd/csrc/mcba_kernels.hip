@@ -352,7 +352,8 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 // Split roles: grid.z = 2, <= 256 VGPRs, two waves per SIMD.
 template <int LOSS>
 __global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
-                                                       double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+                                                       double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, int fb0, int fb1,
+                                                       double fs2, double ifs2) {
   if (!sel_active(sl, true)) return;
   const int sidx = sel_index(sl);
   const double* __restrict__ x = sidx ? x1 : x0;
@@ -363,8 +364,8 @@ __global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict
   if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int fb = blockIdx.x * 4 + wave;
-  if (fb >= nfb) return;
+  const int fb = fb0 + blockIdx.x * 4 + wave;  // this launch covers the frame blocks [fb0, fb1)
+  if (fb >= fb1) return;
   if (blockIdx.z == 0) gram_body<LOSS, 0>(s_cam, obs_t, obj, x, rec, gpart, c, fb, lane, C, N, Fpad, nfb, fs2, ifs2);
   else gram_body<LOSS, 1>(s_cam, obs_t, obj, x, rec, gpart, c, fb, lane, C, N, Fpad, nfb, fs2, ifs2);
 }
@@ -372,7 +373,8 @@ __global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict
 // Both roles in one lane: grid.z = 1, one wave per SIMD (all 87 accumulators + temporaries in the 512-register file).
 template <int LOSS>
 __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
-                                                 double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+                                                 double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, int fb0, int fb1,
+                                                 double fs2, double ifs2) {
   if (!sel_active(sl, true)) return;
   const int sidx = sel_index(sl);
   const double* __restrict__ x = sidx ? x1 : x0;
@@ -383,8 +385,8 @@ __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t,
   if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int fb = blockIdx.x * 4 + wave;
-  if (fb >= nfb) return;
+  const int fb = fb0 + blockIdx.x * 4 + wave;  // this launch covers the frame blocks [fb0, fb1)
+  if (fb >= fb1) return;
   gram_body<LOSS, 2>(s_cam, obs_t, obj, x, rec, gpart, c, fb, lane, C, N, Fpad, nfb, fs2, ifs2);
 }
 
@@ -1023,15 +1025,28 @@ void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int 
 }
 
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split) {
-  int nfb = Fpad / 64;
+  const int nfb = Fpad / 64;
   dim3 block(256);
-  double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
-  if (split) {
-    dim3 grid((nfb + 3) / 4, C, 2);
-    DISPATCH_LOSS(loss, (k_gram_split<L><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fs2, ifs2)));
+  const double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
+  const double2* o2 = reinterpret_cast<const double2*>(obs_t);
+  auto fused = [&](int fb0, int fb1) {
+    dim3 grid((fb1 - fb0 + 3) / 4, C, 1);
+    DISPATCH_LOSS(loss, (k_gram<L><<<grid, block, 0, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)));
+  };
+  auto roles = [&](int fb0, int fb1) {
+    dim3 grid((fb1 - fb0 + 3) / 4, C, 2);
+    DISPATCH_LOSS(loss, (k_gram_split<L><<<grid, block, 0, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)));
+  };
+  if (split == 1) { roles(0, nfb); return; }
+  // split == 2: whole rounds of the 1024 wavefront slots with the fused variant, the (short) last round with the split
+  // roles -- their wavefronts are lighter, so a tail of r items costs ~0.55 of a fused pass instead of a whole one
+  const int items = C * nfb;
+  const int fba = split == 2 ? (((items / 1024) * 1024 / C) & ~3) : nfb;
+  if (split == 2 && fba > 0 && fba < nfb) {
+    fused(0, fba);
+    roles(fba, nfb);
   } else {
-    dim3 grid((nfb + 3) / 4, C, 1);
-    DISPATCH_LOSS(loss, (k_gram<L><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fs2, ifs2)));
+    fused(0, nfb);
   }
 }
 
