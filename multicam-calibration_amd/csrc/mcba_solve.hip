@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
             *reinterpret_cast<solve_d4*>(Bs + row * bst + 4 * c4) = v;
           }
           __syncthreads();
-          constexpr int CH = 6;  // chunks of 16 K indices per work item; the next item's A rows load while this one computes
+          constexpr int CH = 2;  // chunks of 16 K indices per work item (measured at 12C = 288: 2 -> 239k cycles for this phase, 1 -> 274k, 4 -> 259k, 6 -> 287k); the next item's A rows load while this one computes
           const int ngrp = (r0 + 16 * CH - 1) / (16 * CH);
           const int nitems = ((ntile - wave + NW - 1) / NW) * ngrp;
           const double* pb = Bs + (lane & 15) * bst + 4 * (lane >> 4);
