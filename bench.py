@@ -60,9 +60,11 @@ def algorithmic_bytes(kernel, C, F, N):
 
 
 def algorithmic_flops(kernel, C, F, N):
-    """FP64 flops of the per-observation arithmetic (2 per FMA), for the VALU cross-check of k_gram."""
+    """FP64 work of k_gram in FMA-equivalent flops: FP64 VALU instructions counted in the ISA (245 per point-observation in
+    the point loop, ~2500 per (camera, frame) in the expand / reduce epilogue) x 2 -- i.e. the
+    fraction below is the fraction of the FP64 issue rate, whatever the mix of FMA / MUL / ADD."""
     if kernel == "k_gram":
-        return 2 * (270 * C * F * N + 900 * C * F)
+        return 2 * (245 * C * F * N + 2500 * C * F)
     return None
 
 
@@ -212,7 +214,7 @@ def main():
         if fl:
             tf = fl / (dom_ms * 1e-3) / 1e12
             roofline["valu_f64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
-                                    "note": "k_gram does ~50 FP64 flop per byte: the FP64 vector pipe, not HBM, is its nearer roof"}
+                                    "note": "k_gram issues ~19 FMA-equivalent FP64 flop per algorithmic byte (245 FP64 instructions per point-observation): the FP64 vector pipe, not HBM, is its nearer roof"}
         jb = algorithmic_bytes("k_jacobian", C, F, N)
         jach = jb / (ms_jac * 1e-3) / 1e9
         out = {
