@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s sp
 # scripts/micro/write_bw.hip on the gpurun MI355X (1 GiB, 16 B/lane): streaming write 4.5-5.9 TB/s, copy 4.8-5.5, read 6.2-6.6
 HBM_MEASURED_WRITE_GBS = 5930.0
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (AMD datasheet; 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz)
+FP64_VALU_MEASURED_TFLOPS = 57.0  # scripts/micro/fma_f64_rate.hip on the same GPU: 54-58 TFLOP/s of independent v_fma_f64 (one per 4.82 clock64 ticks)
 
 C, F_PER_GPU, ROWS, COLS = 6, 10000, 6, 9
 
@@ -214,6 +215,7 @@ def main():
         if fl:
             tf = fl / (dom_ms * 1e-3) / 1e12
             roofline["valu_f64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                                    "measured_issue_ceiling": FP64_VALU_MEASURED_TFLOPS, "frac_of_measured_issue_ceiling": tf / FP64_VALU_MEASURED_TFLOPS,
                                     "note": "k_gram issues ~19 FMA-equivalent FP64 flop per algorithmic byte (245 FP64 instructions per point-observation): the FP64 vector pipe, not HBM, is its nearer roof"}
         jb = algorithmic_bytes("k_jacobian", C, F, N)
         jach = jb / (ms_jac * 1e-3) / 1e9
