@@ -76,6 +76,29 @@ def _worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
+def test_four_ranks_one_gpu_speculative_ticks(tmp_path):
+    """Four frame shards (ragged: 150 frames -> 38 / 38 / 37 / 37), four per-rank gradient slots, one collective per tick."""
+    import contextlib
+    import io
+
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker, args=(4, _free_port(), str(tmp_path), "device"), nprocs=4, join=True)
+    rs = [np.load(tmp_path / f"device{r}.npz") for r in range(4)]
+    for r in rs[1:]:
+        np.testing.assert_array_equal(r["x"], rs[0]["x"])
+        assert float(r["cost"]) == float(rs[0]["cost"]) and int(r["nfev"]) == int(rs[0]["nfev"])
+    import multicam_calibration_amd as m
+
+    p = _problem(m)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None,
+                                              ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, return_jac=False)
+    assert abs(res.cost - float(rs[0]["cost"])) <= 1e-10 * res.cost
+    cam_a, cam_b = rs[0]["x"][:48].reshape(4, 12), res.x[:48].reshape(4, 12)
+    assert (np.abs(cam_a[:, :6] - cam_b[:, :6]) / np.abs(cam_b[:, :6])).max() < 1e-6
+
+
 @pytest.mark.parametrize("mode", ["device", "device2", "host"])
 def test_two_ranks_one_gpu_match_single_process(tmp_path, mode):
     import contextlib
