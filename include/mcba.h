@@ -191,6 +191,14 @@ int mcba_comm_destroy(mcba_handle* h);
  * (The camera part is the g_c block of the reduce buffer.)  Feeds OptimizeResult.grad (trf.py:557-560). */
 int mcba_get_frame_gradient(mcba_handle* h, double* host);
 
+/* ---- robust triangulation (reference geometry.py:361-433 `triangulate`) ------------------------
+ * Stateless: uvs (C, P, 2) detections (NaN = unseen), cam12 (C, 12) camera blocks in the parameter layout above,
+ * dist5 (C, 5) OpenCV distortion (k1 k2 p1 p2 k3) or NULL (then k1, k2 of cam12), iterations of the undistortion
+ * fixed point (OpenCV's default: 5).  out (P, 3): per-coordinate nan-median over all camera pairs of the linear (DLT)
+ * two-view triangulations, NaN where fewer than two cameras see the point.  2 <= C <= 8.  kernel_ms (may be NULL)
+ * receives the kernel time measured with HIP events. */
+int mcba_triangulate(int n_cameras, size_t n_points, const double* uvs, const double* cam12, const double* dist5, int iterations, int device, double* out, double* kernel_ms);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* When enabled kernel launches are bracketed by hipEvents on the handle's stream.  `on` = 0: off; 1: every
  * kernel; otherwise a bit mask over the kernels in mcba_profile_names() order, shifted left by one

@@ -12,7 +12,8 @@ from . import synth  # noqa: F401
 from . import ops, solver  # noqa: F401
 from .api import bundle_adjust, bundle_adjustment, serialize_params, deserialize_params  # noqa: F401
 from . import calibration  # noqa: F401
+from .triangulation import triangulate  # noqa: F401
 from .calibration import calibrate, get_intrinsics, estimate_pose, estimate_all_extrinsics, consensus_calib_poses, get_camera_spanning_tree, estimate_pairwise_camera_transform  # noqa: F401
 
-__all__ = ["bundle_adjust", "bundle_adjustment", "serialize_params", "deserialize_params", "ops", "solver", "synth", "calibration", "calibrate", "get_intrinsics",
+__all__ = ["bundle_adjust", "bundle_adjustment", "serialize_params", "deserialize_params", "ops", "solver", "synth", "calibration", "calibrate", "triangulate", "get_intrinsics",
            "estimate_pose", "estimate_all_extrinsics", "consensus_calib_poses", "get_camera_spanning_tree", "estimate_pairwise_camera_transform"]

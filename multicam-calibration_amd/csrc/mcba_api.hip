@@ -14,6 +14,7 @@
 
 #include "../../include/mcba.h"
 #include "mcba_kernels.h"
+#include "mcba_math.h"
 
 namespace {
 
@@ -806,6 +807,69 @@ int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state) {
   int sel = (int)state[3];
   if (sel == 0 || sel == 1) h->lin = sel;
   h->have_spec = false;
+  return MCBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Robust triangulation (reference geometry.py:361-433): stateless; host arrays in, host array out.
+int mcba_triangulate(int n_cameras, size_t n_points, const double* uvs, const double* cam12, const double* dist5, int iterations, int device, double* out, double* kernel_ms) {
+  if (n_cameras < 2 || n_cameras > 8 || !uvs || !cam12 || !out || iterations < 0) return fail(MCBA_ERR_ARG, "mcba_triangulate: 2..8 cameras, non-NULL arrays, iterations >= 0 required");
+  if (n_points == 0) return MCBA_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MCBA_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(MCBA_ERR_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  mcba::TriCams cams;
+  memset(&cams, 0, sizeof(cams));
+  for (int c = 0; c < n_cameras; ++c) {
+    const double* q = cam12 + 12 * c;
+    double R[9];
+    mcba::rot_only(q + 6, R);
+    const double fx = q[0], fy = q[1], cx = q[2], cy = q[3];
+    for (int j = 0; j < 3; ++j) {  // P = K [R | t]
+      cams.P[c][j] = fx * R[j] + cx * R[6 + j];
+      cams.P[c][4 + j] = fy * R[3 + j] + cy * R[6 + j];
+      cams.P[c][8 + j] = R[6 + j];
+    }
+    cams.P[c][3] = fx * q[9] + cx * q[11];
+    cams.P[c][7] = fy * q[10] + cy * q[11];
+    cams.P[c][11] = q[11];
+    cams.K[c][0] = fx; cams.K[c][1] = fy; cams.K[c][2] = cx; cams.K[c][3] = cy;
+    if (dist5) for (int k = 0; k < 5; ++k) cams.dist[c][k] = dist5[5 * c + k];
+    else { cams.dist[c][0] = q[4]; cams.dist[c][1] = q[5]; }
+  }
+  double *d_uv = nullptr, *d_out = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = MCBA_OK;
+  auto cleanup = [&]() {
+    if (d_uv) (void)hipFree(d_uv);
+    if (d_out) (void)hipFree(d_out);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  };
+#define TRICHK(expr)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) { g_err = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return MCBA_ERR_HIP; } \
+  } while (0)
+  const size_t nin = (size_t)2 * n_cameras * n_points;
+  TRICHK(hipMalloc(reinterpret_cast<void**>(&d_uv), nin * sizeof(double)));
+  TRICHK(hipMalloc(reinterpret_cast<void**>(&d_out), 3 * n_points * sizeof(double)));
+  TRICHK(hipMemcpy(d_uv, uvs, nin * sizeof(double), hipMemcpyHostToDevice));
+  TRICHK(hipEventCreate(&e0));
+  TRICHK(hipEventCreate(&e1));
+  TRICHK(hipEventRecord(e0, nullptr));
+  if (mcba::launch_triangulate(nullptr, n_cameras, d_uv, cams, d_out, n_points, iterations) != 0) { cleanup(); return fail(MCBA_ERR_ARG, "mcba_triangulate: unsupported camera count"); }
+  if ((rc = check_launch())) { cleanup(); return rc; }
+  TRICHK(hipEventRecord(e1, nullptr));
+  TRICHK(hipMemcpy(out, d_out, 3 * n_points * sizeof(double), hipMemcpyDeviceToHost));
+  if (kernel_ms) {
+    float ms = 0.f;
+    TRICHK(hipEventElapsedTime(&ms, e0, e1));
+    *kernel_ms = ms;
+  }
+#undef TRICHK
+  cleanup();
   return MCBA_OK;
 }
 

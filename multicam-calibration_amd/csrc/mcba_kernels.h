@@ -86,4 +86,11 @@ void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);
 int syrk_set_lds_limit(size_t bytes);
+// triangulation (mcba_triangulate.hip): up to 8 cameras; P = K [R | t] row-major 3x4, K = (fx, fy, cx, cy), dist = (k1 k2 p1 p2 k3)
+struct TriCams {
+  double P[8][12];
+  double K[8][4];
+  double dist[8][5];
+};
+int launch_triangulate(hipStream_t st, int C, const double* uvs, const TriCams& cams, double* out, size_t npts, int iters);
 }  // namespace mcba

@@ -62,6 +62,7 @@ SYMBOLS = [
     ("mcba_comm_allreduce", ctypes.c_int, [_h, ctypes.c_size_t, ctypes.c_size_t]),
     ("mcba_comm_destroy", ctypes.c_int, [_h]),
     ("mcba_get_frame_gradient", ctypes.c_int, [_h, _dp]),
+    ("mcba_triangulate", ctypes.c_int, [ctypes.c_int, ctypes.c_size_t, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
     ("mcba_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_profile_stride", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_profile_read", ctypes.c_int, [_h, _dp, _ip, ctypes.c_int, _ip]),
