@@ -407,7 +407,25 @@ class LevenbergMarquardt:
         self.accepted = accepted
         return status
 
+    def finalize(self):
+        """Device-resident loop: retire what is still in flight and make sure the reduce buffer holds the system of the
+        CURRENT point (api.bundle_adjust reads g_c and the frame gradients from it).  It does not when the loop was stopped
+        from outside (max_nfev) right after a tick whose speculative reduction was mispredicted, or whose solve failed."""
+        if not self.device_solve:
+            return
+        st = None
+        while self.retired < self.issued:
+            self.retired += 1
+            st = self.p.lm_auto_wait(self.retired)
+        if st is None:
+            st = self.p.lm_auto_wait(self.retired)
+        if st[15] == 0 and (st[14] != 0 or st[23] != 0):  # not terminated on the device, and the next tick would have rebuilt
+            self.p.lm_rebuild(self.comm.rank % 12)
+            self.comm.all_reduce_system(self.p)
+            self.p.synchronize()
+
     def result(self, status):
+        self.finalize()
         x = self.p.get_params(self.cur)
         return OptimizeResult(
             x=x, cost=self.cost, optimality=self.g_inf, nfev=self.nfev, njev=self.njev, status=status, message=TERMINATION_MESSAGES[status],

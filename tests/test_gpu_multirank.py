@@ -69,7 +69,8 @@ def _worker(rank, world, port, out_dir, mode):
     p = _problem(m)
     with contextlib.redirect_stdout(io.StringIO()):
         e, it, ps, use, res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, device=0,
-                                              ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, distributed=True, return_jac=False, reduced_solver=mode)
+                                              ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=int(os.environ.get("MCBA_TEST_MAX_NFEV", "100")), verbose=0, distributed=True,
+                                              return_jac=False, reduced_solver=mode)
     m.solver.make_comm = real_make_comm
     np.savez(os.path.join(out_dir, f"{tag}{rank}.npz"), x=res.x, cost=res.cost, nfev=res.nfev, status=res.status, use=use, grad=res.grad,
              rebuilds=res.lm["rebuilds"], steps=res.lm["steps"])
@@ -189,3 +190,29 @@ def test_single_rank_direct_rccl_matches_single_process(tmp_path, speculate):
     assert int(r["status"]) == res.status and int(r["nfev"]) == res.nfev
     assert abs(float(r["cost"]) - res.cost) <= 1e-12 * res.cost
     np.testing.assert_allclose(r["x"], res.x, rtol=0, atol=1e-9 * np.abs(res.x).max())
+
+
+def test_stop_by_max_nfev_after_a_mispredicted_tick_leaves_a_consistent_gradient(tmp_path):
+    """The first trial steps of this problem are rejected, i.e. mispredicted by the speculative reduction; stopping right
+    there (max_nfev) must still return the gradient of the CURRENT point (LevenbergMarquardt.finalize rebuilds the system)."""
+    import contextlib
+    import io
+
+    import torch.multiprocessing as mp
+
+    os.environ["MCBA_TEST_MAX_NFEV"] = "3"
+    try:
+        mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "device"), nprocs=2, join=True)
+    finally:
+        del os.environ["MCBA_TEST_MAX_NFEV"]
+    r0 = np.load(tmp_path / "device0.npz")
+    assert int(r0["status"]) == 0 and int(r0["nfev"]) == 3 and int(r0["rebuilds"]) >= 1
+    import multicam_calibration_amd as m
+
+    p = _problem(m)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None,
+                                              ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=3, verbose=0, return_jac=False, reduced_solver="host")
+    assert abs(res.cost - float(r0["cost"])) <= 1e-12 * res.cost
+    np.testing.assert_allclose(r0["x"], res.x, rtol=0, atol=1e-9 * np.abs(res.x).max())
+    np.testing.assert_allclose(r0["grad"], res.grad, rtol=0, atol=1e-9 * np.abs(res.grad).max())
