@@ -422,7 +422,8 @@ class LevenbergMarquardt:
         if st[15] == 0 and (st[14] != 0 or st[23] != 0):  # not terminated on the device, and the next tick would have rebuilt
             self.p.lm_rebuild(self.comm.rank % 12)
             self.comm.all_reduce_system(self.p)
-            self.p.synchronize()
+            red = self.p.get_reduced()
+            self.g_inf = max(float(np.abs(red["gc"][self.free]).max()) if self.free.any() else 0.0, float(red["scal"][4:16].max()))
 
     def result(self, status):
         self.finalize()
