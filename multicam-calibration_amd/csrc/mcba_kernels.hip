@@ -904,36 +904,51 @@ __global__ __launch_bounds__(64 * kBacksubWaves) void k_backsub(Sel sl, const do
 // Cost partials: element idx of `ncp` lives at (idx / cinner) * couter + (idx % cinner) * cstride  (k_cost: cinner = ncp,
 // cstride = 2; k_gram: per camera a contiguous run of nfb values, cinner = nfb, couter = 92 nfb, cstride = 1).
 __global__ __launch_bounds__(512) void k_sum_trial(Sel sl, const double* __restrict__ cp0, const double* __restrict__ cp1, int cstride, int cinner, size_t couter, int ncp, const double* __restrict__ bpart, int nbp, double* __restrict__ out, DecideArgs da) {
-  if (!sel_active(sl, true)) {
-    if (da.decide && threadIdx.x == 0 && sl.lms[MCBA_LM_DONE] == 0.0) lm_mark_rebuild(da.lms);
-    return;
-  }
-  const double* __restrict__ cpart = sel_index(sl) ? cp1 : cp0;
+  // Which buffer holds the trial point's partials depends on the LM state -- a dependent round trip of ~2 us for a kernel that
+  // does 4 us of everything.  The partials are tiny: BOTH candidates are summed, with the state read in flight next to
+  // them, and the right sum is picked afterwards.
+  double st3 = 0.0, st14 = 0.0, st15 = 0.0;
+  if (sl.lms) { st3 = sl.lms[3]; st14 = sl.lms[MCBA_LM_SKIP]; st15 = sl.lms[MCBA_LM_DONE]; }
+  LmPre pre = {};
+  if (da.decide && threadIdx.x == 0) lm_prefetch(da.lms, pre);  // the decision's inputs travel with the first batch of loads
   __shared__ double s_out[8];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const double* p = nullptr;
+  const double *pa = nullptr, *pb = nullptr;
   int stride = 1, count = 0, inner = 1 << 30;
   size_t outer = 0;
-  if (w == 0) { p = cpart; stride = cstride; count = ncp; inner = cinner; outer = couter; }
-  else if (w >= 1 && w <= 3 && bpart) { p = bpart + (w - 1); stride = 3; count = nbp; }
-  else if (w == 4) { p = cpart + (cstride == 2 ? 1 : (size_t)cinner); stride = cstride; count = ncp; inner = cinner; outer = couter; }  // n_residuals / pairs with data
-  double s = 0.0;
+  if (w == 0) { pa = cp0; pb = cp1; stride = cstride; count = ncp; inner = cinner; outer = couter; }
+  else if (w >= 1 && w <= 3 && bpart) { pa = pb = bpart + (w - 1); stride = 3; count = nbp; }
+  else if (w == 4) {  // n_residuals / pairs with data
+    const size_t off = cstride == 2 ? 1 : (size_t)cinner;
+    pa = cp0 + off; pb = cp1 + off; stride = cstride; count = ncp; inner = cinner; outer = couter;
+  }
+  const bool two = pa != pb;  // wave-uniform
+  double sa = 0.0, sb = 0.0;
   for (int base = 0; base < count; base += 512) {
-    double v[8];
+    double va[8], vb[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       int idx = base + l + 64 * k;
       int hi = idx / inner, lo = idx - hi * inner;
-      v[k] = idx < count ? p[(size_t)hi * outer + (size_t)lo * stride] : 0.0;
+      const size_t at = (size_t)hi * outer + (size_t)lo * stride;
+      va[k] = idx < count ? pa[at] : 0.0;
+      vb[k] = (two && idx < count) ? pb[at] : 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += v[k];
+    for (int k = 0; k < 8; ++k) { sa += va[k]; sb += vb[k]; }
   }
+  const bool active = !sl.lms || (st15 == 0.0 && st14 == 0.0);  // sel_active(sl, true)
+  if (!active) {
+    if (da.decide && threadIdx.x == 0 && st15 == 0.0) lm_mark_rebuild(da.lms);
+    return;
+  }
+  const int sidx = sl.lms ? ((static_cast<int>(st3) ^ sl.idx) & 1) : sl.idx;
+  double s = (two && sidx) ? sb : sa;
   s = wave_sum63(s);
   if (l == 63) { out[w] = s; s_out[w] = s; }
   if (da.decide) {  // single-rank runs: the accept/reject decision rides on the same launch
     __syncthreads();
-    if (threadIdx.x == 0) lm_decide(s_out, da);
+    if (threadIdx.x == 0) lm_decide(s_out, da, pre);
   }
 }
 

@@ -14,14 +14,24 @@ __device__ __forceinline__ double lm_spec_lambda(double lam, double lam_min) { r
 //        8 step_norm  9 x_norm  10 dF.   pred_cam = d_c^T (lam D_c d_c - g_c), dcn2 = |d_c|^2, xcn2 = |x_c|^2 come from
 // whoever solved the camera system (host: DecideArgs; k_solve_cam: the state).  Nielsen's update on acceptance, doubling
 // growth on rejection -- identical to solver.LevenbergMarquardt.iterate.
-__device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs& da) {
+// The state fields the decision reads, fetched in ONE batch (a caller may issue it early, next to its own loads: a
+// dependent global round trip costs ~2 us here)
+struct LmPre {
+  double cost, lam, nu, sel, pred_cam, dcn2, xcn2, nfev, nacc;
+};
+__device__ __forceinline__ void lm_prefetch(const double* lms, LmPre& p) {
+  p.cost = lms[0]; p.lam = lms[1]; p.nu = lms[2]; p.sel = lms[3];
+  p.pred_cam = lms[MCBA_LM_PRED_CAM]; p.dcn2 = lms[MCBA_LM_DCN2]; p.xcn2 = lms[MCBA_LM_XCN2];
+  p.nfev = lms[MCBA_LM_NFEV]; p.nacc = lms[MCBA_LM_NACC];
+}
+__device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs& da, const LmPre& pre) {
   double* lms = da.lms;
-  double cost = lms[0], lam = lms[1], nu = lms[2];
+  double cost = pre.cost, lam = pre.lam, nu = pre.nu;
   const bool dev = da.decide == 2;  // camera-step scalars left in the state by k_solve_cam
-  const double pred_cam = dev ? lms[MCBA_LM_PRED_CAM] : da.pred_cam;
-  const double dcn2 = dev ? lms[MCBA_LM_DCN2] : da.dcn2, xcn2 = dev ? lms[MCBA_LM_XCN2] : da.xcn2;
+  const double pred_cam = dev ? pre.pred_cam : da.pred_cam;
+  const double dcn2 = dev ? pre.dcn2 : da.dcn2, xcn2 = dev ? pre.xcn2 : da.xcn2;
   const double cost_before = cost, lam_used = lam;
-  int sel = static_cast<int>(lms[3]);
+  int sel = static_cast<int>(pre.sel);
   double cost_new = trial8[0];
   double pred = 0.5 * (trial8[1] + pred_cam);
   bool ok = isfinite(cost_new) && pred > 0.0;
@@ -54,12 +64,17 @@ __device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs
     if (!accepted && status == 2.0) status = 0.0;  // ftol needs an accepted step
     if (!accepted && lam >= da.lam_max && status == 0.0) status = 3.0;
     lms[MCBA_LM_PENDING] = status;
-    lms[MCBA_LM_NFEV] += 1.0;
-    lms[MCBA_LM_NACC] += accepted ? 1.0 : 0.0;
+    lms[MCBA_LM_NFEV] = pre.nfev + 1.0;
+    lms[MCBA_LM_NACC] = pre.nacc + (accepted ? 1.0 : 0.0);
     lms[MCBA_LM_LAM_USED] = lam_used;
     lms[MCBA_LM_COST_BEFORE] = cost_before;
     lms[MCBA_LM_REBUILD] = 0.0;
   }
+}
+__device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs& da) {
+  LmPre pre;
+  lm_prefetch(da.lms, pre);
+  lm_decide(trial8, da, pre);
 }
 // a tick that only rebuilds the system (the reduced solve failed): no trial, nothing accepted
 __device__ __forceinline__ void lm_mark_rebuild(double* lms) {
