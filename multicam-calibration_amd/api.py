@@ -161,7 +161,14 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             print("Function evaluations 1, initial cost 0.0000e+00, final cost 0.0000e+00, first-order optimality 0.00e+00.")
         ext, intr, poses = deserialize_params(x0, n_cameras)
         return ext, intr, poses, use_frames, result
-    prob = (backend or ops.Problem)(uvs, calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0))
+    pkw = {}
+    if distributed and backend is None:
+        import torch
+
+        # torch orders its collectives against torch's CURRENT stream: the library must launch on that same stream
+        # (the torch.distributed fallback of solver.make_comm all-reduces the library's reduce buffer in place)
+        pkw["stream"] = torch.cuda.current_stream(device).cuda_stream
+    prob = (backend or ops.Problem)(uvs, calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0), **pkw)
     comm = None
     if distributed:
         import torch
@@ -171,9 +178,14 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     free = None
     if fix_intrinsics:
         free = np.tile(np.r_[np.zeros(6, bool), np.ones(6, bool)], n_cameras)
-    tol = lambda name, default: default if kw.get(name, default) is None else kw.get(name, default)
+    # an explicit None disables that test, as scipy's check_tolerance does (least_squares.py: None -> 0); the device loop
+    # treats a zero tolerance as "never satisfied".  A missing key keeps the reference's / scipy's defaults.
+    tol = lambda name, default: 0.0 if kw.get(name, default) is None else float(kw.get(name, default))
+    max_nfev = kw.get("max_nfev")
+    if max_nfev is None:
+        max_nfev = 100 * (12 * n_cameras + 6 * len(all_use))  # trf.py:437-438 on the GLOBAL vector: identical on every rank
     result = solver.lm_solve(prob, x0, ftol=tol("ftol", 1e-4), xtol=tol("xtol", 1e-8), gtol=tol("gtol", 1e-8),
-                             max_nfev=kw.get("max_nfev"), verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, **lm_kwargs)
+                             max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, **lm_kwargs)
 
     # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560)
     slot = result.lm["slot"]

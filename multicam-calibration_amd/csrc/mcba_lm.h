@@ -1,14 +1,14 @@
 // mcba_lm.h -- the accept/reject decision of the device-resident LM loop (shared by k_sum_trial / k_decide in
-// mcba_kernels.hip and k_solve_cam in mcba_solve.hip).  Device code only.
+// mcba_kernels.hip and k_solve_cam in mcba_solve.hip).  Compiled into the kernels and, for the decision logic, into the host-side unit harness.
 #pragma once
-#include "mcba_kernels.h"
+#include "mcba_lm_state.h"
 #include "mcba_math.h"
 
 namespace mcba {
 
 // damping a speculative Schur reduction assumes for the accepted trial point: Nielsen's factor at its floor of 1/3
 // (ratio >= 0.937, the usual case while converging).  Must be the very expression lm_decide evaluates.
-__device__ __forceinline__ double lm_spec_lambda(double lam, double lam_min) { return fmax(lam * (1.0 / 3.0), lam_min); }
+MCBA_HD double lm_spec_lambda(double lam, double lam_min) { return fmax(lam * (1.0 / 3.0), lam_min); }
 
 // state (lms): 0 cost  1 lambda  2 nu  3 sel (current slot / linearisation)  4 accepted  5 cost_new  6 pred  7 ratio
 //        8 step_norm  9 x_norm  10 dF.   pred_cam = d_c^T (lam D_c d_c - g_c), dcn2 = |d_c|^2, xcn2 = |x_c|^2 come from
@@ -19,12 +19,12 @@ __device__ __forceinline__ double lm_spec_lambda(double lam, double lam_min) { r
 struct LmPre {
   double cost, lam, nu, sel, pred_cam, dcn2, xcn2, nfev, nacc;
 };
-__device__ __forceinline__ void lm_prefetch(const double* lms, LmPre& p) {
+MCBA_HD void lm_prefetch(const double* lms, LmPre& p) {
   p.cost = lms[0]; p.lam = lms[1]; p.nu = lms[2]; p.sel = lms[3];
   p.pred_cam = lms[MCBA_LM_PRED_CAM]; p.dcn2 = lms[MCBA_LM_DCN2]; p.xcn2 = lms[MCBA_LM_XCN2];
   p.nfev = lms[MCBA_LM_NFEV]; p.nacc = lms[MCBA_LM_NACC];
 }
-__device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs& da, const LmPre& pre) {
+MCBA_HD void lm_decide(const double* trial8, const DecideArgs& da, const LmPre& pre) {
   double* lms = da.lms;
   double cost = pre.cost, lam = pre.lam, nu = pre.nu;
   const bool dev = da.decide == 2;  // camera-step scalars left in the state by k_solve_cam
@@ -71,13 +71,13 @@ __device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs
     lms[MCBA_LM_REBUILD] = 0.0;
   }
 }
-__device__ __forceinline__ void lm_decide(const double* trial8, const DecideArgs& da) {
+MCBA_HD void lm_decide(const double* trial8, const DecideArgs& da) {
   LmPre pre;
   lm_prefetch(da.lms, pre);
   lm_decide(trial8, da, pre);
 }
 // a tick that only rebuilds the system (the reduced solve failed): no trial, nothing accepted
-__device__ __forceinline__ void lm_mark_rebuild(double* lms) {
+MCBA_HD void lm_mark_rebuild(double* lms) {
   lms[4] = 0.0;
   lms[MCBA_LM_REBUILD] = 1.0;
 }

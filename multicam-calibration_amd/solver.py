@@ -93,9 +93,16 @@ class DirectRCCL:
         problem.comm_allreduce(problem.nsys, 8)
 
 
+MAX_RANKS = 12  # per-rank max |g_f| slots in the reduce buffer's scalar block (include/mcba.h: scal[4..15])
+
+
 def make_comm(problem, device, group=None, direct=None):
     """Collective backend for a frame-sharded solve: direct RCCL if it can be set up (MCBA_DIRECT_RCCL=0 disables),
     otherwise torch.distributed on a tensor that aliases the reduce buffer."""
+    import torch.distributed as dist
+
+    if dist.get_world_size(group) > MAX_RANKS:
+        raise ValueError(f"frame-sharded solves support at most {MAX_RANKS} ranks (one max|g_f| slot per rank travels in the SUM all-reduce); got {dist.get_world_size(group)}")
     if direct is None:
         direct = os.environ.get("MCBA_DIRECT_RCCL", "1") != "0"
     if direct and hasattr(problem, "comm_init_from_torch"):
@@ -376,14 +383,15 @@ class LevenbergMarquardt:
             ratio = (self.cost - cost_new) / pred if (np.isfinite(cost_new) and pred > 0) else -1.0
             dF = self.cost - cost_new
             self.history.append((self.nfev, self.cost, cost_new, pred, ratio, lam, step_norm))
-            ftol_ok = max(dF, 0.0) < self.ftol * self.cost and ratio > 0.25  # (a neutral step has dF ~ -EPS F: counts as 0)
-            xtol_ok = step_norm < self.xtol * (self.xtol + x_norm)
-            status = 4 if (ftol_ok and xtol_ok) else 2 if ftol_ok else 3 if xtol_ok else None
-            # round-off guard (same rule as k_decide): |dF| below FP64 resolution of the cost = neutral step, accepted
+            # round-off guard (same rule, same ORDER as lm_decide in csrc/mcba_lm.h): |dF| below FP64 resolution of the cost
+            # = neutral step, accepted with ratio := 0.5 BEFORE the termination tests look at the ratio
             neutral = bool(np.isfinite(cost_new) and pred >= 0 and abs(dF) <= 32 * EPS * abs(self.cost))
             accepted = (ratio > 0 and dF >= 0) or neutral
             if accepted and not (ratio > 0 and dF >= 0):
                 ratio = 0.5
+            ftol_ok = max(dF, 0.0) < self.ftol * self.cost and ratio > 0.25  # (a neutral step has dF ~ -EPS F: counts as 0)
+            xtol_ok = step_norm < self.xtol * (self.xtol + x_norm)
+            status = 4 if (ftol_ok and xtol_ok) else 2 if ftol_ok else 3 if xtol_ok else None
             if accepted:
                 self.cur = 1 - self.cur
                 self.x_cam = self.x_cam + dc

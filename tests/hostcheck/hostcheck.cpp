@@ -1,9 +1,11 @@
 // Host-side unit harness for csrc/mcba_math.h -- TEST INFRASTRUCTURE ONLY.
 // Compiles the device math header with g++ and walks it over a small problem on the CPU so the
-// algebra (local Gram matrix + chain-rule expansion, Jacobian rows, robust weights, 6x6 solves)
+// algebra (local Gram matrix + chain-rule expansion, Jacobian rows, robust weights, 6x6 solves) and the LM accept /
+// reject decision of csrc/mcba_lm.h
 // can be checked against oracle/ba_oracle.py in the GPU-less build container.
 // It is never loaded by the product (multicam-calibration_amd/ops.py loads libmcba.so only).
 #include "../../multicam-calibration_amd/csrc/mcba_math.h"
+#include "../../multicam-calibration_amd/csrc/mcba_lm.h"
 #include <cstring>
 
 using namespace mcba;
@@ -117,5 +119,11 @@ int hc_chol_solve(const double* Vt, const double* b, double* x) {
   fwd6(Lp, id, b, y);
   bwd6(Lp, id, y, x);
   return ok ? 1 : 0;
+}
+
+// the device loop's accept / reject + damping update + ftol / xtol verdict (csrc/mcba_lm.h) on a 32-double LM state
+void hc_lm_decide(double* lms, const double* trial8, double lam_min, double lam_max, double ftol, double xtol) {
+  using std::isfinite;
+  lm_decide(trial8, DecideArgs{2, 0.0, 0.0, 0.0, lam_min, lam_max, lms, ftol, xtol});
 }
 }

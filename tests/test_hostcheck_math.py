@@ -22,8 +22,8 @@ def P(a):
 def hc():
     src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
     lib = os.path.join(HERE, "hostcheck", "libhostcheck.so")
-    hdr = os.path.join(HERE, "..", "multicam-calibration_amd", "csrc", "mcba_math.h")
-    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(HERE, "..", "multicam-calibration_amd", "csrc", h) for h in ("mcba_math.h", "mcba_lm.h", "mcba_lm_state.h")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
         subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", lib, src])
     return ctypes.CDLL(lib)
 

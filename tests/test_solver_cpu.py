@@ -95,6 +95,113 @@ def test_wrapper_serialization_and_structure(golden):
     assert i[0][1].shape == (5,) and np.all(i[0][1][2:] == 0)
 
 
+# ------------------------------------------------------------------ explicit None tolerances (scipy: None -> 0 = test disabled)
+def test_none_tolerance_disables_the_test_like_scipy():
+    import contextlib
+    import io
+
+    p = synth.make_problem(2, 12, seed=3)
+    kw = dict(n_frames=None, verbose=0, _backend=OracleProblem, max_nfev=60)
+    with contextlib.redirect_stdout(io.StringIO()):
+        d = api.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], **kw)[4]               # reference default ftol = 1e-4
+        n = api.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], ftol=None, **kw)[4]    # ftol test off
+        z = api.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], ftol=0.0, **kw)[4]
+    assert d.status == 2
+    assert n.status != 2 and n.nfev > d.nfev and n.cost <= d.cost
+    assert (n.status, n.nfev) == (z.status, z.nfev) and n.cost == z.cost
+
+
+# ------------------------------------------------------------------ host-driven decision == the device loop's lm_decide (csrc/mcba_lm.h)
+class ScriptedProblem:
+    """One camera, no frames to speak of: a diagonal reduced system and SCRIPTED trial outcomes, so that the host-driven
+    `LevenbergMarquardt.iterate()` and the device loop's `lm_decide` (compiled for the host by tests/hostcheck) can be fed
+    the same scalars."""
+
+    def __init__(self, cost0, script):
+        self.n, self.C, self.F = 12, 1, 1
+        self.nx = 18
+        self.nsys = self.n * self.n + 3 * self.n + 16
+        self.cost, self.script, self.k = cost0, script, 0
+        self.x = [np.linspace(1.0, 2.0, 18), np.zeros(18)]
+        self.diag = np.linspace(2.0, 5.0, 12)
+        self.gc = np.linspace(-1.0, 1.0, 12) * 1e-3
+        self.trial = np.zeros(8)
+        self.dcs = []
+
+    def set_params(self, slot, x):
+        self.x[slot] = np.array(x)
+
+    def get_params(self, slot):
+        return self.x[slot].copy()
+
+    def linearize(self, slot):
+        pass
+
+    def build_reduced(self, lam, rank_slot=0):
+        pass
+
+    def get_reduced(self):
+        scal = np.zeros(16)
+        scal[0] = self.cost
+        return dict(S0=np.diag(self.diag).copy(), rhs=-self.gc.copy(), diagU=self.diag.copy(), gc=self.gc.copy(), scal=scal)
+
+    def step_linearize(self, dc, lam, src, dst):
+        self.dcs.append(np.array(dc))
+        self.x[dst] = self.x[src].copy()
+        self.x[dst][:12] += dc
+        self.trial[:4] = self.script[self.k]
+        self.k += 1
+
+    def get_trial(self):
+        return self.trial.copy()
+
+    def accept_linearization(self):
+        self.cost = self.trial[0]
+
+
+def test_host_driven_decision_equals_device_lm_decide():
+    import ctypes
+
+    from test_hostcheck_math import P
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "hostcheck", "libhostcheck.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", lib, os.path.join(here, "hostcheck", "hostcheck.cpp")])
+    hc = ctypes.CDLL(lib)
+    hc.hc_lm_decide.argtypes = [ctypes.POINTER(ctypes.c_double)] * 2 + [ctypes.c_double] * 4
+    hc.hc_lm_decide.restype = None
+    cost0 = 100.0
+    # (cost_new, pred_f, |d_f|^2, |x_f|^2): good step, bad step, poor-ratio step, NEUTRAL step (|dF| below FP64 resolution, dF < 0)
+    script = [(90.0, 18.0, 1e-2, 4.0), (95.0, 2.0, 1e-3, 4.0), (89.9, 3.0, 1e-4, 4.0), (89.9 * (1 + 4e-16), 1e-9, 1e-9, 4.0)]
+    ftol, xtol, lam_min, lam_max = 1e-9, 1e-30, 1e-12, 1e12
+    prob = ScriptedProblem(cost0, script)
+    lm = solver.LevenbergMarquardt(prob, ftol=ftol, xtol=xtol, gtol=0.0, reduced_solver="host")
+    assert not lm.device_decide and not lm.device_solve   # the test double drives the host decision
+    lm.start(prob.x[0])
+    lms = np.zeros(32)
+    lms[:4] = cost0, lm.lam, lm.nu, 0
+    statuses = []
+    for k, t in enumerate(script):
+        lam_b, x_cam = lm.lam, lm.x_cam.copy()
+        st = lm.iterate()
+        dc = prob.dcs[k]
+        Dc = prob.diag
+        lms[11] = dc @ (lam_b * Dc * dc - prob.gc)
+        lms[12] = dc @ dc
+        lms[13] = x_cam @ x_cam
+        trial8 = np.zeros(8)
+        trial8[:4] = t
+        hc.hc_lm_decide(P(lms), P(trial8), lam_min, lam_max, ftol, xtol)
+        assert bool(lms[4]) == lm.accepted, k
+        assert lms[1] == lm.lam and lms[2] == lm.nu and lms[0] == lm.cost, k
+        assert int(lms[3]) == lm.cur, k
+        assert (st or 0) == int(lms[19]), (k, st, lms[19])
+        statuses.append(st)
+    assert statuses[:3] == [None, None, None]
+    assert statuses[3] == 2   # the neutral step is accepted with ratio := 0.5 BEFORE the ftol test, as on the device
+
+
 # ------------------------------------------------------------------ world_size 2 over gloo
 def _free_port():
     with socket.socket() as s:
