@@ -186,6 +186,7 @@ int mcba_get_cam_step(mcba_handle* h, double* host);
 int mcba_comm_unique_id(unsigned char* out128);
 int mcba_comm_init(mcba_handle* h, const unsigned char* id128, int rank, int world);
 int mcba_comm_allreduce(mcba_handle* h, size_t offset, size_t count);
+int mcba_comm_count(mcba_handle* h, int* count);   /* ranks of the attached communicator (ncclCommCount); 0 if none */
 int mcba_comm_destroy(mcba_handle* h);
 /* Frame part of the gradient J^T f of the last mcba_build_reduced(): (F,6) doubles, host.
  * (The camera part is the g_c block of the reduce buffer.)  Feeds OptimizeResult.grad (trf.py:557-560). */

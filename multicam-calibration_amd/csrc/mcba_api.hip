@@ -101,6 +101,10 @@ struct Scope {  // brackets one launch with events when profiling
 mcba::Sel host_sel(int idx, double lam = 0.0) { return mcba::Sel{nullptr, idx, lam, 0}; }
 mcba::Sel dev_sel(const mcba_handle* h, int flip) { return mcba::Sel{h->red + h->nsys + 8, flip, 0.0, 0}; }  // LM state lives behind the trial scalars
 mcba::Sel spec_sel(const mcba_handle* h) { return mcba::Sel{h->red + h->nsys + 8, 0, h->lam_min, 1}; }
+// the state AFTER the decision k_syrk took itself (single-GPU ticks): a second buffer behind the first
+double* post_state(const mcba_handle* h) { return h->red + h->nsys + 8 + MCBA_LMS; }
+mcba::Sel post_sel(const mcba_handle* h) { return mcba::Sel{post_state(h), 0, 0.0, 0}; }
+mcba::SyrkFuse no_fuse() { mcba::SyrkFuse z{}; return z; }
 
 int check_launch() {
   hipError_t e = hipGetLastError();
@@ -124,6 +128,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi g_rccl;
@@ -140,6 +145,7 @@ static int load_rccl() {
   g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(lib, "ncclAllReduce"));
   g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(lib, "ncclCommCount"));
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) return fail(MCBA_ERR_ARG, "RCCL symbols missing");
   g_rccl.ok = true;
   return MCBA_OK;
@@ -151,7 +157,7 @@ static int rccl_fail(const char* what, ncclResult_t r) {
 
 extern "C" {
 
-int mcba_abi_version(void) { return 2; }  // 2: 32-double LM state, mcba_lm_auto_*
+int mcba_abi_version(void) { return 3; }  // 3: mcba_comm_count, frame pre-filter, reprojection diagnostics, undistortion (round 2)
 const char* mcba_last_error(void) { return g_err.c_str(); }
 const char* mcba_profile_names(void) { return kKernelNames; }
 
@@ -194,7 +200,7 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
     h->fpc = ((nstage + g - 1) / g) * h->FS;
     h->G = (F + h->fpc - 1) / h->fpc;
   }
-  h->nfblocks = h->Fpad / 64;
+  h->nfblocks = h->G;  // k_syrk's workgroups factorise their own frames: one (max |g_f|, #failures) pair each
   h->nbblocks = h->Fpad / 64;
   // fused k_gram needs >= ~1 wavefront per SIMD (1024) to fill the chip; with fewer (camera, frame-block) pairs the
   // split-role variant doubles the number of wavefronts.  MCBA_GRAM_SPLIT=0/1 overrides (tuning knob).
@@ -226,7 +232,7 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   DA(spart, (size_t)h->G * h->NP * 256 + 64);
   DA(cpart, (size_t)2 * C * h->nfb * h->nch);
   DA(bpart, (size_t)3 * h->nbblocks);
-  DA(red_own, h->nsys + 8 + MCBA_LMS);
+  DA(red_own, h->nsys + 8 + 2 * MCBA_LMS);
   DA(tile_i, (size_t)h->NP);
   DA(tile_j, (size_t)h->NP);
   h->npad = 16 * h->NT;
@@ -447,13 +453,8 @@ int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot) {
   HIPCHK(hipSetDevice(h->device));
   int rc;
   {
-    Scope sc(h, K_FRAME_FACTOR);
-    mcba::launch_frame_factor(h->stream, host_sel(h->lin, lambda), h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->C, h->F, h->Fpad);
-  }
-  if ((rc = check_launch())) return rc;
-  {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, host_sel(h->lin), h->rec2[0], h->rec2[1], h->fbuf, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
+    mcba::launch_syrk(h->stream, host_sel(h->lin, lambda), no_fuse(), h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -465,7 +466,7 @@ int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot) {
   return MCBA_OK;
 }
 
-size_t mcba_reduced_size(const mcba_handle* h) { return h ? h->nsys + 8 + MCBA_LMS : 0; }
+size_t mcba_reduced_size(const mcba_handle* h) { return h ? h->nsys + 8 + 2 * MCBA_LMS : 0; }
 
 int mcba_bind_reduce_buffer(mcba_handle* h, double* p) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
@@ -601,22 +602,33 @@ int mcba_lm_trial(mcba_handle* h, const double* delta_cam) {
   return lm_trial_impl(h, delta_cam, mcba::DecideArgs{0, 0.0, 0.0, 0.0, 0.0, 0.0, nullptr});
 }
 
-static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false) {
+// decide_here: k_syrk itself sums the trial scalars and takes the accept / reject decision (single-GPU ticks); it reads the
+// state the previous tick left and publishes the decided state to the second buffer, which the rest of the tick reads.
+static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, bool decide_here = false) {
   int rc;
   const mcba::Sel sl = spec ? spec_sel(h) : dev_sel(h, 0);
-  {
-    Scope sc(h, K_FRAME_FACTOR);
-    mcba::launch_frame_factor(h->stream, sl, h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->C, h->F, h->Fpad);
+  mcba::SyrkFuse fz = no_fuse();
+  if (decide_here) {
+    fz.decide = 1;
+    fz.cp0 = h->gpart2[0] + (size_t)90 * h->nfb;
+    fz.cp1 = h->gpart2[1] + (size_t)90 * h->nfb;
+    fz.cinner = h->nfb;
+    fz.couter = (size_t)MCBA_GP * h->nfb;
+    fz.ncp = h->C * h->nfb;
+    fz.bpart = h->bpart;
+    fz.nbp = h->nbblocks;
+    fz.trial_out = h->red + h->nsys;
+    fz.lms_post = post_state(h);
+    fz.da = mcba::DecideArgs{2, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, nullptr, h->ftol, h->xtol};
   }
-  if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, sl, h->rec2[0], h->rec2[1], h->fbuf, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
+    mcba::launch_syrk(h->stream, sl, fz, h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_REDUCE);
-    mcba::launch_reduce_system(h->stream, sl, h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
+    mcba::launch_reduce_system(h->stream, decide_here ? post_sel(h) : sl, h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
   }
   if ((rc = check_launch())) return rc;
   h->have_red = true;
@@ -685,12 +697,12 @@ int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, d
   return MCBA_OK;
 }
 
-int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq, int decide) {
+static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, bool decided_by_syrk) {
   if (!h || !h->auto_ready || seq == 0) return fail(MCBA_ERR_ARG, "mcba_lm_auto_solve: call mcba_lm_auto_config first; seq >= 1");
   if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_lm_auto_solve: no reduced system");
   HIPCHK(hipSetDevice(h->device));
   mcba::SolveArgs a;
-  a.red = h->red; a.lms = h->red + h->nsys + 8; a.work = h->swork; a.dc = h->dcbuf; a.x0 = h->x[0]; a.x1 = h->x[1];
+  a.red = h->red; a.lms = h->red + h->nsys + 8; a.lms_in = decided_by_syrk ? post_state(h) : a.lms; a.work = h->swork; a.dc = h->dcbuf; a.x0 = h->x[0]; a.x1 = h->x[1];
   a.fixed = h->have_fixed ? h->fixed : nullptr;
   a.host_state = h->ring_dev + (size_t)(seq % kRing) * MCBA_LMS;
   a.seq = (double)seq; a.gtol = h->gtol; a.lam_max = h->lam_max;
@@ -703,7 +715,10 @@ int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq, int decide) {
   return check_launch();
 }
 
-int mcba_lm_auto_trial(mcba_handle* h, int decide) {
+int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq, int decide) { return auto_solve_impl(h, seq, decide, false); }
+
+// sum_here: k_sum_trial follows (frame-sharded ticks: the trial scalars are all-reduced); otherwise k_syrk sums and decides
+static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   if (!h || !h->auto_ready) return fail(MCBA_ERR_ARG, "mcba_lm_auto_trial: call mcba_lm_auto_config first");
   if (!h->have_lin) return fail(MCBA_ERR_ARG, "mcba_lm_auto_trial: no linearisation");
   HIPCHK(hipSetDevice(h->device));
@@ -718,6 +733,7 @@ int mcba_lm_auto_trial(mcba_handle* h, int decide) {
     mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split);
   }
   if ((rc = check_launch())) return rc;
+  if (!sum_here) return MCBA_OK;
   {
     Scope sc(h, K_SUM_TRIAL);
     mcba::DecideArgs da{decide ? 2 : 0, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, h->red + h->nsys + 8, h->ftol, h->xtol};
@@ -725,6 +741,8 @@ int mcba_lm_auto_trial(mcba_handle* h, int decide) {
   }
   return check_launch();
 }
+
+int mcba_lm_auto_trial(mcba_handle* h, int decide) { return auto_trial_impl(h, decide, true); }
 
 int mcba_lm_auto_reduce(mcba_handle* h, int decide, int rank_slot) {
   if (!h || !h->auto_ready || rank_slot < 0 || rank_slot > 11 || decide < 0 || decide > 2) return fail(MCBA_ERR_ARG, "mcba_lm_auto_reduce: bad argument");
@@ -744,10 +762,11 @@ int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
   const bool coll = h->comm != nullptr;
   int rc;
-  if (!coll) {  // one GPU: the decision rides on k_sum_trial
-    if ((rc = mcba_lm_auto_trial(h, 1))) return rc;
-    if ((rc = mcba_lm_auto_reduce(h, 0, rank_slot))) return rc;
-    return mcba_lm_auto_solve(h, seq, 0);
+  if (!coll) {  // one GPU: k_backsub -> k_gram -> k_syrk (trial sums + decision + frame factors + SYRK) -> k_reduce_system -> k_solve_cam
+    if (rank_slot < 0 || rank_slot > 11) return fail(MCBA_ERR_ARG, "mcba_lm_auto_tick: bad rank slot");
+    if ((rc = auto_trial_impl(h, 0, false))) return rc;
+    if ((rc = lm_reduce_chain(h, rank_slot, false, true))) return rc;
+    return auto_solve_impl(h, seq, 0, true);
   }
   if (h->speculate) {  // ONE collective: speculative reduction, [system | trial scalars] all-reduced together, decision in k_solve_cam
     if ((rc = mcba_lm_auto_trial(h, 0))) return rc;
@@ -903,6 +922,16 @@ int mcba_comm_allreduce(mcba_handle* h, size_t offset, size_t count) {
   if (offset + count > h->nsys + 8 + MCBA_LMS) return fail(MCBA_ERR_ARG, "mcba_comm_allreduce: range outside the reduce buffer");
   ncclResult_t r = g_rccl.AllReduce(h->red + offset, h->red + offset, count, ncclDouble, ncclSum, h->comm, h->stream);
   if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+  return MCBA_OK;
+}
+
+int mcba_comm_count(mcba_handle* h, int* count) {
+  if (!h || !count) return fail(MCBA_ERR_ARG, "mcba_comm_count: bad argument");
+  *count = 0;
+  if (!h->comm) return MCBA_OK;  // no direct communicator attached
+  if (!g_rccl.CommCount) return fail(MCBA_ERR_ARG, "mcba_comm_count: ncclCommCount not available");
+  ncclResult_t r = g_rccl.CommCount(h->comm, count);
+  if (r != ncclSuccess) return rccl_fail("ncclCommCount", r);
   return MCBA_OK;
 }
 

@@ -24,10 +24,25 @@ struct Sel {
   double lam;   // host value of the damping (lms == nullptr); lambda_min when spec != 0
   int spec;     // speculative Schur reduction of the trial linearisation (see sel_spec in mcba_kernels.hip)
 };
+// k_syrk's fused decision prologue (single-GPU ticks of the device-resident loop; see k_syrk in mcba_kernels.hip)
+struct SyrkFuse {
+  int decide;          // != 0: every workgroup sums the trial scalars and takes the accept / reject decision itself
+  const double* cp0;   // per-wavefront cost sums of the two linearisation buffers (gpart + 90 nfb) ...
+  const double* cp1;
+  int cinner;          // ... element idx of `ncp` lives at (idx / cinner) * couter + (idx % cinner)
+  size_t couter;
+  int ncp;
+  const double* bpart; // k_backsub's per-block sums (3 per block)
+  int nbp;
+  double* trial_out;   // 4 trial scalars for the host (cost, pred_f, |d_f|^2, |x_f|^2)
+  double* lms_post;    // the state AFTER the decision (workgroup 0 writes it; later kernels of the tick read it)
+  DecideArgs da;       // lam_min, lam_max, ftol, xtol
+};
 // k_solve_cam (mcba_solve.hip): reduced camera system factorised and solved by one workgroup
 struct SolveArgs {
   const double* red;         // S0 (n x n) | rhs | diag U | g_c | 16 scalars
-  double* lms;               // device LM state
+  const double* lms_in;      // device LM state as the tick's decision left it (== lms unless k_syrk took the decision)
+  double* lms;               // device LM state the NEXT tick starts from (written back here)
   double* work;              // npad x npad scratch (used when the factor does not fit LDS)
   double* dc;                // n doubles: the camera step
   const double* x0;          // parameter slots (camera block first)
@@ -46,8 +61,7 @@ void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int 
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split);
 void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch);
 size_t syrk_lds_bytes(int C, int FS);
-void launch_frame_factor(hipStream_t st, Sel s, const double* rec0, const double* rec1, double* fbuf, double* fpart, int C, int F, int Fpad);
-void launch_syrk(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw);
+void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw);
 int syrk_items_per_thread();
 void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot);
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad);

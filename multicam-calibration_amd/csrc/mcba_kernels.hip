@@ -8,9 +8,9 @@
 //                       all accumulation (12x12 local Gram matrix) is lane-local -- no shuffles in the loop.
 //                       Camera intrinsics + pose are staged in LDS once per workgroup.  The fused variant's point
 //                       loop is branch-free and software-pipelined; rows are accumulated in camera-aligned axes.
-//   k_frame_factor      one lane per frame: 6x6 Cholesky of the damped frame block, z = L^-1 g_f.
-//   k_syrk              per stage of frames: Y = W L^-T built in LDS, S -= Y Y^T on v_mfma_f64_16x16x4 (the one
-//                       GEMM-shaped step); the next stage's operands are prefetched into registers meanwhile.
+//   k_syrk              [the LM accept / reject decision, in every workgroup] + the 6x6 Cholesky factors of the workgroup's
+//                       damped frame blocks (z = L^-1 g_f) + per stage of frames: Y = W L^-T built in LDS, S -= Y Y^T on
+//                       v_mfma_f64_16x16x4 (the one GEMM-shaped step); the next stage's operands are prefetched meanwhile.
 //   k_reduce_system     fixed-order second-stage reduction (deterministic; no FP64 atomics anywhere).
 //   k_backsub           64 frames x min(C, 8) wavefronts: frame steps, trial parameters, predicted-reduction terms.
 //   k_sum_trial/k_decide  trial sums, accept/reject + damping update + ftol/xtol on the device LM state (mcba_lm.h).
@@ -466,98 +466,108 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
   if (lane == 0) { cpart[o] = cs; cpart[o + 1] = ns; }
 }
 
-// ---------------------------------------------------------------- k_frame_factor
-// lane = frame.  V_f = sum_c V_cf; D_f = diag(V_f) (Marquardt); L L^T = V_f + lambda D_f; z = L^-1 g_f.
-// fbuf[f] = {L(21), z(6), g_f(6), D_f(6), pad}.  Per-block partials: max |g_f|, #failed factorisations.
-// The V_cf / g_cf reads are coalesced tile rows; three cameras (81 loads) are in flight per lane at a time.
-__global__ __launch_bounds__(64) void k_frame_factor(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, double* __restrict__ fbuf, double* __restrict__ fpart, int C, int F, int Fpad) {
-  if (!sel_active(sl, false)) return;
-  const double* __restrict__ rec = sel_index(sl) ? rec1 : rec0;
-  const double lambda = sel_lambda(sl);
-  const int f = blockIdx.x * 64 + threadIdx.x;
-  const int nfb = Fpad >> 6;
-  double gmax = 0.0, nfail = 0.0;
-  double V[21], gf[6];
-#pragma unroll
-  for (int k = 0; k < 21; ++k) V[k] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) gf[k] = 0.0;
-  constexpr int CB = 6;  // cameras per batch: 84 loads in flight (a dependent round trip costs ~2 us, the data next to nothing)
-  for (int c0 = 0; c0 < C; c0 += CB) {
-    double t[CB][27];
-#pragma unroll
-    for (int j = 0; j < CB; ++j) {
-      const int cc = min(c0 + j, C - 1);  // clamped duplicate loads are ignored below
-      const double2* r2 = reinterpret_cast<const double2*>(rec + ((size_t)cc * nfb + blockIdx.x) * (MCBA_REC * 64)) + 36 * 64 + threadIdx.x;
-#pragma unroll
-      for (int k = 0; k < 14; ++k) { double2 v = r2[k * 64]; t[j][2 * k] = v.x; if (2 * k + 1 < 27) t[j][2 * k + 1] = v.y; }
-    }
-#pragma unroll
-    for (int j = 0; j < CB; ++j) {
-      if (c0 + j < C) {
-#pragma unroll
-        for (int k = 0; k < 21; ++k) V[k] += t[j][k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) gf[k] += t[j][21 + k];
-      }
-    }
-  }
-  if (f < F) {
-    double D[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      double d = V[tri6(k, k)];
-      D[k] = d > 0.0 ? d : 1.0;
-      V[tri6(k, k)] = d + lambda * D[k];
-    }
-    double Lp[21], id[6], z[6];
-    bool ok = chol6i(V, Lp);  // diagonal slots: 1 / L_ii
-#pragma unroll
-    for (int k = 0; k < 6; ++k) id[k] = Lp[k * (k + 1) / 2 + k];
-    fwd6(Lp, id, gf, z);
-    double o[40];
-#pragma unroll
-    for (int k = 0; k < 21; ++k) o[k] = Lp[k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { o[21 + k] = z[k]; o[27 + k] = gf[k]; o[33 + k] = D[k]; gmax = fmax(gmax, fabs(gf[k])); }
-    o[39] = 0.0;
-    double* fbp = fbuf + (size_t)f * MCBA_FB;
-#pragma unroll
-    for (int k = 0; k < 40; k += 2) *reinterpret_cast<double2*>(fbp + k) = make_double2(o[k], o[k + 1]);
-    nfail = ok ? 0.0 : 1.0;
-  }
-  double wm = wave_max(gmax), wn = wave_sum63(nfail);
-  if (threadIdx.x == 63) { fpart[2 * blockIdx.x] = wm; fpart[2 * blockIdx.x + 1] = wn; }
-}
-
-// ---------------------------------------------------------------- k_syrk:  partial  sum_f Yx_f Yx_f^T  on the FP64 matrix cores
+// ---------------------------------------------------------------- k_syrk:  [decision] + frame factors + partial  sum_f Yx_f Yx_f^T  on the FP64 matrix cores
 // The Schur reduction  S = U - sum_f Y_f Y_f^T,  rhs = sum_f Y_f z_f - g_c  is a genuine GEMM (K = 6 F), so it runs
 // on v_mfma_f64_16x16x4_f64.  Yx_f = [Y_f ; z_f^T] is (12C+1) x 6: with z as an extra ROW the right-hand side is
 // column 12C of the same product.  Rows are padded to NT*16.
-// grid (G, ceil(NP / (4*PPW))), block 256 = 4 wavefronts.  Per stage of FS frames:
-//   1. (prefetched) L_f, z_f -> LDS, 1/diag(L);
+// grid (G, ceil(NP / (4*PPW))), block 256 = 4 wavefronts; workgroup g owns the frames [g fpc, (g+1) fpc).
+//   0. (DECIDE, single-GPU ticks) what used to be k_sum_trial + the decision: EVERY workgroup sums the trial point's cost /
+//      step partials (a few KB, fixed order -> identical in every workgroup) and takes the accept / reject decision on an
+//      LDS copy of the LM state; workgroup 0 publishes the new state to a SECOND state buffer (the old one is still being
+//      read by workgroups that start later).  Saves a launch whose whole content was a 5 us latency chain.
+//   1. what used to be k_frame_factor, per super-stage of <= 64 of the workgroup's frames, by wavefront 0 (lane = frame):
+//      V_f = sum_c V_cf, D_f = diag(V_f) (Marquardt), L L^T = V_f + lambda D_f, z = L^-1 g_f  ->  LDS (L, 1/diag, z) for the
+//      stages below and fbuf[f] = {L(21, diagonal slots 1 / L_ii), z(6), g_f(6), D_f(6), pad} for k_backsub.  The W loads of
+//      the first stage are already in flight meanwhile.
+//   per stage of FS frames:
 //   2. every thread forward-substitutes its IPT (row, frame) items from PREFETCHED registers: y = L_f^-1 w, written
 //      to LDS as s_y[row][frame*6 + k]  (row stride 6 FS + 2 doubles: conflict-free ds_read_b64 for the MFMA operands);
-//   3. the loads of the NEXT stage (W rows from the wave tiles, 6 coalesced loads per item, and L/z) are issued,
+//   3. the loads of the NEXT stage (W rows from the wave tiles, 6 coalesced loads per item) are issued,
 //      then wavefront w accumulates its PPW output tiles (pair q = w + 4k): per K-step of 4 the A operand of tile
 //      row ti is one ds_read_b64 per lane (lane l <- s_y[16 ti + (l & 15)][4 ks + (l >> 4)]); B is the same pattern
 //      of tile row tj (B = Y^T).  The global-load latency hides under the matrix-core phase.
 // Partials: spart[q][reg 0..3][g][lane]  (C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg): the second stage reads
-// each (q, reg) slice as ONE contiguous run of G x 512 B.
+// each (q, reg) slice as ONE contiguous run of G x 512 B.  fpart[g] = {max |g_f|, #failed factorisations} of the workgroup.
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+constexpr int kSyrkSuper = 64;  // frames factorised per super-stage (one wavefront, lane = frame)
 
-template <int PPW, int IPT>
-__global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const int* __restrict__ tile_i,
-                                              const int* __restrict__ tile_j, double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int fpc, int FS) {
-  if (!sel_active(sl, false)) return;
-  const double* __restrict__ rec = sel_index(sl) ? rec1 : rec0;
+template <int PPW, int IPT, bool DECIDE>
+__global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse fz, const double* __restrict__ rec0, const double* __restrict__ rec1, double* __restrict__ fbuf, double* __restrict__ fpart,
+                                              const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int fpc, int FS) {
   extern __shared__ __align__(16) double lds[];
+  __shared__ double s_st[MCBA_LMS];
+  __shared__ double s_sum[8];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: keeps the tile bookkeeping out of the exec mask
+  const bool have_state = sl.lms != nullptr;
+  if (have_state && t < MCBA_LMS) s_st[t] = sl.lms[t];
+  if (DECIDE) {
+    // trial scalars: wavefront 0 the robust cost of the trial point (BOTH linearisation buffers are summed -- which one holds
+    // the trial point depends on the state, and a dependent round trip costs more than the few KB), wavefronts 1..3 the
+    // three back-substitution sums.  Same order of additions in every workgroup: bit-identical decisions.
+    const double *pa, *pb;
+    int stride = 1, count, inner = 1 << 30;
+    size_t outer = 0;
+    if (wave == 0) { pa = fz.cp0; pb = fz.cp1; count = fz.ncp; inner = fz.cinner; outer = fz.couter; }
+    else { pa = pb = fz.bpart + (wave - 1); stride = 3; count = fz.nbp; }
+    const bool two = pa != pb;  // wave-uniform
+    double sa = 0.0, sb = 0.0;
+    for (int base = 0; base < count; base += 512) {
+      double va[8], vb[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = base + lane + 64 * k;
+        const int hi = idx / inner, lo = idx - hi * inner;
+        const size_t at = (size_t)hi * outer + (size_t)lo * stride;
+        va[k] = idx < count ? pa[at] : 0.0;
+        vb[k] = (two && idx < count) ? pb[at] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sa += va[k]; sb += vb[k]; }
+    }
+    sa = wave_sum63(sa);
+    sb = wave_sum63(sb);
+    if (lane == 63) { s_sum[wave] = sa; s_sum[4 + wave] = sb; }
+  }
+  __syncthreads();
+  if (have_state && s_st[MCBA_LM_DONE] != 0.0) {  // terminated: nothing left to do (uniform) -- but the rest of the tick reads
+    if (DECIDE && blockIdx.x == 0 && blockIdx.y == 0 && t < MCBA_LMS) fz.lms_post[t] = s_st[t];  // the state from the second buffer
+    return;
+  }
+  if (DECIDE) {
+    if (t == 0) {
+      if (s_st[MCBA_LM_SKIP] != 0.0) lm_mark_rebuild(s_st);  // the reduced solve had failed: this tick only rebuilds the system
+      else {
+        const bool trial1 = ((static_cast<int>(s_st[3]) ^ 1) & 1) != 0;  // the trial linearisation lives in the buffer that is not current
+        const double tr[8] = {trial1 ? s_sum[4] : s_sum[0], s_sum[1], s_sum[2], s_sum[3], 0.0, 0.0, 0.0, 0.0};
+        s_sum[0] = tr[0];
+        DecideArgs da = fz.da;
+        da.decide = 2;
+        da.lms = s_st;
+        lm_decide(tr, da);
+      }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && blockIdx.y == 0) {  // publish: later kernels of the tick read the state from here
+      if (t < MCBA_LMS) fz.lms_post[t] = s_st[t];
+      if (t < 4) fz.trial_out[t] = s_sum[t];
+    }
+  }
+  int sidx;
+  double lambda;
+  if (have_state) {
+    const bool spec = sl.spec && s_st[MCBA_LM_SKIP] == 0.0;
+    sidx = (static_cast<int>(s_st[3]) ^ sl.idx ^ (spec ? 1 : 0)) & 1;
+    lambda = spec ? lm_spec_lambda(s_st[1], sl.lam) : s_st[1];
+  } else {
+    sidx = sl.idx;
+    lambda = sl.lam;
+  }
+  const double* __restrict__ rec = sidx ? rec1 : rec0;
   const int n = 12 * C, nfb = Fpad >> 6;
   const int RS = 6 * FS + 2;
   double* s_y = lds;                          // [NT*16][RS]
-  double* s_L = lds + (size_t)NT * 16 * RS;   // [FS][34]: L(21) 1/diag(6) z(6) pad
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: keeps the tile bookkeeping out of the exec mask
+  double* s_L = lds + (size_t)NT * 16 * RS;   // [kSyrkSuper][34]: L(21) 1/diag(6) z(6) pad, one super-stage of frames
 
   int qi[PPW], rowa[PPW], rowb[PPW];
   mfma_d4 acc[PPW];
@@ -574,7 +584,6 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
 
   const int f0 = blockIdx.x * fpc, f1 = min(F, f0 + fpc);
   double wreg[IPT][6];
-  double lreg[2];  // FS*27 <= 512 values of (L, z) per stage, two per thread
 
   // thread = (frame b of the stage, row group): its IPT items are rows r0, r0 + 256/FS, ... of the SAME frame, so that
   // frame's L and 1/diag are read from LDS once per stage instead of once per item
@@ -590,11 +599,67 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
         for (int k = 0; k < 3; ++k) { double2 v = w2[k * 64]; wreg[it][2 * k] = v.x; wreg[it][2 * k + 1] = v.y; }
       }
     }
+  };
+  // frame factors of one super-stage: wavefront 0, lane = frame s0 + lane
+  double gmax = 0.0, nfail = 0.0;
+  auto factor = [&](int s0, int ns) {
+    const bool on = lane < ns;
+    const int f = on ? s0 + lane : s0;  // idle lanes load a duplicate, store nothing
+    double V[28];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int i = t + 256 * j;
-      int b = i / 27, k = i - b * 27, f = fb + b;
-      lreg[j] = (i < FS * 27 && f < F) ? fbuf[(size_t)f * MCBA_FB + k] : 0.0;
+    for (int k = 0; k < 28; ++k) V[k] = 0.0;
+    constexpr int CB = 2;  // cameras per batch: 28 loads in flight per lane (the kernel must stay within 256 registers: two workgroups per CU)
+    for (int c0 = 0; c0 < C; c0 += CB) {
+      double2 tt[CB][14];
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        const int cc = min(c0 + j, C - 1);  // clamped duplicate loads are ignored below
+        const double2* r2 = reinterpret_cast<const double2*>(rec + ((size_t)cc * nfb + (f >> 6)) * (MCBA_REC * 64)) + 36 * 64 + (f & 63);
+#pragma unroll
+        for (int k = 0; k < 14; ++k) tt[j][k] = r2[k * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j < C) {
+#pragma unroll
+          for (int k = 0; k < 14; ++k) { V[2 * k] += tt[j][k].x; V[2 * k + 1] += tt[j][k].y; }
+        }
+      }
+    }
+    double* row = s_L + lane * 34;
+    if (on) {
+      double* gf = V + 21;
+      double D[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        double d = V[tri6(k, k)];
+        D[k] = d > 0.0 ? d : 1.0;
+        V[tri6(k, k)] = d + lambda * D[k];
+      }
+      double Lp[21], id[6], z[6];
+      const bool ok = chol6i(V, Lp);  // diagonal slots: 1 / L_ii
+#pragma unroll
+      for (int k = 0; k < 6; ++k) id[k] = Lp[k * (k + 1) / 2 + k];
+      fwd6(Lp, id, gf, z);
+#pragma unroll
+      for (int k = 0; k < 21; ++k) row[k] = Lp[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { row[21 + k] = id[k]; row[27 + k] = z[k]; gmax = fmax(gmax, fabs(gf[k])); }
+      nfail += ok ? 0.0 : 1.0;
+      if (blockIdx.y == 0) {
+        double o[40];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) o[k] = Lp[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { o[21 + k] = z[k]; o[27 + k] = gf[k]; o[33 + k] = D[k]; }
+        o[39] = 0.0;
+        double* fbp = fbuf + (size_t)(s0 + lane) * MCBA_FB;
+#pragma unroll
+        for (int k = 0; k < 40; k += 2) *reinterpret_cast<double2*>(fbp + k) = make_double2(o[k], o[k + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 33; ++k) row[k] = 0.0;  // frames past the end: Y = 0, z = 0
     }
   };
 
@@ -606,71 +671,62 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
 #define SLAP(i) do { } while (0)
 #endif
   prefetch(f0);
-  for (int fb = f0; fb < f1; fb += FS) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int i = t + 256 * j;
-      if (i < FS * 27) {
-        int b = i / 27, k = i - b * 27;
-        s_L[b * 34 + (k < 21 ? k : k + 6)] = lreg[j];  // L -> [0,21), z -> [27,33)
-      }
-    }
-    __syncthreads();
-    if (t < FS * 6) {
-      int b = t / 6, k = t - b * 6;
-      s_L[b * 34 + 21 + k] = s_L[b * 34 + k * (k + 1) / 2 + k];  // k_frame_factor stores 1 / L_kk there (0 for padding frames)
-    }
+  for (int s0 = f0; s0 < f1; s0 += kSyrkSuper) {
+    const int s1 = min(f1, s0 + kSyrkSuper);
+    if (wave == 0) factor(s0, s1 - s0);
     __syncthreads();
     SLAP(0);
-    {
-      double Lr[27];
-      const double* Lp = s_L + tb * 34;
+    for (int fb = s0; fb < s1; fb += FS) {
+      {
+        double Lr[27];
+        const double* Lp = s_L + (fb - s0 + tb) * 34;
 #pragma unroll
-      for (int k = 0; k < 27; ++k) Lr[k] = Lp[k];
-      const bool live = fb + tb < F;
+        for (int k = 0; k < 27; ++k) Lr[k] = Lp[k];
+        const bool live = fb + tb < F;
 #pragma unroll
-      for (int it = 0; it < IPT; ++it) {
-        const int row = tr0 + rstep * it;
-        if (row <= n) {
-          double* dst = s_y + (size_t)row * RS + tb * 6;
-          if (row < n) {
-            double yr[6];
-            fwd6(Lr, Lr + 21, wreg[it], yr);
+        for (int it = 0; it < IPT; ++it) {
+          const int row = tr0 + rstep * it;
+          if (row <= n) {
+            double* dst = s_y + (size_t)row * RS + tb * 6;
+            if (row < n) {
+              double yr[6];
+              fwd6(Lr, Lr + 21, wreg[it], yr);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) dst[k] = live ? yr[k] : 0.0;
-          } else {
+              for (int k = 0; k < 6; ++k) dst[k] = live ? yr[k] : 0.0;
+            } else {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) dst[k] = Lp[27 + k];  // z_f (zero for padding frames)
+              for (int k = 0; k < 6; ++k) dst[k] = Lp[27 + k];  // z_f (zero for padding frames)
+            }
           }
         }
       }
-    }
-    __syncthreads();
-    SLAP(1);
-    if (fb + FS < f1) prefetch(fb + FS);  // flies while the matrix cores work
-    // matrix-core phase: K = 6 FS in steps of 4 (6 FS / 4 is even for every FS we use).  Operands of step ks+1 are
-    // read from LDS while the PPW independent MFMAs of step ks issue back to back (64 cycles each on one SIMD).
-    const int nks = (6 * FS) / 4;
-    // (Measured: skipping the LDS read of a fragment that a neighbouring pair already holds -- wave-uniform branches
-    // between the MFMAs -- costs more than the bandwidth it saves: 55k vs 33k cycles for this phase.  Keep it branch-free.)
-    double a0[PPW], b0[PPW], a1[PPW], b1[PPW];
+      __syncthreads();
+      SLAP(1);
+      if (fb + FS < f1) prefetch(fb + FS);  // flies while the matrix cores work
+      // matrix-core phase: K = 6 FS in steps of 4 (6 FS / 4 is even for every FS we use).  Operands of step ks+1 are
+      // read from LDS while the PPW independent MFMAs of step ks issue back to back (64 cycles each on one SIMD).
+      const int nks = (6 * FS) / 4;
+      // (Measured: skipping the LDS read of a fragment that a neighbouring pair already holds -- wave-uniform branches
+      // between the MFMAs -- costs more than the bandwidth it saves: 55k vs 33k cycles for this phase.  Keep it branch-free.)
+      double a0[PPW], b0[PPW], a1[PPW], b1[PPW];
 #pragma unroll
-    for (int k = 0; k < PPW; ++k) { a0[k] = s_y[rowa[k]]; b0[k] = s_y[rowb[k]]; }
-    for (int ks = 0; ks < nks; ks += 2) {
+      for (int k = 0; k < PPW; ++k) { a0[k] = s_y[rowa[k]]; b0[k] = s_y[rowb[k]]; }
+      for (int ks = 0; ks < nks; ks += 2) {
 #pragma unroll
-      for (int k = 0; k < PPW; ++k) { a1[k] = s_y[rowa[k] + 4 * ks + 4]; b1[k] = s_y[rowb[k] + 4 * ks + 4]; }
+        for (int k = 0; k < PPW; ++k) { a1[k] = s_y[rowa[k] + 4 * ks + 4]; b1[k] = s_y[rowb[k] + 4 * ks + 4]; }
 #pragma unroll
-      for (int k = 0; k < PPW; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], b0[k], acc[k], 0, 0, 0);
-      if (ks + 2 < nks) {
+        for (int k = 0; k < PPW; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], b0[k], acc[k], 0, 0, 0);
+        if (ks + 2 < nks) {
 #pragma unroll
-        for (int k = 0; k < PPW; ++k) { a0[k] = s_y[rowa[k] + 4 * ks + 8]; b0[k] = s_y[rowb[k] + 4 * ks + 8]; }
+          for (int k = 0; k < PPW; ++k) { a0[k] = s_y[rowa[k] + 4 * ks + 8]; b0[k] = s_y[rowb[k] + 4 * ks + 8]; }
+        }
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[k], b1[k], acc[k], 0, 0, 0);
       }
-#pragma unroll
-      for (int k = 0; k < PPW; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[k], b1[k], acc[k], 0, 0, 0);
+      SLAP(2);
+      __syncthreads();
+      SLAP(3);
     }
-    SLAP(2);
-    __syncthreads();
-    SLAP(3);
   }
 #ifdef MCBA_SYRK_TIMING
   if (t == 0 && blockIdx.x == 3 && blockIdx.y == 0) {
@@ -679,6 +735,10 @@ __global__ __launch_bounds__(256) void k_syrk(Sel sl, const double* __restrict__
     dbg[4] = (double)(clock64() - tstart);
   }
 #endif
+  if (wave == 0 && blockIdx.y == 0) {
+    const double wm = wave_max(gmax), wn = wave_sum63(nfail);
+    if (lane == 63) { fpart[2 * blockIdx.x] = wm; fpart[2 * blockIdx.x + 1] = wn; }
+  }
 #pragma unroll
   for (int k = 0; k < PPW; ++k) {
     if (qi[k] >= 0) {
@@ -1078,22 +1138,30 @@ void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, 
 
 size_t syrk_lds_bytes(int C, int FS) {
   int NT = (12 * C + 1 + 15) / 16;
-  return ((size_t)NT * 16 * (6 * FS + 2) + (size_t)FS * 34) * sizeof(double);
+  return ((size_t)NT * 16 * (6 * FS + 2) + (size_t)kSyrkSuper * 34) * sizeof(double);
 }
 
 #define SYRK_IPT 5  // (12C+1)*FS <= 256*SYRK_IPT is guaranteed by the choice of FS in mcba_create
+#define SYRK_IPT_SMALL 3
 
-void launch_frame_factor(hipStream_t st, Sel s, const double* rec0, const double* rec1, double* fbuf, double* fpart, int C, int F, int Fpad) {
-  k_frame_factor<<<dim3(Fpad / 64), dim3(64), 0, st>>>(s, rec0, rec1, fbuf, fpart, C, F, Fpad);
-}
-
-void launch_syrk(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw) {
+void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw) {
   size_t lds = syrk_lds_bytes(C, FS);
+#define SYRK_GO(PPW, IPT, GY)                                                                                                                                   \
+  do {                                                                                                                                                          \
+    dim3 grid(G, GY);                                                                                                                                           \
+    if (fz.decide) k_syrk<PPW, IPT, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);   \
+    else k_syrk<PPW, IPT, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);            \
+  } while (0)
+  // items per thread: (12C + 1) rows x FS frames over 256 threads -- 3 is enough up to 7 cameras at 8 frames per stage
+  // (fewer prefetch registers: the kernel stays within 256 registers, two workgroups per CU, without scratch)
+  const bool small = (12 * C + 1) * FS <= 256 * SYRK_IPT_SMALL;
   if (ppw <= 4) {
-    k_syrk<4, SYRK_IPT><<<dim3(G, (NP + 15) / 16), dim3(256), lds, st>>>(s, rec0, rec1, fbuf, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);
+    if (small) SYRK_GO(4, SYRK_IPT_SMALL, (NP + 15) / 16);
+    else SYRK_GO(4, SYRK_IPT, (NP + 15) / 16);
   } else {
-    k_syrk<16, SYRK_IPT><<<dim3(G, (NP + 63) / 64), dim3(256), lds, st>>>(s, rec0, rec1, fbuf, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);
+    SYRK_GO(16, SYRK_IPT, (NP + 63) / 64);
   }
+#undef SYRK_GO
 }
 
 int syrk_items_per_thread() { return SYRK_IPT; }
@@ -1125,9 +1193,15 @@ void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs
 }
 
 int syrk_set_lds_limit(size_t bytes) {
-  int a = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk<4, SYRK_IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  int b = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk<16, SYRK_IPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return a ? a : b;
+  int rc = 0;
+  const void* ks[] = {reinterpret_cast<const void*>(k_syrk<4, SYRK_IPT, false>), reinterpret_cast<const void*>(k_syrk<4, SYRK_IPT, true>),
+                      reinterpret_cast<const void*>(k_syrk<4, SYRK_IPT_SMALL, false>), reinterpret_cast<const void*>(k_syrk<4, SYRK_IPT_SMALL, true>),
+                      reinterpret_cast<const void*>(k_syrk<16, SYRK_IPT, false>), reinterpret_cast<const void*>(k_syrk<16, SYRK_IPT, true>)};
+  for (const void* k : ks) {
+    int r = (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    rc = rc ? rc : r;
+  }
+  return rc;
 }
 
 }  // namespace mcba

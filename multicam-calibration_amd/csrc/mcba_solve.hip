@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
   }
 
   // ---- LM state -> LDS; first-order optimality of the CURRENT point (the reduced system was built there)
-  if (tid < MCBA_LMS) lst[tid] = a.lms[tid];
+  if (tid < MCBA_LMS) lst[tid] = a.lms_in[tid];
   double gm = 0.0;
   for (int i = tid; i < npad; i += NTHREADS) {
     const bool in = i < n, fx = in && fixed && fixed[i];

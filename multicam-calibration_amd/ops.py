@@ -60,6 +60,7 @@ SYMBOLS = [
     ("mcba_comm_unique_id", ctypes.c_int, [ctypes.c_char_p]),
     ("mcba_comm_init", ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     ("mcba_comm_allreduce", ctypes.c_int, [_h, ctypes.c_size_t, ctypes.c_size_t]),
+    ("mcba_comm_count", ctypes.c_int, [_h, _ip]),
     ("mcba_comm_destroy", ctypes.c_int, [_h]),
     ("mcba_get_frame_gradient", ctypes.c_int, [_h, _dp]),
     ("mcba_triangulate", ctypes.c_int, [ctypes.c_int, ctypes.c_size_t, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
@@ -351,6 +352,12 @@ class Problem:
                 self.lib.mcba_comm_destroy(self.handle)
             raise McbaError(-1, "RCCL communicator could not be created on every rank (%s)" % (err or "another rank failed"))
         return rank, world
+
+    def comm_count(self):
+        """Ranks of the directly attached RCCL communicator as RCCL itself reports them (0: none attached)."""
+        n = ctypes.c_int()
+        self._chk(self.lib.mcba_comm_count(self.handle, ctypes.byref(n)))
+        return n.value
 
     def comm_allreduce(self, offset, count):
         rc = self.lib.mcba_comm_allreduce(self.handle, offset, count)

@@ -93,6 +93,26 @@ class DirectRCCL:
         problem.comm_allreduce(problem.nsys, 8)
 
 
+class HostStagedGloo(TorchDistributed):
+    """The same collectives staged through the host over a `gloo` group: for REHEARSALS of the frame-sharded loop with
+    several ranks sharing one GPU (RCCL refuses two ranks on one device) -- tests and `bench.py --gpus N` on a one-GPU box.
+    `.cpu()` synchronises the stream the library launches on (torch's current stream: bundle_adjust / bench pass it in)."""
+
+    def _ar(self, t):
+        c = t.cpu()
+        self.dist.all_reduce(c, group=self.group)
+        t.copy_(c)
+
+    def all_reduce_system(self, problem):
+        self._ar(problem.reduce_tensor[: problem.nsys])
+
+    def all_reduce_trial(self, problem):
+        self._ar(problem.reduce_tensor[problem.nsys : problem.nsys + 8])
+
+    def all_reduce_tick(self, problem):
+        self._ar(problem.reduce_tensor[: problem.nsys + 8])
+
+
 MAX_RANKS = 12  # per-rank max |g_f| slots in the reduce buffer's scalar block (include/mcba.h: scal[4..15])
 
 
@@ -103,6 +123,9 @@ def make_comm(problem, device, group=None, direct=None):
 
     if dist.get_world_size(group) > MAX_RANKS:
         raise ValueError(f"frame-sharded solves support at most {MAX_RANKS} ranks (one max|g_f| slot per rank travels in the SUM all-reduce); got {dist.get_world_size(group)}")
+    if dist.get_backend(group) == "gloo" and str(device) != "cpu":  # rehearsal: ranks share a GPU, collectives via the host
+        problem.enable_collective(device)
+        return HostStagedGloo(group)
     if direct is None:
         direct = os.environ.get("MCBA_DIRECT_RCCL", "1") != "0"
     if direct and hasattr(problem, "comm_init_from_torch"):

@@ -2,7 +2,7 @@
 through libmcba.so -- trial kernels -> all-reduce of the trial scalars -> decision kernel -> Schur reduction ->
 all-reduce of the reduced system -> k_solve_cam -- against the single-process run on the same data.
 RCCL refuses two ranks on one device, so the collectives here are host-staged gloo all-reduces of the very same
-buffers; the RCCL plumbing itself is exercised by the single-rank `nccl` runs of bench.py (MCBA_BENCH_FORCE_DIST=1)."""
+buffers (solver.HostStagedGloo, chosen by solver.make_comm for a gloo group on a CUDA device); the RCCL plumbing itself is exercised by the single-rank `nccl` runs of bench.py (MCBA_BENCH_FORCE_DIST=1)."""
 import os
 import socket
 import sys
@@ -42,36 +42,12 @@ def _worker(rank, world, port, out_dir, mode):
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
 
-    class HostStaged(m.solver.TorchDistributed):
-        """all-reduce of slices of the library's reduce buffer through the host (gloo)"""
-
-        def _ar(self, t):
-            c = t.cpu()
-            dist.all_reduce(c)
-            t.copy_(c)
-
-        def all_reduce_system(self, problem):
-            self._ar(problem.reduce_tensor[: problem.nsys])
-
-        def all_reduce_trial(self, problem):
-            self._ar(problem.reduce_tensor[problem.nsys : problem.nsys + 8])
-
-        def all_reduce_tick(self, problem):
-            self._ar(problem.reduce_tensor[: problem.nsys + 8])
-
-    real_make_comm = m.solver.make_comm
-
-    def make_comm(problem, device, group=None, direct=None):
-        problem.enable_collective(device)
-        return HostStaged(group)
-
-    m.solver.make_comm = make_comm
+    # gloo group + CUDA device: solver.make_comm picks HostStagedGloo (host-staged all-reduces of the library's reduce buffer)
     p = _problem(m)
     with contextlib.redirect_stdout(io.StringIO()):
         e, it, ps, use, res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, device=0,
                                               ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=int(os.environ.get("MCBA_TEST_MAX_NFEV", "100")), verbose=0, distributed=True,
                                               return_jac=False, reduced_solver=mode)
-    m.solver.make_comm = real_make_comm
     np.savez(os.path.join(out_dir, f"{tag}{rank}.npz"), x=res.x, cost=res.cost, nfev=res.nfev, status=res.status, use=use, grad=res.grad,
              rebuilds=res.lm["rebuilds"], steps=res.lm["steps"])
     dist.destroy_process_group()
