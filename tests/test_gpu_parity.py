@@ -544,3 +544,70 @@ def test_full_size_solve_properties(mc):
     scale = np.abs(res4.jac).T @ np.abs(rho1 * f / js)
     assert np.abs(g - res4.grad).max() <= 1e-9 * scale.max()
     del res4
+
+
+# ------------------------------------------------------------------ the inner seam of INTEGRATION.md section 2, executed literally
+def test_inner_seam_scipy_least_squares_over_the_c_abi(golden):
+    """What a reference maintainer can adopt WITHOUT trusting the new optimiser: scipy.optimize.least_squares exactly as
+    bundle_adjustment.py:301-313 calls it, with `fun` served by mcba_residuals and a callable `jac` served by
+    mcba_jacobian_eval + mcba_jacobian_download -- bound with plain ctypes as INTEGRATION.md section 2 shows (not through ops.py).
+    Inputs and expectations: the reference's own default run on config 1 (tests/golden/default_run.npz)."""
+    import ctypes
+    import os
+
+    from scipy.optimize import least_squares
+
+    from conftest import ROOT
+
+    z = golden("default_run.npz")
+    uvs_all, ext, intr, obj, poses = problem_from_npz(z)
+    use = z["use"]
+    all_calib_uvs = np.ascontiguousarray(uvs_all[:, use])
+    calib_objpoints = np.ascontiguousarray(obj)
+    x0 = orc.serialize_params(ext, intr, poses[use])
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "multicam-calibration_amd", "libmcba.so"))
+    dp = ctypes.POINTER(ctypes.c_double)
+    P = lambda a: a.ctypes.data_as(dp)
+    lib.mcba_last_error.restype = ctypes.c_char_p
+
+    def check(rc):
+        if rc:
+            raise RuntimeError(lib.mcba_last_error().decode())
+
+    h = ctypes.c_void_p()
+    C, F, N = all_calib_uvs.shape[:3]
+    check(lib.mcba_create(ctypes.byref(h), C, F, N, 0))
+    check(lib.mcba_upload_observations(h, P(all_calib_uvs), P(calib_objpoints)))
+    check(lib.mcba_set_loss(h, 1, ctypes.c_double(1.0)))
+    mask = ~np.isnan(all_calib_uvs)
+    A = orc.sparsity_csr(all_calib_uvs)   # the pattern of bundle_adjustment.py:101-125 (checked against the reference's in test_oracle_golden)
+    calls = dict(fun=0, jac=0)
+
+    def fun(x, *_):
+        calls["fun"] += 1
+        check(lib.mcba_set_params(h, 0, P(np.ascontiguousarray(x))))
+        r = np.empty((C, F, N, 2))
+        check(lib.mcba_residuals(h, 0, P(r)))
+        return r[mask]
+
+    def jac(x, *_):
+        calls["jac"] += 1
+        check(lib.mcba_set_params(h, 0, P(np.ascontiguousarray(x))))
+        check(lib.mcba_jacobian_eval(h, 0, 0))
+        J = np.empty((C, F, N, 2, 18))
+        check(lib.mcba_jacobian_download(h, P(J), None))
+        return sp.csr_matrix((J[mask].ravel(), A.indices, A.indptr), shape=A.shape)
+
+    res = least_squares(fun, x0, jac=jac, verbose=0, x_scale="jac", ftol=1e-4, method="trf", loss="soft_l1", args=(all_calib_uvs, calib_objpoints))
+    check(lib.mcba_destroy(h))
+    # same optimiser, same problem, exact instead of finite-difference derivatives: the run of the reference is reproduced
+    assert res.status == int(z["status"]) and res.success
+    assert abs(res.cost - float(z["cost"])) <= 1e-5 * float(z["cost"])
+    assert abs(res.nfev - int(z["nfev"])) <= 1 and abs(res.njev - int(z["njev"])) <= 1
+    pa, pb = orc.predict_from_x(res.x, C, obj), orc.predict_from_x(z["x"], C, obj)
+    assert np.abs(pa - pb).max() < 2e-2   # px, both stopped at ftol = 1e-4
+    np.testing.assert_allclose(res.fun, orc.residuals(res.x, all_calib_uvs, obj), rtol=0, atol=1e-10)
+    # and the saving: the reference's path evaluates residuals() nfev + 18 njev times (18 colour groups per Jacobian)
+    assert calls["fun"] == res.nfev and calls["jac"] == res.njev
+    assert calls["fun"] < (int(z["nfev"]) + 18 * int(z["njev"])) / 10
