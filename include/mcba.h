@@ -200,6 +200,31 @@ int mcba_get_frame_gradient(mcba_handle* h, double* host);
  * receives the kernel time measured with HIP events. */
 int mcba_triangulate(int n_cameras, size_t n_points, const double* uvs, const double* cam12, const double* dist5, int iterations, int device, double* out, double* kernel_ms);
 
+/* ---- the wrapper's frame pre-filter (bundle_adjustment.py:265-285) and frame subsets ------------------------ */
+/* Reprojection error |observed - predicted| of every detection at x[slot].  Host outputs, both (C,F) row-major:
+ * mean_cf = np.nanmean over the board points (NaN where the camera does not see the frame), full_cf = number of
+ * points with both coordinates present (== N  <=>  the detection is complete: bundle_adjustment.py:266).  The per-point
+ * errors stay on the GPU for mcba_error_median. */
+int mcba_frame_errors(mcba_handle* h, int slot, double* mean_cf, double* full_cf);
+/* np.nanmedian of those per-point errors over the frames with frame_mask[f] != 0 (F bytes; NULL = all frames): the exact
+ * order statistic (radix select), mean of the two middle values for an even count; *count = number of values. */
+int mcba_error_median(mcba_handle* h, const unsigned char* frame_mask, double* median, double* count);
+/* New handle on the same device / stream holding the observations of n_frames frames of `src` (indices into its frames,
+ * any order, repeats allowed) -- gathered device to device: what bundle_adjust solves on after the pre-filter, without
+ * a second host upload (the reference slices all_calib_uvs[:, use_frames]: bundle_adjustment.py:298,312). */
+int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, int n_frames);
+
+/* ---- geometry helpers and diagnostics around the solver ---------------------------------------- */
+/* undistort_points (geometry.py:328-358 = cv2.undistortPoints(uvs, K, dist, None, K)): n_points (u,v) pairs, K4 = (fx fy cx cy),
+ * dist5 = (k1 k2 p1 p2 k3) or NULL; fixed-point iteration, `iterations` rounds (OpenCV's default: 5).  NaN rows stay NaN. */
+int mcba_undistort_points(size_t n_points, const double* uvs, const double* K4, const double* dist5, int iterations, int device, double* out);
+/* Numeric core of plot_residuals (viz.py:166-186) at x[slot]: per (camera, frame) with a complete detection the
+ * least-squares homography from the undistorted detections to the board plane, the distortion-free reprojection of the
+ * board mapped through it, and per camera the median distance to the board points (board units).
+ * dist5: (C,5) distortion used for undistorting (NULL: (k1, k2, 0, 0, 0) of x[slot]).  Host outputs: median_error (C);
+ * reprojections (C,F,N,2) and transformed (C,F,N,2, NaN where the detection is incomplete) -- either may be NULL. */
+int mcba_reprojection_diagnostics(mcba_handle* h, int slot, const double* dist5, int undistort_iterations, double* median_error, double* reprojections, double* transformed);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* When enabled kernel launches are bracketed by hipEvents on the handle's stream.  `on` = 0: off; 1: every
  * kernel; otherwise a bit mask over the kernels in mcba_profile_names() order, shifted left by one

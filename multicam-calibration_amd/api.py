@@ -58,29 +58,53 @@ def jacobian_structure(all_calib_uvs):
     return idx.ravel(), np.arange(m + 1, dtype=np.int64) * 18, (m, 12 * C + 6 * F), mask
 
 
-def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device=0, backend=None):
-    """The reference's pre-filter (bundle_adjustment.py:265-296); the reprojection pass runs on the GPU."""
-    use_frames = np.nonzero((~np.isnan(all_calib_uvs).any((-1, -2))).sum(0) > 1)[0]
-    sub = all_calib_uvs[:, use_frames]
-    if use_frames.size:
-        prob = (backend or ops.Problem)(sub, calib_objpoints, device=device)
-        prob.set_params(0, serialize_params(all_extrinsics, all_intrinsics, np.asarray(calib_poses)[use_frames]))
-        res = prob.residuals(0)
-        prob.close()
-        res[np.isnan(sub)] = np.nan
-        err = np.sqrt((res**2).sum(-1))  # NaN wherever either coordinate is missing, like norm(obs - pred)
-    else:
-        err = np.empty(sub.shape[:-1])
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", category=RuntimeWarning)
-        worst_mean_err = np.nanmax(np.nanmean(err, axis=-1), axis=0) if use_frames.size else np.empty(0)
+def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device=0, backend=None, keep_problem=False, **problem_kw):
+    """The reference's pre-filter (bundle_adjustment.py:265-296) on the GPU: ALL frames are uploaded once, the reprojection
+    errors, their per-(camera, frame) nan-means, the completeness counts (k_frame_err) and the exact nan-median (radix
+    select) are computed there; the host sees 2 x (C,F) doubles.  Returns use_frames, or (use_frames, problem) with
+    keep_problem=True -- the handle that still holds every frame, for `Problem.subset` (no second upload)."""
+    all_calib_uvs = np.asarray(all_calib_uvs, dtype=np.float64)
+    C, F_all, N = all_calib_uvs.shape[:3]
+    Problem = backend or ops.Problem
+    prob = None
+    if F_all and hasattr(Problem, "frame_errors"):
+        prob = Problem(all_calib_uvs, calib_objpoints, device=device, **problem_kw)
+        prob.set_params(0, serialize_params(all_extrinsics, all_intrinsics, np.asarray(calib_poses, dtype=np.float64)))
+        mean_cf, full_cf = prob.frame_errors(0)
+        use_frames = np.nonzero((full_cf == N).sum(0) > 1)[0]                     # complete in at least two cameras (:266)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=RuntimeWarning)
+            worst_mean_err = np.nanmax(mean_cf[:, use_frames], axis=0) if use_frames.size else np.empty(0)   # (:279)
         if outlier_threshold is None:
-            outlier_threshold = 5 * np.nanmedian(err)
+            mask = np.zeros(F_all, dtype=np.uint8)
+            mask[use_frames] = 1
+            outlier_threshold = 5 * prob.error_median(mask)[0]                    # 5 * np.nanmedian(err)  (:281-282)
+    else:  # CPU test double (tests/fake_problem.py) or no frames at all: the same arithmetic in numpy
+        use_frames = np.nonzero((~np.isnan(all_calib_uvs).any((-1, -2))).sum(0) > 1)[0]
+        sub = all_calib_uvs[:, use_frames]
+        if use_frames.size:
+            fake = Problem(sub, calib_objpoints, device=device)
+            fake.set_params(0, serialize_params(all_extrinsics, all_intrinsics, np.asarray(calib_poses)[use_frames]))
+            res = fake.residuals(0)
+            fake.close()
+            res[np.isnan(sub)] = np.nan
+            err = np.sqrt((res**2).sum(-1))  # NaN wherever either coordinate is missing, like norm(obs - pred)
+        else:
+            err = np.empty(sub.shape[:-1])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=RuntimeWarning)
+            worst_mean_err = np.nanmax(np.nanmean(err, axis=-1), axis=0) if use_frames.size else np.empty(0)
+            if outlier_threshold is None:
+                outlier_threshold = 5 * np.nanmedian(err)
     exclude = np.nan_to_num(worst_mean_err) > outlier_threshold
     use_frames = use_frames[~exclude]
     print(f"Excluding {int(exclude.sum())} out of {len(use_frames)} frames based on an outlier threshold of {outlier_threshold}")
     if not (n_frames is None or n_frames > len(use_frames)):
         use_frames = np.random.choice(use_frames, n_frames, replace=False)
+    if keep_problem:
+        return use_frames, prob
+    if prob is not None:
+        prob.close()
     return use_frames
 
 
@@ -122,8 +146,9 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     calib_poses = np.asarray(calib_poses, dtype=np.float64)
     n_cameras = all_calib_uvs.shape[0]
 
+    prob_all = None
     if not distributed:
-        use_frames = select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device, backend)
+        use_frames, prob_all = select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device, backend, keep_problem=True)
     else:
         # rank 0 owns the reference's frame selection (its printed line and its use of the global numpy RNG)
         box = [select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device, backend) if rank == 0 else None]
@@ -147,9 +172,10 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         if use_frames.size < world:
             raise ValueError(f"{use_frames.size} usable frames cannot be sharded over {world} ranks")
         use_frames = np.array_split(all_use, world)[rank]  # contiguous shard of the selection, in selection order
-    uvs = np.ascontiguousarray(all_calib_uvs[:, use_frames])
     x0 = serialize_params(all_extrinsics, all_intrinsics, calib_poses[use_frames])
     if use_frames.size == 0:
+        if prob_all is not None:
+            prob_all.close()
         # nothing to fit: scipy's least_squares on an empty residual vector returns x0 with status 1 (gtol) after one
         # evaluation (what the reference then returns: bundle_adjustment.py:307-327)
         from scipy.optimize import OptimizeResult
@@ -168,7 +194,13 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         # torch orders its collectives against torch's CURRENT stream: the library must launch on that same stream
         # (the torch.distributed fallback of solver.make_comm all-reduces the library's reduce buffer in place)
         pkw["stream"] = torch.cuda.current_stream(device).cuda_stream
-    prob = (backend or ops.Problem)(uvs, calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0), **pkw)
+    if prob_all is not None:   # the frames are already on the GPU (pre-filter): gather the selection there, no second upload
+        prob = prob_all.subset(use_frames, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0))
+        prob_all.close()
+        uvs = None             # host copy of the selection: only materialised if result.jac / result.fun need the NaN mask
+    else:
+        uvs = np.ascontiguousarray(all_calib_uvs[:, use_frames])
+        prob = (backend or ops.Problem)(uvs, calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0), **pkw)
     comm = None
     if distributed:
         import torch
@@ -189,6 +221,8 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
 
     # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560)
     slot = result.lm["slot"]
+    if uvs is None:
+        uvs = all_calib_uvs[:, use_frames]
     if backend is None and return_jac:
         idx, indptr, shape, mask = jacobian_structure(uvs)  # CSR indices: 0.25 s of numpy at 6 x 10k x 54 -- only when asked for
     else:

@@ -43,6 +43,9 @@ struct mcba_handle {
   double *spart = nullptr, *cpart = nullptr, *bpart = nullptr;
   double *red_own = nullptr, *red = nullptr;
   double *jac = nullptr, *res = nullptr;
+  double *err = nullptr, *dmean = nullptr, *dfull = nullptr, *repro = nullptr, *trans = nullptr, *und = nullptr;  // pre-filter / diagnostics (lazy)
+  unsigned char *sel = nullptr, *fmask = nullptr;
+  double* obj_host = nullptr;  // board points as uploaded (diagnostics normalise them on the host)
   int *tile_i = nullptr, *tile_j = nullptr;
   int NT = 0, NP = 0, G = 0, fpc = 0, FS = 0, ppw = 4, nfblocks = 0, nbblocks = 0, nch = 1;
   int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD (few frames)
@@ -268,7 +271,11 @@ int mcba_destroy(mcba_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.ok) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
-  double* bufs[] = {h->obs_t, h->obs_raw, h->obj, h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->fbuf, h->fpart, h->spart, h->cpart, h->bpart, h->red_own, h->jac, h->res};
+  double* bufs[] = {h->obs_t, h->obs_raw, h->obj, h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->fbuf, h->fpart, h->spart, h->cpart, h->bpart, h->red_own, h->jac, h->res,
+                    h->err, h->dmean, h->dfull, h->repro, h->trans, h->und};
+  if (h->sel) (void)hipFree(h->sel);
+  if (h->fmask) (void)hipFree(h->fmask);
+  free(h->obj_host);
   for (double* p : bufs) if (p) (void)hipFree(p);
   if (h->tile_i) (void)hipFree(h->tile_i);
   if (h->tile_j) (void)hipFree(h->tile_j);
@@ -309,6 +316,8 @@ int mcba_upload_observations(mcba_handle* h, const double* uvs, const double* ob
   if (e == hipSuccess) e = hipGetLastError();
   hipError_t e2 = hipStreamSynchronize(h->stream);
   if (e != hipSuccess || e2 != hipSuccess) { g_err = std::string("upload: ") + hipGetErrorString(e != hipSuccess ? e : e2); return MCBA_ERR_HIP; }
+  if (!h->obj_host) h->obj_host = static_cast<double*>(malloc((size_t)3 * h->N * sizeof(double)));
+  if (h->obj_host) memcpy(h->obj_host, objpoints, (size_t)3 * h->N * sizeof(double));
   h->have_obs = true;
   h->have_lin = h->have_red = h->have_jac = false;
   return MCBA_OK;
@@ -826,6 +835,167 @@ int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state) {
   int sel = (int)state[3];
   if (sel == 0 || sel == 1) h->lin = sel;
   h->have_spec = false;
+  return MCBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bundle_adjust()'s frame pre-filter on the GPU (reference bundle_adjustment.py:265-285) and frame subsets without a second upload
+static int ensure_diag(mcba_handle* h) {
+  int rc;
+  if (!h->err && (rc = dalloc(&h->err, (size_t)h->C * h->N * h->Fpad))) return rc;
+  if (!h->dmean && (rc = dalloc(&h->dmean, std::max<size_t>((size_t)h->C * h->F, 8)))) return rc;
+  if (!h->dfull && (rc = dalloc(&h->dfull, (size_t)h->C * h->F))) return rc;
+  if (!h->sel && (rc = dalloc(&h->sel, mcba::select_state_bytes(h->C)))) return rc;
+  if (!h->fmask && (rc = dalloc(&h->fmask, (size_t)h->Fpad))) return rc;
+  return MCBA_OK;
+}
+
+int mcba_frame_errors(mcba_handle* h, int slot, double* mean_cf, double* full_cf) {
+  if (!slot_ok(h, slot) || !mean_cf || !full_cf) return fail(MCBA_ERR_ARG, "mcba_frame_errors: bad argument");
+  if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_frame_errors: upload observations first");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_diag(h);
+  if (rc) return rc;
+  mcba::launch_frame_err(h->stream, h->obs_t, h->obj, h->x[slot], h->err, h->dmean, h->dfull, h->C, h->F, h->N, h->Fpad);
+  if ((rc = check_launch())) return rc;
+  const size_t cnt = (size_t)h->C * h->F * sizeof(double);
+  HIPCHK(hipMemcpyAsync(mean_cf, h->dmean, cnt, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(full_cf, h->dfull, cnt, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+// nan-median (exact order statistics) of `groups` equal slices of h->err restricted to the frames of h->fmask
+static int median_of_err(mcba_handle* h, size_t per_group, int groups, bool use_mask, double* median, double* count) {
+  struct Sel { unsigned long long prefix, rank, count, value; unsigned int hist[256]; };
+  std::vector<Sel> lo(groups), hi(groups);
+  for (int upper = 0; upper < 2; ++upper) {
+    mcba::launch_select(h->stream, h->err, use_mask ? h->fmask : nullptr, per_group, groups, h->Fpad, h->sel, upper);
+    int rc = check_launch();
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync((upper ? hi : lo).data(), h->sel, (size_t)groups * sizeof(Sel), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  for (int g = 0; g < groups; ++g) {
+    double a, b;
+    memcpy(&a, &lo[g].value, 8);
+    memcpy(&b, &hi[g].value, 8);
+    median[g] = lo[g].count ? 0.5 * (a + b) : NAN;  // np.median / np.nanmedian: mean of the two middle values
+    if (count) count[g] = (double)lo[g].count;
+  }
+  return MCBA_OK;
+}
+
+int mcba_error_median(mcba_handle* h, const unsigned char* frame_mask, double* median, double* count) {
+  if (!h || !median) return fail(MCBA_ERR_ARG, "mcba_error_median: bad argument");
+  if (!h->err) return fail(MCBA_ERR_ARG, "mcba_error_median: call mcba_frame_errors first");
+  HIPCHK(hipSetDevice(h->device));
+  if (frame_mask) {
+    HIPCHK(hipMemsetAsync(h->fmask, 0, (size_t)h->Fpad, h->stream));
+    HIPCHK(hipMemcpyAsync(h->fmask, frame_mask, (size_t)h->F, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return median_of_err(h, (size_t)h->C * h->N * h->Fpad, 1, frame_mask != nullptr, median, count);
+}
+
+int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, int n_frames) {
+  if (!out || !src || !frames || n_frames < 1) return fail(MCBA_ERR_ARG, "mcba_create_subset: bad argument");
+  if (!src->have_obs) return fail(MCBA_ERR_ARG, "mcba_create_subset: the source handle has no observations");
+  for (int i = 0; i < n_frames; ++i)
+    if (frames[i] < 0 || frames[i] >= src->F) return fail(MCBA_ERR_ARG, "mcba_create_subset: frame index out of range");
+  int rc = mcba_create(out, src->C, n_frames, src->N, src->device);
+  if (rc) return rc;
+  mcba_handle* h = *out;
+  h->stream = src->stream;
+  h->loss = src->loss;
+  h->f_scale = src->f_scale;
+  int* d_frames = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_frames), (size_t)n_frames * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_frames, frames, (size_t)n_frames * sizeof(int), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    mcba::launch_gather_frames(h->stream, src->obs_raw, d_frames, h->obs_raw, h->C, src->F, h->F, h->N);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h->obj, src->obj, (size_t)3 * h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+  if (e == hipSuccess) {
+    Scope sc(h, K_TRANSPOSE);
+    mcba::launch_transpose_obs(h->stream, h->obs_raw, h->obs_t, h->C, h->F, h->N, h->Fpad);
+    e = hipGetLastError();
+  }
+  hipError_t e2 = hipStreamSynchronize(h->stream);
+  if (d_frames) (void)hipFree(d_frames);
+  if (e != hipSuccess || e2 != hipSuccess) {
+    g_err = std::string("mcba_create_subset: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+    mcba_destroy(h);
+    *out = nullptr;
+    return MCBA_ERR_HIP;
+  }
+  if (src->obj_host) {
+    h->obj_host = static_cast<double*>(malloc((size_t)3 * h->N * sizeof(double)));
+    if (h->obj_host) memcpy(h->obj_host, src->obj_host, (size_t)3 * h->N * sizeof(double));
+  }
+  h->have_obs = true;
+  return MCBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Reprojection diagnostics: the numeric core of plot_residuals (reference viz.py:166-186)
+int mcba_reprojection_diagnostics(mcba_handle* h, int slot, const double* dist5, int undistort_iterations, double* median_error, double* reprojections, double* transformed) {
+  if (!slot_ok(h, slot) || !median_error || undistort_iterations < 0) return fail(MCBA_ERR_ARG, "mcba_reprojection_diagnostics: bad argument");
+  if (!h->have_obs || !h->obj_host) return fail(MCBA_ERR_ARG, "mcba_reprojection_diagnostics: upload observations first");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_diag(h);
+  if (rc) return rc;
+  const size_t cnt = (size_t)2 * h->C * h->F * h->N;
+  if (reprojections && !h->repro && (rc = dalloc(&h->repro, cnt))) return rc;
+  if (transformed && !h->trans && (rc = dalloc(&h->trans, cnt))) return rc;
+  if (!h->und && (rc = dalloc(&h->und, (size_t)2 * h->C * h->N * h->Fpad))) return rc;
+  std::vector<double> d5((size_t)5 * h->C, 0.0), xc((size_t)12 * h->C);
+  if (dist5) memcpy(d5.data(), dist5, d5.size() * sizeof(double));
+  else {  // (k1, k2, 0, 0, 0) of the parameter vector
+    HIPCHK(hipMemcpyAsync(xc.data(), h->x[slot], xc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int c = 0; c < h->C; ++c) { d5[5 * c] = xc[12 * c + 4]; d5[5 * c + 1] = xc[12 * c + 5]; }
+  }
+  // Hartley normalisation of the board's XY: centroid and sqrt(2) / mean distance
+  double bn[3] = {0.0, 0.0, 1.0};
+  for (int p = 0; p < h->N; ++p) { bn[0] += h->obj_host[3 * p]; bn[1] += h->obj_host[3 * p + 1]; }
+  bn[0] /= h->N; bn[1] /= h->N;
+  double md = 0.0;
+  for (int p = 0; p < h->N; ++p) md += hypot(h->obj_host[3 * p] - bn[0], h->obj_host[3 * p + 1] - bn[1]);
+  bn[2] = md > 0.0 ? sqrt(2.0) * h->N / md : 1.0;
+  double* d_bn = h->dmean;  // three doubles of scratch (the pre-filter's means are host-side by now)
+  HIPCHK(hipMemcpyAsync(d_bn, bn, sizeof(bn), hipMemcpyHostToDevice, h->stream));
+  mcba::launch_reproj_diag(h->stream, h->obs_t, h->obj, h->x[slot], d5.data(), d_bn, h->und, reprojections ? h->repro : nullptr, transformed ? h->trans : nullptr, h->err, h->C, h->F, h->N, h->Fpad,
+                           undistort_iterations, 16);
+  if ((rc = check_launch())) return rc;
+  if ((rc = median_of_err(h, (size_t)h->N * h->Fpad, h->C, false, median_error, nullptr))) return rc;
+  if (reprojections) HIPCHK(hipMemcpyAsync(reprojections, h->repro, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (transformed) HIPCHK(hipMemcpyAsync(transformed, h->trans, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+// undistort_points (reference geometry.py:328-358): stateless; host arrays in, host array out
+int mcba_undistort_points(size_t n_points, const double* uvs, const double* K4, const double* dist5, int iterations, int device, double* out) {
+  if (!uvs || !K4 || !out || iterations < 0) return fail(MCBA_ERR_ARG, "mcba_undistort_points: bad argument");
+  if (n_points == 0) return MCBA_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MCBA_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(MCBA_ERR_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  double *d_in = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_in), 2 * n_points * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), 2 * n_points * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(d_in, uvs, 2 * n_points * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    mcba::launch_undistort(nullptr, d_in, d_out, n_points, K4, dist5, iterations);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, 2 * n_points * sizeof(double), hipMemcpyDeviceToHost);
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) { g_err = std::string("mcba_undistort_points: ") + hipGetErrorString(e); return MCBA_ERR_HIP; }
   return MCBA_OK;
 }
 

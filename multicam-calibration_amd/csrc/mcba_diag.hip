@@ -1,0 +1,437 @@
+// mcba_diag.hip -- what surrounds the solver on the GPU: the reference's frame pre-filter, frame subsets without a second
+// upload, stand-alone undistortion and the numeric core of its reprojection diagnostics.
+//
+//   k_frame_err      bundle_adjust()'s pre-filter (reference bundle_adjustment.py:265-285): per (camera, frame, point) the
+//                    reprojection error |observed - predicted| (NaN where a coordinate is missing), per (camera, frame) its
+//                    nan-mean over the board points and the number of complete points.  Same mapping as k_cost: lane = frame,
+//                    64 consecutive frames per wavefront, loop over the points -> the means are lane-local.
+//   k_sel_hist/pick  exact nan-median of the errors of the selected frames (`5 * np.nanmedian(err)`, :281) without sorting:
+//                    radix select on the bit patterns of the (non-negative) doubles, 8 passes of one byte; histogram in LDS,
+//                    integer atomics only -> the result is the exact order statistic, bit for bit.
+//   k_gather_frames  observations of a frame subset, device to device, for the handle the solver then runs on.
+//   k_undistort      `undistort_points` (geometry.py:328-358): OpenCV's fixed-point iteration for (k1 k2 p1 p2 k3).
+//   k_reproj_diag    `plot_residuals` (viz.py:166-186) without the plotting: distortion-free reprojection of the board,
+//                    least-squares homography from the undistorted detections to the board plane per (camera, frame),
+//                    reprojections mapped through it, distance to the board points.  Lane = (camera, frame).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <algorithm>
+#include "mcba_kernels.h"
+#include "mcba_math.h"
+
+namespace mcba {
+
+__device__ __forceinline__ double diag_uni(double v) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
+
+// ---------------------------------------------------------------- pre-filter errors
+__global__ __launch_bounds__(256) void k_frame_err(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x, double* __restrict__ err,
+                                                   double* __restrict__ mean_cf, double* __restrict__ full_cf, int C, int F, int N, int Fpad, int nfb) {
+  __shared__ CamConst s_cam;
+  const int c = blockIdx.y;
+  if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int fb = blockIdx.x * 4 + wave;
+  if (fb >= nfb) return;
+  const int f = fb * 64 + lane;
+  Intr K;
+  K.fx = diag_uni(s_cam.fx); K.fy = diag_uni(s_cam.fy); K.cx = diag_uni(s_cam.cx); K.cy = diag_uni(s_cam.cy); K.k1 = diag_uni(s_cam.k1); K.k2 = diag_uni(s_cam.k2);
+  double Rc[9], tc[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rc[i] = diag_uni(s_cam.R[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tc[i] = diag_uni(s_cam.t[i]);
+  const double* pose = x + 12 * C + 6 * (size_t)f;  // padding frames: zeros in x, NaN observations
+  double pz[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) pz[i] = pose[i];
+  PairConst pc;
+  {
+    double Rf[9];
+    rot_only(pz, Rf);
+    make_pair_const(Rc, tc, Rf, pz + 3, pc);
+  }
+  const double2* op = obs_t + (size_t)c * N * Fpad + f;
+  double* ep = err + (size_t)c * N * Fpad + f;
+  constexpr int PF = 4;
+  double2 ring[PF];
+#pragma unroll
+  for (int j = 0; j < PF; ++j) ring[j] = op[(size_t)min(j, N - 1) * Fpad];
+  double sum = 0.0, cnt = 0.0, full = 0.0;
+  auto point = [&](double2 o2, int p) {
+    full += (o2.x == o2.x && o2.y == o2.y) ? 1.0 : 0.0;  // completeness looks at the detections only (bundle_adjustment.py:266)
+    const double Xo[3] = {obj[3 * p], obj[3 * p + 1], obj[3 * p + 2]};
+    double up, vp;
+    project_only(K, pc, Xo, up, vp);
+    const double ru = o2.x - up, rv = o2.y - vp;
+    const double e = sqrt(fma(ru, ru, rv * rv));  // NaN if either coordinate is missing, like np.linalg.norm(obs - pred)
+    const bool ok = e == e;
+    sum += ok ? e : 0.0;
+    cnt += ok ? 1.0 : 0.0;
+    ep[(size_t)p * Fpad] = e;
+  };
+  int p = 0;
+  for (; p + PF <= N; p += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const double2 o2 = ring[j];
+      ring[j] = op[(size_t)min(p + j + PF, N - 1) * Fpad];
+      point(o2, p + j);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (p + j < N) point(ring[j], p + j);
+  if (f < F) {
+    mean_cf[(size_t)c * F + f] = cnt > 0.0 ? sum / cnt : __builtin_nan("");  // np.nanmean of an all-NaN row is NaN
+    full_cf[(size_t)c * F + f] = full;
+  }
+}
+
+// ---------------------------------------------------------------- exact order statistic by radix select
+// st: [0] prefix  [1] rank  [2] count of candidates  [3] result bits ; hist 256 x u32 behind it
+struct SelState {
+  unsigned long long prefix, rank, count, value;
+  unsigned int hist[256];
+};
+
+// values: [groups][stride] doubles with the frame index = i % Fpad; mask (per frame) may be nullptr; group g selects the
+// slice [g * per_group, (g + 1) * per_group) (per-camera medians) -- blockIdx.y = group, one SelState per group
+__global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ v, const unsigned char* __restrict__ fmask, size_t per_group, int Fpad, SelState* __restrict__ sts, int pass) {
+  __shared__ unsigned int s_h[256];
+  SelState* st = sts + blockIdx.y;
+  s_h[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned long long prefix = st->prefix;
+  const int shift_hi = 64 - 8 * pass, shift = 56 - 8 * pass;
+  const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(v) + (size_t)blockIdx.y * per_group;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per_group; i += (size_t)gridDim.x * 256) {
+    const unsigned long long k = keys[i];
+    const double d = __longlong_as_double((long long)k);
+    bool ok = d == d;
+    if (fmask) ok = ok && fmask[i % (size_t)Fpad] != 0;
+    if (ok && (pass == 0 || (k >> shift_hi) == prefix)) atomicAdd(&s_h[(unsigned)(k >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  const unsigned int n = s_h[threadIdx.x];
+  if (n) atomicAdd(&st->hist[threadIdx.x], n);
+}
+
+// one thread per group: which byte holds the wanted rank; upper == 0 selects rank (n-1)/2, upper == 1 rank n/2
+__global__ void k_sel_pick(SelState* __restrict__ sts, int pass, int upper) {
+  SelState* st = sts + blockIdx.x;
+  if (threadIdx.x != 0) return;
+  unsigned long long total = 0;
+  for (int b = 0; b < 256; ++b) total += st->hist[b];
+  if (pass == 0) {
+    st->count = total;
+    st->rank = total ? (upper ? total / 2 : (total - 1) / 2) : 0;
+    st->prefix = 0;
+  }
+  unsigned long long r = st->rank, below = 0;
+  int digit = 0;
+  for (int b = 0; b < 256; ++b) {
+    const unsigned long long h = st->hist[b];
+    if (r < below + h) { digit = b; break; }
+    below += h;
+  }
+  st->rank = r - below;
+  st->prefix = (st->prefix << 8) | (unsigned long long)digit;
+  if (pass == 7) st->value = st->prefix;
+  for (int b = 0; b < 256; ++b) st->hist[b] = 0;
+}
+
+// ---------------------------------------------------------------- frame subsets, device to device
+__global__ void k_gather_frames(const double2* __restrict__ src, const int* __restrict__ frames, double2* __restrict__ dst, int C, int Fsrc, int Fdst, int N) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)C * Fdst * N;
+  if (i >= total) return;
+  const int p = (int)(i % N);
+  const size_t cf = i / N;
+  const int f = (int)(cf % Fdst), c = (int)(cf / Fdst);
+  dst[i] = src[((size_t)c * Fsrc + frames[f]) * N + p];
+}
+
+// ---------------------------------------------------------------- undistortion (cv2.undistortPoints(src, K, dist, None, K))
+__device__ __forceinline__ void undistort_px(double u, double v, double fx, double fy, double cx, double cy, const double* k, int iters, double& uo, double& vo) {
+  const double x0 = (u - cx) / fx, y0 = (v - cy) / fy;
+  double x = x0, y = y0;
+  for (int it = 0; it < iters; ++it) {
+    const double r2 = fma(x, x, y * y);
+    const double icdist = 1.0 / fma(fma(fma(k[4], r2, k[1]), r2, k[0]), r2, 1.0);
+    const double dx = fma(2.0 * k[2] * x, y, k[3] * fma(2.0 * x, x, r2));
+    const double dy = fma(k[2], fma(2.0 * y, y, r2), 2.0 * k[3] * x * y);
+    x = (x0 - dx) * icdist;
+    y = (y0 - dy) * icdist;
+  }
+  uo = fma(x, fx, cx);
+  vo = fma(y, fy, cy);
+}
+
+struct UndistCam {
+  double K[4];
+  double dist[5];
+};
+
+__global__ __launch_bounds__(256) void k_undistort(const double2* __restrict__ uv, double2* __restrict__ out, size_t n, UndistCam cam, int iters) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double2 o = uv[i];
+  double2 r;
+  undistort_px(o.x, o.y, cam.K[0], cam.K[1], cam.K[2], cam.K[3], cam.dist, iters, r.x, r.y);
+  const bool ok = o.x == o.x && o.y == o.y;  // a point with a missing coordinate stays NaN in both (geometry.py:351-352)
+  r.x = ok ? r.x : __builtin_nan("");
+  r.y = ok ? r.y : __builtin_nan("");
+  out[i] = r;
+}
+
+// ---------------------------------------------------------------- reprojection diagnostics
+// 8x8 symmetric positive definite solve in registers (upper triangle packed row-major), in place on b
+__device__ __forceinline__ int tri8(int i, int j) { return i * 8 - (i * (i - 1)) / 2 + (j - i); }
+__device__ __forceinline__ bool chol_solve8(double* A, double* b) {
+  bool ok = true;
+  // A = L L^T, L stored over the upper triangle as L^T (row i = column i of L)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = i; j < 8; ++j) {
+      double s = A[tri8(i, j)];
+#pragma unroll
+      for (int k = 0; k < i; ++k) s = fma(-A[tri8(k, i)], A[tri8(k, j)], s);
+      if (j == i) {
+        ok = ok && s > 0.0;
+        A[tri8(i, i)] = sqrt(s > 0.0 ? s : 1.0);
+      } else {
+        A[tri8(i, j)] = s / A[tri8(i, i)];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s = fma(-A[tri8(k, i)], b[k], s);
+    b[i] = s / A[tri8(i, i)];
+  }
+#pragma unroll
+  for (int i = 7; i >= 0; --i) {
+    double s = b[i];
+#pragma unroll
+    for (int k = i + 1; k < 8; ++k) s = fma(-A[tri8(i, k)], b[k], s);
+    b[i] = s / A[tri8(i, i)];
+  }
+  return ok;
+}
+
+struct DiagCams {   // distortion of every camera (the solver's parameter vector carries k1, k2 only)
+  double dist[40][5];
+};
+
+// lane = (camera c, frame f).  obs_t [C][N][Fpad]; x = parameter vector; board = objpoints (N,3), bn = {mean x, mean y, scale}
+// of the board's XY (Hartley normalisation, computed once on the host); und [C][N][Fpad] (u,v) scratch for the undistorted
+// detections.  Outputs (C,F,N,2): repro (distortion-free projection), trans (reprojection mapped to the board plane; NaN for
+// (camera, frame) pairs with an incomplete detection), and err [C][N][Fpad] = |trans - board| (NaN likewise) for the
+// per-camera medians.
+// Homography: normalised inhomogeneous DLT (h33 = 1; 8x8 normal equations) as the start, then Levenberg-Marquardt on the
+// transfer error in the board plane -- the quantity OpenCV's findHomography refines -- with a FIXED number of rounds (every
+// lane runs the same instruction stream; a rejected step only raises that lane's damping).
+__global__ __launch_bounds__(256) void k_reproj_diag(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x, DiagCams dc, const double* __restrict__ bn,
+                                                     double2* __restrict__ und, double* __restrict__ repro, double* __restrict__ trans, double* __restrict__ err, int C, int F, int N, int Fpad, int nfb, int iters,
+                                                     int lm_iters) {
+  __shared__ CamConst s_cam;
+  const int c = blockIdx.y;
+  if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int fb = blockIdx.x * 4 + wave;
+  if (fb >= nfb) return;
+  const int f = fb * 64 + lane;
+  const double fx = diag_uni(s_cam.fx), fy = diag_uni(s_cam.fy), cx = diag_uni(s_cam.cx), cy = diag_uni(s_cam.cy);
+  double Rc[9], tc[3], kd[5];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rc[i] = diag_uni(s_cam.R[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tc[i] = diag_uni(s_cam.t[i]);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) kd[i] = dc.dist[c][i];
+  const double* pose = x + 12 * C + 6 * (size_t)f;
+  double pz[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) pz[i] = pose[i];
+  PairConst pc;
+  {
+    double Rf[9];
+    rot_only(pz, Rf);
+    make_pair_const(Rc, tc, Rf, pz + 3, pc);
+  }
+  const double2* op = obs_t + (size_t)c * N * Fpad + f;
+  double2* up = und + (size_t)c * N * Fpad + f;
+  const double bmx = bn[0], bmy = bn[1], bs = bn[2];
+
+  // pass 1: undistort; is the detection complete (viz.py:171: all 2N scalars present)?  centroid, then scale (Hartley)
+  bool complete = f < F;
+  double mx = 0.0, my = 0.0;
+  for (int p = 0; p < N; ++p) {
+    const double2 o = op[(size_t)p * Fpad];
+    complete = complete && o.x == o.x && o.y == o.y;
+    double2 u;
+    undistort_px(o.x, o.y, fx, fy, cx, cy, kd, iters, u.x, u.y);
+    up[(size_t)p * Fpad] = u;
+    mx += u.x; my += u.y;
+  }
+  mx /= N; my /= N;
+  double md = 0.0;
+  for (int p = 0; p < N; ++p) {
+    const double2 u = up[(size_t)p * Fpad];
+    md += sqrt(fma(u.x - mx, u.x - mx, (u.y - my) * (u.y - my)));
+  }
+  const double ss = complete ? sqrt(2.0) * N / md : 1.0;
+  // point p in normalised coordinates; incomplete lanes work on (0, 0): finite arithmetic, results discarded
+  auto src = [&](int p, double& sx, double& sy, double& X, double& Y) {
+    const double2 u = up[(size_t)p * Fpad];
+    sx = complete ? (u.x - mx) * ss : 0.0;
+    sy = complete ? (u.y - my) * ss : 0.0;
+    X = (obj[3 * p] - bmx) * bs;
+    Y = (obj[3 * p + 1] - bmy) * bs;
+  };
+  double h[8];
+  {  // start: rows [s 1 0 0 0 -X s] h = X, [0 0 0 s 1 -Y s] h = Y  (s = (sx, sy))
+    double A[36], b[8];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = 0.0;
+    for (int p = 0; p < N; ++p) {
+      double sx, sy, X, Y;
+      src(p, sx, sy, X, Y);
+      const double r0[8] = {sx, sy, 1.0, 0.0, 0.0, 0.0, -X * sx, -X * sy};
+      const double r1[8] = {0.0, 0.0, 0.0, sx, sy, 1.0, -Y * sx, -Y * sy};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = i; j < 8; ++j) A[tri8(i, j)] = fma(r0[i], r0[j], fma(r1[i], r1[j], A[tri8(i, j)]));
+        b[i] = fma(r0[i], X, fma(r1[i], Y, b[i]));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) A[tri8(i, i)] = complete ? A[tri8(i, i)] : 1.0;
+    const bool ok = chol_solve8(A, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = ok ? b[i] : ((i == 0 || i == 4) ? 1.0 : 0.0);  // degenerate detection: start from the identity
+  }
+  auto transfer_error = [&](const double* hh) {
+    double e = 0.0;
+    for (int p = 0; p < N; ++p) {
+      double sx, sy, X, Y;
+      src(p, sx, sy, X, Y);
+      const double iw = 1.0 / fma(hh[6], sx, fma(hh[7], sy, 1.0));
+      const double ex = X - fma(hh[0], sx, fma(hh[1], sy, hh[2])) * iw, ey = Y - fma(hh[3], sx, fma(hh[4], sy, hh[5])) * iw;
+      e = fma(ex, ex, fma(ey, ey, e));
+    }
+    return e;
+  };
+  double e_cur = transfer_error(h), mu = 1e-4;
+  for (int it = 0; it < lm_iters; ++it) {
+    double A[36], g[8];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = 0.0;
+    for (int p = 0; p < N; ++p) {
+      double sx, sy, X, Y;
+      src(p, sx, sy, X, Y);
+      const double iw = 1.0 / fma(h[6], sx, fma(h[7], sy, 1.0));
+      const double px = fma(h[0], sx, fma(h[1], sy, h[2])) * iw, py = fma(h[3], sx, fma(h[4], sy, h[5])) * iw;
+      const double r0[8] = {sx * iw, sy * iw, iw, 0.0, 0.0, 0.0, -px * sx * iw, -px * sy * iw};
+      const double r1[8] = {0.0, 0.0, 0.0, sx * iw, sy * iw, iw, -py * sx * iw, -py * sy * iw};
+      const double ex = X - px, ey = Y - py;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = i; j < 8; ++j) A[tri8(i, j)] = fma(r0[i], r0[j], fma(r1[i], r1[j], A[tri8(i, j)]));
+        g[i] = fma(r0[i], ex, fma(r1[i], ey, g[i]));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) A[tri8(i, i)] = complete ? A[tri8(i, i)] * (1.0 + mu) : 1.0;   // Marquardt damping
+    const bool ok = chol_solve8(A, g);
+    double hn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hn[i] = h[i] + (ok ? g[i] : 0.0);
+    const double e_new = transfer_error(hn);
+    const bool accept = ok && e_new <= e_cur;   // (NaN compares false)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = accept ? hn[i] : h[i];
+    e_cur = accept ? e_new : e_cur;
+    mu = accept ? fmax(mu * 0.1, 1e-15) : fmin(mu * 10.0, 1e8);
+  }
+  // last pass: distortion-free projection of the board (viz.py:166-168) mapped through the homography, distance to the board
+  const double nan = __builtin_nan("");
+  double* ep = err + (size_t)c * N * Fpad + f;
+  for (int p = 0; p < N; ++p) {
+    const double Xo[3] = {obj[3 * p], obj[3 * p + 1], obj[3 * p + 2]};
+    const double xc = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], fma(pc.Rcf[2], Xo[2], pc.tcf[0])));
+    const double yc = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], fma(pc.Rcf[5], Xo[2], pc.tcf[1])));
+    const double zc = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], fma(pc.Rcf[8], Xo[2], pc.tcf[2])));
+    const double ru = fma(fx, xc / zc, cx), rv = fma(fy, yc / zc, cy);
+    const double sx = (ru - mx) * ss, sy = (rv - my) * ss;
+    const double iw = 1.0 / fma(h[6], sx, fma(h[7], sy, 1.0));
+    const double tx = fma(h[0], sx, fma(h[1], sy, h[2])) * iw / bs + bmx, ty = fma(h[3], sx, fma(h[4], sy, h[5])) * iw / bs + bmy;
+    const double e = sqrt(fma(tx - Xo[0], tx - Xo[0], (ty - Xo[1]) * (ty - Xo[1])));
+    ep[(size_t)p * Fpad] = complete ? e : nan;
+    if (f < F) {
+      const size_t o = (((size_t)c * F + f) * N + p) * 2;
+      if (repro) { repro[o] = ru; repro[o + 1] = rv; }
+      if (trans) { trans[o] = complete ? tx : nan; trans[o + 1] = complete ? ty : nan; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- launch wrappers
+void launch_frame_err(hipStream_t st, const double* obs_t, const double* obj, const double* x, double* err, double* mean_cf, double* full_cf, int C, int F, int N, int Fpad) {
+  const int nfb = Fpad / 64;
+  k_frame_err<<<dim3((nfb + 3) / 4, C), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, err, mean_cf, full_cf, C, F, N, Fpad, nfb);
+}
+
+size_t select_state_bytes(int groups) { return (size_t)groups * sizeof(SelState); }
+
+// median(s) of `groups` equal slices of v (per_group doubles each, frame = index % Fpad): after the call sel[g].count and
+// sel[g].value (bit pattern of the order statistic) are valid.  16 tiny launches per call, no host synchronisation.
+void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int groups, int Fpad, void* sel, int upper) {
+  SelState* s = static_cast<SelState*>(sel);
+  (void)hipMemsetAsync(s, 0, select_state_bytes(groups), st);
+  const unsigned bx = (unsigned)std::min<size_t>((per_group + 255) / 256, 1024);
+  for (int pass = 0; pass < 8; ++pass) {
+    k_sel_hist<<<dim3(bx, groups), dim3(256), 0, st>>>(v, fmask, per_group, Fpad, s, pass);
+    k_sel_pick<<<dim3(groups), dim3(64), 0, st>>>(s, pass, upper);
+  }
+}
+
+void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N) {
+  const size_t total = (size_t)C * Fdst * N;
+  k_gather_frames<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(src_raw), frames, reinterpret_cast<double2*>(dst_raw), C, Fsrc, Fdst, N);
+}
+
+void launch_undistort(hipStream_t st, const double* uv, double* out, size_t n, const double* K4, const double* dist5, int iters) {
+  UndistCam cam;
+  for (int i = 0; i < 4; ++i) cam.K[i] = K4[i];
+  for (int i = 0; i < 5; ++i) cam.dist[i] = dist5 ? dist5[i] : 0.0;
+  k_undistort<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(uv), reinterpret_cast<double2*>(out), n, cam, iters);
+}
+
+void launch_reproj_diag(hipStream_t st, const double* obs_t, const double* obj, const double* x, const double* dist5, const double* bn, double* und, double* repro, double* trans, double* err, int C, int F, int N,
+                        int Fpad, int iters, int lm_iters) {
+  DiagCams dc;
+  for (int c = 0; c < C; ++c)
+    for (int i = 0; i < 5; ++i) dc.dist[c][i] = dist5[5 * c + i];
+  const int nfb = Fpad / 64;
+  k_reproj_diag<<<dim3((nfb + 3) / 4, C), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, dc, bn, reinterpret_cast<double2*>(und), repro, trans, err, C, F, N, Fpad, nfb, iters, lm_iters);
+}
+
+}  // namespace mcba

@@ -74,6 +74,14 @@ void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);
 int syrk_set_lds_limit(size_t bytes);
+// pre-filter, frame subsets, undistortion, reprojection diagnostics (mcba_diag.hip)
+void launch_frame_err(hipStream_t st, const double* obs_t, const double* obj, const double* x, double* err, double* mean_cf, double* full_cf, int C, int F, int N, int Fpad);
+size_t select_state_bytes(int groups);  // per group: u64 prefix, rank, count, value (bit pattern of the selected double) + a 256-bin histogram
+void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int groups, int Fpad, void* sel, int upper);
+void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N);
+void launch_undistort(hipStream_t st, const double* uv, double* out, size_t n, const double* K4, const double* dist5, int iters);
+void launch_reproj_diag(hipStream_t st, const double* obs_t, const double* obj, const double* x, const double* dist5, const double* bn, double* und, double* repro, double* trans, double* err, int C, int F, int N,
+                        int Fpad, int iters, int lm_iters);
 // triangulation (mcba_triangulate.hip): up to 8 cameras; P = K [R | t] row-major 3x4, K = (fx, fy, cx, cy), dist = (k1 k2 p1 p2 k3)
 struct TriCams {
   double P[8][12];

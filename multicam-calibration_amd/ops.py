@@ -63,6 +63,11 @@ SYMBOLS = [
     ("mcba_comm_count", ctypes.c_int, [_h, _ip]),
     ("mcba_comm_destroy", ctypes.c_int, [_h]),
     ("mcba_get_frame_gradient", ctypes.c_int, [_h, _dp]),
+    ("mcba_frame_errors", ctypes.c_int, [_h, ctypes.c_int, _dp, _dp]),
+    ("mcba_error_median", ctypes.c_int, [_h, ctypes.c_char_p, _dp, _dp]),
+    ("mcba_create_subset", ctypes.c_int, [ctypes.POINTER(_h), _h, _ip, ctypes.c_int]),
+    ("mcba_undistort_points", ctypes.c_int, [ctypes.c_size_t, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp]),
+    ("mcba_reprojection_diagnostics", ctypes.c_int, [_h, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp, _dp]),
     ("mcba_triangulate", ctypes.c_int, [ctypes.c_int, ctypes.c_size_t, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
     ("mcba_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_profile_stride", ctypes.c_int, [_h, ctypes.c_int]),
@@ -131,6 +136,9 @@ class Problem:
             self._chk(self.lib.mcba_set_stream(self.handle, ctypes.c_void_p(int(stream))))
         self._chk(self.lib.mcba_upload_observations(self.handle, _p(uvs), _p(objpoints)))
         self.set_loss(loss, f_scale)
+        self._init_host_views()
+
+    def _init_host_views(self):
         self.nsys = self.n * self.n + 3 * self.n + 16
         self._all = np.zeros(self.nsys + 8 + LM_STATE)   # system | trial scalars | LM state, as the device lays them out
         self._red = self._all[: self.nsys]
@@ -140,6 +148,47 @@ class Problem:
         self._red_views = self.split_reduced(self._red)
         self._dc = np.empty(self.n)
         self._dc_p = _p(self._dc)
+
+    # ---- frame pre-filter on the GPU + frame subsets without a second upload (bundle_adjustment.py:265-298)
+    def frame_errors(self, slot):
+        """(mean_cf, full_cf), both (C,F): nan-mean reprojection error per (camera, frame) and number of complete points."""
+        mean = np.empty((self.C, self.F))
+        full = np.empty((self.C, self.F))
+        self._chk(self.lib.mcba_frame_errors(self.handle, slot, _p(mean), _p(full)))
+        return mean, full
+
+    def error_median(self, frame_mask=None):
+        """np.nanmedian of the per-point errors of the last frame_errors() over the masked frames -> (median, count)."""
+        med, cnt = ctypes.c_double(), ctypes.c_double()
+        m = None if frame_mask is None else np.ascontiguousarray(frame_mask, dtype=np.uint8).tobytes()
+        self._chk(self.lib.mcba_error_median(self.handle, m, ctypes.byref(med), ctypes.byref(cnt)))
+        return med.value, int(cnt.value)
+
+    def subset(self, frames, loss=None, f_scale=None):
+        """A new Problem holding the observations of `frames` (indices into this one), gathered on the GPU."""
+        idx = np.ascontiguousarray(frames, dtype=np.int32)
+        new = Problem.__new__(Problem)
+        new.lib = self.lib
+        new.C, new.N, new.F = self.C, self.N, int(idx.size)
+        new.n = self.n
+        new.nx = 12 * new.C + 6 * new.F
+        new.handle = _h()
+        self._chk(self.lib.mcba_create_subset(ctypes.byref(new.handle), self.handle, idx.ctypes.data_as(_ip), int(idx.size)))
+        if loss is not None:
+            new.set_loss(loss, 1.0 if f_scale is None else f_scale)
+        new._init_host_views()
+        return new
+
+    def reprojection_diagnostics(self, slot, dist5=None, undistort_iterations=5, arrays=True):
+        """(median_error (C,), reprojections (C,F,N,2), transformed_reprojections (C,F,N,2)) as plot_residuals computes them
+        (viz.py:166-186); the two arrays are None when arrays=False."""
+        med = np.empty(self.C)
+        rep = np.empty((self.C, self.F, self.N, 2)) if arrays else None
+        tra = np.empty((self.C, self.F, self.N, 2)) if arrays else None
+        d5 = None if dist5 is None else _f64(dist5).reshape(self.C, 5)
+        self._chk(self.lib.mcba_reprojection_diagnostics(self.handle, slot, None if d5 is None else _p(d5), int(undistort_iterations), _p(med),
+                                                         None if rep is None else _p(rep), None if tra is None else _p(tra)))
+        return med, rep, tra
 
     def _chk(self, rc):
         if rc != OK:
@@ -400,3 +449,16 @@ class Problem:
         nk = ctypes.c_int()
         self._chk(self.lib.mcba_profile_read(self.handle, ms, calls, len(names), ctypes.byref(nk)))
         return {names[i]: (ms[i], calls[i]) for i in range(nk.value)}
+
+
+def undistort_points(uvs, K4, dist5=None, iterations=5, device=0):
+    """(…,2) pixel coordinates -> undistorted pixel coordinates (same camera matrix); NaN rows stay NaN."""
+    lib = load_library()
+    a = _f64(uvs)
+    out = np.empty_like(a)
+    k = _f64(K4)
+    d = None if dist5 is None else _f64(dist5)
+    rc = lib.mcba_undistort_points(a.size // 2, _p(a), _p(k), None if d is None else _p(d), int(iterations), int(device), _p(out))
+    if rc != OK:
+        raise McbaError(rc, lib.mcba_last_error().decode())
+    return out
