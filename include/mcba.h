@@ -196,7 +196,8 @@ int mcba_get_frame_gradient(mcba_handle* h, double* host);
  * Stateless: uvs (C, P, 2) detections (NaN = unseen), cam12 (C, 12) camera blocks in the parameter layout above,
  * dist5 (C, 5) OpenCV distortion (k1 k2 p1 p2 k3) or NULL (then k1, k2 of cam12), iterations of the undistortion
  * fixed point (OpenCV's default: 5).  out (P, 3): per-coordinate nan-median over all camera pairs of the linear (DLT)
- * two-view triangulations, NaN where fewer than two cameras see the point.  2 <= C <= 8.  kernel_ms (may be NULL)
+ * two-view triangulations, NaN where fewer than two cameras see the point.  2 <= C <= 64 (up to 8 cameras: one lane per point,
+ * everything in registers; beyond: one wavefront per point, the camera pairs across its lanes).  kernel_ms (may be NULL)
  * receives the kernel time measured with HIP events. */
 int mcba_triangulate(int n_cameras, size_t n_points, const double* uvs, const double* cam12, const double* dist5, int iterations, int device, double* out, double* kernel_ms);
 

@@ -1002,37 +1002,49 @@ int mcba_undistort_points(size_t n_points, const double* uvs, const double* K4, 
 // ---------------------------------------------------------------------------------------------------------
 // Robust triangulation (reference geometry.py:361-433): stateless; host arrays in, host array out.
 int mcba_triangulate(int n_cameras, size_t n_points, const double* uvs, const double* cam12, const double* dist5, int iterations, int device, double* out, double* kernel_ms) {
-  if (n_cameras < 2 || n_cameras > 8 || !uvs || !cam12 || !out || iterations < 0) return fail(MCBA_ERR_ARG, "mcba_triangulate: 2..8 cameras, non-NULL arrays, iterations >= 0 required");
+  if (n_cameras < 2 || n_cameras > 64 || !uvs || !cam12 || !out || iterations < 0) return fail(MCBA_ERR_ARG, "mcba_triangulate: 2..64 cameras, non-NULL arrays, iterations >= 0 required");
   if (n_points == 0) return MCBA_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MCBA_ERR_NODEVICE, "no HIP device visible");
   if (device < 0 || device >= ndev) return fail(MCBA_ERR_ARG, "device ordinal out of range");
   HIPCHK(hipSetDevice(device));
-  mcba::TriCams cams;
-  memset(&cams, 0, sizeof(cams));
+  // per camera {P = K [R | t] (12), K (4), dist (5)}: kernel arguments for the register path (<= 8 cameras), a device
+  // array for the wavefront-per-point path
+  std::vector<double> cam21((size_t)21 * n_cameras, 0.0);
   for (int c = 0; c < n_cameras; ++c) {
     const double* q = cam12 + 12 * c;
+    double* P = cam21.data() + (size_t)21 * c;
     double R[9];
     mcba::rot_only(q + 6, R);
     const double fx = q[0], fy = q[1], cx = q[2], cy = q[3];
-    for (int j = 0; j < 3; ++j) {  // P = K [R | t]
-      cams.P[c][j] = fx * R[j] + cx * R[6 + j];
-      cams.P[c][4 + j] = fy * R[3 + j] + cy * R[6 + j];
-      cams.P[c][8 + j] = R[6 + j];
+    for (int j = 0; j < 3; ++j) {
+      P[j] = fx * R[j] + cx * R[6 + j];
+      P[4 + j] = fy * R[3 + j] + cy * R[6 + j];
+      P[8 + j] = R[6 + j];
     }
-    cams.P[c][3] = fx * q[9] + cx * q[11];
-    cams.P[c][7] = fy * q[10] + cy * q[11];
-    cams.P[c][11] = q[11];
-    cams.K[c][0] = fx; cams.K[c][1] = fy; cams.K[c][2] = cx; cams.K[c][3] = cy;
-    if (dist5) for (int k = 0; k < 5; ++k) cams.dist[c][k] = dist5[5 * c + k];
-    else { cams.dist[c][0] = q[4]; cams.dist[c][1] = q[5]; }
+    P[3] = fx * q[9] + cx * q[11];
+    P[7] = fy * q[10] + cy * q[11];
+    P[11] = q[11];
+    P[12] = fx; P[13] = fy; P[14] = cx; P[15] = cy;
+    if (dist5) for (int k = 0; k < 5; ++k) P[16 + k] = dist5[5 * c + k];
+    else { P[16] = q[4]; P[17] = q[5]; }
   }
-  double *d_uv = nullptr, *d_out = nullptr;
+  const bool reg_path = n_cameras <= 8;
+  mcba::TriCams cams;
+  memset(&cams, 0, sizeof(cams));
+  if (reg_path)
+    for (int c = 0; c < n_cameras; ++c) {
+      memcpy(cams.P[c], cam21.data() + (size_t)21 * c, 12 * sizeof(double));
+      memcpy(cams.K[c], cam21.data() + (size_t)21 * c + 12, 4 * sizeof(double));
+      memcpy(cams.dist[c], cam21.data() + (size_t)21 * c + 16, 5 * sizeof(double));
+    }
+  double *d_uv = nullptr, *d_out = nullptr, *d_cams = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = MCBA_OK;
   auto cleanup = [&]() {
     if (d_uv) (void)hipFree(d_uv);
     if (d_out) (void)hipFree(d_out);
+    if (d_cams) (void)hipFree(d_cams);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
   };
@@ -1047,8 +1059,14 @@ int mcba_triangulate(int n_cameras, size_t n_points, const double* uvs, const do
   TRICHK(hipMemcpy(d_uv, uvs, nin * sizeof(double), hipMemcpyHostToDevice));
   TRICHK(hipEventCreate(&e0));
   TRICHK(hipEventCreate(&e1));
+  if (!reg_path) {
+    TRICHK(hipMalloc(reinterpret_cast<void**>(&d_cams), cam21.size() * sizeof(double)));
+    TRICHK(hipMemcpy(d_cams, cam21.data(), cam21.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   TRICHK(hipEventRecord(e0, nullptr));
-  if (mcba::launch_triangulate(nullptr, n_cameras, d_uv, cams, d_out, n_points, iterations) != 0) { cleanup(); return fail(MCBA_ERR_ARG, "mcba_triangulate: unsupported camera count"); }
+  const int lrc = reg_path ? mcba::launch_triangulate(nullptr, n_cameras, d_uv, cams, d_out, n_points, iterations)
+                           : mcba::launch_triangulate_wave(nullptr, n_cameras, d_uv, d_cams, d_out, n_points, iterations);
+  if (lrc != 0) { cleanup(); return fail(MCBA_ERR_ARG, "mcba_triangulate: unsupported camera count"); }
   if ((rc = check_launch())) { cleanup(); return rc; }
   TRICHK(hipEventRecord(e1, nullptr));
   TRICHK(hipMemcpy(out, d_out, 3 * n_points * sizeof(double), hipMemcpyDeviceToHost));

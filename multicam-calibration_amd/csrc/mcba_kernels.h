@@ -89,4 +89,6 @@ struct TriCams {
   double dist[8][5];
 };
 int launch_triangulate(hipStream_t st, int C, const double* uvs, const TriCams& cams, double* out, size_t npts, int iters);
+// 9 .. 64 cameras: cams_dev = C x {P[12], K[4], dist[5]} doubles in device memory; one wavefront per point
+int launch_triangulate_wave(hipStream_t st, int C, const double* uvs, const void* cams_dev, double* out, size_t npts, int iters);
 }  // namespace mcba

@@ -8,6 +8,7 @@
 // The camera count is a template parameter so that the per-camera / per-pair arrays are register arrays.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include "mcba_kernels.h"
 #include "mcba_math.h"
 
@@ -138,6 +139,119 @@ __global__ __launch_bounds__(256) void k_triangulate(const double2* __restrict__
   };
   const double mx = median(X), my = median(Y), mz = median(Z);
   out[3 * p] = mx; out[3 * p + 1] = my; out[3 * p + 2] = mz;
+}
+
+// Any camera count (9 .. 64): ONE WAVEFRONT per 3-D point, the camera pairs spread over its lanes.  Lanes c < C undistort
+// the detection of camera c (LDS), every lane triangulates the pairs k = lane, lane + 64, ... (same 4x4 null vector as
+// above) into LDS, and the per-coordinate nan-median over the <= C (C - 1) / 2 pair results is found by rank counting: each
+// lane counts, for its own values, how many values precede them (ties broken by index) -- the values of rank (n-1)/2 and
+// n/2 are the two middle ones.  Camera constants come from global memory (TriCam per camera) instead of kernel arguments.
+struct TriCam {
+  double P[12], K[4], dist[5];
+};
+
+__global__ __launch_bounds__(256) void k_triangulate_wave(const double2* __restrict__ uvs, const TriCam* __restrict__ cams, double* __restrict__ out, size_t npts, int C, int NP, int iters, int ppb) {
+  extern __shared__ double s_tri[];  // per point slot: ux[C] uy[C] ok[C] | X[NP] Y[NP] Z[NP] | m[2]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave >= ppb) return;
+  const size_t p = (size_t)blockIdx.x * ppb + wave;
+  if (p >= npts) return;  // whole wavefront
+  const int slot = 3 * C + 3 * NP + 2;
+  double* ux = s_tri + (size_t)wave * slot;
+  double* uy = ux + C;
+  double* okf = uy + C;
+  double* XYZ = okf + C;
+  double* mm = XYZ + 3 * NP;
+  for (int c = lane; c < C; c += 64) {
+    const double2 o = uvs[(size_t)c * npts + p];
+    const TriCam& cm = cams[c];
+    double x0 = (o.x - cm.K[2]) / cm.K[0], y0 = (o.y - cm.K[3]) / cm.K[1];
+    double x = x0, y = y0;
+    for (int it = 0; it < iters; ++it) {
+      const double r2 = fma(x, x, y * y);
+      const double icdist = 1.0 / fma(fma(fma(cm.dist[4], r2, cm.dist[1]), r2, cm.dist[0]), r2, 1.0);
+      const double dx = fma(2.0 * cm.dist[2] * x, y, cm.dist[3] * fma(2.0 * x, x, r2));
+      const double dy = fma(cm.dist[2], fma(2.0 * y, y, r2), 2.0 * cm.dist[3] * x * y);
+      x = (x0 - dx) * icdist;
+      y = (y0 - dy) * icdist;
+    }
+    ux[c] = fma(x, cm.K[0], cm.K[2]);
+    uy[c] = fma(y, cm.K[1], cm.K[3]);
+    okf[c] = (o.x == o.x && o.y == o.y) ? 1.0 : 0.0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const double big = 1e300;  // invalid pairs sort to the end
+  int nloc = 0;
+  for (int k = lane; k < NP; k += 64) {
+    // pair k -> (i, j), i < j, in the order (0,1), (0,2), ..., (0,C-1), (1,2), ...
+    int i = 0, rem = k;
+    while (rem >= C - 1 - i) { rem -= C - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    const TriCam& ci = cams[i];
+    const TriCam& cj = cams[j];
+    double a[4][4];
+#pragma unroll
+    for (int col = 0; col < 4; ++col) {
+      a[col][0] = fma(ux[i], ci.P[8 + col], -ci.P[col]);
+      a[col][1] = fma(uy[i], ci.P[8 + col], -ci.P[4 + col]);
+      a[col][2] = fma(ux[j], cj.P[8 + col], -cj.P[col]);
+      a[col][3] = fma(uy[j], cj.P[8 + col], -cj.P[4 + col]);
+    }
+    const bool both = okf[i] != 0.0 && okf[j] != 0.0;
+    if (!both) {
+#pragma unroll
+      for (int col = 0; col < 4; ++col)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[col][r] = col == r ? 1.0 : 0.0;
+    }
+    double xh[4];
+    null_vector4(a, xh);
+    const double iw = 1.0 / xh[3];
+    XYZ[k] = both ? xh[0] * iw : big;
+    XYZ[NP + k] = both ? xh[1] * iw : big;
+    XYZ[2 * NP + k] = both ? xh[2] * iw : big;
+    nloc += both ? 1 : 0;
+  }
+  int n = nloc;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off, 64);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int i0 = (n - 1) >> 1, i1 = n >> 1;
+  double res[3];
+  for (int d = 0; d < 3; ++d) {
+    const double* v = XYZ + d * NP;
+    for (int k = lane; k < NP; k += 64) {
+      const double mine = v[k];
+      int rank = 0;
+      for (int m = 0; m < NP; ++m) {
+        const double o = v[m];
+        rank += (o < mine || (o == mine && m < k)) ? 1 : 0;
+      }
+      if (rank == i0) mm[0] = mine;
+      if (rank == i1) mm[1] = mine;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    res[d] = n > 0 ? 0.5 * (mm[0] + mm[1]) : __builtin_nan("");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) { out[3 * p] = res[0]; out[3 * p + 1] = res[1]; out[3 * p + 2] = res[2]; }
+}
+
+// cams_dev: C x TriCam in device memory (same content as TriCams, any camera count)
+int launch_triangulate_wave(hipStream_t st, int C, const double* uvs, const void* cams_dev, double* out, size_t npts, int iters) {
+  const int NP = C * (C - 1) / 2;
+  const size_t slot = ((size_t)3 * C + 3 * NP + 2) * sizeof(double);
+  int ppb = (int)std::min<size_t>(4, (64 * 1024) / slot);
+  if (ppb < 1) return 1;
+  const dim3 grid((unsigned)((npts + ppb - 1) / ppb)), block(256);
+  k_triangulate_wave<<<grid, block, slot * ppb, st>>>(reinterpret_cast<const double2*>(uvs), static_cast<const TriCam*>(cams_dev), out, npts, C, NP, iters, ppb);
+  return 0;
 }
 
 int launch_triangulate(hipStream_t st, int C, const double* uvs, const TriCams& cams, double* out, size_t npts, int iters) {

@@ -3,7 +3,8 @@
 Same signature and return value as the reference.  The reference undistorts with cv2.undistortPoints, triangulates every
 camera pair with cv2.triangulatePoints and takes the nan-median over the pairs; here one HIP kernel does all three per
 point (`csrc/mcba_triangulate.hip`: OpenCV's fixed-point undistortion for the 5-coefficient model, the 4x4 DLT null vector
-by one-sided Jacobi, a sorting network for the median).  OpenCV is absent from this image, so parity with cv2's numbers is
+by one-sided Jacobi, a sorting network for the median; beyond 8 cameras one wavefront per point with the camera pairs
+across its lanes and the median by rank counting).  OpenCV is absent from this image, so parity with cv2's numbers is
 unpinned; the kernel is checked against a numpy restatement of the two published algorithms (oracle/triangulate_oracle.py)
 and against exact recovery of synthetic points.
 """
@@ -40,8 +41,8 @@ def triangulate(all_uvs, all_extrinsics, all_intrinsics, device=0, undistort_ite
     if uvs.ndim != 3 or uvs.shape[2] != 2 or uvs.shape[0] != len(all_extrinsics) or len(all_extrinsics) != len(all_intrinsics):
         raise ValueError("all_uvs must be one (n_points, 2) array per camera, matching all_extrinsics / all_intrinsics")
     C, P = uvs.shape[:2]
-    if not 2 <= C <= 8:
-        raise NotImplementedError("triangulate() supports 2 to 8 cameras")
+    if not 2 <= C <= 64:
+        raise NotImplementedError("triangulate() supports 2 to 64 cameras")
     cam, dist = _cam_blocks(all_extrinsics, all_intrinsics)
     out = np.empty((P, 3))
     ms = ctypes.c_double(0.0)

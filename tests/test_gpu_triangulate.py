@@ -17,12 +17,12 @@ def mc():
     return m
 
 
-@pytest.mark.parametrize("C", [2, 3, 6, 8])
+@pytest.mark.parametrize("C", [2, 3, 6, 8, 9, 24, 40])   # <= 8: one lane per point; beyond: one wavefront per point, pairs across the lanes
 def test_matches_oracle_with_noise_and_missing_views(mc, C):
-    uvs, ext, intr, X = scene(C=C, P=1000, seed=10 + C, noise=0.3, p_unseen=0.25)
+    uvs, ext, intr, X = scene(C=C, P=1000 if C <= 8 else 300, seed=10 + C, noise=0.3, p_unseen=0.25 if C <= 8 else 0.6)
     want = tri.triangulate(uvs, ext, intr)
     got = mc.triangulate(uvs, ext, intr)
-    assert got.shape == (1000, 3)
+    assert got.shape == want.shape
     assert np.array_equal(np.isnan(got), np.isnan(want))
     ok = ~np.isnan(want).any(1)
     # same algorithm in FP64: SVD by LAPACK vs one-sided Jacobi differ in the last bits, scaled by the DLT conditioning
@@ -44,5 +44,24 @@ def test_argument_checks(mc):
         mc.triangulate(uvs[:2], ext, intr)
     with pytest.raises(NotImplementedError):
         mc.triangulate(uvs[:1], ext[:1], intr[:1])
+    with pytest.raises(NotImplementedError):
+        mc.triangulate(uvs * 22, np.tile(ext, (22, 1)), intr * 22)   # 66 cameras
     empty = mc.triangulate([u[:0] for u in uvs], ext, intr)
     assert empty.shape == (0, 3)
+
+
+def test_the_config5_rig_triangulates(mc):
+    """24 cameras (BASELINE configs[4]'s rig): 276 camera pairs per point; noise-free points are recovered, points seen by
+    fewer than two cameras come back NaN, and the full 5-coefficient distortion model is honoured."""
+    uvs, ext, intr, X = scene(C=24, P=500, seed=77)
+    assert np.abs(mc.triangulate(uvs, ext, intr, undistort_iterations=20) - X).max() < 1e-8
+    uvs2 = [u.copy() for u in uvs]
+    for c in range(1, 24):
+        uvs2[c][:7] = np.nan               # points 0..6: seen by camera 0 only
+    for c in range(24):
+        uvs2[c][7:9] = np.nan              # points 7, 8: seen by nobody
+    got = mc.triangulate(uvs2, ext, intr, undistort_iterations=20)
+    assert np.isnan(got[:9]).all() and np.abs(got[9:] - X[9:]).max() < 1e-8
+    intr_t = [(K, np.array([d[0], d[1], 1e-3, -5e-4, 1e-3])) for K, d in intr]
+    want = tri.triangulate(uvs, ext, intr_t)
+    assert np.abs(mc.triangulate(uvs, ext, intr_t) - want).max() <= 1e-8 * np.abs(want).max()
