@@ -60,6 +60,66 @@ __device__ __forceinline__ double wave_sum63(double v) {
   v = dpp_add<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
   return v;
 }
+// Sums over the 64 lanes of K = 3 * 2^m values at once (m <= 5) by recursive halving: at every level a lane hands half of its
+// values to its partner and adds the partner's copies of the half it keeps, so level t works on K / 2^(t+1) values instead of
+// K -- 3 K (1 - 2^-m) exchanges in all instead of 6 K for K separate butterflies -- and the totals end up SPREAD over the
+// lanes: lane l holds the sums of the values  3 (l >> (6 - m)) + {0, 1, 2}  (the lanes that share l >> (6 - m) hold copies).
+// Pairings: lanes 32 apart (v_permlane32_swap), rows 16 apart (v_permlane16_swap) -- both exchange in place, no selects --,
+// then DPP row_mirror / row_half_mirror / reversed quads / neighbours inside a row.
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm(double v) {
+  union { double d; int i[2]; } a, b;
+  a.d = v;
+  b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], CTRL, 0xF, 0xF, true);
+  b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], CTRL, 0xF, 0xF, true);
+  return b.d;
+}
+template <int LEVEL>
+__device__ __forceinline__ double halve_pair(double x, double y, int lane) {  // lanes with the level's bit clear keep x, the others y
+  if constexpr (LEVEL <= 1) {
+    union { double d; unsigned u[2]; } a, b;
+    a.d = x; b.d = y;
+    if constexpr (LEVEL == 0) {
+      auto r0 = __builtin_amdgcn_permlane32_swap(a.u[0], b.u[0], false, false);
+      auto r1 = __builtin_amdgcn_permlane32_swap(a.u[1], b.u[1], false, false);
+      a.u[0] = r0[0]; b.u[0] = r0[1]; a.u[1] = r1[0]; b.u[1] = r1[1];
+    } else {
+      auto r0 = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
+      auto r1 = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
+      a.u[0] = r0[0]; b.u[0] = r0[1]; a.u[1] = r1[0]; b.u[1] = r1[1];
+    }
+    return a.d + b.d;
+  } else {
+    constexpr int BIT = LEVEL == 2 ? 8 : LEVEL == 3 ? 4 : 2;
+    constexpr int CTRL = LEVEL == 2 ? 0x140 : LEVEL == 3 ? 0x141 : 0x1B;  // row_mirror, row_half_mirror, quad_perm [3,2,1,0]
+    const bool up = (lane & BIT) != 0;
+    const double keep = up ? y : x, send = up ? x : y;
+    return keep + dpp_perm<CTRL>(send);
+  }
+}
+template <int LEVEL>
+__device__ __forceinline__ double pair_sum(double v) {  // plain butterfly of one level (the levels left over when K < 96)
+  if constexpr (LEVEL == 4) return v + dpp_perm<0x1B>(v);
+  else return v + dpp_perm<0xB1>(v);  // level 5: neighbours
+}
+template <int K, int LEVEL = 0>
+__device__ __forceinline__ void wave_reduce_scatter(double* v, double (&out)[3], int lane) {
+  if constexpr (K > 3) {
+    constexpr int H = K / 2;
+#pragma unroll
+    for (int k = 0; k < H; ++k) v[k] = halve_pair<LEVEL>(v[k], v[k + H], lane);
+    wave_reduce_scatter<H, LEVEL + 1>(v, out, lane);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double t = v[r];
+      if constexpr (LEVEL <= 4) t = pair_sum<4>(t);
+      t = pair_sum<5>(t);
+      out[r] = t;
+    }
+    static_assert(LEVEL == 4 || LEVEL == 5, "K must be 48 or 96");
+  }
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
@@ -288,9 +348,15 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
   }
   // records are wave tiles rec[camera][frame block][k/2 = 0..49][lane][2]: every store below is one 1 KiB dwordx4 row
   double2* r2 = reinterpret_cast<double2*>(rec + ((size_t)c * nfb + fb) * (MCBA_REC * 64)) + lane;
-  // per-wavefront sums, stored [camera][k = 0..91][frame block] so that the second stage reads contiguous runs
-  double* gp = gpart + (size_t)c * MCBA_GP * nfb + fb;
-  const bool writer = lane == 63;
+  // per-wavefront sums of U_c (78), g_c (12), the cost and the number of pairs with data: all of them are reduced over the
+  // lanes TOGETHER (wave_reduce_scatter) and leave as three values per lane, stored [camera][k = 0..91][frame block] so that
+  // the second stage reads contiguous runs.  Compact index j of this role's values -> row k:
+  //   both roles (fused): j = k;   role A: j < 21 -> 57 + j (U rows 6..11), else 63 + j (g_c 6..11, cost, pairs);
+  //   role B: j < 57 -> j (U rows 0..5), else 21 + j (g_c 0..5)
+  constexpr int KR = (ROLE == 0) ? 48 : 96;
+  double red[KR];
+#pragma unroll
+  for (int i = 0; i < KR; ++i) red[i] = 0.0;
   if constexpr (DO_A) {
     double U[78], gc[12], W[72], V[21], gf[6];
     gram_expand(ga, ch, U, gc, W, V, gf);
@@ -304,21 +370,15 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       r2[48 * 64] = make_double2(gf[3], gf[4]);
       r2[49 * 64] = make_double2(gf[5], 0.0);
     }
-#pragma unroll
-    for (int a = 6; a < 12; ++a)
-#pragma unroll
-      for (int b = a; b < 12; ++b) {
-        double sm = wave_sum63(U[tri12(a, b)]);
-        if (writer) gp[(size_t)tri12(a, b) * nfb] = sm;
-      }
+    constexpr int OFF = ROLE == 0 ? 57 : 0, OFG = ROLE == 0 ? 63 : 0;
 #pragma unroll
     for (int a = 6; a < 12; ++a) {
-      double sm = wave_sum63(gc[a]);
-      if (writer) gp[(size_t)(78 + a) * nfb] = sm;
+#pragma unroll
+      for (int b = a; b < 12; ++b) red[tri12(a, b) - OFF] = U[tri12(a, b)];
+      red[78 + a - OFG] = gc[a];
     }
-    double cs = wave_sum63(cost);
-    double nv = wave_sum63(any ? 1.0 : 0.0);
-    if (writer) { gp[(size_t)90 * nfb] = cs; gp[(size_t)91 * nfb] = nv; }
+    red[90 - OFG] = cost;
+    red[91 - OFG] = any ? 1.0 : 0.0;
   }
   if constexpr (DO_B) {
     double U[78], gc[12], W[72];
@@ -327,17 +387,30 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #pragma unroll
       for (int i = 0; i < 36; i += 2) r2[(i >> 1) * 64] = make_double2(W[i], W[i + 1]);
     }
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = a; b < 12; ++b) {
-        double sm = wave_sum63(U[tri12(a, b)]);
-        if (writer) gp[(size_t)tri12(a, b) * nfb] = sm;
-      }
+    constexpr int OFG = ROLE == 1 ? 21 : 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      double sm = wave_sum63(gc[a]);
-      if (writer) gp[(size_t)(78 + a) * nfb] = sm;
+#pragma unroll
+      for (int b = a; b < 12; ++b) red[tri12(a, b)] = U[tri12(a, b)];
+      red[78 + a - OFG] = gc[a];
+    }
+  }
+  {
+    double o3[3];
+    wave_reduce_scatter<KR>(red, o3, lane);
+    constexpr int SH = KR == 96 ? 1 : 2;  // lanes that share lane >> SH hold copies: the first of them stores
+    if ((lane & ((1 << SH) - 1)) == 0) {
+      double* gp = gpart + (size_t)c * MCBA_GP * nfb + fb;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int j = 3 * (lane >> SH) + r;
+        int k;
+        bool own;
+        if constexpr (ROLE == 0) { own = j < 29; k = j < 21 ? 57 + j : 63 + j; }
+        else if constexpr (ROLE == 1) { own = j < 63; k = j < 57 ? j : 21 + j; }
+        else { own = j < MCBA_GP; k = j; }
+        if (own) gp[(size_t)k * nfb] = o3[r];
+      }
     }
   }
 #ifdef MCBA_GRAM_TIMING
