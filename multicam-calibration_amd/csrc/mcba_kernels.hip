@@ -548,10 +548,12 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
 //      step partials (a few KB, fixed order -> identical in every workgroup) and takes the accept / reject decision on an
 //      LDS copy of the LM state; workgroup 0 publishes the new state to a SECOND state buffer (the old one is still being
 //      read by workgroups that start later).  Saves a launch whose whole content was a 5 us latency chain.
-//   1. what used to be k_frame_factor, per super-stage of <= 64 of the workgroup's frames, by wavefront 0 (lane = frame):
-//      V_f = sum_c V_cf, D_f = diag(V_f) (Marquardt), L L^T = V_f + lambda D_f, z = L^-1 g_f  ->  LDS (L, 1/diag, z) for the
-//      stages below and fbuf[f] = {L(21, diagonal slots 1 / L_ii), z(6), g_f(6), D_f(6), pad} for k_backsub.  The W loads of
-//      the first stage are already in flight meanwhile.
+//   1. what used to be k_frame_factor, per super-stage of <= 32 of the workgroup's frames: all 256 threads sum the frames'
+//      (V_cf | g_cf) tile rows over the cameras (thread = (frame, part of the rows); every load in flight at once) into LDS,
+//      then the first lanes of wavefront 0 (lane = frame): V_f = sum_c V_cf, D_f = diag(V_f) (Marquardt),
+//      L L^T = V_f + lambda D_f, z = L^-1 g_f  ->  LDS (L, 1/diag, z) for the stages below and
+//      fbuf[f] = {L(21, diagonal slots 1 / L_ii), z(6), g_f(6), D_f(6), pad} for k_backsub.  The W loads of the first stage
+//      are already in flight meanwhile.
 //   per stage of FS frames:
 //   2. every thread forward-substitutes its IPT (row, frame) items from PREFETCHED registers: y = L_f^-1 w, written
 //      to LDS as s_y[row][frame*6 + k]  (row stride 6 FS + 2 doubles: conflict-free ds_read_b64 for the MFMA operands);
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
 // Partials: spart[q][reg 0..3][g][lane]  (C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg): the second stage reads
 // each (q, reg) slice as ONE contiguous run of G x 512 B.  fpart[g] = {max |g_f|, #failed factorisations} of the workgroup.
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
-constexpr int kSyrkSuper = 64;  // frames factorised per super-stage (one wavefront, lane = frame)
+constexpr int kSyrkSuper = 32;  // frames factorised per super-stage: 32 frames x 8 parts of their V / g_f entries = the 256 threads
 
 template <int PPW, int IPT, bool DECIDE>
 __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse fz, const double* __restrict__ rec0, const double* __restrict__ rec1, double* __restrict__ fbuf, double* __restrict__ fpart,
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   const int n = 12 * C, nfb = Fpad >> 6;
   const int RS = 6 * FS + 2;
   double* s_y = lds;                          // [NT*16][RS]
-  double* s_L = lds + (size_t)NT * 16 * RS;   // [kSyrkSuper][34]: L(21) 1/diag(6) z(6) pad, one super-stage of frames
+  double* s_L = lds + (size_t)NT * 16 * RS;   // [kSyrkSuper][34]: L(21) 1/diag(6) z(6) pad, one super-stage of frames; behind it [kSyrkSuper][28] sums
 
   int qi[PPW], rowa[PPW], rowb[PPW];
   mfma_d4 acc[PPW];
@@ -673,34 +675,47 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
       }
     }
   };
-  // frame factors of one super-stage: wavefront 0, lane = frame s0 + lane
+  // frame factors of one super-stage of ns <= 32 frames.  vsum (all 256 threads): thread (frame t & 31, part t >> 5) sums ITS
+  // rows of the (V | g_f) tile -- part p owns the double2 rows k = p and p + 8 of the 14 -- over all cameras, every load in
+  // flight at once (one memory round trip instead of one per camera batch), and leaves them in LDS; after the barrier the
+  // first ns lanes of wavefront 0 damp, factorise (6x6 Cholesky) and forward-substitute their frame.
+  double* s_V = s_L + kSyrkSuper * 34;  // [kSyrkSuper][28]
   double gmax = 0.0, nfail = 0.0;
-  auto factor = [&](int s0, int ns) {
-    const bool on = lane < ns;
-    const int f = on ? s0 + lane : s0;  // idle lanes load a duplicate, store nothing
-    double V[28];
-#pragma unroll
-    for (int k = 0; k < 28; ++k) V[k] = 0.0;
-    constexpr int CB = 2;  // cameras per batch: 28 loads in flight per lane (the kernel must stay within 256 registers: two workgroups per CU)
+  auto vsum = [&](int s0, int ns) {
+    const int fl = t & 31, part = t >> 5;
+    const int f = s0 + min(fl, ns - 1);  // idle threads load a duplicate, store nothing
+    const double2* r2 = reinterpret_cast<const double2*>(rec + (size_t)(f >> 6) * (MCBA_REC * 64)) + (size_t)(36 + part) * 64 + (f & 63);
+    const size_t cstride = (size_t)nfb * (MCBA_REC * 64 / 2);  // double2 elements between two cameras' tiles
+    const bool two = part + 8 < 14;
+    double2 a0 = make_double2(0.0, 0.0), a1 = make_double2(0.0, 0.0);
+    constexpr int CB = 8;  // cameras per batch (16 loads in flight per thread)
     for (int c0 = 0; c0 < C; c0 += CB) {
-      double2 tt[CB][14];
+      double2 u0[CB], u1[CB];
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
-        const int cc = min(c0 + j, C - 1);  // clamped duplicate loads are ignored below
-        const double2* r2 = reinterpret_cast<const double2*>(rec + ((size_t)cc * nfb + (f >> 6)) * (MCBA_REC * 64)) + 36 * 64 + (f & 63);
-#pragma unroll
-        for (int k = 0; k < 14; ++k) tt[j][k] = r2[k * 64];
+        const size_t o = (size_t)min(c0 + j, C - 1) * cstride;  // clamped duplicate loads are ignored below
+        u0[j] = r2[o];
+        u1[j] = r2[o + (two ? 8 * 64 : 0)];
       }
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
-        if (c0 + j < C) {
-#pragma unroll
-          for (int k = 0; k < 14; ++k) { V[2 * k] += tt[j][k].x; V[2 * k + 1] += tt[j][k].y; }
-        }
+        if (c0 + j < C) { a0.x += u0[j].x; a0.y += u0[j].y; a1.x += u1[j].x; a1.y += u1[j].y; }
       }
     }
+    if (fl < ns) {
+      double* v = s_V + fl * 28;
+      v[2 * part] = a0.x; v[2 * part + 1] = a0.y;
+      if (two) { v[2 * (part + 8)] = a1.x; v[2 * (part + 8) + 1] = a1.y; }
+    }
+  };
+  auto factor = [&](int s0, int ns) {  // wavefront 0, lane = frame s0 + lane
+    const bool on = lane < ns;
     double* row = s_L + lane * 34;
+    if (lane >= kSyrkSuper) return;
     if (on) {
+      double V[28];
+#pragma unroll
+      for (int k = 0; k < 28; ++k) V[k] = s_V[lane * 28 + k];
       double* gf = V + 21;
       double D[6];
 #pragma unroll
@@ -746,6 +761,8 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   prefetch(f0);
   for (int s0 = f0; s0 < f1; s0 += kSyrkSuper) {
     const int s1 = min(f1, s0 + kSyrkSuper);
+    vsum(s0, s1 - s0);
+    __syncthreads();
     if (wave == 0) factor(s0, s1 - s0);
     __syncthreads();
     SLAP(0);
@@ -1211,7 +1228,7 @@ void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, 
 
 size_t syrk_lds_bytes(int C, int FS) {
   int NT = (12 * C + 1 + 15) / 16;
-  return ((size_t)NT * 16 * (6 * FS + 2) + (size_t)kSyrkSuper * 34) * sizeof(double);
+  return ((size_t)NT * 16 * (6 * FS + 2) + (size_t)kSyrkSuper * (34 + 28)) * sizeof(double);
 }
 
 #define SYRK_IPT 5  // (12C+1)*FS <= 256*SYRK_IPT is guaranteed by the choice of FS in mcba_create
