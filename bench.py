@@ -47,9 +47,11 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (AMD datasheet; 256 CU x
 FP64_VALU_MEASURED_TFLOPS = 57.0  # scripts/micro/fma_f64_rate.hip on the same GPU: 54-58 TFLOP/s of independent v_fma_f64 (one per 4.82 clock64 ticks)
 
 C, F_PER_GPU, ROWS, COLS = 6, 10000, 6, 9
-# FP64 VALU instructions k_gram issues (counted in the ISA of the built kernel, scripts/isa_count.py)
-GRAM_FP64_PER_POINT = 245
-GRAM_FP64_PER_PAIR = 2500
+# FP64 VALU instructions k_gram issues, counted in the ISA of the built kernel (scripts/isa_count.py on `hipcc -S`, round 2):
+# 1018 in the 4-point loop body = 254 per point-observation; ~1900 per (camera, frame) outside it (pose constants, chain
+# matrices, expansion of the local Gram matrix, the halving reduction).  DESIGN.md section 5.
+GRAM_FP64_PER_POINT = 254
+GRAM_FP64_PER_PAIR = 1900
 
 
 def algorithmic_bytes(kernel, C, F, N):

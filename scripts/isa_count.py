@@ -27,7 +27,7 @@ for l in body[best[0]:best[1] + 1]:
     ops[t[0]] += 1
 cat = Counter()
 for op, n in ops.items():
-    if op.endswith("_f64") and op.startswith("v_"):
+    if op.startswith("v_") and "_f64" in op:
         cat["valu_f64"] += n
     elif op.startswith("v_accvgpr"):
         cat["accvgpr_mov"] += n
@@ -44,4 +44,10 @@ for op, n in ops.items():
     else:
         cat["other"] += n
 print(dict(cat), "total", sum(cat.values()))
+whole = Counter()
+for l in body:
+    t = l.strip().split()
+    if t and not t[0].startswith((".", ";")) and not t[0].endswith(":"):
+        whole["valu_f64" if (t[0].startswith("v_") and "_f64" in t[0]) else "valu_other" if t[0].startswith("v_") else "other"] += 1
+print("whole kernel:", dict(whole), "| outside the hottest loop:", {k: whole[k] - (cat.get(k, 0) if k != "valu_other" else cat.get("valu_other", 0) + cat.get("accvgpr_mov", 0)) for k in ("valu_f64", "valu_other")})
 print(ops.most_common(40))
