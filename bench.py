@@ -48,9 +48,9 @@ FP64_VALU_MEASURED_TFLOPS = 57.0  # scripts/micro/fma_f64_rate.hip on the same G
 
 C, F_PER_GPU, ROWS, COLS = 6, 10000, 6, 9
 # FP64 VALU instructions k_gram issues, counted in the ISA of the built kernel (scripts/isa_count.py on `hipcc -S`, round 2):
-# 1018 in the 4-point loop body = 254 per point-observation; ~1900 per (camera, frame) outside it (pose constants, chain
+# 990 in the 4-point loop body = 248 per point-observation; ~1900 per (camera, frame) outside it (pose constants, chain
 # matrices, expansion of the local Gram matrix, the halving reduction).  DESIGN.md section 5.
-GRAM_FP64_PER_POINT = 254
+GRAM_FP64_PER_POINT = 248
 GRAM_FP64_PER_PAIR = 1900
 
 
@@ -220,7 +220,7 @@ def main():
     # HIP events on the launch stream bracket ONLY the dominant kernel inside the timed region (bracketing all
     # kernels of a step costs ~60 us of host time per step); the per-kernel table comes from an untimed pass.
     DOMINANT = "k_gram"
-    prob.profile_enable(True, only=[DOMINANT], stride=4)  # every 4th launch: the event records must not pace the stream
+    prob.profile_enable(True, only=[DOMINANT], stride=8)  # every 8th launch: the event records must not pace the stream
     prob.profile_read()
     barrier()
     nfev0 = lm.nfev

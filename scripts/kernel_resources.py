@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "multicam-calibration_amd", "csrc")
 srcs = sys.argv[1:] or [os.path.join(CSRC, f) for f in ("mcba_kernels.hip", "mcba_solve.hip", "mcba_triangulate.hip")]
 for src in srcs:
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage", "-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule=1", "-mllvm", "-greedy-reverse-local-assignment=1"]
                          + os.environ.get("MCBA_HIPCC_FLAGS", "").split(), capture_output=True, text=True).stderr
     cur = {}
     for line in out.splitlines():
