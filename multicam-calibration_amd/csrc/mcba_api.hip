@@ -198,7 +198,7 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   {
     int nstage = (F + h->FS - 1) / h->FS;
     int gmax = 512;
-    if (const char* e = getenv("MCBA_SYRK_G")) gmax = std::max(1, atoi(e));  // tuning knob
+    if (const char* e = getenv("MCBA_SYRK_G")) gmax = std::max(1, std::min(512, atoi(e)));  // tuning knob (k_reduce_system holds <= 512 / 16 partial rows per wavefront)
     int g = std::min(nstage, gmax);
     h->fpc = ((nstage + g - 1) / g) * h->FS;
     h->G = (F + h->fpc - 1) / h->fpc;

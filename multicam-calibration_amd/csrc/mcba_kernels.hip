@@ -862,8 +862,6 @@ __device__ __forceinline__ double run_sum(const double* __restrict__ p, int coun
 __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __restrict__ gp0, const double* __restrict__ gp1, const double* __restrict__ spart, const double* __restrict__ fpart,
                                                         const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ red, int C, int nfb, int G, int NT, int NP,
                                                         int nfblocks, int rank_slot) {
-  if (!sel_active(sl, false)) return;
-  const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
   const int n = 12 * C;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ double s_part[16][64];
@@ -872,34 +870,54 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
   if ((int)blockIdx.x < 4 * NP) {
     const int q = blockIdx.x >> 2, reg = blockIdx.x & 3;
     const int ti = tile_i[q], tj = tile_j[q];
-    {  // ---- slice sums of the k_syrk partials
+    // ---- slice sums of the k_syrk partials.  They do not depend on the LM state: ALL of this wavefront's rows (G <= 512
+    // workgroups -> at most 32 per wavefront) go in flight before anything waits for the state -- one memory round trip
+    // where a loop over batches of eight paid one per batch, and the state read rides along.
+    double pv[32];
+    {
       const double* p = spart + (size_t)(4 * q + reg) * G * 64 + lane;
-      const size_t gs = 64;
-      double s = 0.0;
-      for (int base = 0; base < G; base += 128) {
-        double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { int g = base + wave + 16 * k; v[k] = g < G ? p[(size_t)g * gs] : 0.0; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += v[k];
-      }
-      s_part[wave][lane] = s;
+      for (int k = 0; k < 32; ++k) { const int g = wave + 16 * k; pv[k] = g < G ? p[(size_t)g * 64] : 0.0; }
     }
-    // ---- U_c / g_c terms of the elements that need them: element e = wave + 16 j, one wavefront task each
+    if (!sel_active(sl, false)) return;
+    const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
+    // ---- U_c / g_c terms of the elements that need them: element e = wave + 16 j, one wavefront task each; the four
+    // tasks' runs are loaded together as well
+    const double* up[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int e = wave + 16 * j;
       const int row = 16 * ti + (e >> 4) + 4 * reg, col = 16 * tj + (e & 15);
-      double u = 0.0;
+      up[j] = nullptr;
       if (row < n && col < n && row / 12 == col / 12) {
         int cam = row / 12, li = row - 12 * cam, lj = col - 12 * cam;
         int a = li <= lj ? li : lj, b = li <= lj ? lj : li;
-        u = run_sum(gpart + cam * camstride + (size_t)tri12(a, b) * nfb, nfb, lane);
+        up[j] = gpart + cam * camstride + (size_t)tri12(a, b) * nfb;
       } else if (col == n && row < n) {
         int cam = row / 12, li = row - 12 * cam;
-        u = run_sum(gpart + cam * camstride + (size_t)(78 + li) * nfb, nfb, lane);
+        up[j] = gpart + cam * camstride + (size_t)(78 + li) * nfb;
       }
-      if (lane == 63) s_u[e] = u;
+    }
+    double us[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int base = 0; base < nfb; base += 256) {
+      double w[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = base + lane + 64 * k; w[j][k] = (up[j] && i < nfb) ? up[j][i] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) us[j] += (w[j][0] + w[j][1]) + (w[j][2] + w[j][3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double u = wave_sum63(us[j]);
+      if (lane == 63) s_u[wave + 16 * j] = u;
+    }
+    {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) s += pv[k];
+      s_part[wave][lane] = s;
     }
     __syncthreads();
     if (wave == 0) {
@@ -918,6 +936,8 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
     return;
   }
   // ---- diag(U), g_c, scalars: task id per wavefront
+  if (!sel_active(sl, false)) return;
+  const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
   const int task = ((int)blockIdx.x - 4 * NP) * 16 + wave;
   double* tail = red + (size_t)n * n + n;
   if (task < n) {  // diag U
