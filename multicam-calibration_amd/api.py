@@ -101,8 +101,9 @@ def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     print(f"Excluding {int(exclude.sum())} out of {len(use_frames)} frames based on an outlier threshold of {outlier_threshold}")
     if not (n_frames is None or n_frames > len(use_frames)):
         use_frames = np.random.choice(use_frames, n_frames, replace=False)
-    if keep_problem:
-        return use_frames, prob
+    if keep_problem:  # + whether every selected detection is complete (then no NaN mask is needed for result.fun / result.jac)
+        complete = prob is not None and bool(np.all(full_cf[:, use_frames] == N))
+        return use_frames, prob, complete
     if prob is not None:
         prob.close()
     return use_frames
@@ -146,9 +147,9 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     calib_poses = np.asarray(calib_poses, dtype=np.float64)
     n_cameras = all_calib_uvs.shape[0]
 
-    prob_all = None
+    prob_all, all_seen = None, False
     if not distributed:
-        use_frames, prob_all = select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device, backend, keep_problem=True)
+        use_frames, prob_all, all_seen = select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device, backend, keep_problem=True)
     else:
         # rank 0 owns the reference's frame selection (its printed line and its use of the global numpy RNG)
         box = [select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device, backend) if rank == 0 else None]
@@ -221,13 +222,15 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
 
     # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560)
     slot = result.lm["slot"]
-    if uvs is None:
+    if uvs is None and not (all_seen and not return_jac):
         uvs = all_calib_uvs[:, use_frames]
     if backend is None and return_jac:
         idx, indptr, shape, mask = jacobian_structure(uvs)  # CSR indices: 0.25 s of numpy at 6 x 10k x 54 -- only when asked for
-    else:
+    elif uvs is not None:
         mask = ~np.isnan(uvs)
-    if backend is not None:  # test double: no materialised Jacobian kernel
+    if uvs is None:  # every selected detection is complete (the pre-filter counted them on the GPU): no NaN mask to apply
+        result.fun = prob.residuals(slot).ravel()
+    elif backend is not None:  # test double: no materialised Jacobian kernel
         result.fun = prob.residuals(slot)[mask]
     elif return_jac:
         prob.jacobian_eval(slot, robust_scaled=kw["loss"] != "linear")
