@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--fixed-only", action="store_true")
     ap.add_argument("--max-nfev", type=int, default=60)
     ap.add_argument("--no-fd", action="store_true", help="skip the finite-difference certificate (large sizes: hours)")
+    ap.add_argument("--only-start", type=int, default=None, help="compute this start only and park it in --part-dir (large sizes: one process per start)")
+    ap.add_argument("--merge", action="store_true", help="combine the parked starts of --part-dir into the fixture")
+    ap.add_argument("--part-dir", default="/tmp/gold")
     args = ap.parse_args()
     C, F = args.C, args.F
     tag = f"{C}x{F}"
@@ -100,7 +103,13 @@ def main():
         if (mode == "free" and args.fixed_only) or (mode == "fixed" and args.free_only):
             continue
         outs = {}
+        part = lambda k: os.path.join(args.part_dir, f"tight_{tag}_{mode}.s{k}.part.npz")
         for s in range(args.starts):
+            if args.merge:
+                outs.update(np.load(part(s)))
+                continue
+            if args.only_start is not None and s != args.only_start:
+                continue
             pseed = s + 1
             q = synth.make_problem(C, F, seed=0, perturb_seed=pseed)
             if mode == "fixed" and s > 0:  # same frozen intrinsics as start 0; only the extrinsics / poses start elsewhere
@@ -109,8 +118,11 @@ def main():
             t0 = time.perf_counter()
             if mode == "free":
                 jac = lambda x, u, o: orc.jacobian_csr(x, u, o)
+                # the second start must solve the SAME frames: its pre-filter threshold (5 x the median error of ITS initial guess)
+                # is switched off -- the first start, run with the reference's default, excludes nothing on this data either
+                thr = None if s == 0 else 1e30
                 with contextlib.redirect_stdout(io.StringIO()):
-                    ext, intr, poses, use, res = ba.bundle_adjust(q["uvs"], q["extrinsics"], q["intrinsics"], obj, q["poses"], n_frames=None, jac=jac,
+                    ext, intr, poses, use, res = ba.bundle_adjust(q["uvs"], q["extrinsics"], q["intrinsics"], obj, q["poses"], n_frames=None, outlier_threshold=thr, jac=jac,
                                                                   ftol=1e-13, xtol=1e-13, gtol=1e-10, max_nfev=args.max_nfev, verbose=0)
                 uvs = q["uvs"][:, use]
                 x = res.x
@@ -153,7 +165,14 @@ def main():
             if s == 0:
                 outs["uvs_checksum"] = np.array(np.nansum(q["uvs"]))
                 outs["shape"] = np.array([C, F, obj.shape[0]])
+            if args.only_start is not None:
+                os.makedirs(args.part_dir, exist_ok=True)
+                np.savez_compressed(part(s), **{k: v for k, v in outs.items() if k.startswith(f"s{s}_") or k in ("uvs_checksum", "shape")})
+                print("parked", part(s), flush=True)
+        if args.only_start is not None:
+            continue
         if args.starts > 1:
+            assert np.array_equal(outs["s0_use"], outs["s1_use"]), "the two starts selected different frames"
             e0, i0, p0 = orc.deserialize_params(outs["s0_x"], C)
             e1, i1, p1 = orc.deserialize_params(outs["s1_x"], C)
             c0, c1 = outs["s0_x"][: 12 * C].reshape(C, 12)[:, :6], outs["s1_x"][: 12 * C].reshape(C, 12)[:, :6]
