@@ -180,7 +180,10 @@ __global__ void k_transpose_obs(const double2* __restrict__ raw, double2* __rest
 // hide each other's FP64 / memory latency; the roles never exchange data.
 template <int LOSS, int ROLE>
 __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
-                                          double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2) {
+                                          double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2,
+                                          const double (&pz0)[6], const double2 (&pre)[4]) {
+  // pz0: this lane's frame pose, pre: its first four observations -- loaded by the kernel before the camera constants were
+  // staged (those loads, the LM state and the camera rows are all in flight together: one memory round trip at the start)
   const int f = fb * 64 + lane;
 #ifdef MCBA_GRAM_TIMING
   const long long gt0 = clock64();
@@ -196,11 +199,9 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
   const double* pose = x + 12 * C + 6 * (size_t)f;
   PairConst pc;
   {
-    double pz[6], Rf[9];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) pz[i] = pose[i];
-    rot_only(pz, Rf);
-    make_pair_const(Rc, tc, Rf, pz + 3, pc);
+    double Rf[9];
+    rot_only(pz0, Rf);
+    make_pair_const(Rc, tc, Rf, pz0 + 3, pc);
   }
 
   constexpr bool DO_A = ROLE != 1, DO_B = ROLE != 0;
@@ -219,7 +220,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
     const int pj = min(j, N - 1);
-    ring[j] = op[(size_t)pj * Fpad];
+    ring[j] = pre[j];
     xring[j][0] = obj[3 * pj]; xring[j][1] = obj[3 * pj + 1]; xring[j][2] = obj[3 * pj + 2];
   }
   auto point = [&](double2 o2, const double Xo[3]) {
@@ -259,7 +260,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
       const int pj = min(j, N - 1);
-      r4[j] = op[(size_t)pj * Fpad];
+      r4[j] = pre[j];
       x4[j][0] = obj[3 * pj]; x4[j][1] = obj[3 * pj + 1]; x4[j][2] = obj[3 * pj + 2];
     }
     ObsLead qc;
@@ -422,25 +423,73 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #endif
 }
 
+// Common start of the two k_gram kernels.  Which parameter slot / record buffer is the current one lives in the device LM
+// state, the camera row and the frame poses live in that slot: read one after the other that is three dependent memory round
+// trips (~2 us each, the data was just written by kernels on other XCDs) before the first FMA.  Instead the state, the
+// camera row and this lane's pose of BOTH slots and the lane's first four observations (slot-independent) are requested
+// together, and the right copies are picked once the state has arrived.
+struct GramStart {
+  const double* x;
+  double* rec;
+  double* gpart;
+  double pz[6];
+  double2 pre[4];
+  int fb, lane;
+  bool run;
+};
+__device__ __forceinline__ void gram_start(GramStart& g, CamConst& s_cam, const double2* __restrict__ obs_t, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1, double* rec0, double* rec1,
+                                           double* gp0, double* gp1, int C, int N, int Fpad, int fb0, int fb1) {
+  const int c = blockIdx.y;
+  const int wave = threadIdx.x >> 6;
+  g.lane = threadIdx.x & 63;
+  g.fb = fb0 + blockIdx.x * 4 + wave;  // this launch covers the frame blocks [fb0, fb1)
+  const bool have = g.fb < fb1;
+  const int fbc = have ? g.fb : fb1 - 1;
+  double st3 = 0.0, st14 = 0.0, st15 = 0.0;
+  if (sl.lms) { st3 = sl.lms[3]; st14 = sl.lms[MCBA_LM_SKIP]; st15 = sl.lms[MCBA_LM_DONE]; }
+  const size_t po = (size_t)12 * C + 6 * ((size_t)fbc * 64 + g.lane);
+  double pa[6], pb[6], ca[12], cb[12];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { pa[i] = x0[po + i]; pb[i] = x1[po + i]; }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { ca[i] = x0[12 * c + i]; cb[i] = x1[12 * c + i]; }
+  }
+  const double2* op = obs_t + (size_t)c * N * Fpad + (size_t)fbc * 64 + g.lane;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) g.pre[j] = op[(size_t)min(j, N - 1) * Fpad];
+  // ---- the state has arrived: sel_active(sl, true) / sel_index(sl)
+  const bool active = !sl.lms || (st15 == 0.0 && st14 == 0.0);
+  const bool spec = sl.spec && st14 == 0.0;
+  const int sidx = sl.lms ? ((static_cast<int>(st3) ^ sl.idx ^ (spec ? 1 : 0)) & 1) : sl.idx;
+  g.x = sidx ? x1 : x0;
+  g.rec = sidx ? rec1 : rec0;
+  g.gpart = sidx ? gp1 : gp0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g.pz[i] = sidx ? pb[i] : pa[i];
+  if (active && threadIdx.x == 0) {
+    double cm[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) cm[i] = sidx ? cb[i] : ca[i];
+    make_cam_const(cm, s_cam);
+  }
+  g.run = active;
+  if (active) __syncthreads();  // (uniform: the state is the same for every thread)
+  g.run = active && have;
+}
+
 // Split roles: grid.z = 2, <= 256 VGPRs, two waves per SIMD.
 template <int LOSS>
 __global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
                                                        double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, int fb0, int fb1,
                                                        double fs2, double ifs2) {
-  if (!sel_active(sl, true)) return;
-  const int sidx = sel_index(sl);
-  const double* __restrict__ x = sidx ? x1 : x0;
-  double* __restrict__ rec = sidx ? rec1 : rec0;
-  double* __restrict__ gpart = sidx ? gp1 : gp0;
   __shared__ CamConst s_cam;
+  GramStart g;
+  gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1);
+  if (!g.run) return;
   const int c = blockIdx.y;
-  if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int fb = fb0 + blockIdx.x * 4 + wave;  // this launch covers the frame blocks [fb0, fb1)
-  if (fb >= fb1) return;
-  if (blockIdx.z == 0) gram_body<LOSS, 0>(s_cam, obs_t, obj, x, rec, gpart, c, fb, lane, C, N, Fpad, nfb, fs2, ifs2);
-  else gram_body<LOSS, 1>(s_cam, obs_t, obj, x, rec, gpart, c, fb, lane, C, N, Fpad, nfb, fs2, ifs2);
+  if (blockIdx.z == 0) gram_body<LOSS, 0>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre);
+  else gram_body<LOSS, 1>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre);
 }
 
 // Both roles in one lane: grid.z = 1, one wave per SIMD (all 87 accumulators + temporaries in the 512-register file).
@@ -448,19 +497,11 @@ template <int LOSS>
 __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
                                                  double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, int fb0, int fb1,
                                                  double fs2, double ifs2) {
-  if (!sel_active(sl, true)) return;
-  const int sidx = sel_index(sl);
-  const double* __restrict__ x = sidx ? x1 : x0;
-  double* __restrict__ rec = sidx ? rec1 : rec0;
-  double* __restrict__ gpart = sidx ? gp1 : gp0;
   __shared__ CamConst s_cam;  // camera intrinsics + pose (R, t, Jr) staged once per workgroup
-  const int c = blockIdx.y;
-  if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int fb = fb0 + blockIdx.x * 4 + wave;  // this launch covers the frame blocks [fb0, fb1)
-  if (fb >= fb1) return;
-  gram_body<LOSS, 2>(s_cam, obs_t, obj, x, rec, gpart, c, fb, lane, C, N, Fpad, nfb, fs2, ifs2);
+  GramStart g;
+  gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1);
+  if (!g.run) return;
+  gram_body<LOSS, 2>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre);
 }
 
 // ---------------------------------------------------------------- k_cost: robust cost only (trial points), optional residual vector

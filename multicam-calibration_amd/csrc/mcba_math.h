@@ -202,10 +202,7 @@ MCBA_HD void make_chain_const(const double* Rc, const double* Jrc, const double*
 //      gw = rho'(z)                      (gradient weight:  g = J^T (rho' f))
 //      w2 = max(rho' + 2 rho'' f^2, EPS) (scipy's J_scale^2: J~^T J~ = sum w2 j^T j)
 // lm_weight() turns (gw, w2) into the curvature weight the LM normal equations use.
-MCBA_HD double lm_weight(double gw, double w2) {
-  double fl = MCBA_CURV_FLOOR * gw;
-  return w2 > fl ? w2 : fl;
-}
+MCBA_HD double lm_weight(double gw, double w2) { return fmax(w2, MCBA_CURV_FLOOR * gw); }
 template <int LOSS>
 MCBA_HD void loss_weights(double r, double fs2, double inv_fs2, double& rho_half, double& gw, double& w2) {
   double r2 = r * r;
@@ -222,8 +219,7 @@ MCBA_HD void loss_weights(double r, double fs2, double inv_fs2, double& rho_half
     double t = a * it;
     rho_half = fs2 * (t - 1.0);
     gw = it;
-    double js = it * it * it;
-    w2 = js < MCBA_EPS ? MCBA_EPS : js;
+    w2 = fmax(it * it * it, MCBA_EPS);
     return;
   } else if (LOSS == LOSS_HUBER) {
     if (z <= 1.0) { rho0 = z; rho1 = 1.0; rho2 = 0.0; }
