@@ -1229,7 +1229,9 @@ __global__ __launch_bounds__(64) void k_jacobian(const double2* __restrict__ obs
     double2* out = reinterpret_cast<double2*>(jac + (((size_t)c * F + f) * N + p0) * 36);
     for (int j = lane; j < np * 18; j += 64) {
       int pp = j / 18, kk = (j % 18) * 2;
-      out[j] = make_double2(s_rows[pp * 37 + kk], s_rows[pp * 37 + kk + 1]);
+      typedef double nt_d2 __attribute__((ext_vector_type(2)));
+      nt_d2 v = {s_rows[pp * 37 + kk], s_rows[pp * 37 + kk + 1]};
+      __builtin_nontemporal_store(v, reinterpret_cast<nt_d2*>(out) + j);  // 985 MB written once and not read back by the GPU: non-temporal
     }
     __syncthreads();
   }
