@@ -177,12 +177,16 @@ def main():
             e1, i1, p1 = orc.deserialize_params(outs["s1_x"], C)
             c0, c1 = outs["s0_x"][: 12 * C].reshape(C, 12)[:, :6], outs["s1_x"][: 12 * C].reshape(C, 12)[:, :6]
             e1a, p1a = orc.gauge_align(e1, p1, e0[0])
+            # poses are compared as 4x4 transforms (a rotation vector near |r| = pi has two representations), translations
+            # relative to the largest one
+            Ta, Tb = orc.to_matrix(p1a), orc.to_matrix(p0)
+            dpose = max(np.abs(Ta - Tb)[..., :3, :3].max(), (np.abs(Ta - Tb)[..., :3, 3] / np.abs(Tb[..., :3, 3]).max()).max())
             print(f"{tag} {mode}: two-start agreement intrinsics {np.abs(c0 - c1).max() / 1:.2e} abs, rel {(np.abs(c0 - c1) / np.abs(c0)).max():.2e}; "
-                  f"extrinsics {np.abs(e1a - e0).max():.2e}; poses {np.abs(p1a - p0).max():.2e}", flush=True)
+                  f"extrinsics {np.abs(e1a - e0).max():.2e}; poses (as transforms) {dpose:.2e}", flush=True)
             # the second start only certifies the first: keep its camera block and the agreement, not its poses
             outs["s1_cam"] = outs["s1_x"][: 12 * C].copy()
             outs["agree_ext"] = np.array(np.abs(e1a - e0).max())
-            outs["agree_poses"] = np.array(np.abs(p1a - p0).max())
+            outs["agree_poses"] = np.array(dpose)
             if F > 2000:
                 del outs["s1_x"]
         name = f"tight_{tag}.npz" if mode == "free" else f"tight_{tag}_fixed.npz"
