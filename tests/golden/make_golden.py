@@ -16,6 +16,7 @@ Files written
   default_run.npz   default bundle_adjust() on config 1 (2 x 50 x 54)         (golden 5)
   robust.npz        scipy's soft_l1/huber/cauchy/arctan rho + rescale         (golden 7)
   tight_*.npz       (--slow) tight-optimum runs, SURVEY.md section 7 protocol (golden 6)
+  tight_edge_*.npz  (--edge) the same recipe on degenerate inputs (blind camera, 3 frames, 9 / 10 cameras with 40 % missing)
 """
 import contextlib
 import importlib.util
@@ -54,7 +55,7 @@ def problem_arrays(p):
     return dict(uvs=p["uvs"], obj=p["obj"], extrinsics=p["extrinsics"], K=K, dist=dist, poses=p["poses"])
 
 
-def main(slow):
+def main(slow, edge=False):
     from multicam_calibration_amd import synth
     from scipy.optimize._numdiff import approx_derivative, group_columns
     from scipy.optimize._lsq.least_squares import construct_loss_function
@@ -169,7 +170,7 @@ def main(slow):
     np.savez_compressed(os.path.join(HERE, "robust.npz"), **out)
     print("robust.npz")
 
-    if not slow:
+    if not (slow or edge):
         return
 
     # ---------------------------------------------------------------- golden 6: tight optimum (hard part 1)
@@ -183,11 +184,13 @@ def main(slow):
     from oracle import ba_oracle as orc
     from scipy.optimize import least_squares
 
-    def tight(p, tag, pseeds, **extra):
+    def tight(p, tag, pseeds, modify=None, **extra):
         outs = {}
         loss, f_scale = extra.get("loss", "soft_l1"), extra.get("f_scale", 1.0)
         for s, pseed in enumerate(pseeds):
             q = synth.make_problem(perturb_seed=pseed, **p)
+            if modify is not None:
+                modify(q)
             with contextlib.redirect_stdout(io.StringIO()):
                 r0 = ba.bundle_adjust(q["uvs"], q["extrinsics"], q["intrinsics"], q["obj"], q["poses"], n_frames=None, max_nfev=1, verbose=0)
             use = r0[3]
@@ -238,10 +241,22 @@ def main(slow):
                 outs.update({k: v for k, v in problem_arrays(q).items()})
         np.savez_compressed(os.path.join(HERE, f"tight_{tag}.npz"), **outs)
 
-    tight(dict(n_cameras=2, n_frames=50, seed=0), "config1", (1, 2))
-    tight(dict(n_cameras=3, n_frames=30, seed=40, missing=0.25, scalar_nans=6), "missing3", (1, 2))
-    tight(dict(n_cameras=2, n_frames=50, seed=0), "config1_cauchy", (1, 2), loss="cauchy", f_scale=0.5)
+    if slow:
+        tight(dict(n_cameras=2, n_frames=50, seed=0), "config1", (1, 2))
+        tight(dict(n_cameras=3, n_frames=30, seed=40, missing=0.25, scalar_nans=6), "missing3", (1, 2))
+        tight(dict(n_cameras=2, n_frames=50, seed=0), "config1_cauchy", (1, 2), loss="cauchy", f_scale=0.5)
+    if edge:
+        # degenerate inputs (SURVEY 8c edge cases) through the same recipe: a camera that never sees the board (its twelve
+        # columns of the Jacobian vanish: the minimum-norm polish leaves its parameters where they started), fewer frames than
+        # a wavefront, and the two camera counts either side of the LDS-resident reduced solve with 40 % missing detections
+        def blind(q):
+            q["uvs"][2] = np.nan
+
+        tight(dict(n_cameras=3, n_frames=40, seed=1), "edge_blind_camera", (1, 2), modify=blind)
+        tight(dict(n_cameras=2, n_frames=3, seed=2), "edge_three_frames", (1, 2))
+        tight(dict(n_cameras=9, n_frames=20, seed=6, missing=0.4), "edge_nine_cameras", (1, 2))
+        tight(dict(n_cameras=10, n_frames=20, seed=7, missing=0.4), "edge_ten_cameras", (1, 2))
 
 
 if __name__ == "__main__":
-    main("--slow" in sys.argv)
+    main("--slow" in sys.argv, "--edge" in sys.argv)

@@ -14,19 +14,20 @@ from oracle import ba_oracle as orc
 from multicam_calibration_amd import solver, synth, api
 
 
-def compare_to_golden(z, x, C, tol):
+def compare_to_golden(z, x, C, tol, blind=()):
+    keep = np.array([c not in blind for c in range(C)])   # cameras without a detection are not constrained by the data
     ext, intr, poses = orc.deserialize_params(x, C)
     ext_g, intr_g, poses_g = orc.deserialize_params(z["s0_x"], C)
     cam, cam_g = np.asarray(x[:12 * C]).reshape(C, 12), z["s0_x"][:12 * C].reshape(C, 12)
-    assert (np.abs(cam[:, :6] - cam_g[:, :6]) / np.abs(cam_g[:, :6])).max() < tol
+    assert (np.abs(cam[:, :6] - cam_g[:, :6]) / np.abs(cam_g[:, :6]))[keep].max() < tol
     ext_a, poses_a = orc.gauge_align(ext, poses, ext_g[0])
-    assert (np.abs(ext_a - ext_g) / np.maximum(np.abs(ext_g), np.abs(ext_g).max(0) * 1e-3 + 1e-12)).max() < tol
+    assert (np.abs(ext_a - ext_g) / np.maximum(np.abs(ext_g), np.abs(ext_g).max(0) * 1e-3 + 1e-12))[keep].max() < tol
     Ta, Tg = orc.to_matrix(poses_a), orc.to_matrix(poses_g)
     assert np.abs(Ta - Tg)[..., :3, :3].max() < tol
     assert (np.abs(Ta - Tg)[..., :3, 3] / np.abs(Tg[..., :3, 3]).max()).max() < tol
 
 
-@pytest.mark.parametrize("tag", ["config1", "missing3", "config1_cauchy"])
+@pytest.mark.parametrize("tag", ["config1", "missing3", "config1_cauchy", "edge_blind_camera", "edge_three_frames", "edge_nine_cameras", "edge_ten_cameras"])
 def test_goldens_are_certified(golden, tag):
     """The tight goldens: reference FD-gradient ~ 0 and two independent starts agree far below 1e-6."""
     z = golden(f"tight_{tag}.npz")
@@ -34,7 +35,7 @@ def test_goldens_are_certified(golden, tag):
     assert float(z["s0_fd_grad_inf"]) < 1e-5 and float(z["s1_fd_grad_inf"]) < 1e-5
     assert abs(float(z["s0_cost"]) - float(z["s1_cost"])) < 1e-11 * float(z["s0_cost"])
     zz = {"s0_x": z["s0_x"]}
-    compare_to_golden(zz, z["s1_x"], C, 2e-7)
+    compare_to_golden(zz, z["s1_x"], C, 2e-7, blind=(2,) if tag == "edge_blind_camera" else ())
 
 
 @pytest.mark.parametrize("name", ["tight_6x1000.npz", "tight_6x1000_fixed.npz", "tight_6x10000.npz"])
