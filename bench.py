@@ -19,8 +19,8 @@ Workloads
 
 A "step" is ONE complete Levenberg-Marquardt iteration on the rank's shard (a "tick" of the device-resident loop):
 back-substitution (k_backsub), residuals + analytic Jacobian blocks + normal equations of the trial point in one pass over
-the observations (k_gram; its cost decides accept/reject), trial sums + decision, Schur reduction (k_frame_factor,
-k_syrk, k_reduce_system), [all-reduce], the (12C)^2 reduced camera solve (k_solve_cam).  Every step linearises its trial
+the observations (k_gram; its cost decides accept/reject), trial sums + decision + frame factors + Schur product (k_syrk),
+k_reduce_system, [all-reduce], the (12C)^2 reduced camera solve (k_solve_cam).  Every step linearises its trial
 point, accepted or not (never less work than a real iteration).
 
 Extra objects on the same line: `roofline` (dominant kernel of the timed region, HIP-event timed on the launch stream;
@@ -63,8 +63,7 @@ def algorithmic_bytes(kernel, C, F, N):
     return {
         "k_gram": obs + poses + rec + 736 * C * ((F + 63) // 64),
         "k_cost": obs + poses,
-        "k_frame_factor": 216 * C * F + 320 * F,
-        "k_syrk": 576 * C * F + 216 * F,
+        "k_syrk": 576 * C * F + 216 * C * F + 320 * F,
         "k_backsub": 576 * C * F + 320 * F + 2 * poses,
         "k_jacobian": obs + poses + (288 + 16) * C * F * N,
         "k_reduce_system": 8 * (n * n + 3 * n),

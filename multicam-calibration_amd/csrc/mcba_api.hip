@@ -20,8 +20,8 @@ namespace {
 
 thread_local std::string g_err;
 
-enum KernelId { K_TRANSPOSE = 0, K_GRAM, K_COST, K_FRAME_FACTOR, K_SYRK, K_REDUCE, K_BACKSUB, K_SUM_TRIAL, K_JACOBIAN, K_DECIDE, K_SOLVE, K_COUNT };
-const char* kKernelNames = "k_transpose_obs\nk_gram\nk_cost\nk_frame_factor\nk_syrk\nk_reduce_system\nk_backsub\nk_sum_trial\nk_jacobian\nk_decide\nk_solve_cam";
+enum KernelId { K_TRANSPOSE = 0, K_GRAM, K_COST, K_SYRK, K_REDUCE, K_BACKSUB, K_SUM_TRIAL, K_JACOBIAN, K_DECIDE, K_SOLVE, K_COUNT };
+const char* kKernelNames = "k_transpose_obs\nk_gram\nk_cost\nk_syrk\nk_reduce_system\nk_backsub\nk_sum_trial\nk_jacobian\nk_decide\nk_solve_cam";
 constexpr int kRing = 16;  // host-mapped LM state slots (device-resident loop): the host may run at most kRing - 1 ticks ahead
 
 struct EvRec { int kid; hipEvent_t a, b; };
@@ -688,8 +688,9 @@ int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, do
 // ---------------------------------------------------------------------------------------------------------
 // Device-resident LM loop: the reduced camera system is solved on the GPU too (k_solve_cam), the termination tests run
 // there, and the host only enqueues "ticks" and reads the 32-double state each one posts to a host-mapped ring:
-//   tick = k_backsub -> k_gram(trial) -> k_sum_trial [-> all-reduce -> k_decide] -> k_frame_factor -> k_syrk
-//          -> k_reduce_system [-> all-reduce] -> k_solve_cam
+//   one GPU:        tick = k_backsub -> k_gram(trial) -> k_syrk (trial sums + decision + frame factors + SYRK) -> k_reduce_system -> k_solve_cam
+//   frame-sharded:  tick = k_backsub -> k_gram(trial) -> k_sum_trial -> k_syrk (speculative) -> k_reduce_system -> all-reduce -> k_solve_cam (decides)
+//                   (MCBA_SPECULATE=0: k_sum_trial -> all-reduce -> k_decide -> k_syrk -> k_reduce_system -> all-reduce -> k_solve_cam)
 // No host synchronisation inside or between ticks; after termination the remaining ticks return immediately.
 int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, double lam_min, double lam_max, const unsigned char* fixed) {
   if (!h || !(lam_min > 0.0) || !(lam_max > lam_min)) return fail(MCBA_ERR_ARG, "mcba_lm_auto_config: bad argument");

@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
 
 // ---------------------------------------------------------------- k_backsub: frame steps + trial parameters
 // lane = frame.  t = g_f + W_f^T d_c with W read from the wave tiles (each load = 64 consecutive frames, 1 KiB),
-// d_f = -(L L^T)^-1 t with the Cholesky factor k_frame_factor left in fbuf, x_dst = x_src + d.
+// d_f = -(L L^T)^-1 t with the Cholesky factor k_syrk left in fbuf, x_dst = x_src + d.
 // Per-block partials of  sum d^T(lambda D d - g_f),  sum |d_f|^2,  sum |x_f|^2.
 // DcSrc: the camera step either rides in the kernel-argument segment (CamStep, host solve) or sits in device memory
 // where k_solve_cam left it (DevStep); both are wave-uniform scalar loads.
