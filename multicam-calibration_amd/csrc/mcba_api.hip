@@ -797,10 +797,13 @@ int mcba_debug_syrk_stamps(mcba_handle* h, double* host8) {  // development only
   return MCBA_OK;
 }
 
-int mcba_debug_gram_stamps(mcba_handle* h, double* host3) {  // development only (MCBA_GRAM_TIMING builds)
-  if (!h || !host3) return fail(MCBA_ERR_ARG, "bad argument");
-  for (int l = 0; l < 3; ++l)
-    HIPCHK(hipMemcpy(host3 + l, h->rec2[h->lin] + ((size_t)0 * h->nfb + 1) * (MCBA_REC * 64) + (size_t)(49 * 64 + l) * 2 + 1, sizeof(double), hipMemcpyDeviceToHost));
+int mcba_debug_gram_stamps(mcba_handle* h, double* host) {  // development only (MCBA_GRAM_TIMING builds): [C][nfb][8]
+  if (!h || !host) return fail(MCBA_ERR_ARG, "bad argument");
+  HIPCHK(hipDeviceSynchronize());
+  for (int c = 0; c < h->C; ++c)
+    for (int fb = 0; fb < h->nfb; ++fb)
+      HIPCHK(hipMemcpy2D(host + ((size_t)c * h->nfb + fb) * 8, sizeof(double), h->rec2[h->lin] + ((size_t)c * h->nfb + fb) * (MCBA_REC * 64) + (size_t)(49 * 64) * 2 + 1, 2 * sizeof(double),
+                         sizeof(double), 8, hipMemcpyDeviceToHost));
   return MCBA_OK;
 }
 

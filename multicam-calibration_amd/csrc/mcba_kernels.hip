@@ -187,6 +187,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
   const int f = fb * 64 + lane;
 #ifdef MCBA_GRAM_TIMING
   const long long gt0 = clock64();
+  const long long gw0 = wall_clock64();
 #endif
   Intr K;
   K.fx = uni(s_cam.fx); K.fy = uni(s_cam.fy); K.cx = uni(s_cam.cx); K.cy = uni(s_cam.cy); K.k1 = uni(s_cam.k1); K.k2 = uni(s_cam.k2);
@@ -415,9 +416,13 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     }
   }
 #ifdef MCBA_GRAM_TIMING
-  if (c == 0 && fb == 1 && lane < 3) {
+  if (lane < 8) {  // every wavefront: phase lengths in shader cycles, begin / end on the 100 MHz wall clock, where it ran
     const long long gt3 = clock64();
-    const double v = lane == 0 ? (double)(gt1 - gt0) : lane == 1 ? (double)(gt2 - gt1) : (double)(gt3 - gt2);
+    const long long gw3 = wall_clock64();
+    unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+    unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // XCC_ID
+    const double v = lane == 0 ? (double)(gt1 - gt0) : lane == 1 ? (double)(gt2 - gt1) : lane == 2 ? (double)(gt3 - gt2) : lane == 3 ? (double)gw0 : lane == 4 ? (double)gw3
+                   : lane == 5 ? (double)hwid : lane == 6 ? (double)xcc : 0.0;
     r2[49 * 64].y = v;  // pad slot of the record
   }
 #endif

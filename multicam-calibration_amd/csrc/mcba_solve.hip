@@ -14,7 +14,10 @@
 //                         hold the 16 diagonal rows (redundantly), lanes 16..63 hold 48 further panel rows; finished
 //                         entries of the diagonal rows are broadcast with v_readlane (left-looking inside the block), so
 //                         there is no barrier between "factor" and "triangular solve"; pivots: v_rsq_f64 + one cubic step
-//   backward sweep L^T d = y block by block, each step's operands in flight while wavefront 0 does the 16 pivots.
+//   backward sweep L^T d = y block by block.  Factor in LDS: the identity's 16 rows ride through every diagonal block's
+//   triangular solve in otherwise idle lanes, which leaves L_kk^-T -- the sweep's 16 sequential pivots per block become
+//   one 16-term dot product per row (measured at 12 C = 72: 10.6 k -> 6.1 k cycles).  Factor in global memory: each
+//   step's operands in flight while wavefront 0 does the 16 pivots.
 // The factor lives in LDS (odd row stride) when it fits (<= 9 cameras) -- then the whole lower triangle is put in flight
 // before anything else, because a dependent global round trip costs ~2 us here; otherwise in an L2-resident scratch,
 // with the panel's own rows staged in LDS and the A rows streamed 32 B per lane, one work item ahead.
@@ -119,6 +122,7 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
   double* lst = s_red + 72;                            // MCBA_LMS : the LM state, worked on in LDS
   double* W = LDSW ? (lst + MCBA_LMS) : a.work;        // npad rows, row-major: the factor L (lower part)
   const int ldw = LDSW ? npad + 1 : npad;              // odd row stride in LDS: rows land in different banks
+  double* linv = W + (size_t)npad * ldw;               // LDSW: nblk x 16 x 17, the inverse transposes of the diagonal blocks of L
   double* Bs = lst + MCBA_LMS;                         // !LDSW: 16 x bst, the panel's own rows of L (the MFMA B operand)
   const int bst = npad + 2;                            // bst / 2 odd: conflict-free 16-byte LDS reads
 #ifdef MCBA_SOLVE_TIMING
@@ -324,7 +328,11 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
         __syncthreads();
       }
       LAP(0);
-      if (wave == 0 || 16 + 48 * wave < 16 * ntile) {  // wavefronts whose rows are all past the end sit this panel out
+      // With the factor in LDS the last 16 lanes of the last wavefront (row slots no matrix of this variant reaches) carry
+      // the rows of the 16 x 16 IDENTITY through the same triangular solve: what comes out is L_kk^-T, which turns the
+      // 16 sequential pivots of this block in the backward sweep into one 16-term dot product per row.
+      const bool idrow = LDSW && wave == NW - 1 && lane >= 48;
+      if (wave == 0 || 16 + 48 * wave < 16 * ntile || (LDSW && wave == NW - 1)) {  // wavefronts whose rows are all past the end sit this panel out
         const bool rv = q < 16 * ntile;
         double r[16];
         {
@@ -334,6 +342,10 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
           if (k > 0) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) r[c] -= panel[(rv ? q : 0) * 17 + c];
+          }
+          if (idrow) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) r[c] = (c == lane - 48) ? 1.0 : 0.0;
           }
         }
         double myinv = 1.0;
@@ -360,6 +372,11 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
           for (int c = 0; c < 16; ++c) wr[c] = r[c];
         }
         if (wave == 0 && lane < 16) invd[r0 + lane] = myinv;
+        if (idrow) {
+          double* li = linv + (k * 16 + (lane - 48)) * 17;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) li[c] = r[c];
+        }
       }
       __syncthreads();
       LAP(1);
@@ -372,54 +389,86 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
     // ---- backward sweep  L^T d = y,  y = row n of the factor
     for (int j = tid; j < npad; j += NTHREADS) yv[j] = j < n ? W[(size_t)n * ldw + j] : 0.0;
     __syncthreads();
-    // Every step's loads are issued at its top: the off-diagonal rows it needs after the barrier, and (wavefront 0) the
-    // diagonal block of the NEXT step -- both are in flight while wavefront 0 does the 16 sequential pivots.
-    double col[16];   // wavefront 0: col[l] = L[r0 + l][r0 + row] of the block being solved
-    {
-      const int r0 = 16 * (nblk - 1);
+    if constexpr (LDSW) {
+      // d_k = L_kk^-T y_k: row i of the inverse transpose (zero left of the diagonal) times the block's right-hand side; y
+      // beyond row n is zero, so the right-hand-side row and the padding drop out.  Then y_j -= sum_t L[r0+t][j] d[r0+t].
+      for (int k = nblk - 1; k >= 0; --k) {
+        const int r0 = 16 * k;
+        double wcur[16];  // wcur[t] = L[r0 + t][j] for this thread's column j = tid: in flight during the dot products
 #pragma unroll
-      for (int l = 0; l < 16; ++l) col[l] = W[(size_t)(r0 + l) * ldw + r0 + (lane & 15)];
-    }
-    for (int k = nblk - 1; k >= 0; --k) {
-      const int r0 = 16 * k;
-      double wcur[16];  // wcur[t] = L[r0 + t][j] for this thread's column j = tid (first pass over j)
+        for (int t = 0; t < 16; ++t) wcur[t] = W[(size_t)(r0 + t) * ldw + min(tid, npad - 1)];
+        if (tid < 16) {
+          const double* li = linv + (k * 16 + tid) * 17;
+          double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int t = 0; t < 16; ++t) wcur[t] = W[(size_t)(r0 + t) * ldw + min(tid, npad - 1)];
-      if (wave == 0) {
-        const int row = lane & 15;
-        double cnx[16];
-        if (k > 0) {
-#pragma unroll
-          for (int l = 0; l < 16; ++l) cnx[l] = W[(size_t)(r0 - 16 + l) * ldw + r0 - 16 + row];
+          for (int c = 0; c < 16; ++c) s[c & 3] = fma(li[c], yv[r0 + c], s[c & 3]);
+          dv[r0 + tid] = (r0 + tid < n) ? (s[0] + s[1]) + (s[2] + s[3]) : 0.0;
         }
-        double y = yv[r0 + row];
-        const double iv = invd[r0 + row];
+        __syncthreads();
+        for (int j = tid; j < r0; j += NTHREADS) {
+          double s0 = yv[j], s1 = 0.0;
+          if (j == tid) {
 #pragma unroll
-        for (int l = 15; l >= 0; --l) {
-          const double dl = lane_bcast(y * iv, l);
-          if (row == l) y = dl;
-          else if (row < l) y = fma(-col[l], dl, y);
-        }
-        if (lane < 16) dv[r0 + row] = (r0 + row < n) ? y : 0.0;
-        if (k > 0) {
+            for (int t = 0; t < 16; t += 2) { s0 = fma(-wcur[t], dv[r0 + t], s0); s1 = fma(-wcur[t + 1], dv[r0 + t + 1], s1); }
+          } else {
+            const double* wc = W + (size_t)r0 * ldw + j;
 #pragma unroll
-          for (int l = 0; l < 16; ++l) col[l] = cnx[l];
+            for (int t = 0; t < 16; t += 2) { s0 = fma(-wc[(size_t)t * ldw], dv[r0 + t], s0); s1 = fma(-wc[(size_t)(t + 1) * ldw], dv[r0 + t + 1], s1); }
+          }
+          yv[j] = s0 + s1;
         }
+        __syncthreads();
       }
-      __syncthreads();
-      for (int j = tid; j < r0; j += NTHREADS) {
-        double s = yv[j];
-        if (j == tid) {
+    } else {
+      // Every step's loads are issued at its top: the off-diagonal rows it needs after the barrier, and (wavefront 0) the
+      // diagonal block of the NEXT step -- both are in flight while wavefront 0 does the 16 sequential pivots.
+      double col[16];   // wavefront 0: col[l] = L[r0 + l][r0 + row] of the block being solved
+      {
+        const int r0 = 16 * (nblk - 1);
 #pragma unroll
-          for (int t = 0; t < 16; ++t) s = fma(-wcur[t], dv[r0 + t], s);
-        } else {
-          const double* wc = W + (size_t)r0 * ldw + j;
-#pragma unroll
-          for (int t = 0; t < 16; ++t) s = fma(-wc[(size_t)t * ldw], dv[r0 + t], s);
-        }
-        yv[j] = s;
+        for (int l = 0; l < 16; ++l) col[l] = W[(size_t)(r0 + l) * ldw + r0 + (lane & 15)];
       }
-      __syncthreads();
+      for (int k = nblk - 1; k >= 0; --k) {
+        const int r0 = 16 * k;
+        double wcur[16];  // wcur[t] = L[r0 + t][j] for this thread's column j = tid (first pass over j)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) wcur[t] = W[(size_t)(r0 + t) * ldw + min(tid, npad - 1)];
+        if (wave == 0) {
+          const int row = lane & 15;
+          double cnx[16];
+          if (k > 0) {
+#pragma unroll
+            for (int l = 0; l < 16; ++l) cnx[l] = W[(size_t)(r0 - 16 + l) * ldw + r0 - 16 + row];
+          }
+          double y = yv[r0 + row];
+          const double iv = invd[r0 + row];
+#pragma unroll
+          for (int l = 15; l >= 0; --l) {
+            const double dl = lane_bcast(y * iv, l);
+            if (row == l) y = dl;
+            else if (row < l) y = fma(-col[l], dl, y);
+          }
+          if (lane < 16) dv[r0 + row] = (r0 + row < n) ? y : 0.0;
+          if (k > 0) {
+#pragma unroll
+            for (int l = 0; l < 16; ++l) col[l] = cnx[l];
+          }
+        }
+        __syncthreads();
+        for (int j = tid; j < r0; j += NTHREADS) {
+          double s = yv[j];
+          if (j == tid) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s = fma(-wcur[t], dv[r0 + t], s);
+          } else {
+            const double* wc = W + (size_t)r0 * ldw + j;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s = fma(-wc[(size_t)t * ldw], dv[r0 + t], s);
+          }
+          yv[j] = s;
+        }
+        __syncthreads();
+      }
     }
   }
 
@@ -466,7 +515,7 @@ int solve_threads(int npad) {
 
 size_t solve_lds_bytes(int npad, int use_lds) {
   size_t d = (size_t)npad * 17 + 4 * (size_t)npad + 72 + MCBA_LMS;
-  d += use_lds ? (size_t)npad * (npad + 1) : (size_t)16 * (npad + 2);
+  d += use_lds ? (size_t)npad * (npad + 1) + (size_t)(npad / 16) * 16 * 17 : (size_t)16 * (npad + 2);
   return d * sizeof(double);
 }
 

@@ -6,6 +6,9 @@ import numpy as np
 
 sys.path.insert(0, ".")
 import multicam_calibration_amd as m
+import os
+if os.environ.get("MCBA_LIB"):
+    m.ops.LIB_PATH = os.environ["MCBA_LIB"]
 
 for C in [int(a) for a in sys.argv[1:]] or [6, 24]:
     p = m.synth.make_problem(C, 256, seed=0)
