@@ -232,7 +232,7 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   DA(gpart2[1], (size_t)C * h->nfb * MCBA_GP);
   DA(fbuf, (size_t)h->Fpad * MCBA_FB);
   DA(fpart, (size_t)2 * h->nfblocks);
-  DA(spart, (size_t)h->G * h->NP * 256 + 64);
+  DA(spart, (size_t)h->G * h->NP * 256 + 64 + 12 * (size_t)h->G);  // + per-workgroup stamps of MCBA_SYRK_TIMING builds
   DA(cpart, (size_t)2 * C * h->nfb * h->nch);
   DA(bpart, (size_t)3 * h->nbblocks);
   DA(red_own, h->nsys + 8 + 2 * MCBA_LMS);
@@ -791,9 +791,11 @@ int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot) {
   return mcba_lm_auto_solve(h, seq, 0);
 }
 
-int mcba_debug_syrk_stamps(mcba_handle* h, double* host8) {  // development only (MCBA_SYRK_TIMING builds)
-  if (!h || !host8) return fail(MCBA_ERR_ARG, "bad argument");
-  HIPCHK(hipMemcpy(host8, h->spart + (size_t)h->G * h->NP * 256, 8 * sizeof(double), hipMemcpyDeviceToHost));
+int mcba_debug_syrk_stamps(mcba_handle* h, double* host) {  // development only (MCBA_SYRK_TIMING builds): host[0] = G, then [G][12] from host[12]
+  if (!h || !host) return fail(MCBA_ERR_ARG, "bad argument");
+  HIPCHK(hipDeviceSynchronize());
+  host[0] = (double)h->G;
+  HIPCHK(hipMemcpy(host + 12, h->spart + (size_t)h->G * h->NP * 256 + 64, 12 * (size_t)h->G * sizeof(double), hipMemcpyDeviceToHost));
   return MCBA_OK;
 }
 

@@ -620,6 +620,9 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   __shared__ double s_sum[8];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: keeps the tile bookkeeping out of the exec mask
+#ifdef MCBA_SYRK_TIMING
+  const long long t_entry = clock64(), w_entry = wall_clock64();
+#endif
   const bool have_state = sl.lms != nullptr;
   if (have_state && t < MCBA_LMS) s_st[t] = sl.lms[t];
   if (DECIDE) {
@@ -651,6 +654,9 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
     if (lane == 63) { s_sum[wave] = sa; s_sum[4 + wave] = sb; }
   }
   __syncthreads();
+#ifdef MCBA_SYRK_TIMING
+  const long long t_summed = clock64();
+#endif
   if (have_state && s_st[MCBA_LM_DONE] != 0.0) {  // terminated: nothing left to do (uniform) -- but the rest of the tick reads
     if (DECIDE && blockIdx.x == 0 && blockIdx.y == 0 && t < MCBA_LMS) fz.lms_post[t] = s_st[t];  // the state from the second buffer
     return;
@@ -674,6 +680,9 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
       if (t < 4) fz.trial_out[t] = s_sum[t];
     }
   }
+#ifdef MCBA_SYRK_TIMING
+  const long long t_decided = clock64();
+#endif
   int sidx;
   double lambda;
   if (have_state) {
@@ -809,6 +818,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
     const int s1 = min(f1, s0 + kSyrkSuper);
     vsum(s0, s1 - s0);
     __syncthreads();
+    SLAP(4);
     if (wave == 0) factor(s0, s1 - s0);
     __syncthreads();
     SLAP(0);
@@ -865,11 +875,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
     }
   }
 #ifdef MCBA_SYRK_TIMING
-  if (t == 0 && blockIdx.x == 3 && blockIdx.y == 0) {
-    double* dbg = spart + (size_t)gridDim.x * NP * 256;
-    for (int i = 0; i < 4; ++i) dbg[i] = (double)tacc[i];
-    dbg[4] = (double)(clock64() - tstart);
-  }
+  const long long t_loop_end = clock64();
 #endif
   if (wave == 0 && blockIdx.y == 0) {
     const double wm = wave_max(gmax), wn = wave_sum63(nfail);
@@ -883,6 +889,16 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
       o[0] = acc[k][0]; o[G * 64] = acc[k][1]; o[2 * G * 64] = acc[k][2]; o[3 * G * 64] = acc[k][3];
     }
   }
+#ifdef MCBA_SYRK_TIMING
+  if (t == 0 && blockIdx.y == 0) {  // per workgroup, shader cycles: entry -> trial scalars summed -> decided -> stages; V sums, factor, Y build, MFMA, barrier, tile store
+    double* dbg = spart + (size_t)gridDim.x * NP * 256 + 64 + 12 * (size_t)blockIdx.x;
+    dbg[0] = (double)(t_summed - t_entry); dbg[1] = (double)(t_decided - t_summed); dbg[2] = (double)(tstart - t_decided);
+    dbg[3] = (double)tacc[4]; dbg[4] = (double)tacc[0]; dbg[5] = (double)tacc[1]; dbg[6] = (double)tacc[2]; dbg[7] = (double)tacc[3];
+    dbg[8] = (double)(clock64() - t_loop_end);
+    dbg[9] = (double)w_entry; dbg[10] = (double)wall_clock64();  // 100 MHz
+    dbg[11] = (double)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // XCC_ID
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- k_reduce_system: fixed-order second stage
