@@ -849,15 +849,16 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
       __syncthreads();
       SLAP(1);
       if (fb + FS < f1) prefetch(fb + FS);  // flies while the matrix cores work
-      // matrix-core phase: K = 6 FS in steps of 4 (6 FS / 4 is even for every FS we use).  Operands of step ks+1 are
-      // read from LDS while the PPW independent MFMAs of step ks issue back to back (64 cycles each on one SIMD).
+      // matrix-core phase: K = 6 FS in steps of 4 (an even number of steps, except FS = 2 -- more than 26 cameras --
+      // where the third step has no partner).  Operands of step ks+1 are read from LDS while the PPW independent MFMAs
+      // of step ks issue back to back (64 cycles each on one SIMD).
       const int nks = (6 * FS) / 4;
       // (Measured: skipping the LDS read of a fragment that a neighbouring pair already holds -- wave-uniform branches
       // between the MFMAs -- costs more than the bandwidth it saves: 55k vs 33k cycles for this phase.  Keep it branch-free.)
       double a0[PPW], b0[PPW], a1[PPW], b1[PPW];
 #pragma unroll
       for (int k = 0; k < PPW; ++k) { a0[k] = s_y[rowa[k]]; b0[k] = s_y[rowb[k]]; }
-      for (int ks = 0; ks < nks; ks += 2) {
+      for (int ks = 0; ks + 1 < nks; ks += 2) {
 #pragma unroll
         for (int k = 0; k < PPW; ++k) { a1[k] = s_y[rowa[k] + 4 * ks + 4]; b1[k] = s_y[rowb[k] + 4 * ks + 4]; }
 #pragma unroll
@@ -868,6 +869,10 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
         }
 #pragma unroll
         for (int k = 0; k < PPW; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[k], b1[k], acc[k], 0, 0, 0);
+      }
+      if (nks & 1) {  // FS = 2: the last step's operands are already in a0 / b0
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], b0[k], acc[k], 0, 0, 0);
       }
       SLAP(2);
       __syncthreads();

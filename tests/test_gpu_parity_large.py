@@ -145,3 +145,40 @@ def test_shard_shape_properties(mc, C, F, rows, cols, tag):
     truth = np.asarray(p["true_cam"])[:, :4]
     got = res.x[:12 * C].reshape(C, 12)[:, :4]
     assert (np.abs(got - truth) / np.abs(truth)).max() < 2e-3                              # the generating intrinsics, to the noise
+
+
+# ------------------------------------------------------------------ rigs beyond 26 cameras: two frames per k_syrk stage
+@pytest.mark.parametrize("C", [27, 40])
+def test_many_cameras_vs_oracle(mc, C):
+    """12 C + 1 > 320 rows leave k_syrk two frames per stage (mcba_create halves FS until a thread's row items fit): K = 12
+    per stage = an ODD number of MFMA steps, the reduced system is factorised by the 512- / 1024-thread k_solve_cam with the
+    factor in global memory.  Normal equations, Schur reduction and one solved step against the oracle; mcba_create's limit
+    is 40 cameras."""
+    p = mc.synth.make_problem(C, 70, rows=2, cols=3, pitch=60.0, seed=43, missing=0.1)
+    F = p["uvs"].shape[1]
+    x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = mc.ops.Problem(p["uvs"], p["obj"])
+    prob.set_params(0, x)
+    prob.linearize(0)
+    lam = 1e-2
+    prob.build_reduced(lam)
+    red = {k: v.copy() for k, v in prob.get_reduced().items()}
+    U, gc, V, gf, W, cost = orc.normal_equations(x, p["uvs"], p["obj"])
+    Df2 = np.stack([np.where(np.diag(V[f]) > 0, np.diag(V[f]), 1.0) for f in range(F)])
+    S, rhs = orc.schur_reduce(U, gc, V, gf, W, lam, np.zeros((C, 12)), Df2)
+    assert np.abs(red["S0"] - S).max() <= 1e-10 * np.abs(S).max()
+    assert np.abs(red["rhs"] - rhs).max() <= 1e-10 * np.abs(rhs).max()
+    assert abs(red["scal"][0] - cost) <= 1e-12 * cost
+    # the device solve of the same system (k_solve_cam, factor in global memory) against LAPACK
+    prob.lm_set_state(float(red["scal"][0]), lam, 2.0, 0)
+    prob.lm_auto_config(0.0, 0.0, 0.0, 1e-12, 1e12, None)
+    prob.lm_auto_solve(1)
+    st = prob.lm_auto_wait(1)
+    assert st[23] == 0                                                    # solve info: ok
+    dc = prob.cam_step()
+    Sd = red["S0"] + lam * np.diag(np.where(red["diagU"] > 0, red["diagU"], 1.0))
+    ref = np.linalg.solve(Sd, red["rhs"])
+    r = Sd @ dc - red["rhs"]                                              # backward error, then LAPACK at the conditioning of S
+    assert np.abs(r).max() <= 1e-11 * (np.abs(Sd).max() * np.abs(dc).max() + np.abs(red["rhs"]).max())
+    assert np.abs(dc - ref).max() <= 1e-7 * np.abs(ref).max()
+    prob.close()
