@@ -16,7 +16,8 @@ Files written
   default_run.npz   default bundle_adjust() on config 1 (2 x 50 x 54)         (golden 5)
   robust.npz        scipy's soft_l1/huber/cauchy/arctan rho + rescale         (golden 7)
   tight_*.npz       (--slow) tight-optimum runs, SURVEY.md section 7 protocol (golden 6)
-  tight_edge_*.npz  (--edge) the same recipe on degenerate inputs (blind camera, 3 frames, 9 / 10 cameras with 40 % missing)
+  tight_edge_*.npz  (--edge) the same recipe on degenerate inputs (blind camera, 3 frames, 9 / 10 cameras with 40 % missing);
+                    (--many) 24 and 27 cameras
 """
 import contextlib
 import importlib.util
@@ -55,7 +56,7 @@ def problem_arrays(p):
     return dict(uvs=p["uvs"], obj=p["obj"], extrinsics=p["extrinsics"], K=K, dist=dist, poses=p["poses"])
 
 
-def main(slow, edge=False):
+def main(slow, edge=False, many=False):
     from multicam_calibration_amd import synth
     from scipy.optimize._numdiff import approx_derivative, group_columns
     from scipy.optimize._lsq.least_squares import construct_loss_function
@@ -170,7 +171,7 @@ def main(slow, edge=False):
     np.savez_compressed(os.path.join(HERE, "robust.npz"), **out)
     print("robust.npz")
 
-    if not (slow or edge):
+    if not (slow or edge or many):
         return
 
     # ---------------------------------------------------------------- golden 6: tight optimum (hard part 1)
@@ -256,7 +257,12 @@ def main(slow, edge=False):
         tight(dict(n_cameras=2, n_frames=3, seed=2), "edge_three_frames", (1, 2))
         tight(dict(n_cameras=9, n_frames=20, seed=6, missing=0.4), "edge_nine_cameras", (1, 2))
         tight(dict(n_cameras=10, n_frames=20, seed=7, missing=0.4), "edge_ten_cameras", (1, 2))
+    if many:
+        # rigs whose reduced system no longer fits LDS: 24 cameras (BASELINE configs[4]'s rig: 16-tile k_syrk wavefronts, 512-thread
+        # k_solve_cam) and 27 cameras (two frames per k_syrk stage, the regime a bug was found in)
+        tight(dict(n_cameras=24, n_frames=12, seed=8, missing=0.2), "edge_24_cameras", (1, 2))
+        tight(dict(n_cameras=27, n_frames=10, seed=9, missing=0.2), "edge_27_cameras", (1, 2))
 
 
 if __name__ == "__main__":
-    main("--slow" in sys.argv, "--edge" in sys.argv)
+    main("--slow" in sys.argv, "--edge" in sys.argv, "--many" in sys.argv)

@@ -253,7 +253,8 @@ EDGE_BLIND = {"edge_blind_camera": (2,)}
 
 
 @pytest.mark.parametrize("tag,kwargs", [("config1", {}), ("missing3", {}), ("config1_cauchy", dict(loss="cauchy", f_scale=0.5)),
-                                        ("edge_blind_camera", {}), ("edge_three_frames", {}), ("edge_nine_cameras", {}), ("edge_ten_cameras", {})])
+                                        ("edge_blind_camera", {}), ("edge_three_frames", {}), ("edge_nine_cameras", {}), ("edge_ten_cameras", {}),
+                                        ("edge_24_cameras", {}), ("edge_27_cameras", {})])
 def test_solution_matches_tight_reference_optimum(mc, golden, tag, kwargs):
     """north_star: parameters match the reference's least_squares path within 1e-6 relative.
     Golden = the REFERENCE's bundle_adjust driven to a tight optimum (tests/golden/make_golden.py --slow);

@@ -27,7 +27,7 @@ def compare_to_golden(z, x, C, tol, blind=()):
     assert (np.abs(Ta - Tg)[..., :3, 3] / np.abs(Tg[..., :3, 3]).max()).max() < tol
 
 
-@pytest.mark.parametrize("tag", ["config1", "missing3", "config1_cauchy", "edge_blind_camera", "edge_three_frames", "edge_nine_cameras", "edge_ten_cameras"])
+@pytest.mark.parametrize("tag", ["config1", "missing3", "config1_cauchy", "edge_blind_camera", "edge_three_frames", "edge_nine_cameras", "edge_ten_cameras", "edge_24_cameras", "edge_27_cameras"])
 def test_goldens_are_certified(golden, tag):
     """The tight goldens: reference FD-gradient ~ 0 and two independent starts agree far below 1e-6."""
     z = golden(f"tight_{tag}.npz")
