@@ -155,13 +155,16 @@ int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, do
  * mcba_lm_auto_solve  : optimality + termination verdict + solve of the system in the reduce buffer -> camera step on
  *                       the device, state posted to ring slot seq % 16 with sequence number `seq` (>= 1);
  *                       call once after mcba_build_reduced + mcba_lm_set_state (decide = 0), then once per tick;
- * mcba_lm_auto_trial  : back-substitute that step, linearise the trial point, sum its cost; decide != 0: accept/reject on
- *                       the same launch (single GPU);  [sharded: decide = 0, all-reduce the 8 trial scalars]
+ * mcba_lm_auto_trial  : back-substitute that step, linearise the trial point, sum its cost; decide > 0: accept/reject on
+ *                       the same launch (single GPU);  [sharded: decide = 0, all-reduce the 8 trial scalars];  decide = -1:
+ *                       no sums here -- the speculative reduction that follows (mcba_lm_auto_reduce(h, 2, .)) writes the trial
+ *                       scalars itself, one launch less per tick;
  * mcba_lm_auto_reduce : decide = 0: Schur reduction of the current linearisation (the decision has been taken);
  *                       decide = 1: the stand-alone decision kernel first (sharded runs with TWO collectives: trial scalars,
  *                       then the system);  decide = 2: SPECULATIVE reduction (sharded runs with ONE collective): the trial
  *                       linearisation is reduced before the decision is known, on the prediction "accepted, lambda' =
- *                       max(lambda / 3, lambda_min)"; the caller all-reduces [system | trial scalars] in one go
+ *                       max(lambda / 3, lambda_min)", and the 8 trial scalars are (re)written behind the system; the caller
+ *                       all-reduces [system | trial scalars] in one go
  *                       (offset 0, n*n + 3n + 16 + 8 doubles) and calls mcba_lm_auto_solve(seq, decide = 1), which takes
  *                       the decision and, if the prediction does not hold (rejected step, or another damping), marks the
  *                       next tick as a rebuild-only tick instead of solving;

@@ -637,7 +637,8 @@ static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, boo
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_REDUCE);
-    mcba::launch_reduce_system(h->stream, decide_here ? post_sel(h) : sl, h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
+    mcba::launch_reduce_system(h->stream, decide_here ? post_sel(h) : sl, h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot,
+                               spec ? h->bpart : nullptr, h->nbblocks);
   }
   if ((rc = check_launch())) return rc;
   h->have_red = true;
@@ -689,7 +690,7 @@ int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, do
 // Device-resident LM loop: the reduced camera system is solved on the GPU too (k_solve_cam), the termination tests run
 // there, and the host only enqueues "ticks" and reads the 32-double state each one posts to a host-mapped ring:
 //   one GPU:        tick = k_backsub -> k_gram(trial) -> k_syrk (trial sums + decision + frame factors + SYRK) -> k_reduce_system -> k_solve_cam
-//   frame-sharded:  tick = k_backsub -> k_gram(trial) -> k_sum_trial -> k_syrk (speculative) -> k_reduce_system -> all-reduce -> k_solve_cam (decides)
+//   frame-sharded:  tick = k_backsub -> k_gram(trial) -> k_syrk (speculative) -> k_reduce_system (+ trial scalars) -> all-reduce -> k_solve_cam (decides)
 //                   (MCBA_SPECULATE=0: k_sum_trial -> all-reduce -> k_decide -> k_syrk -> k_reduce_system -> all-reduce -> k_solve_cam)
 // No host synchronisation inside or between ticks; after termination the remaining ticks return immediately.
 int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, double lam_min, double lam_max, const unsigned char* fixed) {
@@ -752,7 +753,9 @@ static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   return check_launch();
 }
 
-int mcba_lm_auto_trial(mcba_handle* h, int decide) { return auto_trial_impl(h, decide, true); }
+// decide: 0 k_sum_trial follows (the trial scalars are all-reduced on their own), != 0 it also decides, -1 no k_sum_trial:
+// the speculative reduction (mcba_lm_auto_reduce(h, 2, .)) sums the trial scalars itself
+int mcba_lm_auto_trial(mcba_handle* h, int decide) { return auto_trial_impl(h, decide < 0 ? 0 : decide, decide >= 0); }
 
 int mcba_lm_auto_reduce(mcba_handle* h, int decide, int rank_slot) {
   if (!h || !h->auto_ready || rank_slot < 0 || rank_slot > 11 || decide < 0 || decide > 2) return fail(MCBA_ERR_ARG, "mcba_lm_auto_reduce: bad argument");
@@ -779,7 +782,7 @@ int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot) {
     return auto_solve_impl(h, seq, 0, true);
   }
   if (h->speculate) {  // ONE collective: speculative reduction, [system | trial scalars] all-reduced together, decision in k_solve_cam
-    if ((rc = mcba_lm_auto_trial(h, 0))) return rc;
+    if ((rc = mcba_lm_auto_trial(h, -1))) return rc;
     if ((rc = mcba_lm_auto_reduce(h, 2, rank_slot))) return rc;
     if ((rc = mcba_comm_allreduce(h, 0, h->nsys + 8))) return rc;
     return mcba_lm_auto_solve(h, seq, 1);

@@ -928,7 +928,7 @@ __device__ __forceinline__ double run_sum(const double* __restrict__ p, int coun
 
 __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __restrict__ gp0, const double* __restrict__ gp1, const double* __restrict__ spart, const double* __restrict__ fpart,
                                                         const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ red, int C, int nfb, int G, int NT, int NP,
-                                                        int nfblocks, int rank_slot) {
+                                                        int nfblocks, int rank_slot, const double* __restrict__ bpart, int nbp) {
   const int n = 12 * C;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ double s_part[16][64];
@@ -1042,6 +1042,34 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
       v = wave_max(a);
     }
     if (lane == 63) tail[2 * n + jj] = v;
+  } else if (bpart && task < 2 * n + 24) {
+    // speculative (frame-sharded) ticks: the trial point's scalars [cost, pred_f, |d_f|^2, |x_f|^2, #pairs, 0, 0, 0] for the
+    // all-reduce that follows -- the reduction is built from the trial linearisation, so its cost and pair count are the
+    // trial point's; what used to be a launch of its own (k_sum_trial) is eight more wavefront tasks here
+    const int jj = task - (2 * n + 16);
+    double a = 0.0;
+    if (jj == 0 || jj == 4) {
+      const int total = C * nfb, kk = jj == 0 ? 90 : 91;
+      for (int base = 0; base < total; base += 512) {
+        double w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = base + lane + 64 * k;
+          const int cam = i / nfb, fbk = i - cam * nfb;
+          w[k] = i < total ? gpart[cam * camstride + (size_t)kk * nfb + fbk] : 0.0;
+        }
+        a += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+      }
+    } else if (jj >= 1 && jj <= 3) {
+      for (int base = 0; base < nbp; base += 512) {
+        double w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = base + lane + 64 * k; w[k] = i < nbp ? bpart[3 * i + (jj - 1)] : 0.0; }
+        a += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+      }
+    }
+    const double v = wave_sum63(a);
+    if (lane == 63) tail[2 * n + 16 + jj] = v;
   }
 }
 
@@ -1345,10 +1373,11 @@ void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, 
 
 int syrk_items_per_thread() { return SYRK_IPT; }
 
-void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot) {
+void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot,
+                          const double* bpart, int nbp) {
   int n = 12 * C;
-  int tail_blocks = (2 * n + 16 + 15) / 16;
-  k_reduce_system<<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot);
+  int tail_blocks = (2 * n + 16 + (bpart ? 8 : 0) + 15) / 16;
+  k_reduce_system<<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp);
 }
 
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {

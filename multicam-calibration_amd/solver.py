@@ -223,7 +223,7 @@ class LevenbergMarquardt:
         self.issued += 1
         slot = comm.rank % 12
         if isinstance(comm, TorchDistributed):  # torch issues the collectives, on the stream the library launches on
-            p.lm_auto_trial(0)
+            p.lm_auto_trial(-1 if self.speculate else 0)  # -1: the speculative reduction sums the trial scalars itself
             if self.speculate:  # ONE collective per tick: speculative Schur reduction, decision inside k_solve_cam
                 p.lm_auto_reduce(2, slot)
                 comm.all_reduce_tick(p)
