@@ -60,6 +60,9 @@ struct mcba_handle {
   double* ring = nullptr;      // kRing x MCBA_LMS doubles, host-coherent pinned memory the GPU writes directly
   double* ring_dev = nullptr;  // the same memory as the device sees it
   int npad = 0, solve_lds = 0;
+  // k_solve_backsub (single-GPU ticks, factor in LDS): the solve's launch also runs the back-substitution of the NEXT trial step;
+  // trial_ready = the last tick did so, the next one must not back-substitute again.  The flag word sits behind the camera step.
+  bool fuse_backsub = false, trial_ready = false;
   double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8, lam_min = 1e-12, lam_max = 1e12;
   // profiling
   bool prof = false;
@@ -240,11 +243,14 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   DA(tile_j, (size_t)h->NP);
   h->npad = 16 * h->NT;
   h->solve_lds = mcba::solve_fits_lds(h->npad);
-  DA(dcbuf, (size_t)h->n);
+  DA(dcbuf, (size_t)h->n + 8);  // + the word k_solve_backsub's solve releases
   DA(swork, h->solve_lds ? 16 : (size_t)h->npad * h->npad);
   DA(fixed, (size_t)h->n);
 #undef DA
   if (mcba::solve_set_lds_limit(h->npad, h->solve_lds) != 0) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_solve_cam"); }
+  h->fuse_backsub = h->solve_lds != 0;
+  if (const char* e = getenv("MCBA_FUSE_BACKSUB")) h->fuse_backsub = h->fuse_backsub && atoi(e) != 0;  // tuning knob
+  if (h->fuse_backsub && mcba::solve_backsub_set_lds_limit(h->npad) != 0) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_solve_backsub"); }
   {
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h->ring), (size_t)kRing * MCBA_LMS * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostMalloc(reinterpret_cast<void**>(&h->ring), (size_t)kRing * MCBA_LMS * sizeof(double), hipHostMallocDefault); }
@@ -580,6 +586,7 @@ int mcba_lm_set_state(mcba_handle* h, const double* state) {
     std::swap(h->gpart2[0], h->gpart2[1]);
     h->lin = sel;
   }
+  h->trial_ready = false;
   return MCBA_OK;
 }
 
@@ -703,12 +710,15 @@ int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, d
     HIPCHK(hipStreamSynchronize(h->stream));
   }
   memset(h->ring, 0, (size_t)kRing * MCBA_LMS * sizeof(double));
+  HIPCHK(hipMemsetAsync(h->dcbuf + h->n, 0, 8 * sizeof(double), h->stream));  // sequence numbers restart: no stale release word
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->trial_ready = false;
   h->auto_ready = true;
   if (const char* e = getenv("MCBA_SPECULATE")) h->speculate = atoi(e) != 0;
   return MCBA_OK;
 }
 
-static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, bool decided_by_syrk) {
+static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, bool decided_by_syrk, bool fuse_next = false) {
   if (!h || !h->auto_ready || seq == 0) return fail(MCBA_ERR_ARG, "mcba_lm_auto_solve: call mcba_lm_auto_config first; seq >= 1");
   if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_lm_auto_solve: no reduced system");
   HIPCHK(hipSetDevice(h->device));
@@ -716,13 +726,18 @@ static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, b
   a.red = h->red; a.lms = h->red + h->nsys + 8; a.lms_in = decided_by_syrk ? post_state(h) : a.lms; a.work = h->swork; a.dc = h->dcbuf; a.x0 = h->x[0]; a.x1 = h->x[1];
   a.fixed = h->have_fixed ? h->fixed : nullptr;
   a.host_state = h->ring_dev + (size_t)(seq % kRing) * MCBA_LMS;
+  a.flag = fuse_next ? h->dcbuf + h->n : nullptr;
   a.seq = (double)seq; a.gtol = h->gtol; a.lam_max = h->lam_max;
   a.n = h->n; a.npad = h->npad; a.use_lds = h->solve_lds;
   a.decide = decide ? 1 : 0; a.lam_min = h->lam_min; a.ftol = h->ftol; a.xtol = h->xtol;
   {
     Scope sc(h, K_SOLVE);
-    mcba::launch_solve_cam(h->stream, a);
+    if (fuse_next)  // + the back-substitution of the next tick's trial step, overlapped with the solve (polls bounded: ~0.5 s)
+      mcba::launch_solve_backsub(h->stream, a, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad, a.lms_in, 200000);
+    else
+      mcba::launch_solve_cam(h->stream, a);
   }
+  h->trial_ready = fuse_next;
   return check_launch();
 }
 
@@ -734,10 +749,11 @@ static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   if (!h->have_lin) return fail(MCBA_ERR_ARG, "mcba_lm_auto_trial: no linearisation");
   HIPCHK(hipSetDevice(h->device));
   int rc;
-  {
+  if (!h->trial_ready) {  // (else the previous tick's k_solve_backsub has already produced this trial step)
     Scope sc(h, K_BACKSUB);
     mcba::launch_backsub_dev(h->stream, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->dcbuf, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad);
   }
+  h->trial_ready = false;
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);
@@ -779,7 +795,7 @@ int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot) {
     if (rank_slot < 0 || rank_slot > 11) return fail(MCBA_ERR_ARG, "mcba_lm_auto_tick: bad rank slot");
     if ((rc = auto_trial_impl(h, 0, false))) return rc;
     if ((rc = lm_reduce_chain(h, rank_slot, false, true))) return rc;
-    return auto_solve_impl(h, seq, 0, true);
+    return auto_solve_impl(h, seq, 0, true, h->fuse_backsub);
   }
   if (h->speculate) {  // ONE collective: speculative reduction, [system | trial scalars] all-reduced together, decision in k_solve_cam
     if ((rc = mcba_lm_auto_trial(h, -1))) return rc;
@@ -799,6 +815,13 @@ int mcba_debug_syrk_stamps(mcba_handle* h, double* host) {  // development only 
   HIPCHK(hipDeviceSynchronize());
   host[0] = (double)h->G;
   HIPCHK(hipMemcpy(host + 12, h->spart + (size_t)h->G * h->NP * 256 + 64, 12 * (size_t)h->G * sizeof(double), hipMemcpyDeviceToHost));
+  return MCBA_OK;
+}
+
+int mcba_debug_fuse_stamps(mcba_handle* h, double* host8) {  // development only (MCBA_FUSE_TIMING builds): the 8 doubles behind the camera step
+  if (!h || !host8) return fail(MCBA_ERR_ARG, "bad argument");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host8, h->dcbuf + h->n, 8 * sizeof(double), hipMemcpyDeviceToHost));
   return MCBA_OK;
 }
 

@@ -1,0 +1,177 @@
+// mcba_backsub.h -- body of k_backsub (frame steps + trial parameters), shared by the stand-alone kernel (mcba_kernels.hip) and
+// by k_solve_backsub (mcba_solve.hip), where the same workgroups run NEXT to the reduced solve and wait for its result.
+//
+// lane = frame.  t = g_f + W_f^T d_c with W read from the wave tiles (each load = 64 consecutive frames, 1 KiB),
+// d_f = -(L L^T)^-1 t with the Cholesky factor k_syrk left in fbuf, x_dst = x_src + d.
+// Per-block partials of  sum d^T(lambda D d - g_f),  sum |d_f|^2,  sum |x_f|^2.
+// DcSrc: the camera step either rides in the kernel-argument segment (CamStep, host solve) or sits in device memory
+// where k_solve_cam left it (DevStep); both are wave-uniform loads.
+// Workgroup = 64 frames x BW wavefronts: wavefront w accumulates W_cf^T d_c for the cameras c = w, w + BW, ... (each
+// load = 64 consecutive frames, 1 KiB), the partial 6-vectors meet in LDS, wavefront 0 finishes the frame solve.
+#pragma once
+#include "mcba_device.h"
+#include "mcba_math.h"
+
+namespace mcba {
+
+struct DevStep {
+  const double* __restrict__ v;
+};
+constexpr int kBacksubWaves = 8;
+
+// k_solve_backsub: the camera step does not exist yet when these workgroups start.  What does not depend on it -- the W
+// blocks (39 MB at 6 x 10 000: the whole memory time of this kernel), the frame factors, the poses -- is requested first;
+// which buffers are current is already final in `early` (the state k_syrk published after its decision; the solve does not
+// touch the slot bit).  Then the workgroup polls `flag` until the solve has posted sequence number `seq` (every exit of the
+// solve posts it), with a bound on the number of polls so that a solve that never ran cannot hang the grid.
+struct BacksubWait {
+  const double* early;  // LM state after the tick's decision
+  const double* flag;   // device word the solve releases with the tick's sequence number
+  const double* dc;     // the camera step the solve writes before it releases the flag
+  double* mail;         // LDS, 8 + 12 C doubles: what the polling wavefront fetched, for the others
+  double seq;
+  int max_polls;
+};
+
+__device__ __forceinline__ double load_coherent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <class DcSrc>
+__device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const DcSrc dcs, double* __restrict__ x0,
+                                             double* __restrict__ x1, double* __restrict__ bpart, int C, int F, int Fpad, int block, int nw, double (*s_t)[6][64], const BacksubWait* wait) {
+  const int n = 12 * C, nfb = Fpad >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= nw) return;  // (k_solve_backsub launches more wavefronts than a small rig has cameras)
+  const int f = block * 64 + lane;
+  const bool fin = wave == 0 && f < F;
+#ifdef MCBA_FUSE_TIMING
+  const bool stamp = wait && block == 1 && threadIdx.x == 0;
+  double* dbg = wait ? const_cast<double*>(wait->flag) : nullptr;
+  if (stamp) dbg[1] = (double)wall_clock64();
+#define FSTAMP(k) do { if (stamp) dbg[k] = (double)wall_clock64(); } while (0)
+#else
+#define FSTAMP(k) do { } while (0)
+#endif
+  double2 v[36];
+  double xv[6], Lp[21], gf[6], D[6];
+  int sidx_early = 0;
+  if (wait) {
+    sidx_early = (static_cast<int>(wait->early[3]) ^ sl.idx) & 1;
+    if (wave < C) {
+      const double2* w2 = reinterpret_cast<const double2*>((sidx_early ? rec1 : rec0) + ((size_t)wave * nfb + block) * (MCBA_REC * 64)) + lane;
+#pragma unroll
+      for (int k = 0; k < 36; ++k) v[k] = w2[k * 64];
+    }
+    if (fin) {
+      const double* xf = (sidx_early ? x1 : x0) + n + 6 * (size_t)f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) xv[k] = xf[k];
+    }
+  }
+  // frame data of wavefront 0: in flight while the W blocks arrive
+  if (fin) {
+    const double* fbp = fbuf + (size_t)f * MCBA_FB;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) Lp[k] = fbp[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { gf[k] = fbp[27 + k]; D[k] = fbp[33 + k]; }
+  }
+  bool active;
+  int sidx;
+  double lambda;
+  if (wait) {
+    // ONE wavefront per workgroup polls (a thousand wavefronts hammering one memory channel delay the very store they wait
+    // for), then fetches the camera step and the four state words with cache-bypassing loads and hands them to the other
+    // wavefronts through LDS.  No cache is invalidated: an agent-scope acquire in every wavefront costs an L2 invalidation
+    // each (measured: 6.2 us between "flag seen" and "state read" with 118 of them queueing per XCD).
+    double* mail = wait->mail;  // [0] posted, [1..4] lambda, slot, skip, done, [8 ..] camera step
+    if (wave == 0) {
+      int polls = 0;
+      bool posted = true;
+      while (load_coherent(wait->flag) != wait->seq) {
+        if (++polls > wait->max_polls) { posted = false; break; }  // the solve never posted: leave the trial slot alone
+        __builtin_amdgcn_s_sleep(8);
+      }
+      asm volatile("" ::: "memory");  // (compiler: the fetches below stay behind the poll; the hardware issues in order)
+      if (posted) {
+        for (int i = lane; i < n; i += 64) mail[8 + i] = load_coherent(wait->dc + i);
+        if (lane < 4) mail[1 + lane] = load_coherent(sl.lms + (lane == 0 ? 1 : lane == 1 ? 3 : lane == 2 ? MCBA_LM_SKIP : MCBA_LM_DONE));
+      }
+      if (lane == 0) mail[0] = posted ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (mail[0] == 0.0) return;
+    FSTAMP(2);
+    active = mail[4] == 0.0 && mail[3] == 0.0;
+    sidx = (static_cast<int>(mail[2]) ^ sl.idx) & 1;
+    lambda = mail[1];
+  } else {
+    active = sel_active(sl, true);
+    sidx = active ? sel_index(sl) : 0;  // current slot / linearisation; the trial goes to the other slot
+    lambda = active ? sel_lambda(sl) : 0.0;
+  }
+  if (!active) return;
+  FSTAMP(3);
+  const double* __restrict__ rec = sidx ? rec1 : rec0;
+  const double* xs = sidx ? x1 : x0;
+  double* xd = sidx ? x0 : x1;
+  const bool pre = wait != nullptr && sidx == sidx_early;  // uniform; always true unless the state changed under us
+  auto dc = [&](int i) { return wait ? wait->mail[8 + i] : dcs.v[i]; };
+  if (block == 0)
+    for (int i = threadIdx.x; i < n; i += 64 * nw) xd[i] = xs[i] + dc(i);
+  if (fin && !pre) {
+    const double* xf = xs + n + 6 * (size_t)f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xv[k] = xf[k];
+  }
+  double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int c = wave; c < C; c += nw) {
+    // all 36 loads of the camera's W block in flight at once: a dependent round trip costs ~2 us, the data 0.1 us
+    if (!(pre && c == wave)) {
+      const double2* w2 = reinterpret_cast<const double2*>(rec + ((size_t)c * nfb + block) * (MCBA_REC * 64)) + lane;
+#pragma unroll
+      for (int k = 0; k < 36; ++k) v[k] = w2[k * 64];
+    }
+    double d[12];
+#pragma unroll
+    for (int lr = 0; lr < 12; ++lr) d[lr] = dc(12 * c + lr);  // wave-uniform
+#pragma unroll
+    for (int lr = 0; lr < 12; ++lr) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { t[2 * k] = fma(v[3 * lr + k].x, d[lr], t[2 * k]); t[2 * k + 1] = fma(v[3 * lr + k].y, d[lr], t[2 * k + 1]); }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s_t[wave][k][lane] = t[k];
+  }
+  FSTAMP(4);
+  // (workgroup barrier among the wavefronts that got here: wavefronts past `nw` have ended, which the barrier accounts for)
+  __syncthreads();
+  if (wave != 0) return;
+  for (int w = 1; w < nw; ++w) {  // fixed order: bit-reproducible
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] += s_t[w][k][lane];
+  }
+  double pred = 0.0, dn2 = 0.0, xn2 = 0.0;
+  if (fin) {
+    double id[6], y[6], dl[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { id[k] = Lp[k * (k + 1) / 2 + k]; t[k] += gf[k]; }  // diagonal slots hold 1 / L_kk
+    fwd6(Lp, id, t, y);
+    bwd6(Lp, id, y, dl);
+    double* xo = xd + n + 6 * (size_t)f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double d = -dl[k];
+      xo[k] = xv[k] + d;
+      pred += d * (lambda * D[k] * d - gf[k]);
+      dn2 += d * d;
+      xn2 += xv[k] * xv[k];
+    }
+  }
+  double a = wave_sum63(pred), b = wave_sum63(dn2), cc = wave_sum63(xn2);
+  if (lane == 63) { bpart[3 * block] = a; bpart[3 * block + 1] = b; bpart[3 * block + 2] = cc; }
+  FSTAMP(5);
+}
+
+}  // namespace mcba

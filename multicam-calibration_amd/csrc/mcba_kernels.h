@@ -49,6 +49,7 @@ struct SolveArgs {
   const double* x1;
   const unsigned char* fixed;  // n flags (1 = parameter held fixed) or nullptr
   double* host_state;        // host-mapped ring slot of MCBA_LMS doubles, or nullptr
+  double* flag;              // k_solve_backsub: device word released with `seq` when the camera step is in place (else nullptr)
   double seq;
   double gtol, lam_max;
   int n, npad, use_lds;
@@ -72,6 +73,11 @@ size_t solve_lds_bytes(int npad, int use_lds);
 int solve_fits_lds(int npad);
 int solve_set_lds_limit(int npad, int use_lds);
 void launch_solve_cam(hipStream_t st, const SolveArgs& a);
+// solve + the back-substitution of the next trial step in one launch (a.use_lds variants, a.flag set); early_state = the LM state
+// the tick's decision left (final as far as the slot bit goes)
+int solve_backsub_set_lds_limit(int npad);
+void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const double* rec0, const double* rec1, const double* fbuf, double* x0, double* x1, double* bpart, int C, int F, int Fpad,
+                          const double* early_state, int max_polls);
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da);
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);

@@ -24,6 +24,8 @@
 #include <algorithm>
 #include "mcba_kernels.h"
 #include "mcba_lm.h"
+#include "mcba_device.h"
+#include "mcba_backsub.h"
 
 #ifndef MCBA_GRAM_PIPE
 #define MCBA_GRAM_PIPE 1
@@ -31,35 +33,6 @@
 
 namespace mcba {
 
-// ---------------------------------------------------------------- small device helpers
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-// Sum over the 64 lanes, result valid in lane 63 only.  DPP moves (pure VALU, no LDS round trip):
-// xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror -> every lane holds its 16-lane row total;
-// row_bcast15 (rows 1,3) and row_bcast31 (rows 2,3) fold the four rows into row 3.
-// v_mov_b32_dpp with an UNDEFINED previous destination (mov_dpp): lanes the move does not write (rows masked out by
-// the two row_bcast steps) hold garbage afterwards -- harmless, because only lane 63 of the final value is used -- and
-// the compiler no longer has to zero the destination before every move (1 100 instructions per k_gram epilogue).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add(double v) {
-  union { double d; int i[2]; } a, b;
-  a.d = v;
-  b.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], CTRL, ROW_MASK, 0xF, true);
-  b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], CTRL, ROW_MASK, 0xF, true);
-  return v + b.d;
-}
-__device__ __forceinline__ double wave_sum63(double v) {
-  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
-  v = dpp_add<0x140, 0xF>(v);  // row_mirror
-  v = dpp_add<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
-  v = dpp_add<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
-  return v;
-}
 // Sums over the 64 lanes of K = 3 * 2^m values at once (m <= 5) by recursive halving: at every level a lane hands half of its
 // values to its partner and adds the partner's copies of the half it keeps, so level t works on K / 2^(t+1) values instead of
 // K -- 3 K (1 - 2^-m) exchanges in all instead of 6 K for K separate butterflies -- and the totals end up SPREAD over the
@@ -134,20 +107,6 @@ __device__ __forceinline__ double uni(double v) {
   return u.d;
 }
 __device__ __forceinline__ bool is_num(double v) { return v == v; }
-// spec (frame-sharded ticks with ONE collective): the Schur reduction runs BEFORE the decision is known, on the
-// prediction "trial step accepted, lambda' = max(lambda / 3, lambda_min)" -- except in a rebuild tick (state[SKIP] != 0),
-// which reduces the current linearisation with the state's own damping.  k_solve_cam checks the prediction afterwards.
-__device__ __forceinline__ bool sel_spec(const Sel& s) { return s.spec && s.lms[MCBA_LM_SKIP] == 0.0; }
-__device__ __forceinline__ int sel_index(const Sel& s) { return s.lms ? ((static_cast<int>(s.lms[3]) ^ s.idx ^ (sel_spec(s) ? 1 : 0)) & 1) : s.idx; }
-__device__ __forceinline__ double sel_lambda(const Sel& s) { return s.lms ? (sel_spec(s) ? lm_spec_lambda(s.lms[1], s.lam) : s.lms[1]) : s.lam; }
-// device-resident LM loop: after termination every kernel of a tick returns at once; a tick that follows a failed
-// reduced solve skips its trial kernels (`trial` = true) and only rebuilds the system with the raised damping
-__device__ __forceinline__ bool sel_active(const Sel& s, bool trial) {
-  if (!s.lms) return true;
-  if (s.lms[MCBA_LM_DONE] != 0.0) return false;
-  return !(trial && s.lms[MCBA_LM_SKIP] != 0.0);
-}
-
 template <int LOSS>
 __device__ __forceinline__ void obs_weights(double r, bool valid, double fs2, double ifs2, double& cost, double& w2, double& g) {
   double rh, gw, ww;
@@ -1073,89 +1032,12 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
   }
 }
 
-// ---------------------------------------------------------------- k_backsub: frame steps + trial parameters
-// lane = frame.  t = g_f + W_f^T d_c with W read from the wave tiles (each load = 64 consecutive frames, 1 KiB),
-// d_f = -(L L^T)^-1 t with the Cholesky factor k_syrk left in fbuf, x_dst = x_src + d.
-// Per-block partials of  sum d^T(lambda D d - g_f),  sum |d_f|^2,  sum |x_f|^2.
-// DcSrc: the camera step either rides in the kernel-argument segment (CamStep, host solve) or sits in device memory
-// where k_solve_cam left it (DevStep); both are wave-uniform scalar loads.
-struct DevStep {
-  const double* __restrict__ v;
-};
-// Workgroup = 64 frames x BW wavefronts: wavefront w accumulates W_cf^T d_c for the cameras c = w, w + BW, ... (each
-// load = 64 consecutive frames, 1 KiB), the partial 6-vectors meet in LDS, wavefront 0 finishes the frame solve.
-constexpr int kBacksubWaves = 8;
+// ---------------------------------------------------------------- k_backsub: frame steps + trial parameters (body: mcba_backsub.h)
 template <class DcSrc>
 __global__ __launch_bounds__(64 * kBacksubWaves) void k_backsub(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const DcSrc dcs,
                                                                 double* __restrict__ x0, double* __restrict__ x1, double* __restrict__ bpart, int C, int F, int Fpad) {
-  if (!sel_active(sl, true)) return;
-  const int sidx = sel_index(sl);  // current slot / linearisation; the trial goes to the other slot
-  const double* __restrict__ rec = sidx ? rec1 : rec0;
-  const double* __restrict__ xs = sidx ? x1 : x0;
-  double* __restrict__ xd = sidx ? x0 : x1;
-  const double lambda = sel_lambda(sl);
-  const int n = 12 * C, nfb = Fpad >> 6;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-  const int f = blockIdx.x * 64 + lane;
   __shared__ double s_t[kBacksubWaves][6][64];
-  if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < n; i += blockDim.x) xd[i] = xs[i] + dcs.v[i];
-  double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int c = wave; c < C; c += nw) {
-    // all 36 loads of the camera's W block in flight at once: a dependent round trip costs ~2 us, the data 0.1 us
-    const double2* w2 = reinterpret_cast<const double2*>(rec + ((size_t)c * nfb + blockIdx.x) * (MCBA_REC * 64)) + lane;
-    double2 v[36];
-    double d[12];
-#pragma unroll
-    for (int k = 0; k < 36; ++k) v[k] = w2[k * 64];
-#pragma unroll
-    for (int lr = 0; lr < 12; ++lr) d[lr] = dcs.v[12 * c + lr];  // wave-uniform: scalar loads
-#pragma unroll
-    for (int lr = 0; lr < 12; ++lr) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { t[2 * k] = fma(v[3 * lr + k].x, d[lr], t[2 * k]); t[2 * k + 1] = fma(v[3 * lr + k].y, d[lr], t[2 * k + 1]); }
-    }
-  }
-  // frame data of wavefront 0 in flight while the partial sums meet
-  double Lp[21], gf[6], D[6];
-  const bool fin = wave == 0 && f < F;
-  if (fin) {
-    const double* fbp = fbuf + (size_t)f * MCBA_FB;
-#pragma unroll
-    for (int k = 0; k < 21; ++k) Lp[k] = fbp[k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { gf[k] = fbp[27 + k]; D[k] = fbp[33 + k]; }
-  }
-  if (wave > 0) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s_t[wave][k][lane] = t[k];
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  for (int w = 1; w < nw; ++w) {  // fixed order: bit-reproducible
-#pragma unroll
-    for (int k = 0; k < 6; ++k) t[k] += s_t[w][k][lane];
-  }
-  double pred = 0.0, dn2 = 0.0, xn2 = 0.0;
-  if (fin) {
-    double id[6], y[6], dl[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { id[k] = Lp[k * (k + 1) / 2 + k]; t[k] += gf[k]; }  // diagonal slots hold 1 / L_kk
-    fwd6(Lp, id, t, y);
-    bwd6(Lp, id, y, dl);
-    const double* xf = xs + n + 6 * (size_t)f;
-    double* xo = xd + n + 6 * (size_t)f;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      double d = -dl[k], xv = xf[k];
-      xo[k] = xv + d;
-      pred += d * (lambda * D[k] * d - gf[k]);
-      dn2 += d * d;
-      xn2 += xv * xv;
-    }
-  }
-  double a = wave_sum63(pred), b = wave_sum63(dn2), cc = wave_sum63(xn2);
-  if (lane == 63) { bpart[3 * blockIdx.x] = a; bpart[3 * blockIdx.x + 1] = b; bpart[3 * blockIdx.x + 2] = cc; }
+  backsub_body<DcSrc>(sl, rec0, rec1, fbuf, dcs, x0, x1, bpart, C, F, Fpad, (int)blockIdx.x, (int)(blockDim.x >> 6), s_t, nullptr);
 }
 
 // trial scalars: [cost, pred_f, dn2_f, xn2_f, n_residuals, 0, 0, 0].  One block of 512 threads: wavefront w

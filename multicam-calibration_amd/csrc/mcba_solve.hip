@@ -28,6 +28,7 @@
 #include "mcba_kernels.h"
 #include "mcba_lm.h"
 #include "mcba_math.h"
+#include "mcba_backsub.h"
 
 namespace mcba {
 
@@ -85,11 +86,17 @@ __device__ __forceinline__ void post_state(const SolveArgs& a, const double* st,
     if (write_back) a.lms[tid] = v;
     if (a.host_state) a.host_state[tid] = v;
   }
-  if (!a.host_state) return;
+  if (!a.host_state && !a.flag) return;
   __threadfence_system();
   __syncthreads();
   if (tid == 0) {
-    *reinterpret_cast<volatile double*>(a.host_state + MCBA_LMS - 1) = a.seq;  // (the end of the kernel releases it)
+    if (a.host_state) *reinterpret_cast<volatile double*>(a.host_state + MCBA_LMS - 1) = a.seq;  // (the end of the kernel releases it)
+    // k_solve_backsub: the back-substitution workgroups of the same launch are polling this word; the camera step (a.dc) and
+    // the state were written by other threads of this workgroup before the fence and the barrier above
+#ifdef MCBA_FUSE_TIMING
+    if (a.flag) a.flag[6] = (double)wall_clock64();
+#endif
+    if (a.flag) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -105,7 +112,7 @@ __device__ __forceinline__ void post_state(const SolveArgs& a, const double* st,
 constexpr int kStageMax = 7;
 
 template <int NTHREADS, bool LDSW, int KS>
-__global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
+__device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
   constexpr int kStage = KS;
   extern __shared__ double smem[];
   const int n = a.n, npad = a.npad, nblk = npad >> 4;
@@ -506,6 +513,38 @@ __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
   post_state(a, lst, true);
 }
 
+template <int NTHREADS, bool LDSW, int KS>
+__global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
+  solve_cam_body<NTHREADS, LDSW, KS>(a);
+}
+
+// The reduced solve AND the back-substitution of the next trial step in one launch (single-GPU ticks, factor in LDS, <= 8
+// cameras): workgroup 0 is k_solve_cam (its first four wavefronts), workgroups 1 .. Fpad / 64 are k_backsub -- they put
+// their 39 MB of W blocks, the frame factors and the poses in flight at once, then wait for workgroup 0 to release the
+// camera step.  The solve is one workgroup of latency; the memory system is idle meanwhile, so the back-substitution's
+// whole load time disappears behind it and one launch is saved.  Workgroup 0 is dispatched first and waits for nobody.
+struct BacksubArgs {
+  Sel sl;
+  const double *rec0, *rec1, *fbuf;
+  double *x0, *x1, *bpart;
+  int C, F, Fpad;
+  BacksubWait wait;
+};
+template <int KS>
+__global__ __launch_bounds__(64 * kBacksubWaves) void k_solve_backsub(SolveArgs a, BacksubArgs b) {
+  __shared__ double s_t[kBacksubWaves][6][64];
+  __shared__ double s_mail[8 + 12 * 9];  // (the LDS-resident solve serves at most 9 cameras)
+  if (blockIdx.x == 0) {
+#ifdef MCBA_FUSE_TIMING
+    if (threadIdx.x == 0) a.flag[7] = (double)wall_clock64();
+#endif
+    if (threadIdx.x < 256) solve_cam_body<256, true, KS>(a);
+    return;
+  }
+  b.wait.mail = s_mail;
+  backsub_body<DevStep>(b.sl, b.rec0, b.rec1, b.fbuf, DevStep{a.dc}, b.x0, b.x1, b.bpart, b.C, b.F, b.Fpad, (int)blockIdx.x - 1, b.C < kBacksubWaves ? b.C : kBacksubWaves, s_t, &b.wait);
+}
+
 // rows a launch can hold: 16 diagonal rows + 48 per wavefront
 int solve_threads(int npad) {
   int t = npad <= 16 + 4 * 48 ? 256 : npad <= 16 + 8 * 48 ? 512 : 1024;
@@ -535,6 +574,22 @@ int solve_set_lds_limit(int npad, int use_lds) {
   size_t bytes = solve_lds_bytes(npad, use_lds);
   if (bytes <= 64 * 1024) return 0;
   return hipFuncSetAttribute(solve_kernel(npad, use_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : 1;
+}
+
+int solve_backsub_set_lds_limit(int npad) {
+  const size_t bytes = solve_lds_bytes(npad, 1) + sizeof(double) * (kBacksubWaves * 6 * 64 + 8 + 12 * 9);
+  if (bytes <= 64 * 1024) return 0;
+  const void* k = npad <= 80 ? reinterpret_cast<const void*>(&k_solve_backsub<5>) : reinterpret_cast<const void*>(&k_solve_backsub<kStageMax>);
+  return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes(npad, 1)) == hipSuccess ? 0 : 1;
+}
+
+void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const double* rec0, const double* rec1, const double* fbuf, double* x0, double* x1, double* bpart, int C, int F, int Fpad,
+                          const double* early_state, int max_polls) {
+  BacksubArgs b{sl, rec0, rec1, fbuf, x0, x1, bpart, C, F, Fpad, BacksubWait{early_state, a.flag, a.dc, nullptr, a.seq, max_polls}};
+  const size_t lds = solve_lds_bytes(a.npad, 1);
+  const dim3 grid(1 + Fpad / 64), block(64 * kBacksubWaves);
+  if (a.npad <= 80) hipLaunchKernelGGL((k_solve_backsub<5>), grid, block, lds, st, a, b);
+  else hipLaunchKernelGGL((k_solve_backsub<kStageMax>), grid, block, lds, st, a, b);
 }
 
 void launch_solve_cam(hipStream_t st, const SolveArgs& a) {

@@ -1,0 +1,31 @@
+"""Wall-clock stamps of k_solve_backsub (development aid; build with MCBA_HIPCC_FLAGS=-DMCBA_FUSE_TIMING): the solve workgroup
+and back-substitution workgroup 1, 10 ns ticks.   usage: [MCBA_LIB=lib.so] python scripts/fuse_stamps.py"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import multicam_calibration_amd as m
+
+if os.environ.get("MCBA_LIB"):
+    m.ops.LIB_PATH = os.environ["MCBA_LIB"]
+p = m.synth.make_problem(6, 10000, seed=0)
+x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+prob = m.ops.Problem(p["uvs"], p["obj"])
+lm = m.solver.LevenbergMarquardt(prob, ftol=0.0, xtol=0.0, gtol=0.0, reduced_solver="device", depth=2)
+lm.start(x0)
+for i in range(200):
+    lm.iterate(always_linearize=True)
+prob.synchronize()
+out = np.zeros(8)
+f = prob.lib.mcba_debug_fuse_stamps
+f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+f.restype = ctypes.c_int
+assert f(prob.handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 0
+t0 = min(out[1], out[7])
+us = lambda v: (v - t0) / 100.0
+print("us from the first stamp: solve entry %.2f | backsub entry %.2f | solve releases %.2f | backsub sees the flag %.2f | state read %.2f | products done %.2f | backsub end %.2f"
+      % (us(out[7]), us(out[1]), us(out[6]), us(out[2]), us(out[3]), us(out[4]), us(out[5])))
+prob.close()

@@ -2,6 +2,7 @@
 reference-generated golden fixtures.  Run with `-m gpu` on an MI355X."""
 import contextlib
 import io
+import os
 
 import numpy as np
 import pytest
@@ -465,6 +466,35 @@ def test_device_loop_equals_host_solve_loop(mc, kw):
     assert abs(a.optimality - b.optimality) <= 0.1 * b.optimality + 1e-9   # round-off level of a gradient that started at ~1e6
     ha, hb = np.array(a.lm["history"]), np.array(b.lm["history"])
     np.testing.assert_allclose(ha[:, 1:3], hb[:, 1:3], rtol=1e-10)   # cost before / after every trial step
+
+
+@pytest.mark.parametrize("shape", [(6, 300, {}), (9, 70, dict(missing=0.3)), (3, 130, dict(missing=0.2, outlier_frames=4))])
+def test_fused_solve_backsub_is_bit_identical(mc, shape):
+    """k_solve_backsub (the reduced solve and the NEXT trial step's back-substitution in one launch, the back-substitution
+    workgroups waiting for the solve's release word) against the two separate launches (MCBA_FUSE_BACKSUB=0, read in
+    mcba_create): same arithmetic in the same order -> the same iterates to the last bit, incl. rejected steps (bad start)."""
+    C, F, extra = shape
+    p = mc.synth.make_problem(C, F, seed=80 + C, **extra)
+    p["poses"][::7, 3:] += 40.0                                  # a start bad enough for rejected steps and growing damping
+    out = {}
+    old = os.environ.get("MCBA_FUSE_BACKSUB")
+    try:
+        for mode in ("1", "0"):
+            os.environ["MCBA_FUSE_BACKSUB"] = mode
+            with contextlib.redirect_stdout(io.StringIO()):
+                out[mode] = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=1e-12, xtol=1e-12, gtol=1e-9,
+                                             verbose=0, return_jac=False, max_nfev=120)[4]
+    finally:
+        if old is None:
+            del os.environ["MCBA_FUSE_BACKSUB"]
+        else:
+            os.environ["MCBA_FUSE_BACKSUB"] = old
+    a, b = out["1"], out["0"]
+    assert a.status == b.status and a.nfev == b.nfev and a.lm["iterations"] == b.lm["iterations"]
+    assert a.lm["iterations"] < a.nfev - 1                       # some steps were rejected
+    np.testing.assert_array_equal(a.x, b.x)
+    assert a.cost == b.cost
+    np.testing.assert_array_equal(np.array(a.lm["history"]), np.array(b.lm["history"]))
 
 
 def test_device_loop_max_nfev_and_verbose(mc, capsys):
