@@ -696,7 +696,8 @@ int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, do
 // ---------------------------------------------------------------------------------------------------------
 // Device-resident LM loop: the reduced camera system is solved on the GPU too (k_solve_cam), the termination tests run
 // there, and the host only enqueues "ticks" and reads the 32-double state each one posts to a host-mapped ring:
-//   one GPU:        tick = k_backsub -> k_gram(trial) -> k_syrk (trial sums + decision + frame factors + SYRK) -> k_reduce_system -> k_solve_cam
+//   one GPU:        tick = k_gram(trial) -> k_syrk (trial sums + decision + frame factors + SYRK) -> k_reduce_system -> k_solve_backsub (solve + the
+//                   back-substitution of the next trial step; k_backsub / k_solve_cam apart for the first tick, > 9 cameras, MCBA_FUSE_BACKSUB=0)
 //   frame-sharded:  tick = k_backsub -> k_gram(trial) -> k_syrk (speculative) -> k_reduce_system (+ trial scalars) -> all-reduce -> k_solve_cam (decides)
 //                   (MCBA_SPECULATE=0: k_sum_trial -> all-reduce -> k_decide -> k_syrk -> k_reduce_system -> all-reduce -> k_solve_cam)
 // No host synchronisation inside or between ticks; after termination the remaining ticks return immediately.
@@ -791,7 +792,7 @@ int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
   const bool coll = h->comm != nullptr;
   int rc;
-  if (!coll) {  // one GPU: k_backsub -> k_gram -> k_syrk (trial sums + decision + frame factors + SYRK) -> k_reduce_system -> k_solve_cam
+  if (!coll) {  // one GPU: [k_backsub ->] k_gram -> k_syrk (trial sums + decision + frame factors + SYRK) -> k_reduce_system -> k_solve_backsub
     if (rank_slot < 0 || rank_slot > 11) return fail(MCBA_ERR_ARG, "mcba_lm_auto_tick: bad rank slot");
     if ((rc = auto_trial_impl(h, 0, false))) return rc;
     if ((rc = lm_reduce_chain(h, rank_slot, false, true))) return rc;

@@ -22,11 +22,14 @@ constexpr int kBacksubWaves = 8;
 // k_solve_backsub: the camera step does not exist yet when these workgroups start.  What does not depend on it -- the W
 // blocks (39 MB at 6 x 10 000: the whole memory time of this kernel), the frame factors, the poses -- is requested first;
 // which buffers are current is already final in `early` (the state k_syrk published after its decision; the solve does not
-// touch the slot bit).  Then the workgroup polls `flag` until the solve has posted sequence number `seq` (every exit of the
-// solve posts it), with a bound on the number of polls so that a solve that never ran cannot hang the grid.
+// touch the slot bit, and changes the damping only when it fails).  The solve releases TWO words with the tick's sequence
+// number: flag[1] as soon as the camera step is in memory, flag[0] at its very end, when the state is final (every exit of the
+// solve posts flag[0]; exits without a step never post flag[1]).  The workgroup computes the frame steps after the first and
+// stores them after the second, if the final state still wants a trial step.  Polls are bounded, so a solve that never ran
+// cannot hang the grid.
 struct BacksubWait {
   const double* early;  // LM state after the tick's decision
-  const double* flag;   // device word the solve releases with the tick's sequence number
+  const double* flag;   // flag[0] final, flag[1] camera step in place: released by the solve with the tick's sequence number
   const double* dc;     // the camera step the solve writes before it releases the flag
   double* mail;         // LDS, 8 + 12 C doubles: what the polling wavefront fetched, for the others
   double seq;
@@ -46,8 +49,8 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
 #ifdef MCBA_FUSE_TIMING
   const bool stamp = wait && block == 1 && threadIdx.x == 0;
   double* dbg = wait ? const_cast<double*>(wait->flag) : nullptr;
-  if (stamp) dbg[1] = (double)wall_clock64();
-#define FSTAMP(k) do { if (stamp) dbg[k] = (double)wall_clock64(); } while (0)
+  if (stamp) dbg[2] = (double)wall_clock64();  // ([0], [1] are the release words)
+#define FSTAMP(k) do { if (stamp) dbg[(k) + 1] = (double)wall_clock64(); } while (0)
 #else
 #define FSTAMP(k) do { } while (0)
 #endif
@@ -83,27 +86,27 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
     // for), then fetches the camera step and the four state words with cache-bypassing loads and hands them to the other
     // wavefronts through LDS.  No cache is invalidated: an agent-scope acquire in every wavefront costs an L2 invalidation
     // each (measured: 6.2 us between "flag seen" and "state read" with 118 of them queueing per XCD).
-    double* mail = wait->mail;  // [0] posted, [1..4] lambda, slot, skip, done, [8 ..] camera step
+    double* mail = wait->mail;  // [0]: 1 camera step fetched, 0 no step this tick (or the solve never posted); [8 ..] camera step
     if (wave == 0) {
-      int polls = 0;
-      bool posted = true;
-      while (load_coherent(wait->flag) != wait->seq) {
-        if (++polls > wait->max_polls) { posted = false; break; }  // the solve never posted: leave the trial slot alone
+      int polls = 0, got = 0;
+      for (;;) {
+        if (load_coherent(wait->flag + 1) == wait->seq) { got = 1; break; }
+        if (load_coherent(wait->flag) == wait->seq) break;   // the solve ended without a step (terminated, or nothing to solve)
+        if (++polls > wait->max_polls) break;                // the solve never posted: leave the trial slot alone
         __builtin_amdgcn_s_sleep(8);
       }
       asm volatile("" ::: "memory");  // (compiler: the fetches below stay behind the poll; the hardware issues in order)
-      if (posted) {
+      if (got) {
         for (int i = lane; i < n; i += 64) mail[8 + i] = load_coherent(wait->dc + i);
-        if (lane < 4) mail[1 + lane] = load_coherent(sl.lms + (lane == 0 ? 1 : lane == 1 ? 3 : lane == 2 ? MCBA_LM_SKIP : MCBA_LM_DONE));
       }
-      if (lane == 0) mail[0] = posted ? 1.0 : 0.0;
+      if (lane == 0) mail[0] = got ? 1.0 : 0.0;
     }
     __syncthreads();
     if (mail[0] == 0.0) return;
     FSTAMP(2);
-    active = mail[4] == 0.0 && mail[3] == 0.0;
-    sidx = (static_cast<int>(mail[2]) ^ sl.idx) & 1;
-    lambda = mail[1];
+    active = true;  // so far: the final word is awaited before anything is stored
+    sidx = sidx_early;
+    lambda = wait->early[1];
   } else {
     active = sel_active(sl, true);
     sidx = active ? sel_index(sl) : 0;  // current slot / linearisation; the trial goes to the other slot
@@ -116,8 +119,6 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
   double* xd = sidx ? x0 : x1;
   const bool pre = wait != nullptr && sidx == sidx_early;  // uniform; always true unless the state changed under us
   auto dc = [&](int i) { return wait ? wait->mail[8 + i] : dcs.v[i]; };
-  if (block == 0)
-    for (int i = threadIdx.x; i < n; i += 64 * nw) xd[i] = xs[i] + dc(i);
   if (fin && !pre) {
     const double* xf = xs + n + 6 * (size_t)f;
 #pragma unroll
@@ -144,7 +145,6 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 6; ++k) s_t[wave][k][lane] = t[k];
   }
-  FSTAMP(4);
   // (workgroup barrier among the wavefronts that got here: wavefronts past `nw` have ended, which the barrier accounts for)
   __syncthreads();
   if (wave != 0) return;
@@ -153,23 +153,41 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
     for (int k = 0; k < 6; ++k) t[k] += s_t[w][k][lane];
   }
   double pred = 0.0, dn2 = 0.0, xn2 = 0.0;
+  double xnew[6];
   if (fin) {
     double id[6], y[6], dl[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { id[k] = Lp[k * (k + 1) / 2 + k]; t[k] += gf[k]; }  // diagonal slots hold 1 / L_kk
     fwd6(Lp, id, t, y);
     bwd6(Lp, id, y, dl);
-    double* xo = xd + n + 6 * (size_t)f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const double d = -dl[k];
-      xo[k] = xv[k] + d;
+      xnew[k] = xv[k] + d;
       pred += d * (lambda * D[k] * d - gf[k]);
       dn2 += d * d;
       xn2 += xv[k] * xv[k];
     }
   }
   double a = wave_sum63(pred), b = wave_sum63(dn2), cc = wave_sum63(xn2);
+  FSTAMP(4);
+  if (wait) {  // the steps are ready; they count only if the solve's FINAL state still wants a trial step (a failed solve does not)
+    int polls = 0;
+    bool posted = true;
+    while (load_coherent(wait->flag) != wait->seq) {
+      if (++polls > wait->max_polls) { posted = false; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    asm volatile("" ::: "memory");
+    if (!posted || load_coherent(sl.lms + MCBA_LM_DONE) != 0.0 || load_coherent(sl.lms + MCBA_LM_SKIP) != 0.0) return;
+  }
+  if (block == 0)
+    for (int i = lane; i < n; i += 64) xd[i] = xs[i] + dc(i);
+  if (fin) {
+    double* xo = xd + n + 6 * (size_t)f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xo[k] = xnew[k];
+  }
   if (lane == 63) { bpart[3 * block] = a; bpart[3 * block + 1] = b; bpart[3 * block + 2] = cc; }
   FSTAMP(5);
 }

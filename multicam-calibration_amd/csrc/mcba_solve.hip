@@ -21,6 +21,8 @@
 // The factor lives in LDS (odd row stride) when it fits (<= 9 cameras) -- then the whole lower triangle is put in flight
 // before anything else, because a dependent global round trip costs ~2 us here; otherwise in an L2-resident scratch,
 // with the panel's own rows staged in LDS and the A rows streamed 32 B per lane, one work item ahead.
+// k_solve_backsub (single-GPU ticks, factor in LDS) runs the back-substitution of the NEXT trial step in the same launch, in
+// workgroups that wait for two words this workgroup releases (mcba_backsub.h).
 // The same launch evaluates first-order optimality, applies the termination verdict (pending from k_sum_trial / k_decide,
 // or taken here on the all-reduced trial scalars: one-collective ticks), handles a failed factorisation (more damping,
 // next tick rebuild-only) and posts the LM state to a host-mapped ring slot.
@@ -94,7 +96,7 @@ __device__ __forceinline__ void post_state(const SolveArgs& a, const double* st,
     // k_solve_backsub: the back-substitution workgroups of the same launch are polling this word; the camera step (a.dc) and
     // the state were written by other threads of this workgroup before the fence and the barrier above
 #ifdef MCBA_FUSE_TIMING
-    if (a.flag) a.flag[6] = (double)wall_clock64();
+    if (a.flag) a.flag[7] = (double)wall_clock64();
 #endif
     if (a.flag) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -492,6 +494,11 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
       sums[2] += xv * xv;
     }
   }
+  if (a.flag && mode == 0) {  // k_solve_backsub: the camera step is in memory -- the back-substitution workgroups may start on it
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.flag + 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
   block_reduce4<NTHREADS>(sums, false, s_red);
   if (tid == 0) {
     const bool failed = mode == 2 || sums[3] != 0.0 || !(fabs(sums[0]) < 1e300);
@@ -535,9 +542,6 @@ __global__ __launch_bounds__(64 * kBacksubWaves) void k_solve_backsub(SolveArgs 
   __shared__ double s_t[kBacksubWaves][6][64];
   __shared__ double s_mail[8 + 12 * 9];  // (the LDS-resident solve serves at most 9 cameras)
   if (blockIdx.x == 0) {
-#ifdef MCBA_FUSE_TIMING
-    if (threadIdx.x == 0) a.flag[7] = (double)wall_clock64();
-#endif
     if (threadIdx.x < 256) solve_cam_body<256, true, KS>(a);
     return;
   }

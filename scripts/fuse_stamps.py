@@ -24,8 +24,8 @@ f = prob.lib.mcba_debug_fuse_stamps
 f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
 f.restype = ctypes.c_int
 assert f(prob.handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 0
-t0 = min(out[1], out[7])
+t0 = out[2]
 us = lambda v: (v - t0) / 100.0
-print("us from the first stamp: solve entry %.2f | backsub entry %.2f | solve releases %.2f | backsub sees the flag %.2f | state read %.2f | products done %.2f | backsub end %.2f"
-      % (us(out[7]), us(out[1]), us(out[6]), us(out[2]), us(out[3]), us(out[4]), us(out[5])))
+print("us from the back-substitution workgroup's entry: camera step fetched %.2f | products start %.2f | frame steps ready %.2f | end %.2f || the solve releases its final word %.2f"
+      % (us(out[3]), us(out[4]), us(out[5]), us(out[6]), us(out[7])))
 prob.close()
