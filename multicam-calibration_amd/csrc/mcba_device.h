@@ -27,11 +27,6 @@ __device__ __forceinline__ double dpp_add(double v) {
   b.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], CTRL, ROW_MASK, 0xF, true);
   return v + b.d;
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return v;
-}
 __device__ __forceinline__ double wave_sum63(double v) {
   v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
   v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]

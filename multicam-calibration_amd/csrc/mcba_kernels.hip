@@ -26,7 +26,6 @@
 #include "mcba_lm.h"
 #include "mcba_device.h"
 #include "mcba_backsub.h"
-#include "mcba_reduce.h"
 
 #ifndef MCBA_GRAM_PIPE
 #define MCBA_GRAM_PIPE 1
@@ -93,6 +92,11 @@ __device__ __forceinline__ void wave_reduce_scatter(double* v, double (&out)[3],
     }
     static_assert(LEVEL == 4 || LEVEL == 5, "K must be 48 or 96");
   }
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
 }
 // value known to be wave-uniform -> SGPR pair (frees two VGPRs and a ds_read per use)
 __device__ __forceinline__ double uni(double v) {
@@ -861,11 +865,171 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
 #endif
 }
 
-// ---------------------------------------------------------------- k_reduce_system: fixed-order second stage (body: mcba_reduce.h)
-__global__ __launch_bounds__(1024) void k_reduce_system(ReduceArgs r) {
+// ---------------------------------------------------------------- k_reduce_system: fixed-order second stage
+// Sums the per-workgroup partials of k_syrk and the per-wavefront partials of k_gram into the reduce buffer (layout in
+// include/mcba.h) with coalesced reads and a FIXED summation order (bit-reproducible; no FP64 atomics anywhere).
+//   blocks [0, 4 NP): one per (tile pair q, accumulator register reg) = 64 elements that are 512 contiguous bytes in
+//       every k_syrk partial.  Wave s of 16 sums partials g = s, s+16, ... (all loads in flight), LDS, then wave 0 adds
+//       the 16 slices in order.  Elements that fall on a camera's diagonal block also need U_c (and column 12C needs
+//       g_c): those sums over the frame blocks are contiguous runs of gpart[camera][k][frame block] -- one wavefront
+//       task each, four per wave.  Off-diagonal tiles are mirrored on write.
+//   blocks [4 NP, ...): diag(U), g_c and the 16 scalars, one wavefront task per output.
+__device__ __forceinline__ double run_sum(const double* __restrict__ p, int count, int lane) {  // sum of a contiguous run, result in lane 63
+  double s = 0.0;
+  for (int base = 0; base < count; base += 256) {
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { int i = base + lane + 64 * k; v[k] = i < count ? p[i] : 0.0; }
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  return wave_sum63(s);
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __restrict__ gp0, const double* __restrict__ gp1, const double* __restrict__ spart, const double* __restrict__ fpart,
+                                                        const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ red, int C, int nfb, int G, int NT, int NP,
+                                                        int nfblocks, int rank_slot, const double* __restrict__ bpart, int nbp) {
+  const int n = 12 * C;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ double s_part[16][64];
   __shared__ double s_u[64];
-  reduce_system_body<16>(r, (int)blockIdx.x, s_part, s_u);
+  const size_t camstride = (size_t)MCBA_GP * nfb;
+  if ((int)blockIdx.x < 4 * NP) {
+    const int q = blockIdx.x >> 2, reg = blockIdx.x & 3;
+    const int ti = tile_i[q], tj = tile_j[q];
+    // ---- slice sums of the k_syrk partials.  They do not depend on the LM state: ALL of this wavefront's rows (G <= 512
+    // workgroups -> at most 32 per wavefront) go in flight before anything waits for the state -- one memory round trip
+    // where a loop over batches of eight paid one per batch, and the state read rides along.
+    double pv[32];
+    {
+      const double* p = spart + (size_t)(4 * q + reg) * G * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) { const int g = wave + 16 * k; pv[k] = g < G ? p[(size_t)g * 64] : 0.0; }
+    }
+    if (!sel_active(sl, false)) return;
+    const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
+    // ---- U_c / g_c terms of the elements that need them: element e = wave + 16 j, one wavefront task each; the four
+    // tasks' runs are loaded together as well
+    const double* up[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = wave + 16 * j;
+      const int row = 16 * ti + (e >> 4) + 4 * reg, col = 16 * tj + (e & 15);
+      up[j] = nullptr;
+      if (row < n && col < n && row / 12 == col / 12) {
+        int cam = row / 12, li = row - 12 * cam, lj = col - 12 * cam;
+        int a = li <= lj ? li : lj, b = li <= lj ? lj : li;
+        up[j] = gpart + cam * camstride + (size_t)tri12(a, b) * nfb;
+      } else if (col == n && row < n) {
+        int cam = row / 12, li = row - 12 * cam;
+        up[j] = gpart + cam * camstride + (size_t)(78 + li) * nfb;
+      }
+    }
+    double us[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int base = 0; base < nfb; base += 256) {
+      double w[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = base + lane + 64 * k; w[j][k] = (up[j] && i < nfb) ? up[j][i] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) us[j] += (w[j][0] + w[j][1]) + (w[j][2] + w[j][3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double u = wave_sum63(us[j]);
+      if (lane == 63) s_u[wave + 16 * j] = u;
+    }
+    {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) s += pv[k];
+      s_part[wave][lane] = s;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v += s_part[k][lane];
+      const int row = 16 * ti + (lane >> 4) + 4 * reg, col = 16 * tj + (lane & 15);
+      if (row < n && col < n) {
+        double out = s_u[lane] - v;  // S0 = blockdiag(U) - sum Y Y^T
+        red[(size_t)row * n + col] = out;
+        if (ti != tj) red[(size_t)col * n + row] = out;
+      } else if (col == n && row < n) {
+        red[(size_t)n * n + row] = v - s_u[lane];  // rhs = sum Y z - g_c
+      }
+    }
+    return;
+  }
+  // ---- diag(U), g_c, scalars: task id per wavefront
+  if (!sel_active(sl, false)) return;
+  const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
+  const int task = ((int)blockIdx.x - 4 * NP) * 16 + wave;
+  double* tail = red + (size_t)n * n + n;
+  if (task < n) {  // diag U
+    int cam = task / 12, l = task - 12 * cam;
+    double v = run_sum(gpart + cam * camstride + (size_t)tri12(l, l) * nfb, nfb, lane);
+    if (lane == 63) tail[task] = v;
+  } else if (task < 2 * n) {  // g_c
+    int jj = task - n, cam = jj / 12, l = jj - 12 * cam;
+    double v = run_sum(gpart + cam * camstride + (size_t)(78 + l) * nfb, nfb, lane);
+    if (lane == 63) tail[n + jj] = v;
+  } else if (task < 2 * n + 16) {
+    int jj = task - 2 * n;
+    double v = 0.0;
+    if (jj == 0 || jj == 1) {  // cost, (camera, frame) pairs with data: one pass over all C x nfb per-wavefront sums, 8 loads in
+      double a = 0.0;          // flight per lane (a run_sum per camera would be C dependent round trips of ~2 us each)
+      const int total = C * nfb;
+      for (int base = 0; base < total; base += 512) {
+        double w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = base + lane + 64 * k;
+          const int cam = i / nfb, fbk = i - cam * nfb;
+          w[k] = i < total ? gpart[cam * camstride + (size_t)(90 + jj) * nfb + fbk] : 0.0;
+        }
+        a += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+      }
+      v = wave_sum63(a);
+    } else if (jj == 2) {
+      double a = 0.0;
+      for (int k = lane; k < nfblocks; k += 64) a += fpart[2 * k + 1];
+      v = wave_sum63(a);
+    } else if (jj == 4 + rank_slot) {
+      double a = 0.0;
+      for (int k = lane; k < nfblocks; k += 64) a = fmax(a, fpart[2 * k]);
+      v = wave_max(a);
+    }
+    if (lane == 63) tail[2 * n + jj] = v;
+  } else if (bpart && task < 2 * n + 24) {
+    // speculative (frame-sharded) ticks: the trial point's scalars [cost, pred_f, |d_f|^2, |x_f|^2, #pairs, 0, 0, 0] for the
+    // all-reduce that follows -- the reduction is built from the trial linearisation, so its cost and pair count are the
+    // trial point's; what used to be a launch of its own (k_sum_trial) is eight more wavefront tasks here
+    const int jj = task - (2 * n + 16);
+    double a = 0.0;
+    if (jj == 0 || jj == 4) {
+      const int total = C * nfb, kk = jj == 0 ? 90 : 91;
+      for (int base = 0; base < total; base += 512) {
+        double w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = base + lane + 64 * k;
+          const int cam = i / nfb, fbk = i - cam * nfb;
+          w[k] = i < total ? gpart[cam * camstride + (size_t)kk * nfb + fbk] : 0.0;
+        }
+        a += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+      }
+    } else if (jj >= 1 && jj <= 3) {
+      for (int base = 0; base < nbp; base += 512) {
+        double w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = base + lane + 64 * k; w[k] = i < nbp ? bpart[3 * i + (jj - 1)] : 0.0; }
+        a += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+      }
+    }
+    const double v = wave_sum63(a);
+    if (lane == 63) tail[2 * n + 16 + jj] = v;
+  }
 }
 
 // ---------------------------------------------------------------- k_backsub: frame steps + trial parameters (body: mcba_backsub.h)
@@ -1093,8 +1257,9 @@ int syrk_items_per_thread() { return SYRK_IPT; }
 
 void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot,
                           const double* bpart, int nbp) {
-  ReduceArgs r{s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp};
-  k_reduce_system<<<dim3(reduce_blocks(C, NP, bpart != nullptr, 16)), dim3(1024), 0, st>>>(r);
+  int n = 12 * C;
+  int tail_blocks = (2 * n + 16 + (bpart ? 8 : 0) + 15) / 16;
+  k_reduce_system<<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp);
 }
 
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {

@@ -17,17 +17,6 @@
 
 namespace mcba {
 
-struct ReduceArgs {
-  Sel sl;
-  const double *gp0, *gp1, *spart, *fpart;
-  const int *tile_i, *tile_j;
-  double* red;
-  int C, nfb, G, NT, NP, nfblocks, rank_slot;
-  const double* bpart;  // != nullptr: the trial scalars are summed here as well (red + nsys .. + 8)
-  int nbp;
-};
-inline int reduce_blocks(int C, int NP, bool trial, int nw) { return 4 * NP + (2 * 12 * C + 16 + (trial ? 8 : 0) + nw - 1) / nw; }
-
 __device__ __forceinline__ double run_sum(const double* __restrict__ p, int count, int lane) {  // sum of a contiguous run, result in lane 63
   double s = 0.0;
   for (int base = 0; base < count; base += 256) {
