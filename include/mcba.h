@@ -168,6 +168,9 @@ int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, do
  *                       (offset 0, n*n + 3n + 16 + 8 doubles) and calls mcba_lm_auto_solve(seq, decide = 1), which takes
  *                       the decision and, if the prediction does not hold (rejected step, or another damping), marks the
  *                       next tick as a rebuild-only tick instead of solving;
+ *                       With <= 9 cameras the solve's launch also carries the back-substitution of the NEXT trial step (after a
+ *                       speculative reduction, or inside mcba_lm_auto_tick on one GPU): the following mcba_lm_auto_trial /
+ *                       mcba_lm_auto_tick then starts with the linearisation of that trial point.  MCBA_FUSE_BACKSUB=0 disables it.
  * mcba_lm_auto_tick   : trial + reduce + solve in one call; with a direct RCCL communicator attached (mcba_comm_init) the
  *                       library issues the collective(s) itself -- one per tick (speculative), or two with MCBA_SPECULATE=0;
  * mcba_lm_auto_wait   : spin on the ring slot until tick `seq` has posted (falls back to a stream synchronisation after

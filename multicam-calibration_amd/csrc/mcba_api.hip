@@ -63,6 +63,7 @@ struct mcba_handle {
   // k_solve_backsub (single-GPU ticks, factor in LDS): the solve's launch also runs the back-substitution of the NEXT trial step;
   // trial_ready = the last tick did so, the next one must not back-substitute again.  The flag word sits behind the camera step.
   bool fuse_backsub = false, trial_ready = false;
+  bool spec_copy_ready = false;  // the last k_reduce_system was a speculative one: the pre-decision state copy is in place
   double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8, lam_min = 1e-12, lam_max = 1e12;
   // profiling
   bool prof = false;
@@ -645,10 +646,11 @@ static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, boo
   {
     Scope sc(h, K_REDUCE);
     mcba::launch_reduce_system(h->stream, decide_here ? post_sel(h) : sl, h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot,
-                               spec ? h->bpart : nullptr, h->nbblocks);
+                               spec ? h->bpart : nullptr, h->nbblocks, spec ? post_state(h) : nullptr);
   }
   if ((rc = check_launch())) return rc;
   h->have_red = true;
+  h->spec_copy_ready = spec;
   return MCBA_OK;
 }
 
@@ -720,6 +722,9 @@ int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, d
 }
 
 static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, bool decided_by_syrk, bool fuse_next = false) {
+  // frame-sharded ticks with one collective (the decision is taken here, after a speculative reduction that left a copy of the
+  // pre-decision state behind): the back-substitution of the next trial step rides along as well
+  if (decide && h && h->fuse_backsub && h->spec_copy_ready) fuse_next = true;
   if (!h || !h->auto_ready || seq == 0) return fail(MCBA_ERR_ARG, "mcba_lm_auto_solve: call mcba_lm_auto_config first; seq >= 1");
   if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_lm_auto_solve: no reduced system");
   HIPCHK(hipSetDevice(h->device));
@@ -734,7 +739,7 @@ static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, b
   {
     Scope sc(h, K_SOLVE);
     if (fuse_next)  // + the back-substitution of the next tick's trial step, overlapped with the solve (polls bounded: ~0.5 s)
-      mcba::launch_solve_backsub(h->stream, a, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad, a.lms_in, 200000);
+      mcba::launch_solve_backsub(h->stream, a, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad, decide ? post_state(h) : a.lms_in, 200000, decide ? 1 : 0);
     else
       mcba::launch_solve_cam(h->stream, a);
   }

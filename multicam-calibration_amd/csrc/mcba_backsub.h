@@ -34,6 +34,11 @@ struct BacksubWait {
   double* mail;         // LDS, 8 + 12 C doubles: what the polling wavefront fetched, for the others
   double seq;
   int max_polls;
+  // frame-sharded ticks with ONE collective: `early` is the state BEFORE the decision (the solve of this launch takes it).  The
+  // loads go to the buffers an ACCEPTED step with the predicted damping makes current -- the prediction the speculative Schur
+  // reduction was built on; if it fails the solve marks the next tick rebuild-only and the steps computed here are dropped.
+  int spec;
+  double lam_min;
 };
 
 __device__ __forceinline__ double load_coherent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -58,7 +63,8 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
   double xv[6], Lp[21], gf[6], D[6];
   int sidx_early = 0;
   if (wait) {
-    sidx_early = (static_cast<int>(wait->early[3]) ^ sl.idx) & 1;
+    const bool flip = wait->spec && wait->early[MCBA_LM_SKIP] == 0.0;  // (a rebuild-only tick decides nothing)
+    sidx_early = (static_cast<int>(wait->early[3]) ^ sl.idx ^ (flip ? 1 : 0)) & 1;
     if (wave < C) {
       const double2* w2 = reinterpret_cast<const double2*>((sidx_early ? rec1 : rec0) + ((size_t)wave * nfb + block) * (MCBA_REC * 64)) + lane;
 #pragma unroll
@@ -106,7 +112,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
     FSTAMP(2);
     active = true;  // so far: the final word is awaited before anything is stored
     sidx = sidx_early;
-    lambda = wait->early[1];
+    lambda = (wait->spec && wait->early[MCBA_LM_SKIP] == 0.0) ? lm_spec_lambda(wait->early[1], wait->lam_min) : wait->early[1];
   } else {
     active = sel_active(sl, true);
     sidx = active ? sel_index(sl) : 0;  // current slot / linearisation; the trial goes to the other slot

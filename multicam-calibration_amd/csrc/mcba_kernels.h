@@ -64,9 +64,10 @@ void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, 
 size_t syrk_lds_bytes(int C, int FS);
 void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw);
 int syrk_items_per_thread();
-// bpart != nullptr (speculative frame-sharded ticks): the trial scalars are summed here as well (red + nsys .. + 8)
+// bpart != nullptr (speculative frame-sharded ticks): the trial scalars are summed here as well (red + nsys .. + 8) and the LM
+// state is copied to state_copy (MCBA_LMS doubles)
 void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot,
-                          const double* bpart = nullptr, int nbp = 0);
+                          const double* bpart = nullptr, int nbp = 0, double* state_copy = nullptr);
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad);
 void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const double* dc_dev, double* x0, double* x1, double* bpart, int C, int F, int Fpad);
 size_t solve_lds_bytes(int npad, int use_lds);
@@ -74,10 +75,10 @@ int solve_fits_lds(int npad);
 int solve_set_lds_limit(int npad, int use_lds);
 void launch_solve_cam(hipStream_t st, const SolveArgs& a);
 // solve + the back-substitution of the next trial step in one launch (a.use_lds variants, a.flag set); early_state = the LM state
-// the tick's decision left (final as far as the slot bit goes)
+// the tick's decision left (final as far as the slot bit goes), or -- spec != 0, the solve decides -- a copy of the state before it
 int solve_backsub_set_lds_limit(int npad);
 void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const double* rec0, const double* rec1, const double* fbuf, double* x0, double* x1, double* bpart, int C, int F, int Fpad,
-                          const double* early_state, int max_polls);
+                          const double* early_state, int max_polls, int spec);
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da);
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);

@@ -887,7 +887,7 @@ __device__ __forceinline__ double run_sum(const double* __restrict__ p, int coun
 
 __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __restrict__ gp0, const double* __restrict__ gp1, const double* __restrict__ spart, const double* __restrict__ fpart,
                                                         const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ red, int C, int nfb, int G, int NT, int NP,
-                                                        int nfblocks, int rank_slot, const double* __restrict__ bpart, int nbp) {
+                                                        int nfblocks, int rank_slot, const double* __restrict__ bpart, int nbp, double* __restrict__ state_copy) {
   const int n = 12 * C;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ double s_part[16][64];
@@ -1029,6 +1029,10 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
     }
     const double v = wave_sum63(a);
     if (lane == 63) tail[2 * n + 16 + jj] = v;
+  } else if (bpart && state_copy && task == 2 * n + 24) {
+    // ... and a copy of the LM state as it stands BEFORE the decision: k_solve_backsub's back-substitution workgroups read it
+    // while the solve of the same launch is already rewriting the original
+    if (lane < MCBA_LMS) state_copy[lane] = sl.lms[lane];
   }
 }
 
@@ -1256,10 +1260,10 @@ void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, 
 int syrk_items_per_thread() { return SYRK_IPT; }
 
 void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot,
-                          const double* bpart, int nbp) {
+                          const double* bpart, int nbp, double* state_copy) {
   int n = 12 * C;
-  int tail_blocks = (2 * n + 16 + (bpart ? 8 : 0) + 15) / 16;
-  k_reduce_system<<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp);
+  int tail_blocks = (2 * n + 16 + (bpart ? 9 : 0) + 15) / 16;
+  k_reduce_system<<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy);
 }
 
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {
