@@ -47,7 +47,7 @@ struct mcba_handle {
   unsigned char *sel = nullptr, *fmask = nullptr;
   double* obj_host = nullptr;  // board points as uploaded (diagnostics normalise them on the host)
   int *tile_i = nullptr, *tile_j = nullptr;
-  int NT = 0, NP = 0, G = 0, fpc = 0, FS = 0, ppw = 4, nfblocks = 0, nbblocks = 0, nch = 1;
+  int NT = 0, NP = 0, G = 0, sq = 0, sr = 0, FS = 0, ppw = 4, nfblocks = 0, nbblocks = 0, nch = 1;  // k_syrk: G workgroups, sq stages of FS frames each, the first sr one more
   int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD (few frames)
   size_t nx = 0, nsys = 0;
   double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
@@ -204,8 +204,21 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
     int gmax = 512;
     if (const char* e = getenv("MCBA_SYRK_G")) gmax = std::max(1, std::min(512, atoi(e)));  // tuning knob (k_reduce_system holds <= 512 / 16 partial rows per wavefront)
     int g = std::min(nstage, gmax);
-    h->fpc = ((nstage + g - 1) / g) * h->FS;
-    h->G = (F + h->fpc - 1) / h->fpc;
+    // Two workgroups per CU (ppw == 4: <= 10 cameras): deal the stages out evenly over g workgroups -- measured at 6 x 10 000:
+    // 1250 stages as 226 x 3 + 286 x 2 (no CU above five stages) 107.5 us per tick against 109.0 us for 417 x 3 (161 CUs with six).
+    // One workgroup per CU (the 16-tile variant): every workgroup costs a prologue of its own, fewer and equal ones win
+    // (24 x 6250 x 200: 873 us against 918 us).
+    bool balance = h->ppw == 4;
+    if (const char* e = getenv("MCBA_SYRK_BALANCE")) balance = atoi(e) != 0;  // development knob
+    if (balance) {
+      h->G = g;
+      h->sq = nstage / g;
+      h->sr = nstage % g;
+    } else {
+      h->sq = (nstage + g - 1) / g;
+      h->sr = 0;
+      h->G = (nstage + h->sq - 1) / h->sq;
+    }
   }
   h->nfblocks = h->G;  // k_syrk's workgroups factorise their own frames: one (max |g_f|, #failures) pair each
   h->nbblocks = h->Fpad / 64;
@@ -470,7 +483,7 @@ int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot) {
   int rc;
   {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, host_sel(h->lin, lambda), no_fuse(), h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
+    mcba::launch_syrk(h->stream, host_sel(h->lin, lambda), no_fuse(), h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->sq, h->sr, h->FS, h->ppw);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -640,7 +653,7 @@ static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, boo
   }
   {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, sl, fz, h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->fpc, h->FS, h->ppw);
+    mcba::launch_syrk(h->stream, sl, fz, h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->sq, h->sr, h->FS, h->ppw);
   }
   if ((rc = check_launch())) return rc;
   {

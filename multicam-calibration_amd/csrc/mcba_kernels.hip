@@ -548,7 +548,9 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
 // The Schur reduction  S = U - sum_f Y_f Y_f^T,  rhs = sum_f Y_f z_f - g_c  is a genuine GEMM (K = 6 F), so it runs
 // on v_mfma_f64_16x16x4_f64.  Yx_f = [Y_f ; z_f^T] is (12C+1) x 6: with z as an extra ROW the right-hand side is
 // column 12C of the same product.  Rows are padded to NT*16.
-// grid (G, ceil(NP / (4*PPW))), block 256 = 4 wavefronts; workgroup g owns the frames [g fpc, (g+1) fpc).
+// grid (G, ceil(NP / (4*PPW))), block 256 = 4 wavefronts; the stages of FS frames are dealt out evenly: workgroup g owns sq stages,
+// the first sr workgroups one more (6 x 10 000: 1250 stages over 512 workgroups = 226 x 3 + 286 x 2 -- workgroups g and g + 256
+// share a CU, so no CU gets more than five stages; a uniform 3 stages per workgroup left 161 CUs with six and 95 with three).
 //   0. (DECIDE, single-GPU ticks) what used to be k_sum_trial + the decision: EVERY workgroup sums the trial point's cost /
 //      step partials (a few KB, fixed order -> identical in every workgroup) and takes the accept / reject decision on an
 //      LDS copy of the LM state; workgroup 0 publishes the new state to a SECOND state buffer (the old one is still being
@@ -573,7 +575,7 @@ constexpr int kSyrkSuper = 32;  // frames factorised per super-stage: 32 frames 
 
 template <int PPW, int IPT, bool DECIDE>
 __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse fz, const double* __restrict__ rec0, const double* __restrict__ rec1, double* __restrict__ fbuf, double* __restrict__ fpart,
-                                              const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int fpc, int FS) {
+                                              const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int sq, int sr, int FS) {
   extern __shared__ __align__(16) double lds[];
   __shared__ double s_st[MCBA_LMS];
   __shared__ double s_sum[8];
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   }
   for (int i = t; i < (NT * 16 - (n + 1)) * RS; i += 256) s_y[(size_t)(n + 1) * RS + i] = 0.0;  // padding rows stay zero
 
-  const int f0 = blockIdx.x * fpc, f1 = min(F, f0 + fpc);
+  const int f0 = ((int)blockIdx.x * sq + min((int)blockIdx.x, sr)) * FS, f1 = min(F, f0 + (sq + ((int)blockIdx.x < sr ? 1 : 0)) * FS);
   double wreg[IPT][6];
 
   // thread = (frame b of the stage, row group): its IPT items are rows r0, r0 + 256/FS, ... of the SAME frame, so that
@@ -1237,13 +1239,13 @@ size_t syrk_lds_bytes(int C, int FS) {
 #define SYRK_IPT 5  // (12C+1)*FS <= 256*SYRK_IPT is guaranteed by the choice of FS in mcba_create
 #define SYRK_IPT_SMALL 3
 
-void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int fpc, int FS, int ppw) {
+void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int sq, int sr, int FS, int ppw) {
   size_t lds = syrk_lds_bytes(C, FS);
 #define SYRK_GO(PPW, IPT, GY)                                                                                                                                   \
   do {                                                                                                                                                          \
     dim3 grid(G, GY);                                                                                                                                           \
-    if (fz.decide) k_syrk<PPW, IPT, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);   \
-    else k_syrk<PPW, IPT, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, fpc, FS);            \
+    if (fz.decide) k_syrk<PPW, IPT, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS);   \
+    else k_syrk<PPW, IPT, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS);            \
   } while (0)
   // items per thread: (12C + 1) rows x FS frames over 256 threads -- 3 is enough up to 7 cameras at 8 frames per stage
   // (fewer prefetch registers: the kernel stays within 256 registers, two workgroups per CU, without scratch)
