@@ -89,9 +89,9 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
   double lambda;
   if (wait) {
     // ONE wavefront per workgroup polls (a thousand wavefronts hammering one memory channel delay the very store they wait
-    // for), then fetches the camera step and the four state words with cache-bypassing loads and hands them to the other
-    // wavefronts through LDS.  No cache is invalidated: an agent-scope acquire in every wavefront costs an L2 invalidation
-    // each (measured: 6.2 us between "flag seen" and "state read" with 118 of them queueing per XCD).
+    // for), then fetches the camera step with cache-bypassing loads and hands it to the other wavefronts through LDS.  No cache
+    // is invalidated: an agent-scope acquire in every wavefront costs an L2 invalidation each (measured: 6.2 us between "flag
+    // seen" and "state read" with 118 of them queueing per XCD).
     double* mail = wait->mail;  // [0]: 1 camera step fetched, 0 no step this tick (or the solve never posted); [8 ..] camera step
     if (wave == 0) {
       int polls = 0, got = 0;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
   const double* __restrict__ rec = sidx ? rec1 : rec0;
   const double* xs = sidx ? x1 : x0;
   double* xd = sidx ? x0 : x1;
-  const bool pre = wait != nullptr && sidx == sidx_early;  // uniform; always true unless the state changed under us
+  const bool pre = wait != nullptr;  // the first camera's W block and the pose are already in registers
   auto dc = [&](int i) { return wait ? wait->mail[8 + i] : dcs.v[i]; };
   if (fin && !pre) {
     const double* xf = xs + n + 6 * (size_t)f;
