@@ -30,6 +30,10 @@ def _worker(rank, world, port, out_dir, mode):
         os.environ["MCBA_SPECULATE"] = "0"
         mode = "device"
         tag = "device2"
+    elif mode == "device_nofuse":  # the solve and the next trial step's back-substitution as two launches
+        os.environ["MCBA_FUSE_BACKSUB"] = "0"
+        mode = "device"
+        tag = "device_nofuse"
     else:
         tag = mode
     import contextlib
@@ -109,6 +113,21 @@ def test_two_ranks_one_gpu_match_single_process(tmp_path, mode):
     cam_a, cam_b = r0["x"][: 12 * C].reshape(C, 12), res.x[: 12 * C].reshape(C, 12)
     assert (np.abs(cam_a[:, :6] - cam_b[:, :6]) / np.abs(cam_b[:, :6])).max() < 1e-6   # intrinsics + distortion: gauge-free
     assert np.abs(r0["grad"]).max() <= 10 * max(res.optimality, 1e-6)   # the sharded run is as stationary as the single-process one
+
+
+def test_two_ranks_fused_backsub_is_bit_identical(tmp_path):
+    """Speculative frame-sharded ticks with the next trial step's back-substitution inside the solve's launch (its loads
+    addressed on the reduction's prediction, its result dropped when the solve finds the prediction wrong) against the same
+    ticks with a k_backsub launch of their own: the same iterates to the last bit, mispredicted ticks included."""
+    import torch.multiprocessing as mp
+
+    for mode in ("device", "device_nofuse"):
+        mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "device0.npz"), np.load(tmp_path / "device_nofuse0.npz")
+    assert int(a["rebuilds"]) >= 1 and int(a["rebuilds"]) == int(b["rebuilds"])
+    assert int(a["nfev"]) == int(b["nfev"]) and int(a["steps"]) == int(b["steps"]) and float(a["cost"]) == float(b["cost"])
+    np.testing.assert_array_equal(a["x"], b["x"])
+    np.testing.assert_array_equal(a["grad"], b["grad"])
 
 
 # ------------------------------------------------------------------ the direct RCCL path (one rank: RCCL needs one device per rank)
