@@ -46,6 +46,7 @@ struct mcba_handle {
   double *err = nullptr, *dmean = nullptr, *dfull = nullptr, *repro = nullptr, *trans = nullptr, *und = nullptr;  // pre-filter / diagnostics (lazy)
   unsigned char *sel = nullptr, *fmask = nullptr;
   double* obj_host = nullptr;  // board points as uploaded (diagnostics normalise them on the host)
+  int planar = 0;              // every board point has z = 0 exactly (the fused k_gram then runs its planar instance)
   int *tile_i = nullptr, *tile_j = nullptr;
   int NT = 0, NP = 0, G = 0, sq = 0, sr = 0, FS = 0, ppw = 4, nfblocks = 0, nbblocks = 0, nch = 1;  // k_syrk: G workgroups, sq stages of FS frames each, the first sr one more
   int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD (few frames)
@@ -338,6 +339,9 @@ int mcba_upload_observations(mcba_handle* h, const double* uvs, const double* ob
   if (e != hipSuccess || e2 != hipSuccess) { g_err = std::string("upload: ") + hipGetErrorString(e != hipSuccess ? e : e2); return MCBA_ERR_HIP; }
   if (!h->obj_host) h->obj_host = static_cast<double*>(malloc((size_t)3 * h->N * sizeof(double)));
   if (h->obj_host) memcpy(h->obj_host, objpoints, (size_t)3 * h->N * sizeof(double));
+  h->planar = 1;
+  for (int p = 0; p < h->N; ++p) if (objpoints[3 * p + 2] != 0.0) h->planar = 0;
+  if (const char* e = getenv("MCBA_GRAM_FAST")) { if (atoi(e) == 0) h->planar = 0; }  // development knob: the general instance
   h->have_obs = true;
   h->have_lin = h->have_red = h->have_jac = false;
   return MCBA_OK;
@@ -466,7 +470,7 @@ int mcba_linearize(mcba_handle* h, int slot) {
   HIPCHK(hipSetDevice(h->device));
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar);
   }
   int rc = check_launch();
   if (rc) return rc;
@@ -543,7 +547,7 @@ int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, 
   const int alt = 1 - h->lin;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -618,7 +622,7 @@ static int lm_trial_impl(mcba_handle* h, const double* delta_cam, const mcba::De
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);  // trial point = the OTHER slot / buffer
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -776,7 +780,7 @@ static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar);
   }
   if ((rc = check_launch())) return rc;
   if (!sum_here) return MCBA_OK;
@@ -984,6 +988,7 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
   if (src->obj_host) {
     h->obj_host = static_cast<double*>(malloc((size_t)3 * h->N * sizeof(double)));
     if (h->obj_host) memcpy(h->obj_host, src->obj_host, (size_t)3 * h->N * sizeof(double));
+    h->planar = src->planar;
   }
   h->have_obs = true;
   return MCBA_OK;

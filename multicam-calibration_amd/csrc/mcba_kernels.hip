@@ -107,10 +107,10 @@ __device__ __forceinline__ double uni(double v) {
   return u.d;
 }
 __device__ __forceinline__ bool is_num(double v) { return v == v; }
-template <int LOSS>
+template <int LOSS, bool UNIT = false>
 __device__ __forceinline__ void obs_weights(double r, bool valid, double fs2, double ifs2, double& cost, double& w2, double& g) {
   double rh, gw, ww;
-  loss_weights<LOSS>(r, fs2, ifs2, rh, gw, ww);
+  loss_weights<LOSS, UNIT>(r, fs2, ifs2, rh, gw, ww);
   cost += valid ? rh : 0.0;
   w2 = valid ? lm_weight(gw, ww) : 0.0;
   g = valid ? gw * r : 0.0;
@@ -137,7 +137,9 @@ __global__ void k_transpose_obs(const double2* __restrict__ raw, double2* __rest
 // (mcba_math.h: role A = [A|P] block -> V, g_f, W rows of rho/t, U_(rho,t)x(rho,t); role B = intrinsics blocks).
 // Splitting the 87 accumulators over two wavefronts keeps each under 256 VGPRs, so two waves share a SIMD and
 // hide each other's FP64 / memory latency; the roles never exchange data.
-template <int LOSS, int ROLE>
+// FAST (fused variant only): planar board (every z = 0) and f_scale = 1 -- the reference's own set-up -- known at compile time:
+// seven FP64 instructions per point-observation less (products with 0.0 / 1.0 dropped; results equal to round-off).
+template <int LOSS, int ROLE, bool FAST = false>
 __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
                                           double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2,
                                           const double (&pz0)[6], const double2 (&pre)[4]) {
@@ -224,15 +226,15 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       x4[j][0] = obj[3 * pj]; x4[j][1] = obj[3 * pj + 1]; x4[j][2] = obj[3 * pj + 2];
     }
     ObsLead qc;
-    obs_lead<true>(pc, x4[0], qc, is_num(r4[0].x) || is_num(r4[0].y));
+    obs_lead<true, FAST>(pc, x4[0], qc, is_num(r4[0].x) || is_num(r4[0].y));
     auto accumulate = [&](double2 o2, const double Xo[3], const ObsLead& ql) {
       ObsCommon q;
       obs_finish(K, ql, q);
       const bool vu = is_num(o2.x), vv = is_num(o2.y);
       any = any || vu || vv;
       double wu2, wv2, gu, gv;
-      obs_weights<LOSS>(o2.x - q.up, vu, fs2, ifs2, cost, wu2, gu);
-      obs_weights<LOSS>(o2.y - q.vp, vv, fs2, ifs2, cost, wv2, gv);
+      obs_weights<LOSS, FAST>(o2.x - q.up, vu, fs2, ifs2, cost, wu2, gu);
+      obs_weights<LOSS, FAST>(o2.y - q.vp, vv, fs2, ifs2, cost, wv2, gv);
       {
         double E[6];
         obs_row_cam<0>(q, E);
@@ -254,7 +256,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       for (int j = 0; j < RD; ++j) {
         const int jn = (j + 1) % RD;
         ObsLead qn;
-        obs_lead<true>(pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));  // point p + j + 1 (clamped duplicate at the very end)
+        obs_lead<true, FAST>(pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));  // point p + j + 1 (clamped duplicate at the very end)
         const double2 o2 = r4[j];
         const double Xo[3] = {x4[j][0], x4[j][1], x4[j][2]};
         const int pn = min(p + j + RD, N - 1);
@@ -269,7 +271,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       if (p + j < N) {
         const int jn = (j + 1) % RD;
         ObsLead qn;
-        obs_lead<true>(pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));
+        obs_lead<true, FAST>(pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));
         accumulate(r4[j], x4[j], qc);
         qc = qn;
       }
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict
 }
 
 // Both roles in one lane: grid.z = 1, one wave per SIMD (all 87 accumulators + temporaries in the 512-register file).
-template <int LOSS>
+template <int LOSS, bool FAST>
 __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
                                                  double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, int fb0, int fb1,
                                                  double fs2, double ifs2) {
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t,
   GramStart g;
   gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1);
   if (!g.run) return;
-  gram_body<LOSS, 2>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre);
+  gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre);
 }
 
 // ---------------------------------------------------------------- k_cost: robust cost only (trial points), optional residual vector
@@ -1194,14 +1196,19 @@ void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int 
   k_transpose_obs<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(raw), reinterpret_cast<double2*>(obs_t), C, F, N, Fpad);
 }
 
-void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split) {
+void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,
+                 int planar) {
   const int nfb = Fpad / 64;
   dim3 block(256);
   const double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
   const double2* o2 = reinterpret_cast<const double2*>(obs_t);
   auto fused = [&](int fb0, int fb1) {
     dim3 grid((fb1 - fb0 + 3) / 4, C, 1);
-    DISPATCH_LOSS(loss, (k_gram<L><<<grid, block, 0, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)));
+    if (planar && f_scale == 1.0) {
+      DISPATCH_LOSS(loss, (k_gram<L, true><<<grid, block, 0, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)));
+    } else {
+      DISPATCH_LOSS(loss, (k_gram<L, false><<<grid, block, 0, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)));
+    }
   };
   auto roles = [&](int fb0, int fb1) {
     dim3 grid((fb1 - fb0 + 3) / 4, C, 2);

@@ -203,21 +203,24 @@ MCBA_HD void make_chain_const(const double* Rc, const double* Jrc, const double*
 //      w2 = max(rho' + 2 rho'' f^2, EPS) (scipy's J_scale^2: J~^T J~ = sum w2 j^T j)
 // lm_weight() turns (gw, w2) into the curvature weight the LM normal equations use.
 MCBA_HD double lm_weight(double gw, double w2) { return fmax(w2, MCBA_CURV_FLOOR * gw); }
-template <int LOSS>
+// UNIT: f_scale == 1 (the reference's default), known at compile time: the two multiplications by 1.0 disappear (and 1 + r^2
+// becomes one fused multiply-add: results agree with the general code to the last bit or two)
+template <int LOSS, bool UNIT = false>
 MCBA_HD void loss_weights(double r, double fs2, double inv_fs2, double& rho_half, double& gw, double& w2) {
   double r2 = r * r;
   if (LOSS == LOSS_LINEAR) {
     rho_half = 0.5 * r2; gw = 1.0; w2 = 1.0;
     return;
   }
-  double z = r2 * inv_fs2;
+  if (UNIT) { fs2 = 1.0; inv_fs2 = 1.0; }
+  double z = UNIT ? r2 : r2 * inv_fs2;
   double rho0, rho1, rho2;
   if (LOSS == LOSS_SOFT_L1) {
     // rho = 2(sqrt(1+z)-1): rho' = (1+z)^-1/2, rho' + 2 rho'' z = (1+z)^-3/2 -- one rsqrt, no division
     double a = 1.0 + z;
     double it = fast_rsqrt(a);
     double t = a * it;
-    rho_half = fs2 * (t - 1.0);
+    rho_half = UNIT ? t - 1.0 : fs2 * (t - 1.0);
     gw = it;
     w2 = fmax(it * it * it, MCBA_EPS);
     return;
@@ -337,11 +340,18 @@ MCBA_HD void obs_common(const Intr& K, const PairConst& pc, const double Xo[3], 
 struct ObsLead {
   double a, b, iz, xr[3];
 };
-template <bool MASKED = false>
+// PLANAR: every board point has z = 0 exactly (checked on the host): the third column of the rotation drops out
+template <bool MASKED = false, bool PLANAR = false>
 MCBA_HD void obs_lead(const PairConst& pc, const double Xo[3], ObsLead& l, bool ok = true) {
-  l.xr[0] = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], pc.Rcf[2] * Xo[2]));
-  l.xr[1] = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], pc.Rcf[5] * Xo[2]));
-  l.xr[2] = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], pc.Rcf[8] * Xo[2]));
+  if (PLANAR) {
+    l.xr[0] = fma(pc.Rcf[0], Xo[0], pc.Rcf[1] * Xo[1]);
+    l.xr[1] = fma(pc.Rcf[3], Xo[0], pc.Rcf[4] * Xo[1]);
+    l.xr[2] = fma(pc.Rcf[6], Xo[0], pc.Rcf[7] * Xo[1]);
+  } else {
+    l.xr[0] = fma(pc.Rcf[0], Xo[0], fma(pc.Rcf[1], Xo[1], pc.Rcf[2] * Xo[2]));
+    l.xr[1] = fma(pc.Rcf[3], Xo[0], fma(pc.Rcf[4], Xo[1], pc.Rcf[5] * Xo[2]));
+    l.xr[2] = fma(pc.Rcf[6], Xo[0], fma(pc.Rcf[7], Xo[1], pc.Rcf[8] * Xo[2]));
+  }
   double x = l.xr[0] + pc.tcf[0], y = l.xr[1] + pc.tcf[1], z = l.xr[2] + pc.tcf[2];
   if (MASKED) { x = ok ? x : 0.0; y = ok ? y : 0.0; z = ok ? z : 1.0; }
   l.iz = fast_rcp(z);
@@ -352,7 +362,7 @@ MCBA_HD void obs_finish(const Intr& K, const ObsLead& l, ObsCommon& q) {
   q.a = l.a; q.b = l.b;
   q.s = fma(q.a, q.a, q.b * q.b);
   q.d = fma(q.s, fma(K.k2, q.s, K.k1), 1.0);
-  q.dp2 = 2.0 * fma(2.0 * K.k2, q.s, K.k1);
+  q.dp2 = fma(4.0 * K.k2, q.s, 2.0 * K.k1);  // = 2 (2 k2 s + k1) to the bit; the two products are loop invariants
   q.abdp = (q.a * q.b) * q.dp2;
   q.izx = K.fx * l.iz; q.izy = K.fy * l.iz;
   q.fa = K.fx * q.a; q.fb = K.fy * q.b;

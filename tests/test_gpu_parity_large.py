@@ -182,3 +182,35 @@ def test_many_cameras_vs_oracle(mc, C):
     assert np.abs(r).max() <= 1e-11 * (np.abs(Sd).max() * np.abs(dc).max() + np.abs(red["rhs"]).max())
     assert np.abs(dc - ref).max() <= 1e-7 * np.abs(ref).max()
     prob.close()
+
+
+def test_gram_planar_unit_scale_instance_vs_general(mc):
+    """The fused k_gram has an instance for the reference's own set-up -- planar board (every z = 0) and f_scale = 1 -- in which
+    the products with 0.0 and 1.0 are dropped at compile time (eight FP64 instructions per point-observation less).  Against the
+    general instance (MCBA_GRAM_FAST=0, read when the observations are uploaded) on the same problem, 1 024 wavefront items
+    (= the fused variant): equal to round-off (the dropped products themselves change no bit -- scripts/micro/planar_bits.hip --
+    but the two template instances are contracted into fused multiply-adds differently, e.g. 1 + r^2), every loss family."""
+    p = mc.synth.make_problem(8, 8192 - 5, rows=2, cols=3, seed=3, missing=0.1)
+    assert np.all(p["obj"][:, 2] == 0.0)
+    x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    for loss in ("soft_l1", "linear", "cauchy"):
+        out = {}
+        old = os.environ.get("MCBA_GRAM_FAST")
+        try:
+            for mode in ("1", "0"):
+                os.environ["MCBA_GRAM_FAST"] = mode
+                prob = mc.ops.Problem(p["uvs"], p["obj"], loss=loss, f_scale=1.0)
+                prob.set_params(0, x)
+                prob.linearize(0)
+                prob.build_reduced(1e-3)
+                out[mode] = {k: v.copy() for k, v in prob.get_reduced().items()}
+                out[mode]["gf"] = prob.frame_gradient()
+                prob.close()
+        finally:
+            if old is None:
+                del os.environ["MCBA_GRAM_FAST"]
+            else:
+                os.environ["MCBA_GRAM_FAST"] = old
+        for k in out["1"]:
+            a, b = out["1"][k], out["0"][k]
+            assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), f"{loss}: {k}"
