@@ -48,9 +48,10 @@ FP64_VALU_MEASURED_TFLOPS = 57.0  # scripts/micro/fma_f64_rate.hip on the same G
 
 C, F_PER_GPU, ROWS, COLS = 6, 10000, 6, 9
 # FP64 VALU instructions k_gram issues, counted in the ISA of the built kernel (scripts/isa_count.py on `hipcc -S`, round 2):
-# 990 in the 4-point loop body = 248 per point-observation; ~1900 per (camera, frame) outside it (pose constants, chain
+# 958 in the 4-point loop body of the instance this workload runs (planar board, f_scale = 1: k_gram<soft_l1, true>) = 240 per
+# point-observation (the general instance: 986 = 247); ~1900 per (camera, frame) outside it (pose constants, chain
 # matrices, expansion of the local Gram matrix, the halving reduction).  DESIGN.md section 5.
-GRAM_FP64_PER_POINT = 248
+GRAM_FP64_PER_POINT = 240
 GRAM_FP64_PER_PAIR = 1900
 
 
