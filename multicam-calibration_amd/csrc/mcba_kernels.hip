@@ -160,9 +160,10 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 
   const double* pose = x + 12 * C + 6 * (size_t)f;
   PairConst pc;
+  double abc[3];  // sin t / t, (1 - cos t) / t^2, (t - sin t) / t^3 of the frame's rotation: needed again after the point loop
   {
     double Rf[9];
-    rot_only(pz0, Rf);
+    rot_only(pz0, Rf, abc);
     make_pair_const(Rc, tc, Rf, pz0 + 3, pc);
   }
 
@@ -303,7 +304,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     double pz[6], Rf[9], Jrf[9], Jrc[9];
 #pragma unroll
     for (int i = 0; i < 6; ++i) pz[i] = pose[i];
-    rot_and_jr(pz, Rf, Jrf);
+    rot_and_jr(pz, Rf, Jrf, abc);
 #pragma unroll
     for (int i = 0; i < 9; ++i) Jrc[i] = uni(s_cam.Jr[i]);
     make_chain_const(Rc, Jrc, Rf, Jrf, pz + 3, ch);

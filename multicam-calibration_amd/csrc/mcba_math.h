@@ -71,20 +71,24 @@ MCBA_HD void rot_coeffs(double th2, double& a, double& b, double& c) {
     b = 0.5 * (1.0 - th2 * (1.0 / 12.0) * (1.0 - th2 * (1.0 / 30.0) * (1.0 - th2 * (1.0 / 56.0))));
     c = (1.0 / 6.0) * (1.0 - th2 * (1.0 / 20.0) * (1.0 - th2 * (1.0 / 42.0) * (1.0 - th2 * (1.0 / 72.0))));
   } else {
-    double th = sqrt(th2);
-    double s = sin(th), co = cos(th);
-    a = s / th;
-    b = (1.0 - co) / th2;
-    c = (th - s) / (th * th2);
+    // 1 / theta from the reciprocal square root (hardware estimate + one cubic step, full FP64): no square root and none of the
+    // three divisions (~25 instructions each) that used to follow; sine and cosine share one range reduction
+    const double ith = fast_rsqrt(th2), th = th2 * ith, ith2 = ith * ith;
+    double s, co;
+    sincos(th, &s, &co);
+    a = s * ith;
+    b = (1.0 - co) * ith2;
+    c = (th - s) * (ith * ith2);
   }
 }
 
 // R(r) = I + a [r]x + b [r]x^2  (reference convention, R(0) = I: geometry.py:8-35)
 // Jr(r) = I - b [r]x + c [r]x^2 (right Jacobian: R(r + e) ~ R(r) Exp(Jr e))
-MCBA_HD void rot_and_jr(const double r[3], double R[9], double Jr[9]) {
+MCBA_HD void rot_and_jr(const double r[3], double R[9], double Jr[9], const double* abc = nullptr) {
   double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
   double a, b, c;
-  rot_coeffs(th2, a, b, c);
+  if (abc) { a = abc[0]; b = abc[1]; c = abc[2]; }
+  else rot_coeffs(th2, a, b, c);
   double dR = 1.0 - b * th2, dJ = 1.0 - c * th2;
   R[0] = dR + b * r[0] * r[0];
   R[4] = dR + b * r[1] * r[1];
@@ -107,10 +111,12 @@ MCBA_HD void rot_and_jr(const double r[3], double R[9], double Jr[9]) {
   Jr[7] = c * r12 - b * r[0];
 }
 
-MCBA_HD void rot_only(const double r[3], double R[9]) {
+// (abc: the three coefficients handed out / taken in, so that a caller needing R now and (R, Jr) later pays for them once)
+MCBA_HD void rot_only(const double r[3], double R[9], double* abc = nullptr) {
   double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
   double a, b, c;
   rot_coeffs(th2, a, b, c);
+  if (abc) { abc[0] = a; abc[1] = b; abc[2] = c; }
   double dR = 1.0 - b * th2;
   double r01 = r[0] * r[1], r02 = r[0] * r[2], r12 = r[1] * r[2];
   R[0] = dR + b * r[0] * r[0];
