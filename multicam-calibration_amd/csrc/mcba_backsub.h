@@ -22,14 +22,14 @@ constexpr int kBacksubWaves = 8;
 // k_solve_backsub: the camera step does not exist yet when these workgroups start.  What does not depend on it -- the W
 // blocks (39 MB at 6 x 10 000: the whole memory time of this kernel), the frame factors, the poses -- is requested first;
 // which buffers are current is already final in `early` (the state k_syrk published after its decision; the solve does not
-// touch the slot bit, and changes the damping only when it fails).  The solve releases TWO words with the tick's sequence
-// number: flag[1] as soon as the camera step is in memory, flag[0] at its very end, when the state is final (every exit of the
-// solve posts flag[0]; exits without a step never post flag[1]).  The workgroup computes the frame steps after the first and
-// stores them after the second, if the final state still wants a trial step.  Polls are bounded, so a solve that never ran
+// touch the slot bit, and changes the damping only when it fails).  The solve releases ONE word twice, built on the tick's
+// sequence number: as soon as the camera step is in memory, and at its very end, when the state is final (every exit of the
+// solve posts the final value; exits without a step skip the first).  The workgroup computes the frame steps after the first
+// and stores them after the second, if the final state still wants a trial step.  Polls are bounded, so a solve that never ran
 // cannot hang the grid.
 struct BacksubWait {
   const double* early;  // LM state after the tick's decision
-  const double* flag;   // flag[0] final, flag[1] camera step in place: released by the solve with the tick's sequence number
+  const double* flag;   // one word the solve releases: 4 seq + 1 camera step in memory, + 2 state final, + 3 state final and no step
   const double* dc;     // the camera step the solve writes before it releases the flag
   double* mail;         // LDS, 8 + 12 C doubles: what the polling wavefront fetched, for the others
   double seq;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
 #ifdef MCBA_FUSE_TIMING
   const bool stamp = wait && block == 1 && threadIdx.x == 0;
   double* dbg = wait ? const_cast<double*>(wait->flag) : nullptr;
-  if (stamp) dbg[2] = (double)wall_clock64();  // ([0], [1] are the release words)
+  if (stamp) dbg[2] = (double)wall_clock64();  // ([0] is the release word)
 #define FSTAMP(k) do { if (stamp) dbg[(k) + 1] = (double)wall_clock64(); } while (0)
 #else
 #define FSTAMP(k) do { } while (0)
@@ -95,11 +95,13 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
     double* mail = wait->mail;  // [0]: 1 camera step fetched, 0 no step this tick (or the solve never posted); [8 ..] camera step
     if (wave == 0) {
       int polls = 0, got = 0;
+      const double base = 4.0 * wait->seq;
       for (;;) {
-        if (load_coherent(wait->flag + 1) == wait->seq) { got = 1; break; }
-        if (load_coherent(wait->flag) == wait->seq) break;   // the solve ended without a step (terminated, or nothing to solve)
+        const double v = load_coherent(wait->flag);
+        if (v == base + 1.0 || v == base + 2.0) { got = 1; break; }
+        if (v == base + 3.0) break;                          // the solve ended without a step (terminated, or nothing to solve)
         if (++polls > wait->max_polls) break;                // the solve never posted: leave the trial slot alone
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(4);
       }
       asm volatile("" ::: "memory");  // (compiler: the fetches below stay behind the poll; the hardware issues in order)
       if (got) {
@@ -180,7 +182,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
   if (wait) {  // the steps are ready; they count only if the solve's FINAL state still wants a trial step (a failed solve does not)
     int polls = 0;
     bool posted = true;
-    while (load_coherent(wait->flag) != wait->seq) {
+    while (load_coherent(wait->flag) != 4.0 * wait->seq + 2.0) {
       if (++polls > wait->max_polls) { posted = false; break; }
       __builtin_amdgcn_s_sleep(4);
     }

@@ -81,7 +81,7 @@ __device__ __forceinline__ void block_reduce4(double (&v)[4], bool take_max, dou
 
 // LM state (LDS copy `st`) -> device state and the host-mapped ring slot; the sequence number goes last, after a
 // system-scope fence, so that a host that sees it also sees the rest.  Called by every thread of the block.
-__device__ __forceinline__ void post_state(const SolveArgs& a, const double* st, bool write_back) {
+__device__ __forceinline__ void post_state(const SolveArgs& a, const double* st, bool write_back, bool stepped = false) {
   const int tid = threadIdx.x;
   if (tid < MCBA_LMS - 1) {
     const double v = st[tid];
@@ -98,7 +98,9 @@ __device__ __forceinline__ void post_state(const SolveArgs& a, const double* st,
 #ifdef MCBA_FUSE_TIMING
     if (a.flag) a.flag[7] = (double)wall_clock64();
 #endif
-    if (a.flag) __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // ONE word, three values per tick: 4 seq + 1 camera step in memory, 4 seq + 2 state final (after a step), 4 seq + 3 state
+    // final and no step this tick -- a poll is one cache-bypassing load, not two
+    if (a.flag) __hip_atomic_store(a.flag, 4.0 * a.seq + (stepped ? 2.0 : 3.0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -497,7 +499,7 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
   if (a.flag && mode == 0) {  // k_solve_backsub: the camera step is in memory -- the back-substitution workgroups may start on it
     __threadfence();
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(a.flag + 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(a.flag, 4.0 * a.seq + 1.0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   block_reduce4<NTHREADS>(sums, false, s_red);
   if (tid == 0) {
@@ -517,7 +519,7 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
     }
   }
   __syncthreads();
-  post_state(a, lst, true);
+  post_state(a, lst, true, a.flag != nullptr && mode == 0);
 }
 
 template <int NTHREADS, bool LDSW, int KS>
