@@ -646,9 +646,10 @@ static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, boo
     fz.decide = 1;
     fz.cp0 = h->gpart2[0] + (size_t)90 * h->nfb;
     fz.cp1 = h->gpart2[1] + (size_t)90 * h->nfb;
-    fz.cinner = h->nfb;
+    fz.cstride = 4;  // k_gram: per-workgroup sums in every fourth frame block's slot
+    fz.cinner = (h->nfb + 3) / 4;
     fz.couter = (size_t)MCBA_GP * h->nfb;
-    fz.ncp = h->C * h->nfb;
+    fz.ncp = h->C * ((h->nfb + 3) / 4);
     fz.bpart = h->bpart;
     fz.nbp = h->nbblocks;
     fz.trial_out = h->red + h->nsys;

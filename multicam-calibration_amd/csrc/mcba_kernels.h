@@ -29,7 +29,8 @@ struct SyrkFuse {
   int decide;          // != 0: every workgroup sums the trial scalars and takes the accept / reject decision itself
   const double* cp0;   // per-wavefront cost sums of the two linearisation buffers (gpart + 90 nfb) ...
   const double* cp1;
-  int cinner;          // ... element idx of `ncp` lives at (idx / cinner) * couter + (idx % cinner)
+  int cinner;          // ... element idx of `ncp` lives at (idx / cinner) * couter + (idx % cinner) * cstride
+  int cstride;         // 4: k_gram leaves the cost of a whole workgroup (four frame blocks) in its first wavefront's slot, zeros in the others
   size_t couter;
   int ncp;
   const double* bpart; // k_backsub's per-block sums (3 per block)

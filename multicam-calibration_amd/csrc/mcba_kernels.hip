@@ -142,7 +142,7 @@ __global__ void k_transpose_obs(const double2* __restrict__ raw, double2* __rest
 template <int LOSS, int ROLE, bool FAST = false>
 __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
                                           double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2,
-                                          const double (&pz0)[6], const double2 (&pre)[4]) {
+                                          const double (&pz0)[6], const double2 (&pre)[4], double* s_cost, int nrun) {
   // pz0: this lane's frame pose, pre: its first four observations -- loaded by the kernel before the camera constants were
   // staged (those loads, the LM state and the camera rows are all in flight together: one memory round trip at the start)
   const int f = fb * 64 + lane;
@@ -363,6 +363,22 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     double o3[3];
     wave_reduce_scatter<KR>(red, o3, lane);
     constexpr int SH = KR == 96 ? 1 : 2;  // lanes that share lane >> SH hold copies: the first of them stores
+    if constexpr (DO_A) {
+      // The cost and the pair count (k = 90, 91) of the workgroup's wavefronts are summed HERE, in wavefront order, and stored
+      // by wavefront 0 (the others store zeros): k_syrk's decision prologue -- on the critical path of every one of its
+      // workgroups -- then reads a quarter of the entries (every fourth frame block) instead of all of them.
+      constexpr int LQ = ROLE == 0 ? 9 : 30;  // lane >> SH that holds the values k = 90 (r = 0) and 91 (r = 1)
+      const int wv = threadIdx.x >> 6;
+      const bool holder = (lane >> SH) == LQ && (lane & ((1 << SH) - 1)) == 0;
+      if (holder) { s_cost[2 * wv] = o3[0]; s_cost[2 * wv + 1] = o3[1]; }
+      __syncthreads();  // (wavefronts past the last frame block have ended: the barrier does not wait for them)
+      if (holder) {
+        double a = 0.0, b = 0.0;
+        if (wv == 0)
+          for (int w = 0; w < nrun; ++w) { a += s_cost[2 * w]; b += s_cost[2 * w + 1]; }
+        o3[0] = a; o3[1] = b;
+      }
+    }
     if ((lane & ((1 << SH) - 1)) == 0) {
       double* gp = gpart + (size_t)c * MCBA_GP * nfb + fb;
 #pragma unroll
@@ -451,12 +467,14 @@ __global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict
                                                        double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, int fb0, int fb1,
                                                        double fs2, double ifs2) {
   __shared__ CamConst s_cam;
+  __shared__ double s_cost[8];
   GramStart g;
   gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1);
   if (!g.run) return;
   const int c = blockIdx.y;
-  if (blockIdx.z == 0) gram_body<LOSS, 0>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre);
-  else gram_body<LOSS, 1>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre);
+  const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));  // wavefronts of this workgroup that have a frame block
+  if (blockIdx.z == 0) gram_body<LOSS, 0>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun);
+  else gram_body<LOSS, 1>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun);
 }
 
 // Both roles in one lane: grid.z = 1, one wave per SIMD (all 87 accumulators + temporaries in the 512-register file).
@@ -465,10 +483,12 @@ __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t,
                                                  double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, int fb0, int fb1,
                                                  double fs2, double ifs2) {
   __shared__ CamConst s_cam;  // camera intrinsics + pose (R, t, Jr) staged once per workgroup
+  __shared__ double s_cost[8];
   GramStart g;
   gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1);
   if (!g.run) return;
-  gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre);
+  const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));  // wavefronts of this workgroup that have a frame block
+  gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun);
 }
 
 // ---------------------------------------------------------------- k_cost: robust cost only (trial points), optional residual vector
@@ -596,7 +616,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
     const double *pa, *pb;
     int stride = 1, count, inner = 1 << 30;
     size_t outer = 0;
-    if (wave == 0) { pa = fz.cp0; pb = fz.cp1; count = fz.ncp; inner = fz.cinner; outer = fz.couter; }
+    if (wave == 0) { pa = fz.cp0; pb = fz.cp1; count = fz.ncp; inner = fz.cinner; outer = fz.couter; stride = fz.cstride; }
     else { pa = pb = fz.bpart + (wave - 1); stride = 3; count = fz.nbp; }
     const bool two = pa != pb;  // wave-uniform
     double sa = 0.0, sb = 0.0;
