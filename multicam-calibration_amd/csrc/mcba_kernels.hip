@@ -689,7 +689,15 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   for (int k = 0; k < PPW; ++k) {
     int q = blockIdx.y * (4 * PPW) + wave + 4 * k;
     qi[k] = q < NP ? q : -1;  // a missing pair still multiplies tile (0,0) -- branch-free MFMA loop -- but is never stored
-    int ti = q < NP ? tile_i[q] : 0, tj = q < NP ? tile_j[q] : 0;
+    // tile pair q -> (ti, tj), ti <= tj, rows of NT - ti pairs each (the order of the host's table tile_i / tile_j): computed --
+    // q is wave-uniform, a few scalar instructions -- because a load here is a dependent global round trip on the critical
+    // path of every workgroup, right after the decision
+    int ti = 0, tj = 0;
+    if (q < NP) {
+      int rem = q;
+      while (rem >= NT - ti) { rem -= NT - ti; ++ti; }
+      tj = ti + rem;
+    }
     rowa[k] = (16 * ti + (lane & 15)) * RS + (lane >> 4);
     rowb[k] = (16 * tj + (lane & 15)) * RS + (lane >> 4);
     acc[k] = mfma_d4{0.0, 0.0, 0.0, 0.0};
