@@ -901,12 +901,13 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
 // ---------------------------------------------------------------- k_reduce_system: fixed-order second stage
 // Sums the per-workgroup partials of k_syrk and the per-wavefront partials of k_gram into the reduce buffer (layout in
 // include/mcba.h) with coalesced reads and a FIXED summation order (bit-reproducible; no FP64 atomics anywhere).
-//   blocks [0, 4 NP): one per (tile pair q, accumulator register reg) = 64 elements that are 512 contiguous bytes in
-//       every k_syrk partial.  Wave s of 16 sums partials g = s, s+16, ... (all loads in flight), LDS, then wave 0 adds
-//       the 16 slices in order.  Elements that fall on a camera's diagonal block also need U_c (and column 12C needs
-//       g_c): those sums over the frame blocks are contiguous runs of gpart[camera][k][frame block] -- one wavefront
-//       task each, four per wave.  Off-diagonal tiles are mirrored on write.
-//   blocks [4 NP, ...): diag(U), g_c and the 16 scalars, one wavefront task per output.
+//   blocks [0, 16 NP): one per (tile pair q, accumulator register reg, row rr) = 16 elements that are 128 contiguous bytes in
+//       every k_syrk partial (240 blocks at 6 cameras: every CU pulls its share of the 16 MB; one block per (q, reg) left the
+//       whole read to 60 CUs: 10.3 -> 7.0 us).  Wave s of 16 sums partials g = s, s+16, ... (all loads in flight: each lane a
+//       quarter of the slice's rows), LDS, then wave 0 adds the 16 slices in order and the four row groups.  Elements that fall
+//       on a camera's diagonal block also need U_c (and column 12C needs g_c): those sums over the frame blocks are contiguous
+//       runs of gpart[camera][k][frame block] -- one wavefront task each.  Off-diagonal tiles are mirrored on write.
+//   blocks [16 NP, ...): diag(U), g_c and the 16 scalars, one wavefront task per output.
 __device__ __forceinline__ double run_sum(const double* __restrict__ p, int count, int lane) {  // sum of a contiguous run, result in lane 63
   double s = 0.0;
   for (int base = 0; base < count; base += 256) {
@@ -926,70 +927,69 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
   __shared__ double s_part[16][64];
   __shared__ double s_u[64];
   const size_t camstride = (size_t)MCBA_GP * nfb;
-  if ((int)blockIdx.x < 4 * NP) {
-    const int q = blockIdx.x >> 2, reg = blockIdx.x & 3;
+  if ((int)blockIdx.x < 16 * NP) {
+    // One block per (tile pair q, accumulator register reg, row rr of the register's four): 16 elements = one 128-byte
+    // segment of every k_syrk partial -- four times as many blocks as one per (q, reg), so that the 16 MB of partials are
+    // pulled by (almost) every CU instead of 60 of them.  Wavefront s sums slice s (the partials g = s, s + 16, ...): lane
+    // (rg, el) = (lane >> 4, lane & 15) takes every fourth row of the slice for element el.
+    const int q = blockIdx.x >> 4, reg = (blockIdx.x >> 2) & 3, rr = blockIdx.x & 3;
     const int ti = tile_i[q], tj = tile_j[q];
-    // ---- slice sums of the k_syrk partials.  They do not depend on the LM state: ALL of this wavefront's rows (G <= 512
-    // workgroups -> at most 32 per wavefront) go in flight before anything waits for the state -- one memory round trip
-    // where a loop over batches of eight paid one per batch, and the state read rides along.
-    double pv[32];
+    const int rg = lane >> 4, el = lane & 15;
+    // ---- the partials do not depend on the LM state: all of this lane's rows (G <= 512 -> at most 8) go in flight before
+    // anything waits for the state, which rides along
+    double pv[8];
     {
-      const double* p = spart + (size_t)(4 * q + reg) * G * 64 + lane;
+      const double* p = spart + (size_t)(4 * q + reg) * G * 64 + 16 * rr + el;
 #pragma unroll
-      for (int k = 0; k < 32; ++k) { const int g = wave + 16 * k; pv[k] = g < G ? p[(size_t)g * 64] : 0.0; }
+      for (int k = 0; k < 8; ++k) { const int g = wave + 16 * (rg + 4 * k); pv[k] = g < G ? p[(size_t)g * 64] : 0.0; }
     }
     if (!sel_active(sl, false)) return;
     const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
-    // ---- U_c / g_c terms of the elements that need them: element e = wave + 16 j, one wavefront task each; the four
-    // tasks' runs are loaded together as well
-    const double* up[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = wave + 16 * j;
-      const int row = 16 * ti + (e >> 4) + 4 * reg, col = 16 * tj + (e & 15);
-      up[j] = nullptr;
+    // ---- U_c / g_c term of element `wave` of this block's 16, if it needs one: one wavefront task
+    const double* up = nullptr;
+    {
+      const int row = 16 * ti + rr + 4 * reg, col = 16 * tj + wave;
       if (row < n && col < n && row / 12 == col / 12) {
         int cam = row / 12, li = row - 12 * cam, lj = col - 12 * cam;
-        int a = li <= lj ? li : lj, b = li <= lj ? lj : li;
-        up[j] = gpart + cam * camstride + (size_t)tri12(a, b) * nfb;
+        int a = li <= lj ? li : lj, b2 = li <= lj ? lj : li;
+        up = gpart + cam * camstride + (size_t)tri12(a, b2) * nfb;
       } else if (col == n && row < n) {
         int cam = row / 12, li = row - 12 * cam;
-        up[j] = gpart + cam * camstride + (size_t)(78 + li) * nfb;
+        up = gpart + cam * camstride + (size_t)(78 + li) * nfb;
       }
     }
-    double us[4] = {0.0, 0.0, 0.0, 0.0};
+    double us = 0.0;
     for (int base = 0; base < nfb; base += 256) {
-      double w[4][4];
+      double w[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const int i = base + lane + 64 * k; w[j][k] = (up[j] && i < nfb) ? up[j][i] : 0.0; }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) us[j] += (w[j][0] + w[j][1]) + (w[j][2] + w[j][3]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double u = wave_sum63(us[j]);
-      if (lane == 63) s_u[wave + 16 * j] = u;
+      for (int k = 0; k < 4; ++k) { const int i = base + lane + 64 * k; w[k] = (up && i < nfb) ? up[i] : 0.0; }
+      us += (w[0] + w[1]) + (w[2] + w[3]);
     }
     {
-      double s = 0.0;
+      const double u = wave_sum63(us);
+      if (lane == 63) s_u[wave] = u;
+    }
+    {
+      double sum = 0.0;
 #pragma unroll
-      for (int k = 0; k < 32; ++k) s += pv[k];
-      s_part[wave][lane] = s;
+      for (int k = 0; k < 8; ++k) sum += pv[k];
+      s_part[wave][lane] = sum;
     }
     __syncthreads();
     if (wave == 0) {
-      double v = 0.0;
+      double t = 0.0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v += s_part[k][lane];
-      const int row = 16 * ti + (lane >> 4) + 4 * reg, col = 16 * tj + (lane & 15);
-      if (row < n && col < n) {
-        double out = s_u[lane] - v;  // S0 = blockdiag(U) - sum Y Y^T
-        red[(size_t)row * n + col] = out;
-        if (ti != tj) red[(size_t)col * n + row] = out;
-      } else if (col == n && row < n) {
-        red[(size_t)n * n + row] = v - s_u[lane];  // rhs = sum Y z - g_c
+      for (int k = 0; k < 16; ++k) t += s_part[k][lane];  // the 16 slices in order, per (row group, element)
+      const double v = (__shfl(t, el, 64) + __shfl(t, el + 16, 64)) + (__shfl(t, el + 32, 64) + __shfl(t, el + 48, 64));  // the four row groups
+      if (lane < 16) {
+        const int row = 16 * ti + rr + 4 * reg, col = 16 * tj + el;
+        if (row < n && col < n) {
+          double out = s_u[el] - v;  // S0 = blockdiag(U) - sum Y Y^T
+          red[(size_t)row * n + col] = out;
+          if (ti != tj) red[(size_t)col * n + row] = out;
+        } else if (col == n && row < n) {
+          red[(size_t)n * n + row] = v - s_u[el];  // rhs = sum Y z - g_c
+        }
       }
     }
     return;
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
   // ---- diag(U), g_c, scalars: task id per wavefront
   if (!sel_active(sl, false)) return;
   const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
-  const int task = ((int)blockIdx.x - 4 * NP) * 16 + wave;
+  const int task = ((int)blockIdx.x - 16 * NP) * 16 + wave;
   double* tail = red + (size_t)n * n + n;
   if (task < n) {  // diag U
     int cam = task / 12, l = task - 12 * cam;
@@ -1301,7 +1301,7 @@ void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double
                           const double* bpart, int nbp, double* state_copy) {
   int n = 12 * C;
   int tail_blocks = (2 * n + 16 + (bpart ? 9 : 0) + 15) / 16;
-  k_reduce_system<<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy);
+  k_reduce_system<<<dim3(16 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy);
 }
 
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {
