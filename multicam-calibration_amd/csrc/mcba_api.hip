@@ -202,7 +202,11 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   if (mcba::syrk_lds_bytes(C, h->FS) > 160 * 1024) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for the LDS staging of k_syrk"); }
   {
     int nstage = (F + h->FS - 1) / h->FS;
-    int gmax = 512;
+    // the 16-tile variant (> 13 cameras) runs ONE workgroup per CU and grid.y = ceil(NP / 64) of them share a set of frames:
+    // one round of the 256 CUs, every workgroup as many stages as that allows -- 24 x 6250 x 200: 83 x 3 workgroups of 19 stages
+    // 776 us per tick (33 MB of partial tiles) against 839 us for 391 x 3 of 4 stages (152 MB), 806 / 796 / 822 / 809 / 874 us
+    // for G = 256 / 171 / 128 / 64 / 43
+    int gmax = h->ppw == 4 ? 512 : std::max(1, 256 / ((h->NP + 63) / 64));
     if (const char* e = getenv("MCBA_SYRK_G")) gmax = std::max(1, std::min(512, atoi(e)));  // tuning knob (k_reduce_system holds <= 512 / 16 partial rows per wavefront)
     int g = std::min(nstage, gmax);
     // Two workgroups per CU (ppw == 4: <= 10 cameras): deal the stages out evenly over g workgroups -- measured at 6 x 10 000:

@@ -1,6 +1,7 @@
 """Per-workgroup stamps of k_syrk inside the device-resident LM loop (development aid; needs a build with
-MCBA_HIPCC_FLAGS=-DMCBA_SYRK_TIMING).   usage: python scripts/syrk_stamps.py [lib.so]"""
+MCBA_HIPCC_FLAGS=-DMCBA_SYRK_TIMING).   usage: [MCBA_SHAPE=C,F,rows,cols] python scripts/syrk_stamps.py [lib.so]"""
 import ctypes
+import os
 import sys
 
 import numpy as np
@@ -10,12 +11,13 @@ import multicam_calibration_amd as m
 
 if len(sys.argv) > 1:
     m.ops.LIB_PATH = sys.argv[1]
-p = m.synth.make_problem(6, 10000, seed=0)
+C, F, rows, cols = (int(a) for a in os.environ.get("MCBA_SHAPE", "6,10000,6,9").split(","))
+p = m.synth.make_problem(C, F, rows=rows, cols=cols, seed=0)
 x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
 prob = m.ops.Problem(p["uvs"], p["obj"])
 lm = m.solver.LevenbergMarquardt(prob, ftol=0.0, xtol=0.0, gtol=0.0, reduced_solver="device", depth=2)
 lm.start(x0)
-for _ in range(200):
+for _ in range(200 if C * F <= 60000 else 40):
     lm.iterate(always_linearize=True)
 prob.synchronize()
 out = np.zeros(12 + 12 * 512)
