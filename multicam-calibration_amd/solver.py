@@ -197,6 +197,7 @@ class LevenbergMarquardt:
         self.lam, self.nu = self.lam0, 2.0
         self.iteration, self.steps = 0, 0
         self.rebuilds = 0
+        self._terminated = False
         self.cost = None
         self.step_norm = None
         self.actual_reduction = None
@@ -250,8 +251,12 @@ class LevenbergMarquardt:
         if self.issued == self.retired:
             return 0
         self.retired += 1
-        st = self.p.lm_auto_wait(self.retired)
+        return self._retire(self.p.lm_auto_wait(self.retired))
+
+    def _retire(self, st):
+        """Book-keeping for one finished tick from the state it posted."""
         done = int(st[15])
+        self._terminated = self._terminated or done != 0  # (ticks enqueued behind this one return at once and post the same state)
         if st[24] != 0:  # a rebuild-only tick (the reduced solve had failed, or a speculative reduction was mispredicted)
             self.rebuilds += 1
             self.lam, self.nu = float(st[1]), float(st[2])
@@ -445,9 +450,11 @@ class LevenbergMarquardt:
         if not self.device_solve:
             return
         st = None
-        while self.retired < self.issued:
+        while self.retired < self.issued:  # (stopped from outside with ticks in flight: their accepted steps count)
             self.retired += 1
             st = self.p.lm_auto_wait(self.retired)
+            if not self._terminated:
+                self._retire(st)
         if st is None:
             st = self.p.lm_auto_wait(self.retired)
         if st[15] == 0 and (st[14] != 0 or st[23] != 0):  # not terminated on the device, and the next tick would have rebuilt

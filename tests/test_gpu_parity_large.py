@@ -214,3 +214,33 @@ def test_gram_planar_unit_scale_instance_vs_general(mc):
         for k in out["1"]:
             a, b = out["1"][k], out["0"][k]
             assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), f"{loss}: {k}"
+
+
+@pytest.mark.parametrize("C,F", [(6, 10000), (8, 30000)])
+def test_fused_backsub_full_size_bit_identical(mc, C, F):
+    """The release-word protocol of k_solve_backsub with as many waiting workgroups as the benchmark has (157 at 6 x 10 000,
+    469 at 8 x 30 000: more than one per CU): 150 device-resident ticks with the back-substitution inside the solve's launch
+    and as a launch of its own (MCBA_FUSE_BACKSUB=0, read in mcba_create) must leave the same parameters to the last bit."""
+    p = mc.synth.make_problem(C, F, seed=5)
+    x0 = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    out = {}
+    old = os.environ.get("MCBA_FUSE_BACKSUB")
+    try:
+        for mode in ("1", "0"):
+            os.environ["MCBA_FUSE_BACKSUB"] = mode
+            prob = mc.ops.Problem(p["uvs"], p["obj"])
+            lm = mc.solver.LevenbergMarquardt(prob, ftol=0.0, xtol=0.0, gtol=0.0, reduced_solver="device", depth=2)
+            lm.start(x0)
+            for _ in range(150):
+                assert lm.iterate(always_linearize=True) is None
+            res = lm.result(0)
+            out[mode] = (res.x.copy(), res.cost, res.nfev)
+            prob.close()
+    finally:
+        if old is None:
+            del os.environ["MCBA_FUSE_BACKSUB"]
+        else:
+            os.environ["MCBA_FUSE_BACKSUB"] = old
+    assert out["1"][2] == out["0"][2]
+    assert out["1"][1] == out["0"][1] and out["1"][1] < 1e-2 * 0.5 * 4.0 * 2 * C * F * 54   # and it went somewhere
+    np.testing.assert_array_equal(out["1"][0], out["0"][0])
