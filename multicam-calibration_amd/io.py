@@ -12,8 +12,10 @@ as 3x3 camera matrix + distortion coefficients (k1, k2, p1, p2, k3).
           that FileStorage emits for dense double matrices (`!!opencv-matrix`, rows / cols / dt / data) is written and
           parsed directly.  Parity with cv2's byte-level output is UNPINNED (no cv2 to produce a file); the layout follows
           OpenCV's documented YAML persistence format and the round trip is tested.
-  gimbal  one HDF5 file (io.py:82-95, 216-242): needs h5py, exactly like the reference -- an ImportError says so when it
-          is missing (it is not in this image, so that branch is untested here).
+  gimbal  one HDF5 file, group "camera_parameters" with datasets camera_names / dist_coefs / intrinsic / rotation / translation
+          (format description: io.py:22-25).  Needs h5py, like the reference -- an ImportError says so when it is missing.  h5py
+          is not in this image: the array logic (_gimbal_pack / _gimbal_unpack) is tested directly and the two h5py loops against
+          a dict-backed stand-in (tests/test_io_cpu.py); a real HDF5 file has not been written here.
 """
 import json
 import os
@@ -53,6 +55,55 @@ def _cv_yaml_read(path):
     return out
 
 
+# ---- gimbal: one HDF5 file, group "camera_parameters" with five datasets (the format description in the reference's
+# docstring, io.py:22-25): camera_names (n strings), dist_coefs (n, 5), intrinsic (n, 3, 3), rotation (n, 3, 3), translation (n, 3).
+# The array logic lives in two pure functions that are tested without h5py; the h5py calls themselves are the two loops in
+# save_calibration / load_calibration (executed in the tests against a dict-backed stand-in when h5py is not installed).
+_GIMBAL_GROUP = "camera_parameters"
+_GIMBAL_KEYS = ("camera_names", "dist_coefs", "intrinsic", "rotation", "translation")
+
+
+def _require_h5py():
+    try:
+        import h5py
+    except ImportError as e:  # same dependency as the reference (io.py:3)
+        raise ImportError("the gimbal calibration format is an HDF5 file: it needs h5py, as the reference does") from e
+    return h5py
+
+
+def _gimbal_pack(transforms, all_intrinsics, camera_names):
+    """4x4 world -> camera transforms (n, 4, 4) + intrinsics -> the five datasets, camera axis first."""
+    n = len(camera_names)
+    out = {
+        "camera_names": list(camera_names),   # h5py stores a list of str as variable-length UTF-8 strings
+        "dist_coefs": np.empty((n, 5)),
+        "intrinsic": np.empty((n, 3, 3)),
+        "rotation": np.ascontiguousarray(transforms[:, :3, :3]),
+        "translation": np.ascontiguousarray(transforms[:, :3, 3]),
+    }
+    for c, (K, dist) in enumerate(all_intrinsics):
+        out["intrinsic"][c] = K
+        out["dist_coefs"][c] = np.ravel(dist)
+    return out
+
+
+def _gimbal_unpack(stored, camera_names=None):
+    """The five datasets as read back ([()] of each) -> (all_extrinsics, all_intrinsics, camera_names), optionally a subset /
+    re-ordering by name.  String datasets come back from h5py as bytes objects."""
+    names = [n.decode("utf-8") if isinstance(n, bytes) else str(n) for n in np.asarray(stored["camera_names"]).tolist()]
+    pick = range(len(names))
+    if camera_names is not None:
+        assert set(camera_names) <= set(names), "Camera names must be a subset of names in calibration file"
+        pick = [names.index(n) for n in camera_names]
+    else:
+        camera_names = names
+    rot, tra = np.asarray(stored["rotation"]), np.asarray(stored["translation"])
+    K, dist = np.asarray(stored["intrinsic"]), np.asarray(stored["dist_coefs"])
+    all_extrinsics = [np.concatenate([rodrigues_inv(rot[c]), tra[c]]) for c in pick]
+    all_intrinsics = [(K[c], dist[c]) for c in pick]
+    return all_extrinsics, all_intrinsics, list(camera_names)
+
+
 def save_calibration(all_extrinsics, all_intrinsics, camera_names, save_path, save_format="json"):
     """Save calibration results (io.py:8-99; parameters as there)."""
     assert len(all_extrinsics) == len(all_intrinsics) == len(camera_names), "Number of camera names must match number of extrinsics and intrinsics"
@@ -80,17 +131,13 @@ def save_calibration(all_extrinsics, all_intrinsics, camera_names, save_path, sa
                 f.write(_cv_yaml_matrix("R", transforms[i, :3, :3].T))
                 f.write(_cv_yaml_matrix("T", transforms[i, :3, 3:]))
     elif save_format == "gimbal":
-        import h5py  # same dependency as the reference (io.py:3); not part of this image
-
+        h5py = _require_h5py()
         if not save_path.endswith(".h5"):
             save_path += ".h5"
         with h5py.File(save_path, "w") as h5:
-            grp = h5.create_group("camera_parameters")
-            grp.create_dataset("dist_coefs", data=np.stack([np.asarray(k[1]) for k in all_intrinsics]))
-            grp.create_dataset("intrinsic", data=np.stack([np.asarray(k[0]) for k in all_intrinsics]))
-            grp.create_dataset("rotation", data=transforms[:, :3, :3])
-            grp.create_dataset("translation", data=transforms[:, :3, 3])
-            grp.create_dataset("camera_names", data=camera_names)
+            grp = h5.create_group(_GIMBAL_GROUP)
+            for key, value in _gimbal_pack(transforms, all_intrinsics, camera_names).items():
+                grp.create_dataset(key, data=value)
     else:
         raise ValueError(f"Unknown format {save_format}")
 
@@ -127,22 +174,12 @@ def load_calibration(load_path, load_format="json", camera_names=None):
             all_intrinsics.append((fs["intrinsicMatrix"].T, fs["distortionCoefficients"].reshape(-1)))
         return all_extrinsics, all_intrinsics, camera_names
     elif load_format == "gimbal":
-        import h5py  # see save_calibration
-
+        h5py = _require_h5py()
         if not load_path.endswith(".h5"):
             load_path += ".h5"
         with h5py.File(load_path, "r") as h5:
-            grp = h5["camera_parameters"]
-            h5_names = [n.decode("utf-8") for n in grp["camera_names"][()].tolist()]
-            all_intrinsics = list(zip(grp["intrinsic"][()], grp["dist_coefs"][()]))
-            all_extrinsics = np.concatenate([rodrigues_inv(grp["rotation"][()]), grp["translation"][()]], axis=1)
-            if camera_names is None:
-                camera_names = h5_names
-            else:
-                assert set(camera_names) <= set(h5_names), "Camera names must be a subset of names in calibration file"
-                ix = np.array([h5_names.index(n) for n in camera_names])
-                all_extrinsics = all_extrinsics[ix]
-                all_intrinsics = [all_intrinsics[i] for i in ix]
-            return list(all_extrinsics), all_intrinsics, camera_names
+            grp = h5[_GIMBAL_GROUP]
+            stored = {key: grp[key][()] for key in _GIMBAL_KEYS}
+        return _gimbal_unpack(stored, camera_names)
     else:
         raise ValueError(f"Unknown format {load_format}")

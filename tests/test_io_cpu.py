@@ -1,6 +1,7 @@
 """save_calibration / load_calibration (multicam-calibration_amd/io.py; reference multicam_calibration/io.py:8-245)."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -8,6 +9,8 @@ import pytest
 from oracle import ba_oracle as orc
 from multicam_calibration_amd import io as mio
 from multicam_calibration_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _calibration():
@@ -75,7 +78,79 @@ def test_jarvis_directory_round_trips(tmp_path):
     assert n3 == sorted(names)
 
 
-def test_unknown_format_and_gimbal_dependency(tmp_path):
+def test_json_is_byte_identical_to_the_file_the_reference_writer_produced(tmp_path):
+    """tests/golden/calibration_ref.json was written by the reference's own save_calibration(..., "json") (io.py:54-66;
+    generator: tests/golden/make_golden_io.py, cv2 / h5py stubbed -- the JSON branch touches neither)."""
+    g = np.load(os.path.join(GOLDEN, "calibration_io.npz"))
+    names = [str(n) for n in g["camera_names"]]
+    intr = [(g["camera_matrices"][c], g["dist_coefs"][c]) for c in range(len(names))]
+    path = str(tmp_path / "calib")
+    mio.save_calibration(g["extrinsics"], intr, names, path)
+    want = open(os.path.join(GOLDEN, "calibration_ref.json"), "rb").read()
+    assert open(path + ".json", "rb").read() == want
+    # ... and the reference-written file loads (the upstream reader cannot: it looks up "rotation" / "translation", io.py:161-164)
+    e2, i2, n2 = mio.load_calibration(os.path.join(GOLDEN, "calibration_ref.json"), camera_names=names)
+    _check(g["extrinsics"], intr, e2, i2)
+
+
+class _FakeH5:
+    """Dict-backed stand-in for the five h5py calls io.py makes (File as a context manager, create_group, create_dataset,
+    group[key], dataset[()]); string datasets come back as bytes objects, as h5py returns variable-length strings."""
+
+    files = {}
+
+    class _Dataset:
+        def __init__(self, data):
+            a = np.asarray(data)
+            self.a = np.array([s.encode("utf-8") for s in a.tolist()], dtype=object) if a.dtype.kind == "U" else a.copy()
+
+        def __getitem__(self, key):
+            assert key == ()
+            return self.a
+
+    class _Group(dict):
+        def create_group(self, name):
+            self[name] = _FakeH5._Group()
+            return self[name]
+
+        def create_dataset(self, name, data):
+            self[name] = _FakeH5._Dataset(data)
+
+    class File:
+        def __init__(self, path, mode):
+            if mode == "w":
+                _FakeH5.files[path] = _FakeH5._Group()
+            self.root = _FakeH5.files[path]
+
+        def __enter__(self):
+            return self.root
+
+        def __exit__(self, *exc):
+            return False
+
+
+def test_gimbal_pack_and_unpack_follow_the_format_description():
+    """Group camera_parameters: camera_names, dist_coefs (n,5), intrinsic (n,3,3), rotation (n,3,3), translation (n,3) (io.py:22-25)."""
+    ext, intr, names = _calibration()
+    T = np.stack([np.block([[orc.rodrigues(e[:3]), e[3:, None]], [np.zeros((1, 3)), np.ones((1, 1))]]) for e in ext])
+    d = mio._gimbal_pack(T, intr, names)
+    assert set(d) == set(mio._GIMBAL_KEYS) and d["camera_names"] == names
+    assert d["dist_coefs"].shape == (4, 5) and d["intrinsic"].shape == (4, 3, 3) and d["rotation"].shape == (4, 3, 3) and d["translation"].shape == (4, 3)
+    np.testing.assert_array_equal(d["rotation"][2], T[2, :3, :3])
+    np.testing.assert_array_equal(d["translation"][2], ext[2, 3:])
+    np.testing.assert_array_equal(d["intrinsic"][1], intr[1][0])
+    stored = dict(d, camera_names=np.array([n.encode() for n in names], dtype=object))
+    e2, i2, n2 = mio._gimbal_unpack(stored)
+    assert n2 == names                                              # stored order, not alphabetical (io.py:232-233)
+    _check(ext, intr, e2, i2)
+    e3, i3, n3 = mio._gimbal_unpack(stored, camera_names=["bottom", "side_b"])   # subset / re-ordering by name (:234-241)
+    assert n3 == ["bottom", "side_b"]
+    _check(ext[[3, 1]], [intr[3], intr[1]], e3, i3)
+    with pytest.raises(AssertionError):
+        mio._gimbal_unpack(stored, camera_names=["top", "nope"])
+
+
+def test_unknown_format_and_gimbal_branch(tmp_path, monkeypatch):
     ext, intr, names = _calibration()
     with pytest.raises(ValueError, match="Unknown format"):
         mio.save_calibration(ext, intr, names, str(tmp_path / "x"), save_format="toml")
@@ -85,10 +160,18 @@ def test_unknown_format_and_gimbal_dependency(tmp_path):
         mio.save_calibration(ext, intr, names[:3], str(tmp_path / "x"))
     try:
         import h5py  # noqa: F401
+        real = True
     except ImportError:
-        with pytest.raises(ImportError):
+        real = False
+        with pytest.raises(ImportError, match="h5py"):
             mio.save_calibration(ext, intr, names, str(tmp_path / "g"), save_format="gimbal")
-    else:
-        mio.save_calibration(ext, intr, names, str(tmp_path / "g"), save_format="gimbal")
-        e2, i2, n2 = mio.load_calibration(str(tmp_path / "g"), load_format="gimbal")
-        _check(ext, intr, e2, i2)
+        monkeypatch.setitem(sys.modules, "h5py", _FakeH5)        # execute the branch against the stand-in
+    mio.save_calibration(ext, intr, names, str(tmp_path / "g"), save_format="gimbal")   # ".h5" is appended (io.py:88-89)
+    if not real:
+        assert list(_FakeH5.files) == [str(tmp_path / "g") + ".h5"]
+        assert set(_FakeH5.files[str(tmp_path / "g") + ".h5"]["camera_parameters"]) == set(mio._GIMBAL_KEYS)
+    e2, i2, n2 = mio.load_calibration(str(tmp_path / "g"), load_format="gimbal")
+    assert n2 == names
+    _check(ext, intr, e2, i2)
+    e3, i3, n3 = mio.load_calibration(str(tmp_path / "g.h5"), load_format="gimbal", camera_names=["side_a", "top"])
+    _check(ext[[2, 0]], [intr[2], intr[0]], e3, i3)
