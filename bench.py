@@ -47,12 +47,14 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (AMD datasheet; 256 CU x
 FP64_VALU_MEASURED_TFLOPS = 57.0  # scripts/micro/fma_f64_rate.hip on the same GPU: 54-58 TFLOP/s of independent v_fma_f64 (one per 4.82 clock64 ticks)
 
 C, F_PER_GPU, ROWS, COLS = 6, 10000, 6, 9
-# FP64 VALU instructions k_gram issues, counted in the ISA of the built kernel (scripts/isa_count.py on `hipcc -S`, round 2):
-# 958 in the 4-point loop body of the instance this workload runs (planar board, f_scale = 1: k_gram<soft_l1, true>) = 240 per
-# point-observation (the general instance: 986 = 247); ~1900 per (camera, frame) outside it (pose constants, chain
-# matrices, expansion of the local Gram matrix, the halving reduction).  DESIGN.md section 5.
-GRAM_FP64_PER_POINT = 240
-GRAM_FP64_PER_PAIR = 1900
+# FP64 instruction mix of k_gram: profiles/gram_flops.json, written by scripts/gram_isa_mix.py -- the 4-point loop body of the
+# instance this workload runs (k_gram<soft_l1, planar + unit f_scale>) counted in the ISA of the built kernel (FMA / MUL / ADD /
+# other FP64 per point-observation), the per-(camera, frame) remainder taken from the SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 counters of
+# the profile named in that file.  REAL flops = 2 FMA + MUL + ADD; issue slots = every FP64 instruction (priced as an FMA).
+GRAM_FLOPS_FILE = os.path.join(ROOT, "profiles", "gram_flops.json")
+# algorithmic bytes of one fused LM iteration at 6 x 10 000 x 54 (observations read once for the trial
+# linearisation, W / V / g_f written, re-read by the Schur pass and by the back-substitution)
+TICK_ALGORITHMIC_BYTES_10K = 218e6
 
 
 def algorithmic_bytes(kernel, C, F, N):
@@ -72,12 +74,86 @@ def algorithmic_bytes(kernel, C, F, N):
     }[kernel]
 
 
-def algorithmic_flops(kernel, C, F, N):
-    """FP64 work of k_gram in FMA-equivalent flops: FP64 VALU instructions counted in the ISA x 2 -- i.e. the fraction below is
-    the fraction of the FP64 issue rate, whatever the mix of FMA / MUL / ADD."""
-    if kernel == "k_gram":
-        return 2 * (GRAM_FP64_PER_POINT * C * F * N + GRAM_FP64_PER_PAIR * C * F)
-    return None
+def gram_work(C, F, N):
+    """(real FP64 flops, FP64 issue slots x 2, per-point mix) of one k_gram launch.  Every lane of every wavefront runs the
+    point loop, the lanes of the padding frames included (Fpad = frames rounded up to 64): that is what the counters see."""
+    with open(GRAM_FLOPS_FILE) as fh:
+        g = json.load(fh)
+    pp, out = g["per_point_observation"], g["per_pair_outside_loop"]
+    lanes = C * ((F + 63) // 64) * 64
+    flop_pt = 2 * pp["fma"] + pp["mul"] + pp["add"]
+    real = lanes * (N * flop_pt + out["flop"])
+    slots = 2 * lanes * (N * pp["fp64"] + out["fp64"])
+    return real, slots, {"fma": pp["fma"], "mul": pp["mul"], "add": pp["add"], "other_fp64": pp["other_f64"], "fp64": pp["fp64"], "accvgpr_moves": pp["accvgpr_mov"],
+                         "other_valu": pp["valu_other"], "valu": pp["valu"], "fp64_outside_loop_per_pair": out["fp64"], "source": "profiles/gram_flops.json (" + g["source"] + ")"}
+
+
+def end_to_end(m, p, reps=5):
+    """The call users make (reference bundle_adjustment.py:195 -> 5-tuple): host arrays in, 5-tuple out, return_jac=False, default
+    tolerances, warm.  Wall-clock per stage: every ops.Problem method is a C-ABI crossing (those that return host data
+    synchronise), the host-side stages are timed around them."""
+    import contextlib
+    import functools
+    import io
+
+    from multicam_calibration_amd import api, ops, solver
+
+    acc = {}
+
+    def timed(name, fn):
+        @functools.wraps(fn)
+        def w(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+        return w
+
+    saved = []
+    for owner, names in ((ops.Problem, ["__init__", "set_params", "frame_errors", "error_median", "subset", "close", "get_params", "get_reduced", "frame_gradient", "residuals_detach",
+                                        "lm_auto_wait", "lm_auto_tick"]),
+                         (api, ["select_frames", "deserialize_params", "serialize_params"]), (solver, ["lm_solve"])):
+        for n in names:
+            saved.append((owner, n, getattr(owner, n)))
+            setattr(owner, n, timed(("ops." if owner is ops.Problem else owner.__name__.split(".")[-1] + ".") + n, getattr(owner, n)))
+    F = p["uvs"].shape[1]
+
+    def run():
+        np.random.seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            return m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=F, verbose=0, return_jac=False)
+
+    try:
+        run()
+        run()
+        acc.clear()
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = run()
+            times.append(1e3 * (time.perf_counter() - t0))
+        res = out[4]
+        t_fun0 = time.perf_counter()
+        nres = int(res.fun.size)   # first read of the lazily attached residual vector: the device-to-host copy happens here
+        t_fun = 1e3 * (time.perf_counter() - t_fun0)
+    finally:
+        for owner, n, f in saved:
+            setattr(owner, n, f)
+    ms = {k: 1e3 * v / reps for k, v in acc.items()}
+    total = float(np.median(times))
+    upload = ms.get("ops.__init__", 0.0)
+    prefilter = ms.get("api.select_frames", 0.0) - upload
+    lm = ms.get("solver.lm_solve", 0.0)
+    d2h = ms.get("ops.get_params", 0.0) + ms.get("ops.get_reduced", 0.0) + ms.get("ops.frame_gradient", 0.0) + ms.get("ops.residuals_detach", 0.0)
+    gather = ms.get("ops.subset", 0.0)
+    close = ms.get("ops.close", 0.0)
+    return {"ms": total, "ms_min": float(min(times)), "reps": reps, "nfev": int(res.nfev), "status": int(res.status),
+            "what": f"bundle_adjust(host arrays (6,{F},54,2) -> 5-tuple), n_frames={F}, return_jac=False, default tolerances (ftol=1e-4), warm (third call onwards), median of {reps}",
+            "breakdown_ms": {"h2d_upload_and_relayout": upload, "prefilter_kernels_median_host_logic": prefilter, "device_gather_of_selection": gather, "lm_loop": lm,
+                             "d2h_params_gradient": d2h, "handle_teardown": close, "python_rest": total - (upload + prefilter + gather + lm + d2h + close)},
+            "result_fun_first_read_ms": t_fun, "result_fun_size": nres,
+            "note": "result.fun stays on the GPU until first read (LazyOptimizeResult); its download is timed separately above and is not part of `ms`"}
 
 
 def cpu_baseline(sample_frames=500, max_nfev=12):
@@ -110,6 +186,9 @@ def cpu_baseline(sample_frames=500, max_nfev=12):
     scale = sample_frames / F_PER_GPU
     return {
         "value": it_per_s_sample * scale, "unit": "it/s", "cores": round(cores, 2), "kind": "port",
+        "config": {"cameras": C, "frames": sample_frames, "points": ROWS * COLS, "trf_iterations": iters, "nfev": int(res.nfev), "njev": int(res.njev), "seconds": dt,
+                   "it_per_s_on_sample": it_per_s_sample, "scale_to_workload": scale, "scaling_rule": "cost per iteration linear in frames (BASELINE.md section 2)",
+                   "host_cpu_count": os.cpu_count(), "cores_busy_observed": round(cores, 2), "cores_note": "os.times / wall: BLAS threads spinning, the path is single-threaded (SURVEY: 1.6-1.8 cores)"},
         "sample": f"{C}x{sample_frames}x{ROWS * COLS} sample of the workload, {iters} TRF iterations (nfev {res.nfev}, njev {res.njev}) in {dt:.1f}s = {it_per_s_sample:.3f} it/s on the sample; "
                   f"scaled x{scale:g} to 10k frames (cost per iteration is linear in frames: BASELINE.md section 2); sparsity pattern {t_pat:.2f}s + colouring excluded; "
                   f"observed {cores:.2f} cores busy of os.cpu_count()={os.cpu_count()}",
@@ -151,6 +230,7 @@ def main():
     ap.add_argument("--frames", type=int, default=F_PER_GPU, help="frames per GPU, weak scaling (default = BASELINE config 3 per GPU)")
     ap.add_argument("--frames-total", type=int, default=0, help="strong scaling: this many frames of ONE rig sharded over the ranks (100000 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the wall-clock measurement of the user-level bundle_adjust() call")
     ap.add_argument("--prewarm", type=int, default=300, help="untimed clock-ramp iterations of a throw-away solve before the W warm-up steps")
     args = ap.parse_args()
 
@@ -277,27 +357,37 @@ def main():
         dom = max(kern, key=lambda k: kern[k][0] / kern[k][1])
         dom_ms = kern[dom][0] / kern[dom][1]
         dom_bytes = algorithmic_bytes(dom, C, F, N)
-        traffic = jtraffic = None
+        # HBM bytes from the PMC counters are NOT measured in this run (counter passes need rocprofv3): the figure printed is the
+        # one of the committed profile named next to it, collected at the default shard size with the same kernels
+        traffic = jtraffic = traffic_source = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_file) and F == F_PER_GPU:  # PMC passes were collected at the default shard size
+        if os.path.exists(pmc_file) and F == F_PER_GPU:
             with open(pmc_file) as fh:
                 pmc = json.load(fh)
             traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
             jtraffic = pmc.get("k_jacobian", {}).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/pmc_traffic.json <- " + str(pmc.get("_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier gpurun call")) + " (not measured in this run)"
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
         hbm = {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": dom_bytes}
-        roofline = {"kernel": dom, "bound": "hbm", **hbm, "traffic": traffic, "avg_launch_us": dom_ms * 1e3}
-        fl = algorithmic_flops(dom, C, F, N)
-        if fl:
-            # the binding roof of this kernel is FP64 vector issue, not HBM (PMC traffic = 1.02 x algorithmic bytes; ~19 FMA-
-            # equivalent flop per byte): `frac` is reported against THAT roof, with the HBM figures next to it.  (The
-            # contract's "bound" enum has no FP64-vector entry; "valu_f64" names it, the matrix pipe is not the limit.)
-            tf = fl / (dom_ms * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "hbm", **hbm, "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": dom_ms * 1e3}
+        if dom == "k_gram":
+            # the binding roof of this kernel is the FP64 vector pipe, not HBM (PMC traffic = 1.02 x algorithmic bytes).  `frac` =
+            # REAL flops (2 FMA + MUL + ADD, as the SQ_INSTS_VALU_*_F64 counters count them) / the FP64 vector peak;
+            # `frac_issue_slots` = every FP64 instruction priced as an FMA: how full the FP64 issue slots are, whatever the mix.
+            # (The contract's "bound" enum has no FP64-vector entry; "valu_f64" names it -- on gfx950 the FP64 MFMA rate equals
+            # the FP64 vector rate, so the dense-MFMA peak for this dtype is the same 78.6 TFLOP/s.)
+            real, slots, mix = gram_work(C, F, N)
+            tf, tfs = real / (dom_ms * 1e-3) / 1e12, slots / (dom_ms * 1e-3) / 1e12
             roofline = {"kernel": dom, "bound": "valu_f64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
-                        "traffic": traffic, "avg_launch_us": dom_ms * 1e3, "algorithmic_flops_per_launch": fl,
-                        "measured_issue_ceiling": FP64_VALU_MEASURED_TFLOPS, "frac_of_measured_issue_ceiling": tf / FP64_VALU_MEASURED_TFLOPS,
-                        "hbm": hbm,
-                        "note": f"k_gram issues {GRAM_FP64_PER_POINT} FP64 VALU instructions per point-observation (~19 FMA-equivalent flop per algorithmic byte): the FP64 vector pipe, not HBM, is its binding roof"}
+                        "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": dom_ms * 1e3, "flops_per_launch": real,
+                        "frac_issue_slots": tfs / FP64_VALU_PEAK_TFLOPS, "issue_slot_flops_per_launch": slots,
+                        "measured_issue_ceiling": FP64_VALU_MEASURED_TFLOPS, "frac_issue_slots_of_measured_ceiling": tfs / FP64_VALU_MEASURED_TFLOPS,
+                        "instructions_per_point_observation": mix, "hbm": hbm,
+                        "note": "frac = real FP64 flops (2 x FMA + MUL + ADD) / 78.6 TFLOP/s; frac_issue_slots counts every FP64 instruction as an FMA"}
+        tick_bytes = TICK_ALGORITHMIC_BYTES_10K * F / F_PER_GPU
+        tick_ach = tick_bytes / (dt / args.steps) / 1e9
+        tick_roofline = {"bound": "hbm", "achieved": tick_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tick_ach / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": tick_bytes,
+                         "note": "SURVEY 8(d): 218 MB per fused LM iteration at 6 x 10 000 x 54 (scaled by frames) / ms_per_step of the timed region"}
         jb = algorithmic_bytes("k_jacobian", C, F, N)
         jach = jb / (ms_jac * 1e-3) / 1e9
         units = frames_total / F_PER_GPU  # 10k-frame problem units processed per step by all ranks together
@@ -332,8 +422,9 @@ def main():
             "value_in_10k_frame_units": args.steps * units / dt,
             "ms_per_jacobian_eval": ms_jac,
             "roofline": roofline,
+            "tick_roofline": tick_roofline,
             "jacobian_eval": {"kernel": "k_jacobian", "ms": ms_jac, "roofline": {"bound": "hbm", "achieved": jach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": jach / HBM_PEAK_GBS,
-                              "traffic": jtraffic, "algorithmic_bytes_per_launch": jb,
+                              "traffic": jtraffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": jb,
                               "frac_of_measured_write_ceiling": jach / HBM_MEASURED_WRITE_GBS}},
             "kernels_us": {k: round(1e3 * ms / n, 3) for k, (ms, n) in kern.items()},
             "kernel_calls": {k: n for k, (ms, n) in kern.items()},
@@ -343,6 +434,10 @@ def main():
         }
         if share_gpu:
             out["rehearsal"] = f"{world} ranks SHARE GPU 0 (fewer GPUs than ranks on this box): collectives are host-staged gloo all-reduces, not RCCL; `value` is not a scaling measurement"
+        if world == 1 and not args.no_end_to_end and not args.frames_total:
+            e2e = end_to_end(m, p)
+            out["end_to_end_ms"] = e2e["ms"]
+            out["end_to_end"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"]["reference_measured_in_survey_container"] = {"value": 0.0098, "unit": "it/s", "ms_per_jacobian_eval": 68679, "source": "BASELINE.md section 2 (the reference itself, 6x10kx54)"}

@@ -48,6 +48,7 @@ extern "C" {
 #define MCBA_LOSS_ARCTAN 4
 
 typedef struct mcba_handle mcba_handle;
+typedef struct mcba_buffer mcba_buffer;   /* a device array that outlives its handle (mcba_residuals_detach) */
 
 /* ---- library ------------------------------------------------------------------------------- */
 int mcba_abi_version(void);            /* bumped when this header changes incompatibly */
@@ -58,6 +59,12 @@ int mcba_device_count(int* count);
 /* n_cameras C, n_frames F (local shard), n_points N, HIP device ordinal. */
 int mcba_create(mcba_handle** out, int n_cameras, int n_frames, int n_points, int device);
 int mcba_destroy(mcba_handle* h);
+/* Device and pinned buffers of destroyed handles are parked in a per-process pool and handed out again (hipMalloc / hipFree are
+ * synchronising driver calls: 4 ms of a 16 ms bundle_adjust() at 6 x 10 000 x 54 before the pool).  MCBA_POOL_MB caps what is
+ * parked (default 8192; 0 = no pool); this returns everything to the driver.  The solver's own buffers (records, partial sums,
+ * reduce buffer, state ring) are allocated on the first call that needs them: a handle that only runs the pre-filter over all
+ * frames of a long recording holds the observations and nothing else. */
+int mcba_pool_trim(void);
 /* hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream); NULL = null stream. */
 int mcba_set_stream(mcba_handle* h, void* hip_stream);
 /* Observations (C,F,N,2) and board points (N,3), host pointers.  Re-laid out on the GPU as
@@ -65,6 +72,12 @@ int mcba_set_stream(mcba_handle* h, void* hip_stream);
 int mcba_upload_observations(mcba_handle* h, const double* uvs, const double* objpoints);
 /* Robust loss and f_scale of least_squares (default soft_l1, 1.0: bundle_adjustment.py:301-303). */
 int mcba_set_loss(mcba_handle* h, int loss, double f_scale);
+
+/* least_squares' numeric `x_scale` (forwarded verbatim by the reference: bundle_adjustment.py:301-313; scipy least_squares.py
+ * :243, trf.py:415-420): 12C + 6F positive doubles in the layout of x -> the FIXED damping matrix D = diag(1 / x_scale^2) replaces
+ * Marquardt's D = diag(J^T J) (which is x_scale = 'jac', the reference's default) in the frame blocks, the camera block and the
+ * predicted reduction.  NULL returns to 'jac'.  MCBA_ERR_ARG with scipy's message if an entry is not positive and finite. */
+int mcba_set_x_scale(mcba_handle* h, const double* x_scale);
 
 /* ---- parameter slots (two flat vectors live on the GPU: 0 and 1) ----------------------------- */
 int mcba_set_params(mcba_handle* h, int slot, const double* x);   /* 12C+6F doubles, host */
@@ -77,6 +90,14 @@ int mcba_copy_params(mcba_handle* h, int dst_slot, int src_slot);  /* device to 
 int mcba_cost(mcba_handle* h, int slot, double* cost, double* n_residuals);
 /* Dense residual array (C,F,N,2), observed - predicted, 0 where the observation is NaN (host). */
 int mcba_residuals(mcba_handle* h, int slot, double* res);
+/* The same array left ON THE DEVICE as an object of its own (it outlives the handle): api.bundle_adjust hands it to the
+ * OptimizeResult and downloads it when `result.fun` is first read -- scipy materialises `fun` (trf.py:557-560), but 52 MB of
+ * device-to-host copy at 6 x 10 000 x 54 for a field few callers read was the largest single item of the call.
+ * mcba_buffer_count: doubles in it; mcba_buffer_download: copy to host (synchronises); mcba_buffer_free: back to the pool. */
+int mcba_residuals_detach(mcba_handle* h, int slot, mcba_buffer** out);
+size_t mcba_buffer_count(const mcba_buffer* b);
+int mcba_buffer_download(mcba_buffer* b, double* host);
+int mcba_buffer_free(mcba_buffer* b);
 /* Materialise residuals + analytic Jacobian blocks on the GPU: per scalar residual 18 doubles
  * [12 camera columns | 6 frame-pose columns] in (C,F,N,2,18) order = the CSR `data` array of the
  * reference's Jacobian when no observation is missing.  robust_scaled != 0 applies scipy's
@@ -182,6 +203,12 @@ int mcba_lm_auto_trial(mcba_handle* h, int decide);
 int mcba_lm_auto_reduce(mcba_handle* h, int decide, int rank_slot);
 int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot);
 int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state);
+/* k_solve_backsub's back-substitution workgroups wait for the solve of the same launch with a BOUNDED poll (~0.5 s).  If one ever
+ * runs out, it stamps the tick's number into a device word and a host-mapped word: the next tick's decision discards its (stale)
+ * trial point and only rebuilds the system, and mcba_lm_auto_wait switches the handle to the two-launch path (k_solve_cam, then
+ * k_backsub) for good.  *timeouts = number of the last tick in which that happened (0: never), *fused = the fused launch is still
+ * in use.  MCBA_FUSE_MAX_POLLS=0 forces the event (tests). */
+int mcba_lm_fuse_status(mcba_handle* h, double* timeouts, int* fused);
 /* The camera step (12C doubles) the last mcba_lm_auto_solve left on the device; synchronises. */
 int mcba_get_cam_step(mcba_handle* h, double* host);
 /* ---- direct RCCL (optional; frame-sharded runs) ------------------------------------------------------------
@@ -216,6 +243,13 @@ int mcba_frame_errors(mcba_handle* h, int slot, double* mean_cf, double* full_cf
 /* np.nanmedian of those per-point errors over the frames with frame_mask[f] != 0 (F bytes; NULL = all frames): the exact
  * order statistic (radix select), mean of the two middle values for an even count; *count = number of values. */
 int mcba_error_median(mcba_handle* h, const unsigned char* frame_mask, double* median, double* count);
+/* One pass of that radix select for a caller that holds only a SHARD of the frames (frame-sharded bundle_adjust: every rank runs
+ * the pre-filter on its own slice): hist256[b] = number of per-point errors of the frames with frame_mask[f] != 0 (F bytes; NULL =
+ * the mask of the previous call) whose leading `pass` bytes equal `prefix` and whose next byte is b (pass 0 = most significant
+ * byte of the IEEE bit pattern; the errors are non-negative, so bit-pattern order is numeric order).  The caller sums the
+ * histograms over the ranks, picks the bin that holds the wanted rank, extends the prefix and calls again: 8 passes give the exact
+ * order statistic whatever the sharding.  Synchronises. */
+int mcba_error_histogram(mcba_handle* h, const unsigned char* frame_mask, unsigned long long prefix, int pass, unsigned long long* hist256);
 /* New handle on the same device / stream holding the observations of n_frames frames of `src` (indices into its frames,
  * any order, repeats allowed) -- gathered device to device: what bundle_adjust solves on after the pre-filter, without
  * a second host upload (the reference slices all_calib_uvs[:, use_frames]: bundle_adjustment.py:298,312). */

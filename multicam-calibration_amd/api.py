@@ -16,11 +16,12 @@ import warnings
 
 import numpy as np
 import scipy.sparse as sp
+from scipy.optimize import OptimizeResult
 
 from . import ops, solver
 
 # least_squares kwargs that only steer scipy's own iteration (no effect on the minimiser): accepted, ignored
-_PATH_ONLY = ("jac", "tr_solver", "tr_options", "jac_sparsity", "diff_step", "x_scale", "method", "workers", "callback")
+_PATH_ONLY = ("jac", "tr_solver", "tr_options", "jac_sparsity", "diff_step", "method", "workers", "callback")
 
 
 def serialize_params(all_extrinsics, all_intrinsics, calib_poses):
@@ -58,55 +59,175 @@ def jacobian_structure(all_calib_uvs):
     return idx.ravel(), np.arange(m + 1, dtype=np.int64) * 18, (m, 12 * C + 6 * F), mask
 
 
-def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device=0, backend=None, keep_problem=False, **problem_kw):
-    """The reference's pre-filter (bundle_adjustment.py:265-296) on the GPU: ALL frames are uploaded once, the reprojection
+class _Lazy:
+    """Placeholder for an OptimizeResult field that is produced on first access."""
+
+    def __init__(self, thunk):
+        self.thunk = thunk
+
+
+class LazyOptimizeResult(OptimizeResult):
+    """scipy's OptimizeResult (a dict with attribute access) whose expensive fields are materialised when first read.
+    `result.fun` (the residual vector at the solution, trf.py:557-560) stays on the GPU until then: 52 MB of device-to-host copy at
+    6 x 10 000 x 54 that most callers never look at.  Every way of reading the field (attribute, item, get, items, values, repr,
+    copy, pickling) goes through `_resolve`, after which the object is an ordinary OptimizeResult."""
+
+    def _resolve(self, key=None):
+        for k in ([key] if key is not None else list(dict.keys(self))):
+            v = dict.get(self, k)
+            if isinstance(v, _Lazy):
+                dict.__setitem__(self, k, v.thunk())
+
+    def __getitem__(self, key):
+        self._resolve(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._resolve(key)
+        return dict.get(self, key, default)
+
+    def items(self):
+        self._resolve()
+        return dict.items(self)
+
+    def values(self):
+        self._resolve()
+        return dict.values(self)
+
+    def copy(self):
+        self._resolve()
+        return OptimizeResult(dict.copy(self))
+
+    def __repr__(self):
+        self._resolve()
+        return OptimizeResult.__repr__(self)
+
+    def __reduce__(self):
+        self._resolve()
+        return (OptimizeResult, (dict(self),))
+
+
+def _split_bounds(n, world):
+    """Contiguous slices of range(n), one per rank (np.array_split's sizes)."""
+    sizes = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+def _median_from_histograms(hist):
+    """np.nanmedian by radix select: hist(prefix, pass) -> 256 global counts of the next byte among the values with that prefix
+    (the per-point errors are non-negative doubles, so the order of their bit patterns is their numeric order); the two middle order
+    statistics are averaged like np.median.  Integer arithmetic only: exact whatever the sharding."""
+    first = hist(0, 0)
+    total = int(first.sum())
+    if total == 0:
+        return float("nan")
+    vals = []
+    for rank in ((total - 1) // 2, total // 2):
+        prefix, r = 0, rank
+        for p in range(8):
+            h = first if p == 0 else hist(prefix, p)
+            below = np.concatenate([[0], np.cumsum(h.astype(np.int64))])
+            digit = int(np.searchsorted(below, r, side="right")) - 1
+            r -= int(below[digit])
+            prefix = (prefix << 8) | digit
+        vals.append(np.array([prefix], dtype=np.uint64).view(np.float64)[0])
+        if rank == total // 2:
+            break
+    return float(0.5 * (vals[0] + vals[-1]))
+
+
+def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device=0, keep_problem=False, group=None, **problem_kw):
+    """The reference's pre-filter (bundle_adjustment.py:265-296) on the GPU: the frames are uploaded once, the reprojection
     errors, their per-(camera, frame) nan-means, the completeness counts (k_frame_err) and the exact nan-median (radix
-    select) are computed there; the host sees 2 x (C,F) doubles.  Returns use_frames, or (use_frames, problem) with
-    keep_problem=True -- the handle that still holds every frame, for `Problem.subset` (no second upload)."""
-    all_calib_uvs = np.asarray(all_calib_uvs, dtype=np.float64)
+    select) are computed there; the host sees 2 x (C,F) doubles.  Returns use_frames, or (use_frames, problem, complete, lo)
+    with keep_problem=True -- the handle that still holds the frames, for `Problem.subset` (no second upload).
+
+    group: a torch.distributed process group -> the FRAME-SHARDED pre-filter: every rank uploads and scores only its contiguous
+    slice [lo, hi) of the frames (the handle returned holds that slice), the (C,F) statistics are all-gathered, the median's
+    radix-select histograms are all-reduced (8 passes x 256 integer bins per order statistic), and rank 0 alone prints the
+    reference's line and draws the subsample from the global numpy RNG (:293-296); the selection is broadcast."""
     C, F_all, N = all_calib_uvs.shape[:3]
-    Problem = backend or ops.Problem
+    dist, rank, world = None, 0, 1
+    if group is not None:
+        import torch
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        coll_dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    bounds = _split_bounds(F_all, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     prob = None
-    if F_all and hasattr(Problem, "frame_errors"):
-        prob = Problem(all_calib_uvs, calib_objpoints, device=device, **problem_kw)
-        prob.set_params(0, serialize_params(all_extrinsics, all_intrinsics, np.asarray(calib_poses, dtype=np.float64)))
-        mean_cf, full_cf = prob.frame_errors(0)
+    mean_cf = full_cf = np.empty((C, 0))
+    try:
+        if hi > lo:
+            prob = ops.Problem(all_calib_uvs[:, lo:hi], calib_objpoints, device=device, **problem_kw)
+            prob.set_params(0, serialize_params(all_extrinsics, all_intrinsics, calib_poses[lo:hi]))
+            mean_cf, full_cf = prob.frame_errors(0)
+        if dist is not None:
+            parts = [None] * world
+            dist.all_gather_object(parts, (mean_cf, full_cf), group=group)
+            mean_cf = np.concatenate([p[0] for p in parts], axis=1)
+            full_cf = np.concatenate([p[1] for p in parts], axis=1)
         use_frames = np.nonzero((full_cf == N).sum(0) > 1)[0]                     # complete in at least two cameras (:266)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", category=RuntimeWarning)
             worst_mean_err = np.nanmax(mean_cf[:, use_frames], axis=0) if use_frames.size else np.empty(0)   # (:279)
-        if outlier_threshold is None:
-            mask = np.zeros(F_all, dtype=np.uint8)
-            mask[use_frames] = 1
-            outlier_threshold = 5 * prob.error_median(mask)[0]                    # 5 * np.nanmedian(err)  (:281-282)
-    else:  # CPU test double (tests/fake_problem.py) or no frames at all: the same arithmetic in numpy
-        use_frames = np.nonzero((~np.isnan(all_calib_uvs).any((-1, -2))).sum(0) > 1)[0]
-        sub = all_calib_uvs[:, use_frames]
-        if use_frames.size:
-            fake = Problem(sub, calib_objpoints, device=device)
-            fake.set_params(0, serialize_params(all_extrinsics, all_intrinsics, np.asarray(calib_poses)[use_frames]))
-            res = fake.residuals(0)
-            fake.close()
-            res[np.isnan(sub)] = np.nan
-            err = np.sqrt((res**2).sum(-1))  # NaN wherever either coordinate is missing, like norm(obs - pred)
-        else:
-            err = np.empty(sub.shape[:-1])
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore", category=RuntimeWarning)
-            worst_mean_err = np.nanmax(np.nanmean(err, axis=-1), axis=0) if use_frames.size else np.empty(0)
-            if outlier_threshold is None:
-                outlier_threshold = 5 * np.nanmedian(err)
+        if outlier_threshold is None:                                             # 5 * np.nanmedian(err)  (:281-282)
+            mask = np.zeros(hi - lo, dtype=np.uint8)
+            mask[use_frames[(use_frames >= lo) & (use_frames < hi)] - lo] = 1
+            if dist is None:
+                outlier_threshold = 5 * prob.error_median(mask)[0] if prob is not None else float("nan")
+            else:
+                state = {"first": True}
+
+                def hist(prefix, p):
+                    h = np.zeros(256, dtype=np.uint64)
+                    if prob is not None:
+                        h = prob.error_histogram(mask if state["first"] else None, prefix, p)
+                        state["first"] = False
+                    t = torch.from_numpy(h.astype(np.int64)).to(coll_dev)
+                    dist.all_reduce(t, group=group)
+                    return t.cpu().numpy()
+
+                outlier_threshold = 5 * _median_from_histograms(hist)
+    except BaseException:
+        if prob is not None:
+            prob.close()
+        raise
     exclude = np.nan_to_num(worst_mean_err) > outlier_threshold
     use_frames = use_frames[~exclude]
-    print(f"Excluding {int(exclude.sum())} out of {len(use_frames)} frames based on an outlier threshold of {outlier_threshold}")
-    if not (n_frames is None or n_frames > len(use_frames)):
-        use_frames = np.random.choice(use_frames, n_frames, replace=False)
+    if rank == 0:
+        print(f"Excluding {int(exclude.sum())} out of {len(use_frames)} frames based on an outlier threshold of {outlier_threshold}")
+        if not (n_frames is None or n_frames > len(use_frames)):
+            use_frames = np.random.choice(use_frames, n_frames, replace=False)
+    if dist is not None:
+        box = [use_frames]
+        dist.broadcast_object_list(box, src=0, group=group)
+        use_frames = box[0]
     if keep_problem:  # + whether every selected detection is complete (then no NaN mask is needed for result.fun / result.jac)
-        complete = prob is not None and bool(np.all(full_cf[:, use_frames] == N))
-        return use_frames, prob, complete
+        complete = bool(np.all(full_cf[:, use_frames] == N))
+        return use_frames, prob, complete, lo
     if prob is not None:
         prob.close()
     return use_frames
+
+
+def _check_x_scale(x_scale, n_total):
+    """least_squares.py:  `x_scale` must be 'jac' or array_like with positive numbers; a scalar is broadcast."""
+    if isinstance(x_scale, str) and x_scale == "jac":
+        return None
+    try:
+        xs = np.asarray(x_scale, dtype=np.float64)
+        valid = bool(np.all(np.isfinite(xs)) and np.all(xs > 0))
+    except (ValueError, TypeError):
+        valid = False
+    if not valid:
+        raise ValueError("`x_scale` must be 'jac' or array_like with positive numbers.")
+    if xs.ndim == 0:
+        xs = np.resize(xs, n_total)
+    if xs.shape != (n_total,):
+        raise ValueError("Inconsistent shapes between `x_scale` and `x0`.")
+    return xs
 
 
 def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames=10000, outlier_threshold=None, **opt_kwargs):
@@ -118,43 +239,31 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
       fix_intrinsics=False hold fx fy cx cy k1 k2 of every camera (BASELINE config 2); extrinsics + poses only
       return_jac=True      attach the robust-rescaled CSR Jacobian as `result.jac` (18 nnz/row; 1.4 GB at 6x10k x54)
       distributed=False    one process per GPU under torch.distributed (an initialised process group, backend nccl =
-                           RCCL): the frames chosen by rank 0 are sharded contiguously over the ranks, every LM iteration
-                           all-reduces the reduced camera system, and every rank returns the full 5-tuple (poses
-                           all-gathered).  `result.fun` / `result.jac` then cover the calling rank's shard only.
+                           RCCL): every rank uploads and pre-filters its contiguous slice of ALL frames, solves the selected
+                           frames of that slice, every LM iteration all-reduces the reduced camera system, and every rank
+                           returns the full 5-tuple (poses gathered in selection order).  `result.fun` / `result.jac` then
+                           cover the calling rank's frames only (`result.lm["frame_positions"]` = their places in use_frames).
+    `result.fun` is downloaded from the GPU when it is first read (LazyOptimizeResult).  `result.lm` carries the solver's own
+    record: iterations, damping history, which collective backend and reduced solver ran.
     """
     distributed = opt_kwargs.pop("distributed", False)
-    backend = opt_kwargs.pop("_backend", None)  # test hook: a drop-in for ops.Problem (tests/fake_problem.py)
-    rank, world, dist = 0, 1, None
+    rank, world, dist, group = 0, 1, None, None
     if distributed:
         import os
+        import torch
         import torch.distributed as dist
 
         if not dist.is_initialized():
             raise RuntimeError("distributed=True needs an initialised torch.distributed process group (launch with torchrun)")
+        group = dist.group.WORLD
         rank, world = dist.get_rank(), dist.get_world_size()
         opt_kwargs.setdefault("device", int(os.environ.get("LOCAL_RANK", rank)))
-        if backend is None:
-            import torch
-
+        if dist.get_backend() == "nccl":
             torch.cuda.set_device(opt_kwargs["device"])  # object collectives of the nccl backend use the current device
     device = opt_kwargs.pop("device", 0)
     fix_intrinsics = opt_kwargs.pop("fix_intrinsics", False)
     return_jac = opt_kwargs.pop("return_jac", True)
     lm_kwargs = {k: opt_kwargs.pop(k) for k in ("lam0", "reduced_solver") if k in opt_kwargs}
-
-    all_calib_uvs = np.asarray(all_calib_uvs, dtype=np.float64)
-    calib_objpoints = np.asarray(calib_objpoints, dtype=np.float64)
-    calib_poses = np.asarray(calib_poses, dtype=np.float64)
-    n_cameras = all_calib_uvs.shape[0]
-
-    prob_all, all_seen = None, False
-    if not distributed:
-        use_frames, prob_all, all_seen = select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device, backend, keep_problem=True)
-    else:
-        # rank 0 owns the reference's frame selection (its printed line and its use of the global numpy RNG)
-        box = [select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device, backend) if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        use_frames = box[0]
 
     kw = dict(verbose=2, x_scale="jac", ftol=1e-4, method="trf", loss="soft_l1")
     kw.update(opt_kwargs)
@@ -162,98 +271,121 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         raise NotImplementedError("bounds are not supported by the GPU solver")
     if callable(kw.get("loss")):
         raise NotImplementedError("callable losses are not supported by the GPU solver")
-    if not (isinstance(kw["x_scale"], str) and kw["x_scale"] == "jac"):
-        warnings.warn("x_scale is ignored: the GPU solver always uses Jacobian (Marquardt) scaling", stacklevel=2)
-    unknown = set(kw) - set(_PATH_ONLY) - {"verbose", "ftol", "xtol", "gtol", "max_nfev", "loss", "f_scale"}
+    unknown = set(kw) - set(_PATH_ONLY) - {"verbose", "ftol", "xtol", "gtol", "max_nfev", "loss", "f_scale", "x_scale"}
     if unknown:
         raise TypeError(f"unsupported least_squares keyword(s) for the GPU solver: {sorted(unknown)}")
 
-    all_use = use_frames
+    all_calib_uvs = np.asarray(all_calib_uvs, dtype=np.float64)
+    calib_objpoints = np.asarray(calib_objpoints, dtype=np.float64)
+    calib_poses = np.asarray(calib_poses, dtype=np.float64)
+    n_cameras = all_calib_uvs.shape[0]
+
+    pkw = {}
     if distributed:
-        if use_frames.size < world:
-            raise ValueError(f"{use_frames.size} usable frames cannot be sharded over {world} ranks")
-        use_frames = np.array_split(all_use, world)[rank]  # contiguous shard of the selection, in selection order
-    x0 = serialize_params(all_extrinsics, all_intrinsics, calib_poses[use_frames])
-    if use_frames.size == 0:
+        import torch
+
+        if torch.cuda.is_available():
+            # torch orders its collectives against torch's CURRENT stream: the library must launch on that same stream
+            # (the torch.distributed fallback of solver.make_comm all-reduces the library's reduce buffer in place)
+            pkw["stream"] = torch.cuda.current_stream(device).cuda_stream
+    all_use, prob_all, all_seen, lo = select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device,
+                                                    keep_problem=True, group=group, **pkw)
+    prob = None
+    try:
+        # ---- which of the selected frames this process solves: all of them, or (frame-sharded) those of its own slice -- they are
+        # already on this GPU.  If a rank's slice holds none of the selection the shards are cut from the selection instead and
+        # uploaded from the host array.
+        positions = np.arange(all_use.size)
+        local = True
+        if distributed:
+            if all_use.size < world:
+                raise ValueError(f"{all_use.size} usable frames cannot be sharded over {world} ranks")
+            bounds = _split_bounds(all_calib_uvs.shape[1], world)
+            owner = np.searchsorted(bounds, all_use, side="right") - 1
+            local = bool(np.bincount(owner, minlength=world).min() > 0)
+            positions = np.nonzero(owner == rank)[0] if local else np.array_split(np.arange(all_use.size), world)[rank]
+        use_frames = all_use[positions]
+        x0 = serialize_params(all_extrinsics, all_intrinsics, calib_poses[use_frames])
+        x_scale = _check_x_scale(kw["x_scale"], 12 * n_cameras + 6 * all_use.size)
+        if x_scale is not None:  # this shard's part: the camera block and its own frames' blocks
+            x_scale = np.concatenate([x_scale[: 12 * n_cameras], x_scale[12 * n_cameras:].reshape(-1, 6)[positions].ravel()])
+        if use_frames.size == 0:
+            # nothing to fit: scipy's least_squares on an empty residual vector returns x0 with status 1 (gtol) after one
+            # evaluation (what the reference then returns: bundle_adjustment.py:307-327)
+            result = OptimizeResult(x=x0, cost=0.0, fun=np.empty(0), jac=sp.csr_matrix((0, x0.size)), grad=np.zeros(x0.size), optimality=0.0,
+                                    active_mask=np.zeros(x0.size), nfev=1, njev=1, status=1, message=solver.TERMINATION_MESSAGES[1], success=True)
+            if kw["verbose"] >= 1:
+                print(result.message)
+                print("Function evaluations 1, initial cost 0.0000e+00, final cost 0.0000e+00, first-order optimality 0.00e+00.")
+            ext, intr, poses = deserialize_params(x0, n_cameras)
+            return ext, intr, poses, use_frames, result
+        if local:          # the frames are already on the GPU (pre-filter): gather the selection there, no second upload
+            prob = prob_all.subset(use_frames - lo, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0))
+        else:
+            prob = ops.Problem(np.ascontiguousarray(all_calib_uvs[:, use_frames]), calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0), **pkw)
         if prob_all is not None:
             prob_all.close()
-        # nothing to fit: scipy's least_squares on an empty residual vector returns x0 with status 1 (gtol) after one
-        # evaluation (what the reference then returns: bundle_adjustment.py:307-327)
-        from scipy.optimize import OptimizeResult
+            prob_all = None
+        comm = None
+        if distributed:
+            import torch
 
-        result = OptimizeResult(x=x0, cost=0.0, fun=np.empty(0), jac=sp.csr_matrix((0, x0.size)), grad=np.zeros(x0.size), optimality=0.0,
-                                active_mask=np.zeros(x0.size), nfev=1, njev=1, status=1, message=solver.TERMINATION_MESSAGES[1], success=True)
-        if kw["verbose"] >= 1:
-            print(result.message)
-            print("Function evaluations 1, initial cost 0.0000e+00, final cost 0.0000e+00, first-order optimality 0.00e+00.")
-        ext, intr, poses = deserialize_params(x0, n_cameras)
-        return ext, intr, poses, use_frames, result
-    pkw = {}
-    if distributed and backend is None:
-        import torch
+            comm = solver.make_comm(prob, torch.device(f"cuda:{device}"))
+        free = None
+        if fix_intrinsics:
+            free = np.tile(np.r_[np.zeros(6, bool), np.ones(6, bool)], n_cameras)
+        # an explicit None disables that test, as scipy's check_tolerance does (least_squares.py: None -> 0); the device loop
+        # treats a zero tolerance as "never satisfied".  A missing key keeps the reference's / scipy's defaults.
+        tol = lambda name, default: 0.0 if kw.get(name, default) is None else float(kw.get(name, default))
+        max_nfev = kw.get("max_nfev")
+        if max_nfev is None:
+            max_nfev = 100 * (12 * n_cameras + 6 * len(all_use))  # trf.py:437-438 on the GLOBAL vector: identical on every rank
+        result = solver.lm_solve(prob, x0, ftol=tol("ftol", 1e-4), xtol=tol("xtol", 1e-8), gtol=tol("gtol", 1e-8),
+                                 max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, x_scale=x_scale, **lm_kwargs)
+        result = LazyOptimizeResult(result)
 
-        # torch orders its collectives against torch's CURRENT stream: the library must launch on that same stream
-        # (the torch.distributed fallback of solver.make_comm all-reduces the library's reduce buffer in place)
-        pkw["stream"] = torch.cuda.current_stream(device).cuda_stream
-    if prob_all is not None:   # the frames are already on the GPU (pre-filter): gather the selection there, no second upload
-        prob = prob_all.subset(use_frames, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0))
-        prob_all.close()
-        uvs = None             # host copy of the selection: only materialised if result.jac / result.fun need the NaN mask
-    else:
-        uvs = np.ascontiguousarray(all_calib_uvs[:, use_frames])
-        prob = (backend or ops.Problem)(uvs, calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0), **pkw)
-    comm = None
-    if distributed:
-        import torch
+        # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560)
+        slot = result.lm["slot"]
+        need_mask = not all_seen  # (every selected detection complete -- the pre-filter counted them on the GPU: no NaN mask to apply)
+        if return_jac:
+            uvs = all_calib_uvs[:, use_frames]
+            idx, indptr, shape, mask = jacobian_structure(uvs)  # CSR indices: 0.25 s of numpy at 6 x 10k x 54 -- only when asked for
+            prob.jacobian_eval(slot, robust_scaled=kw["loss"] != "linear")
+            jac, res = prob.jacobian_download()
+            result.jac = sp.csr_matrix((jac[mask].ravel(), idx, indptr), shape=shape)
+            result.fun = res[mask]
+            del jac
+        else:
+            vec = prob.residuals_detach(slot)   # stays on the GPU until result.fun is read
+            src, frames = (all_calib_uvs, use_frames) if need_mask else (None, None)
 
-        comm = solver.make_comm(prob, torch.device(f"cuda:{device}") if backend is None else "cpu")
-        return_jac = False if backend is not None else return_jac
-    free = None
-    if fix_intrinsics:
-        free = np.tile(np.r_[np.zeros(6, bool), np.ones(6, bool)], n_cameras)
-    # an explicit None disables that test, as scipy's check_tolerance does (least_squares.py: None -> 0); the device loop
-    # treats a zero tolerance as "never satisfied".  A missing key keeps the reference's / scipy's defaults.
-    tol = lambda name, default: 0.0 if kw.get(name, default) is None else float(kw.get(name, default))
-    max_nfev = kw.get("max_nfev")
-    if max_nfev is None:
-        max_nfev = 100 * (12 * n_cameras + 6 * len(all_use))  # trf.py:437-438 on the GLOBAL vector: identical on every rank
-    result = solver.lm_solve(prob, x0, ftol=tol("ftol", 1e-4), xtol=tol("xtol", 1e-8), gtol=tol("gtol", 1e-8),
-                             max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, **lm_kwargs)
+            def fun(vec=vec, src=src, frames=frames):
+                r = vec.download()
+                return r.ravel() if src is None else r[~np.isnan(src[:, frames])]
 
-    # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560)
-    slot = result.lm["slot"]
-    if uvs is None and not (all_seen and not return_jac):
-        uvs = all_calib_uvs[:, use_frames]
-    if backend is None and return_jac:
-        idx, indptr, shape, mask = jacobian_structure(uvs)  # CSR indices: 0.25 s of numpy at 6 x 10k x 54 -- only when asked for
-    elif uvs is not None:
-        mask = ~np.isnan(uvs)
-    if uvs is None:  # every selected detection is complete (the pre-filter counted them on the GPU): no NaN mask to apply
-        result.fun = prob.residuals(slot).ravel()
-    elif backend is not None:  # test double: no materialised Jacobian kernel
-        result.fun = prob.residuals(slot)[mask]
-    elif return_jac:
-        prob.jacobian_eval(slot, robust_scaled=kw["loss"] != "linear")
-        jac, res = prob.jacobian_download()
-        result.jac = sp.csr_matrix((jac[mask].ravel(), idx, indptr), shape=shape)
-        result.fun = res[mask]
-        del jac
-    else:
-        result.fun = prob.residuals(slot)[mask]
-    red = prob.get_reduced()
-    grad = np.concatenate([red["gc"], prob.frame_gradient().ravel()])
-    if free is not None:
-        grad[: 12 * n_cameras][~free] = 0.0
-    if distributed:
-        # assemble the global vectors: cameras are identical on every rank, poses / frame gradients are gathered
-        parts = [None] * world
-        dist.all_gather_object(parts, (result.x[12 * n_cameras:], grad[12 * n_cameras:]))
-        result.x = np.concatenate([result.x[: 12 * n_cameras]] + [p[0] for p in parts])
-        grad = np.concatenate([grad[: 12 * n_cameras]] + [p[1] for p in parts])
-        result.active_mask = np.zeros_like(result.x)
-        result.optimality = float(np.abs(grad).max())
-    result.grad = grad
-    prob.close()
+            dict.__setitem__(result, "fun", _Lazy(fun))
+        red = prob.get_reduced()
+        grad = np.concatenate([red["gc"], prob.frame_gradient().ravel()])
+        if free is not None:
+            grad[: 12 * n_cameras][~free] = 0.0
+        if distributed:
+            # assemble the global vectors in selection order: cameras are identical on every rank, poses / frame gradients are gathered
+            parts = [None] * world
+            dist.all_gather_object(parts, (positions, result.x[12 * n_cameras:].reshape(-1, 6), grad[12 * n_cameras:].reshape(-1, 6)))
+            poses_all, gradf_all = np.empty((all_use.size, 6)), np.empty((all_use.size, 6))
+            for pos, po, gr in parts:
+                poses_all[pos], gradf_all[pos] = po, gr
+            result.x = np.concatenate([result.x[: 12 * n_cameras], poses_all.ravel()])
+            grad = np.concatenate([grad[: 12 * n_cameras], gradf_all.ravel()])
+            result.active_mask = np.zeros_like(result.x)
+            result.optimality = float(np.abs(grad).max())
+            result.lm["frame_positions"] = positions
+        result.grad = grad
+    finally:
+        if prob_all is not None:
+            prob_all.close()
+        if prob is not None:
+            prob.close()
 
     adjusted_extrinsics, adjusted_intrinsics, adjusted_calib_poses = deserialize_params(result.x, n_cameras)
     return adjusted_extrinsics, adjusted_intrinsics, adjusted_calib_poses, all_use, result

@@ -8,6 +8,8 @@
 #include <atomic>
 #include <chrono>
 #include <dlfcn.h>
+#include <map>
+#include <mutex>
 #include <rccl/rccl.h>
 #include <string>
 #include <vector>
@@ -25,6 +27,7 @@ const char* kKernelNames = "k_transpose_obs\nk_gram\nk_cost\nk_syrk\nk_reduce_sy
 constexpr int kRing = 16;  // host-mapped LM state slots (device-resident loop): the host may run at most kRing - 1 ticks ahead
 
 struct EvRec { int kid; hipEvent_t a, b; };
+struct DevBuf { void** slot; size_t bytes; };  // a pooled device buffer of a handle: where its pointer lives, its size
 
 }  // namespace
 
@@ -55,6 +58,9 @@ struct mcba_handle {
   ncclComm_t comm = nullptr;  // direct RCCL communicator (optional)
   // device-resident LM loop (mcba_lm_auto_*)
   double *dcbuf = nullptr, *swork = nullptr;
+  double* dscale = nullptr;   // numeric x_scale (least_squares): D = 1 / x_scale^2 in the layout of x; have_xscale says whether it is in use
+  bool have_xscale = false;
+  int fuse_max_polls = 200000;
   unsigned char* fixed = nullptr;
   bool have_fixed = false, auto_ready = false;
   bool speculate = true;       // frame-sharded ticks: one collective (speculative Schur reduction) instead of two
@@ -73,6 +79,10 @@ struct mcba_handle {
   unsigned prof_count[32] = {};
   std::vector<EvRec> evs;
   std::vector<hipEvent_t> pool;
+  std::vector<DevBuf> bufs;        // every pooled device buffer (mcba_destroy parks them)
+  bool have_solver = false;        // solver buffers are allocated on first use (ensure_solver): a pre-filter handle never needs them
+  size_t ring_bytes = 0, pinned_bytes = 0;
+  unsigned ring_flags = 0;
 };
 
 namespace {
@@ -120,10 +130,64 @@ int check_launch() {
   return MCBA_OK;
 }
 
+// ---- buffer pool.  hipMalloc / hipFree / hipHostMalloc are synchronising driver calls of 50-400 us each, and a
+// bundle_adjust() call creates and destroys three handles of ~25 buffers: 4 ms of its 16 ms at 6 x 10 000 x 54 was hipFree alone.
+// Freed buffers are parked here (per device, keyed by their exact size -- repeated calls ask for the same sizes) and handed out
+// again; MCBA_POOL_MB caps what is parked (default 8192 MiB of the 288 GB; 0 switches the pool off), mcba_pool_trim() returns
+// everything to the driver.  Re-use is safe without events: every kernel and copy of this library is enqueued on the handle's
+// stream and mcba_destroy synchronises that stream before it parks a buffer.
+struct BufferPool {
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, void*> dev;     // (device, bytes) -> pointer
+  std::multimap<std::pair<unsigned, size_t>, void*> host;  // (hipHostMalloc flags, bytes) -> pointer
+  size_t parked = 0;
+  size_t cap() {
+    static size_t c = [] { const char* e = getenv("MCBA_POOL_MB"); return (size_t)(e ? atoll(e) : 8192) << 20; }();
+    return c;
+  }
+};
+BufferPool g_pool;
+
+hipError_t pool_malloc(void** p, size_t bytes, int device) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.dev.find({device, bytes});
+    if (it != g_pool.dev.end()) { *p = it->second; g_pool.dev.erase(it); g_pool.parked -= bytes; return hipSuccess; }
+  }
+  return hipMalloc(p, bytes);
+}
+void pool_free(void* p, size_t bytes, int device) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    if (g_pool.parked + bytes <= g_pool.cap()) { g_pool.dev.insert({{device, bytes}, p}); g_pool.parked += bytes; return; }
+  }
+  (void)hipFree(p);
+}
+hipError_t pool_host_malloc(void** p, size_t bytes, unsigned flags) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.host.find({flags, bytes});
+    if (it != g_pool.host.end()) { *p = it->second; g_pool.host.erase(it); return hipSuccess; }
+  }
+  return hipHostMalloc(p, bytes, flags);
+}
+void pool_host_free(void* p, size_t bytes, unsigned flags) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  if (g_pool.cap() == 0) { (void)hipHostFree(p); return; }
+  g_pool.host.insert({{flags, bytes}, p});
+}
+
+// zero-filled device buffer from the pool, registered with the handle (mcba_destroy parks it again).  The fill is
+// enqueued on the handle's stream (no host synchronisation); `zero = false` for buffers a kernel overwrites completely
+// before anything reads them (observation layouts, Jacobian blocks).
 template <class T>
-int dalloc(T** p, size_t count) {
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
-  HIPCHK(hipMemset(*p, 0, count * sizeof(T)));
+int dalloc(mcba_handle* h, T** p, size_t count, bool zero = true) {
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  HIPCHK(pool_malloc(reinterpret_cast<void**>(p), bytes, h->device));
+  h->bufs.push_back({reinterpret_cast<void**>(p), bytes});
+  if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
   return MCBA_OK;
 }
 
@@ -165,7 +229,7 @@ static int rccl_fail(const char* what, ncclResult_t r) {
 
 extern "C" {
 
-int mcba_abi_version(void) { return 3; }  // 3: mcba_comm_count, frame pre-filter, reprojection diagnostics, undistortion (round 2)
+int mcba_abi_version(void) { return 4; }  // 4: buffer pool, detachable residuals, x_scale, sharded select, fuse status (round 3)
 const char* mcba_last_error(void) { return g_err.c_str(); }
 const char* mcba_profile_names(void) { return kKernelNames; }
 
@@ -225,7 +289,6 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
       h->G = (nstage + h->sq - 1) / h->sq;
     }
   }
-  h->nfblocks = h->G;  // k_syrk's workgroups factorise their own frames: one (max |g_f|, #failures) pair each
   h->nbblocks = h->Fpad / 64;
   // fused k_gram needs >= ~1 wavefront per SIMD (1024) to fill the chip; with fewer (camera, frame-block) pairs the
   // split-role variant doubles the number of wavefronts.  MCBA_GRAM_SPLIT=0/1 overrides (tuning knob).
@@ -241,13 +304,31 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   if (const char* e = getenv("MCBA_GRAM_SPLIT")) h->gram_split = std::max(0, std::min(2, atoi(e)));  // 0 fused, 1 split roles, 2 fused + split tail
   // k_cost: split the board points so that ~4 waves per SIMD (1024 SIMDs) are in flight
   h->nch = std::max(1, std::min(std::min(8, N / 8), (4096 + C * h->nfb - 1) / (C * h->nfb)));
+  h->nfblocks = h->G;  // (kept: k_syrk's workgroups factorise their own frames: one (max |g_f|, #failures) pair each)
+  h->npad = 16 * h->NT;
+  h->solve_lds = mcba::solve_fits_lds(h->npad);
   int rc;
-#define DA(p, cnt) if ((rc = dalloc(&h->p, (cnt))) != MCBA_OK) { mcba_destroy(h); return rc; }
-  DA(obs_t, (size_t)2 * C * N * h->Fpad);
-  DA(obs_raw, (size_t)2 * C * F * N);
-  DA(obj, (size_t)3 * N);
-  DA(x[0], h->nx);
-  DA(x[1], h->nx);
+#define DA(p, cnt, zero) if ((rc = dalloc(h, &h->p, (cnt), zero)) != MCBA_OK) { mcba_destroy(h); return rc; }
+  // what every handle needs (a pre-filter handle needs nothing else): the two observation layouts, the board, the parameter slots
+  DA(obs_t, (size_t)2 * C * N * h->Fpad, false);
+  DA(obs_raw, (size_t)2 * C * F * N, false);
+  DA(obj, (size_t)3 * N, true);
+  DA(x[0], h->nx, true);   // (zero: the poses of the padding frames must be finite)
+  DA(x[1], h->nx, true);
+#undef DA
+  HIPCHK(hipStreamSynchronize(h->stream));  // the zero fills above ran on the creation stream; the caller may switch streams next
+  *out = h;
+  return MCBA_OK;
+}
+
+// Solver buffers, allocated on first use (linearise / reduce / LM entry points): records, partial sums, reduce buffer, the host-
+// mapped state ring.  A handle that only runs the pre-filter (api.select_frames over ALL frames of a long recording) never gets
+// here, so its footprint is the observations alone.
+static int ensure_solver(mcba_handle* h) {
+  if (h->have_solver) return MCBA_OK;
+  const int C = h->C;
+  int rc;
+#define DA(p, cnt) if ((rc = dalloc(h, &h->p, (cnt))) != MCBA_OK) return rc;
   DA(rec2[0], (size_t)h->Fpad * C * MCBA_REC);
   DA(rec2[1], (size_t)h->Fpad * C * MCBA_REC);
   DA(gpart2[0], (size_t)C * h->nfb * MCBA_GP);
@@ -260,63 +341,74 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   DA(red_own, h->nsys + 8 + 2 * MCBA_LMS);
   DA(tile_i, (size_t)h->NP);
   DA(tile_j, (size_t)h->NP);
-  h->npad = 16 * h->NT;
-  h->solve_lds = mcba::solve_fits_lds(h->npad);
-  DA(dcbuf, (size_t)h->n + 8);  // + the word k_solve_backsub's solve releases
+  DA(dcbuf, (size_t)h->n + 8);  // + the word k_solve_backsub's solve releases, + the poll-timeout stamp
   DA(swork, h->solve_lds ? 16 : (size_t)h->npad * h->npad);
   DA(fixed, (size_t)h->n);
+  DA(dscale, h->nx);
 #undef DA
-  if (mcba::solve_set_lds_limit(h->npad, h->solve_lds) != 0) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_solve_cam"); }
+  if (mcba::solve_set_lds_limit(h->npad, h->solve_lds) != 0) return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_solve_cam");
   h->fuse_backsub = h->solve_lds != 0;
   if (const char* e = getenv("MCBA_FUSE_BACKSUB")) h->fuse_backsub = h->fuse_backsub && atoi(e) != 0;  // tuning knob
-  if (h->fuse_backsub && mcba::solve_backsub_set_lds_limit(h->npad) != 0) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_solve_backsub"); }
+  // (a part whose LDS limit cannot be raised keeps the two-launch k_solve_cam + k_backsub path instead of failing)
+  if (h->fuse_backsub && mcba::solve_backsub_set_lds_limit(h->npad) != 0) h->fuse_backsub = false;
+  h->fuse_max_polls = 200000;
+  if (const char* e = getenv("MCBA_FUSE_MAX_POLLS")) h->fuse_max_polls = std::max(0, atoi(e));  // test knob: 0 forces every poll to time out
   {
-    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h->ring), (size_t)kRing * MCBA_LMS * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostMalloc(reinterpret_cast<void**>(&h->ring), (size_t)kRing * MCBA_LMS * sizeof(double), hipHostMallocDefault); }
-    if (e != hipSuccess) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "cannot allocate the host-mapped LM state ring"); }
-    memset(h->ring, 0, (size_t)kRing * MCBA_LMS * sizeof(double));
-    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&h->ring_dev), h->ring, 0) != hipSuccess) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "hipHostGetDevicePointer failed for the LM state ring"); }
+    h->ring_bytes = ((size_t)kRing * MCBA_LMS + 8) * sizeof(double);  // + the poll-timeout counter the GPU bumps
+    h->ring_flags = hipHostMallocMapped | hipHostMallocCoherent;
+    hipError_t e = pool_host_malloc(reinterpret_cast<void**>(&h->ring), h->ring_bytes, h->ring_flags);
+    if (e != hipSuccess) { (void)hipGetLastError(); h->ring_flags = hipHostMallocDefault; e = pool_host_malloc(reinterpret_cast<void**>(&h->ring), h->ring_bytes, h->ring_flags); }
+    if (e != hipSuccess) return fail(MCBA_ERR_HIP, "cannot allocate the host-mapped LM state ring");
+    memset(h->ring, 0, h->ring_bytes);
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&h->ring_dev), h->ring, 0) != hipSuccess) return fail(MCBA_ERR_HIP, "hipHostGetDevicePointer failed for the LM state ring");
   }
   h->red = h->red_own;
   std::vector<int> ci, cj;
   for (int a = 0; a < h->NT; ++a) for (int b = a; b < h->NT; ++b) { ci.push_back(a); cj.push_back(b); }
-  HIPCHK(hipMemcpy(h->tile_i, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->tile_j, cj.data(), cj.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pinned), (h->nsys + 8 + MCBA_LMS + h->n) * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipMemcpyAsync(h->tile_i, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));  // (pageable source: staged before the call returns)
+  HIPCHK(hipMemcpyAsync(h->tile_j, cj.data(), cj.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  h->pinned_bytes = (h->nsys + 8 + MCBA_LMS + h->n) * sizeof(double);
+  HIPCHK(pool_host_malloc(reinterpret_cast<void**>(&h->pinned), h->pinned_bytes, hipHostMallocDefault));
   size_t lds = mcba::syrk_lds_bytes(C, h->FS);
   if (lds > 64 * 1024) {
-    if (mcba::syrk_set_lds_limit(lds) != 0) { mcba_destroy(h); return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_syrk"); }
+    if (mcba::syrk_set_lds_limit(lds) != 0) return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_syrk");
   }
-  *out = h;
+  h->have_solver = true;
   return MCBA_OK;
 }
+#define NEED_SOLVER(h) do { int rc_ = ensure_solver(h); if (rc_) return rc_; } while (0)
 
 int mcba_destroy(mcba_handle* h) {
   if (!h) return MCBA_OK;
   (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamSynchronize(h->stream);  // nothing in flight may still touch a buffer that is parked below
   if (h->comm && g_rccl.ok) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
-  double* bufs[] = {h->obs_t, h->obs_raw, h->obj, h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->fbuf, h->fpart, h->spart, h->cpart, h->bpart, h->red_own, h->jac, h->res,
-                    h->err, h->dmean, h->dfull, h->repro, h->trans, h->und};
-  if (h->sel) (void)hipFree(h->sel);
-  if (h->fmask) (void)hipFree(h->fmask);
+  for (auto& b : h->bufs) { pool_free(*b.slot, b.bytes, h->device); *b.slot = nullptr; }
   free(h->obj_host);
-  for (double* p : bufs) if (p) (void)hipFree(p);
-  if (h->tile_i) (void)hipFree(h->tile_i);
-  if (h->tile_j) (void)hipFree(h->tile_j);
-  if (h->pinned) (void)hipHostFree(h->pinned);
-  if (h->ring) (void)hipHostFree(h->ring);
-  if (h->dcbuf) (void)hipFree(h->dcbuf);
-  if (h->swork) (void)hipFree(h->swork);
-  if (h->fixed) (void)hipFree(h->fixed);
+  pool_host_free(h->pinned, h->pinned_bytes, hipHostMallocDefault);
+  pool_host_free(h->ring, h->ring_bytes, h->ring_flags);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->pool) (void)hipEventDestroy(e);
   delete h;
   return MCBA_OK;
 }
 
+int mcba_pool_trim(void) {
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (auto& kv : g_pool.dev) { (void)hipSetDevice(kv.first.first); (void)hipFree(kv.second); }
+  for (auto& kv : g_pool.host) (void)hipHostFree(kv.second);
+  g_pool.dev.clear();
+  g_pool.host.clear();
+  g_pool.parked = 0;
+  (void)hipSetDevice(cur);
+  return MCBA_OK;
+}
+
 int mcba_set_stream(mcba_handle* h, void* s) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  if (h->stream != reinterpret_cast<hipStream_t>(s)) HIPCHK(hipStreamSynchronize(h->stream));  // work (and zero fills) enqueued so far
   h->stream = reinterpret_cast<hipStream_t>(s);
   return MCBA_OK;
 }
@@ -409,6 +501,7 @@ int mcba_cost(mcba_handle* h, int slot, double* cost, double* n_residuals) {
   if (!slot_ok(h, slot) || !cost) return fail(MCBA_ERR_ARG, "mcba_cost: bad argument");
   if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_cost: upload observations first");
   HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
   int rc = run_cost(h, slot, nullptr, nullptr, 0);
   if (rc) return rc;
   double t[8];
@@ -421,7 +514,7 @@ int mcba_cost(mcba_handle* h, int slot, double* cost, double* n_residuals) {
 }
 
 static int ensure_res(mcba_handle* h) {
-  if (!h->res) return dalloc(&h->res, (size_t)2 * h->C * h->F * h->N);
+  if (!h->res) return dalloc(h, &h->res, (size_t)2 * h->C * h->F * h->N, false);
   return MCBA_OK;
 }
 
@@ -429,6 +522,7 @@ int mcba_residuals(mcba_handle* h, int slot, double* res) {
   if (!slot_ok(h, slot) || !res) return fail(MCBA_ERR_ARG, "mcba_residuals: bad argument");
   if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_residuals: upload observations first");
   HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
   int rc = ensure_res(h);
   if (rc) return rc;
   rc = run_cost(h, slot, h->res, nullptr, 0);
@@ -445,7 +539,7 @@ int mcba_jacobian_eval(mcba_handle* h, int slot, int robust_scaled) {
   int rc = ensure_res(h);
   if (rc) return rc;
   if (!h->jac) {
-    rc = dalloc(&h->jac, (size_t)36 * h->C * h->F * h->N);
+    rc = dalloc(h, &h->jac, (size_t)36 * h->C * h->F * h->N, false);
     if (rc) return rc;
   }
   {
@@ -472,6 +566,7 @@ int mcba_linearize(mcba_handle* h, int slot) {
   if (!slot_ok(h, slot)) return fail(MCBA_ERR_ARG, "mcba_linearize: bad argument");
   if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_linearize: upload observations first");
   HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
   {
     Scope sc(h, K_GRAM);
     mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar);
@@ -491,7 +586,7 @@ int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot) {
   int rc;
   {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, host_sel(h->lin, lambda), no_fuse(), h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->sq, h->sr, h->FS, h->ppw);
+    mcba::launch_syrk(h->stream, host_sel(h->lin, lambda), no_fuse(), h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->sq, h->sr, h->FS, h->ppw, h->have_xscale ? h->dscale : nullptr);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -507,6 +602,8 @@ size_t mcba_reduced_size(const mcba_handle* h) { return h ? h->nsys + 8 + 2 * MC
 
 int mcba_bind_reduce_buffer(mcba_handle* h, double* p) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
   h->red = p ? p : h->red_own;
   h->have_red = false;
   return MCBA_OK;
@@ -598,6 +695,7 @@ int mcba_lm_set_state(mcba_handle* h, const double* state) {
   int sel = (int)state[3];
   if (sel != 0 && sel != 1) return fail(MCBA_ERR_ARG, "mcba_lm_set_state: state[3] must be 0 or 1");
   HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
   double* stage = h->pinned + h->nsys + 8;
   memcpy(stage, state, MCBA_LMS * sizeof(double));
   HIPCHK(hipMemcpyAsync(h->red + h->nsys + 8, stage, MCBA_LMS * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -642,7 +740,8 @@ int mcba_lm_trial(mcba_handle* h, const double* delta_cam) {
 
 // decide_here: k_syrk itself sums the trial scalars and takes the accept / reject decision (single-GPU ticks); it reads the
 // state the previous tick left and publishes the decided state to the second buffer, which the rest of the tick reads.
-static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, bool decide_here = false) {
+static double* timeout_word(const mcba_handle* h) { return h->dcbuf + h->n + 1; }  // behind the camera step and the release word
+static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, bool decide_here = false, unsigned long long seq = 0) {
   int rc;
   const mcba::Sel sl = spec ? spec_sel(h) : dev_sel(h, 0);
   mcba::SyrkFuse fz = no_fuse();
@@ -659,10 +758,12 @@ static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, boo
     fz.trial_out = h->red + h->nsys;
     fz.lms_post = post_state(h);
     fz.da = mcba::DecideArgs{2, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, nullptr, h->ftol, h->xtol};
+    fz.timeout_word = timeout_word(h);
+    fz.seq_prev = seq > 0 ? (double)(seq - 1) : 0.0;
   }
   {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, sl, fz, h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->sq, h->sr, h->FS, h->ppw);
+    mcba::launch_syrk(h->stream, sl, fz, h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->sq, h->sr, h->FS, h->ppw, h->have_xscale ? h->dscale : nullptr);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -728,6 +829,7 @@ int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, do
 int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, double lam_min, double lam_max, const unsigned char* fixed) {
   if (!h || !(lam_min > 0.0) || !(lam_max > lam_min)) return fail(MCBA_ERR_ARG, "mcba_lm_auto_config: bad argument");
   HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
   h->ftol = ftol; h->xtol = xtol; h->gtol = gtol; h->lam_min = lam_min; h->lam_max = lam_max;
   h->have_fixed = fixed != nullptr;
   if (fixed) {
@@ -753,15 +855,18 @@ static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, b
   mcba::SolveArgs a;
   a.red = h->red; a.lms = h->red + h->nsys + 8; a.lms_in = decided_by_syrk ? post_state(h) : a.lms; a.work = h->swork; a.dc = h->dcbuf; a.x0 = h->x[0]; a.x1 = h->x[1];
   a.fixed = h->have_fixed ? h->fixed : nullptr;
+  a.dscale = h->have_xscale ? h->dscale : nullptr;
   a.host_state = h->ring_dev + (size_t)(seq % kRing) * MCBA_LMS;
   a.flag = fuse_next ? h->dcbuf + h->n : nullptr;
+  a.timeout_word = timeout_word(h);
   a.seq = (double)seq; a.gtol = h->gtol; a.lam_max = h->lam_max;
   a.n = h->n; a.npad = h->npad; a.use_lds = h->solve_lds;
   a.decide = decide ? 1 : 0; a.lam_min = h->lam_min; a.ftol = h->ftol; a.xtol = h->xtol;
   {
     Scope sc(h, K_SOLVE);
     if (fuse_next)  // + the back-substitution of the next tick's trial step, overlapped with the solve (polls bounded: ~0.5 s)
-      mcba::launch_solve_backsub(h->stream, a, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad, decide ? post_state(h) : a.lms_in, 200000, decide ? 1 : 0);
+      mcba::launch_solve_backsub(h->stream, a, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad, decide ? post_state(h) : a.lms_in, h->fuse_max_polls, decide ? 1 : 0,
+                                 timeout_word(h), h->ring_dev + (size_t)kRing * MCBA_LMS);
     else
       mcba::launch_solve_cam(h->stream, a);
   }
@@ -822,7 +927,7 @@ int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot) {
   if (!coll) {  // one GPU: [k_backsub ->] k_gram -> k_syrk (trial sums + decision + frame factors + SYRK) -> k_reduce_system -> k_solve_backsub
     if (rank_slot < 0 || rank_slot > 11) return fail(MCBA_ERR_ARG, "mcba_lm_auto_tick: bad rank slot");
     if ((rc = auto_trial_impl(h, 0, false))) return rc;
-    if ((rc = lm_reduce_chain(h, rank_slot, false, true))) return rc;
+    if ((rc = lm_reduce_chain(h, rank_slot, false, true, seq))) return rc;
     return auto_solve_impl(h, seq, 0, true, h->fuse_backsub);
   }
   if (h->speculate) {  // ONE collective: speculative reduction, [system | trial scalars] all-reduced together, decision in k_solve_cam
@@ -892,6 +997,12 @@ int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state) {
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   for (int i = 0; i < MCBA_LMS; ++i) state[i] = slot[i];
+  if (h->fuse_backsub && const_cast<volatile double*>(h->ring)[(size_t)kRing * MCBA_LMS] != 0.0) {
+    // a back-substitution workgroup of k_solve_backsub gave up waiting for the solve (mcba_backsub.h): the ticks already in
+    // flight discard their stale trial points on the device; from here on the solve and the back-substitution are two launches
+    h->fuse_backsub = false;
+    h->trial_ready = false;
+  }
   int sel = (int)state[3];
   if (sel == 0 || sel == 1) h->lin = sel;
   h->have_spec = false;
@@ -902,11 +1013,11 @@ int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state) {
 // bundle_adjust()'s frame pre-filter on the GPU (reference bundle_adjustment.py:265-285) and frame subsets without a second upload
 static int ensure_diag(mcba_handle* h) {
   int rc;
-  if (!h->err && (rc = dalloc(&h->err, (size_t)h->C * h->N * h->Fpad))) return rc;
-  if (!h->dmean && (rc = dalloc(&h->dmean, std::max<size_t>((size_t)h->C * h->F, 8)))) return rc;
-  if (!h->dfull && (rc = dalloc(&h->dfull, (size_t)h->C * h->F))) return rc;
-  if (!h->sel && (rc = dalloc(&h->sel, mcba::select_state_bytes(h->C)))) return rc;
-  if (!h->fmask && (rc = dalloc(&h->fmask, (size_t)h->Fpad))) return rc;
+  if (!h->err && (rc = dalloc(h, &h->err, (size_t)h->C * h->N * h->Fpad))) return rc;
+  if (!h->dmean && (rc = dalloc(h, &h->dmean, std::max<size_t>((size_t)h->C * h->F, 8)))) return rc;
+  if (!h->dfull && (rc = dalloc(h, &h->dfull, (size_t)h->C * h->F))) return rc;
+  if (!h->sel && (rc = dalloc(h, &h->sel, mcba::select_state_bytes(h->C)))) return rc;
+  if (!h->fmask && (rc = dalloc(h, &h->fmask, (size_t)h->Fpad))) return rc;
   return MCBA_OK;
 }
 
@@ -970,7 +1081,7 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
   h->loss = src->loss;
   h->f_scale = src->f_scale;
   int* d_frames = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_frames), (size_t)n_frames * sizeof(int));
+  hipError_t e = pool_malloc(reinterpret_cast<void**>(&d_frames), (size_t)n_frames * sizeof(int), h->device);
   if (e == hipSuccess) e = hipMemcpyAsync(d_frames, frames, (size_t)n_frames * sizeof(int), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) {
     mcba::launch_gather_frames(h->stream, src->obs_raw, d_frames, h->obs_raw, h->C, src->F, h->F, h->N);
@@ -983,7 +1094,7 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
     e = hipGetLastError();
   }
   hipError_t e2 = hipStreamSynchronize(h->stream);
-  if (d_frames) (void)hipFree(d_frames);
+  pool_free(d_frames, (size_t)n_frames * sizeof(int), h->device);  // (after the synchronisation above)
   if (e != hipSuccess || e2 != hipSuccess) {
     g_err = std::string("mcba_create_subset: ") + hipGetErrorString(e != hipSuccess ? e : e2);
     mcba_destroy(h);
@@ -1008,9 +1119,9 @@ int mcba_reprojection_diagnostics(mcba_handle* h, int slot, const double* dist5,
   int rc = ensure_diag(h);
   if (rc) return rc;
   const size_t cnt = (size_t)2 * h->C * h->F * h->N;
-  if (reprojections && !h->repro && (rc = dalloc(&h->repro, cnt))) return rc;
-  if (transformed && !h->trans && (rc = dalloc(&h->trans, cnt))) return rc;
-  if (!h->und && (rc = dalloc(&h->und, (size_t)2 * h->C * h->N * h->Fpad))) return rc;
+  if (reprojections && !h->repro && (rc = dalloc(h, &h->repro, cnt))) return rc;
+  if (transformed && !h->trans && (rc = dalloc(h, &h->trans, cnt))) return rc;
+  if (!h->und && (rc = dalloc(h, &h->und, (size_t)2 * h->C * h->N * h->Fpad))) return rc;
   std::vector<double> d5((size_t)5 * h->C, 0.0), xc((size_t)12 * h->C);
   if (dist5) memcpy(d5.data(), dist5, d5.size() * sizeof(double));
   else {  // (k1, k2, 0, 0, 0) of the parameter vector
@@ -1188,6 +1299,100 @@ int mcba_comm_destroy(mcba_handle* h) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
   if (h->comm && g_rccl.ok) { (void)hipStreamSynchronize(h->stream); g_rccl.CommDestroy(h->comm); }
   h->comm = nullptr;
+  return MCBA_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// least_squares' numeric x_scale (the reference forwards **opt_kwargs verbatim: bundle_adjustment.py:301-313).  scipy's trust
+// region lives in the variables x / x_scale; for Levenberg-Marquardt that is a FIXED damping matrix D = diag(1 / x_scale^2)
+// in place of Marquardt's D = diag(J^T J) (= x_scale 'jac').  x_scale: 12C + 6F positive doubles in the layout of x, or NULL
+// to return to 'jac'.
+int mcba_set_x_scale(mcba_handle* h, const double* x_scale) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
+  h->have_red = false;
+  if (!x_scale) { h->have_xscale = false; return MCBA_OK; }
+  const size_t cnt = (size_t)12 * h->C + (size_t)6 * h->F;
+  std::vector<double> d(h->nx, 1.0);
+  for (size_t i = 0; i < cnt; ++i) {
+    if (!(x_scale[i] > 0.0) || !std::isfinite(x_scale[i])) return fail(MCBA_ERR_ARG, "`x_scale` must be 'jac' or array_like with positive numbers.");
+    d[i] = 1.0 / (x_scale[i] * x_scale[i]);
+  }
+  HIPCHK(hipMemcpyAsync(h->dscale, d.data(), h->nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_xscale = true;
+  return MCBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Residual vector left ON THE DEVICE and handed to the caller as an object of its own: api.bundle_adjust attaches it to the
+// OptimizeResult and downloads it when (if) `result.fun` is first read -- 52 MB of D2H at 6 x 10 000 x 54 that most callers
+// never look at (the reference materialises it: scipy trf.py:557-560).  The buffer outlives the handle.
+struct mcba_buffer { double* dev; size_t count; int device; hipStream_t stream; };
+
+int mcba_residuals_detach(mcba_handle* h, int slot, mcba_buffer** out) {
+  if (!slot_ok(h, slot) || !out) return fail(MCBA_ERR_ARG, "mcba_residuals_detach: bad argument");
+  if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_residuals_detach: upload observations first");
+  HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
+  int rc = ensure_res(h);
+  if (rc) return rc;
+  if ((rc = run_cost(h, slot, h->res, nullptr, 0))) return rc;
+  mcba_buffer* b = new mcba_buffer{h->res, (size_t)2 * h->C * h->F * h->N, h->device, h->stream};
+  for (size_t i = 0; i < h->bufs.size(); ++i)
+    if (h->bufs[i].slot == reinterpret_cast<void**>(&h->res)) { h->bufs.erase(h->bufs.begin() + i); break; }
+  h->res = nullptr;
+  h->have_jac = false;
+  *out = b;
+  return MCBA_OK;
+}
+size_t mcba_buffer_count(const mcba_buffer* b) { return b ? b->count : 0; }
+int mcba_buffer_download(mcba_buffer* b, double* host) {
+  if (!b || !host) return fail(MCBA_ERR_ARG, "mcba_buffer_download: bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipMemcpyAsync(host, b->dev, b->count * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return MCBA_OK;
+}
+int mcba_buffer_free(mcba_buffer* b) {
+  if (!b) return MCBA_OK;
+  (void)hipSetDevice(b->device);
+  (void)hipStreamSynchronize(b->stream);
+  pool_free(b->dev, b->count * sizeof(double), b->device);
+  delete b;
+  return MCBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One pass of the radix select behind mcba_error_median, for callers that hold only a SHARD of the frames (frame-sharded
+// bundle_adjust: every rank runs the pre-filter on its own slice): the 256-bin histogram of byte `pass` (0 = most significant)
+// over this handle's per-point errors whose leading `pass` bytes equal `prefix`, restricted to frame_mask (F bytes, NULL = the mask
+// of the previous call).  The caller sums the histograms over the ranks, picks the bin that holds the wanted rank and calls again
+// with the longer prefix -- integer arithmetic only, so the order statistic is exact whatever the sharding.
+int mcba_error_histogram(mcba_handle* h, const unsigned char* frame_mask, unsigned long long prefix, int pass, unsigned long long* hist256) {
+  if (!h || !hist256 || pass < 0 || pass > 7) return fail(MCBA_ERR_ARG, "mcba_error_histogram: bad argument");
+  if (!h->err) return fail(MCBA_ERR_ARG, "mcba_error_histogram: call mcba_frame_errors first");
+  HIPCHK(hipSetDevice(h->device));
+  if (frame_mask) {
+    HIPCHK(hipMemsetAsync(h->fmask, 0, (size_t)h->Fpad, h->stream));
+    HIPCHK(hipMemcpyAsync(h->fmask, frame_mask, (size_t)h->F, hipMemcpyHostToDevice, h->stream));
+  }
+  unsigned int hist[256];
+  int rc = mcba::launch_select_hist(h->stream, h->err, h->fmask, (size_t)h->C * h->N * h->Fpad, h->Fpad, h->sel, prefix, pass, hist);
+  if (rc) { g_err = "mcba_error_histogram: HIP error"; return MCBA_ERR_HIP; }
+  for (int b = 0; b < 256; ++b) hist256[b] = hist[b];
+  return MCBA_OK;
+}
+
+// device-resident loop: how often a back-substitution workgroup of k_solve_backsub gave up waiting for the solve (a bounded
+// poll, ~0.5 s) since mcba_lm_auto_config, and whether the fused launch is still in use (the first such event switches the
+// handle to the two-launch k_solve_cam + k_backsub path for good)
+int mcba_lm_fuse_status(mcba_handle* h, double* timeouts, int* fused) {
+  if (!h || !h->have_solver) return fail(MCBA_ERR_ARG, "mcba_lm_fuse_status: bad argument");
+  if (timeouts) *timeouts = const_cast<volatile double*>(h->ring)[(size_t)kRing * MCBA_LMS];
+  if (fused) *fused = h->fuse_backsub ? 1 : 0;
   return MCBA_OK;
 }
 

@@ -39,7 +39,18 @@ struct BacksubWait {
   // reduction was built on; if it fails the solve marks the next tick rebuild-only and the steps computed here are dropped.
   int spec;
   double lam_min;
+  // A poll that runs out (the solve never posted within max_polls) must not pass silently: the trial slot is then stale or half
+  // written.  The workgroup stamps the tick's sequence number into a device word -- the NEXT tick's decision (k_syrk, or the
+  // solve of a one-collective tick) discards its trial point and only rebuilds the system when it finds its predecessor's number
+  // there -- and into a host-mapped word, on which mcba_lm_auto_wait switches the handle to the two-launch path.
+  double* timeout_dev;
+  double* timeout_host;
 };
+
+__device__ __forceinline__ void backsub_stamp_timeout(const BacksubWait* w) {
+  __hip_atomic_store(w->timeout_dev, w->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (w->timeout_host) __hip_atomic_store(w->timeout_host, w->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ double load_coherent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -100,7 +111,10 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
         const double v = load_coherent(wait->flag);
         if (v == base + 1.0 || v == base + 2.0) { got = 1; break; }
         if (v == base + 3.0) break;                          // the solve ended without a step (terminated, or nothing to solve)
-        if (++polls > wait->max_polls) break;                // the solve never posted: leave the trial slot alone
+        if (++polls > wait->max_polls) {                     // the solve never posted: leave the trial slot alone, and say so
+          if (lane == 0) backsub_stamp_timeout(wait);
+          break;
+        }
         __builtin_amdgcn_s_sleep(4);
       }
       asm volatile("" ::: "memory");  // (compiler: the fetches below stay behind the poll; the hardware issues in order)
@@ -187,6 +201,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
       __builtin_amdgcn_s_sleep(4);
     }
     asm volatile("" ::: "memory");
+    if (!posted && lane == 0) backsub_stamp_timeout(wait);
     if (!posted || load_coherent(sl.lms + MCBA_LM_DONE) != 0.0 || load_coherent(sl.lms + MCBA_LM_SKIP) != 0.0) return;
   }
   if (block == 0)

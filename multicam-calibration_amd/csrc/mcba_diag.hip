@@ -15,6 +15,7 @@
 //                    reprojections mapped through it, distance to the board points.  Lane = (camera, frame).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <string.h>
 #include <algorithm>
 #include "mcba_kernels.h"
 #include "mcba_math.h"
@@ -411,6 +412,19 @@ void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, 
     k_sel_hist<<<dim3(bx, groups), dim3(256), 0, st>>>(v, fmask, per_group, Fpad, s, pass);
     k_sel_pick<<<dim3(groups), dim3(64), 0, st>>>(s, pass, upper);
   }
+}
+
+// one histogram pass with a host-given prefix (sharded select: the caller combines the histograms of several handles)
+int launch_select_hist(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int Fpad, void* sel, unsigned long long prefix, int pass, unsigned int* hist256) {
+  SelState* s = static_cast<SelState*>(sel);
+  SelState init;
+  memset(&init, 0, sizeof(init));
+  init.prefix = prefix;
+  if (hipMemcpyAsync(s, &init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+  const unsigned bx = (unsigned)std::min<size_t>((per_group + 255) / 256, 1024);
+  k_sel_hist<<<dim3(bx, 1), dim3(256), 0, st>>>(v, fmask, per_group, Fpad, s, pass);
+  if (hipMemcpyAsync(hist256, s->hist, 256 * sizeof(unsigned int), hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
+  return hipStreamSynchronize(st) == hipSuccess ? 0 : 1;
 }
 
 void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N) {

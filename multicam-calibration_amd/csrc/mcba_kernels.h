@@ -38,6 +38,8 @@ struct SyrkFuse {
   double* trial_out;   // 4 trial scalars for the host (cost, pred_f, |d_f|^2, |x_f|^2)
   double* lms_post;    // the state AFTER the decision (workgroup 0 writes it; later kernels of the tick read it)
   DecideArgs da;       // lam_min, lam_max, ftol, xtol
+  const double* timeout_word;  // device word a back-substitution workgroup of k_solve_backsub stamps with its tick's number when its poll ran out
+  double seq_prev;             // the previous tick's number: found in the word, this tick's trial point is stale -> rebuild only
 };
 // k_solve_cam (mcba_solve.hip): reduced camera system factorised and solved by one workgroup
 struct SolveArgs {
@@ -49,8 +51,10 @@ struct SolveArgs {
   const double* x0;          // parameter slots (camera block first)
   const double* x1;
   const unsigned char* fixed;  // n flags (1 = parameter held fixed) or nullptr
+  const double* dscale;      // numeric x_scale: D_c = dscale[0 .. n) instead of diag(U), or nullptr
   double* host_state;        // host-mapped ring slot of MCBA_LMS doubles, or nullptr
   double* flag;              // k_solve_backsub: device word released with `seq` when the camera step is in place (else nullptr)
+  const double* timeout_word;  // see SyrkFuse (one-collective ticks: the decision taken here checks it); may be nullptr
   double seq;
   double gtol, lam_max;
   int n, npad, use_lds;
@@ -64,7 +68,8 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
                  int planar = 0);  // planar: every board point has z = 0 exactly (with f_scale = 1 the fused kernel's FAST instance runs)
 void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch);
 size_t syrk_lds_bytes(int C, int FS);
-void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int sq, int sr, int FS, int ppw);
+void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int sq, int sr, int FS, int ppw,
+                 const double* dscale = nullptr);  // dscale: D = 1 / x_scale^2 in the layout of x (numeric x_scale), nullptr: D = diag(J^T J)
 int syrk_items_per_thread();
 // bpart != nullptr (speculative frame-sharded ticks): the trial scalars are summed here as well (red + nsys .. + 8) and the LM
 // state is copied to state_copy (MCBA_LMS doubles)
@@ -80,7 +85,7 @@ void launch_solve_cam(hipStream_t st, const SolveArgs& a);
 // the tick's decision left (final as far as the slot bit goes), or -- spec != 0, the solve decides -- a copy of the state before it
 int solve_backsub_set_lds_limit(int npad);
 void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const double* rec0, const double* rec1, const double* fbuf, double* x0, double* x1, double* bpart, int C, int F, int Fpad,
-                          const double* early_state, int max_polls, int spec);
+                          const double* early_state, int max_polls, int spec, double* timeout_dev, double* timeout_host);
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da);
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);
@@ -89,6 +94,7 @@ int syrk_set_lds_limit(size_t bytes);
 void launch_frame_err(hipStream_t st, const double* obs_t, const double* obj, const double* x, double* err, double* mean_cf, double* full_cf, int C, int F, int N, int Fpad);
 size_t select_state_bytes(int groups);  // per group: u64 prefix, rank, count, value (bit pattern of the selected double) + a 256-bin histogram
 void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int groups, int Fpad, void* sel, int upper);
+int launch_select_hist(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int Fpad, void* sel, unsigned long long prefix, int pass, unsigned int* hist256);
 void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N);
 void launch_undistort(hipStream_t st, const double* uv, double* out, size_t n, const double* K4, const double* dist5, int iters);
 void launch_reproj_diag(hipStream_t st, const double* obs_t, const double* obj, const double* x, const double* dist5, const double* bn, double* und, double* repro, double* trans, double* err, int C, int F, int N,

@@ -598,7 +598,8 @@ constexpr int kSyrkSuper = 32;  // frames factorised per super-stage: 32 frames 
 
 template <int PPW, int IPT, bool DECIDE>
 __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse fz, const double* __restrict__ rec0, const double* __restrict__ rec1, double* __restrict__ fbuf, double* __restrict__ fpart,
-                                              const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int sq, int sr, int FS) {
+                                              const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int sq, int sr, int FS,
+                                              const double* __restrict__ dscale) {
   extern __shared__ __align__(16) double lds[];
   __shared__ double s_st[MCBA_LMS];
   __shared__ double s_sum[8];
@@ -647,7 +648,9 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   }
   if (DECIDE) {
     if (t == 0) {
-      if (s_st[MCBA_LM_SKIP] != 0.0) lm_mark_rebuild(s_st);  // the reduced solve had failed: this tick only rebuilds the system
+      // (a back-substitution workgroup of the previous tick's k_solve_backsub gave up waiting: this tick's trial point is stale)
+      const bool stale = fz.timeout_word && *fz.timeout_word == fz.seq_prev && fz.seq_prev > 0.0;
+      if (s_st[MCBA_LM_SKIP] != 0.0 || stale) lm_mark_rebuild(s_st);  // the reduced solve had failed: this tick only rebuilds the system
       else {
         const bool trial1 = ((static_cast<int>(s_st[3]) ^ 1) & 1) != 0;  // the trial linearisation lives in the buffer that is not current
         const double tr[8] = {trial1 ? s_sum[4] : s_sum[0], s_sum[1], s_sum[2], s_sum[3], 0.0, 0.0, 0.0, 0.0};
@@ -768,7 +771,8 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         double d = V[tri6(k, k)];
-        D[k] = d > 0.0 ? d : 1.0;
+        // Marquardt scaling D = diag(J^T J) (x_scale = 'jac'), or the caller's fixed D = 1 / x_scale^2 (numeric x_scale)
+        D[k] = dscale ? dscale[(size_t)12 * C + 6 * (size_t)(s0 + lane) + k] : (d > 0.0 ? d : 1.0);
         V[tri6(k, k)] = d + lambda * D[k];
       }
       double Lp[21], id[6], z[6];
@@ -1275,13 +1279,14 @@ size_t syrk_lds_bytes(int C, int FS) {
 #define SYRK_IPT 5  // (12C+1)*FS <= 256*SYRK_IPT is guaranteed by the choice of FS in mcba_create
 #define SYRK_IPT_SMALL 3
 
-void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int sq, int sr, int FS, int ppw) {
+void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int sq, int sr, int FS, int ppw,
+                 const double* dscale) {
   size_t lds = syrk_lds_bytes(C, FS);
 #define SYRK_GO(PPW, IPT, GY)                                                                                                                                   \
   do {                                                                                                                                                          \
     dim3 grid(G, GY);                                                                                                                                           \
-    if (fz.decide) k_syrk<PPW, IPT, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS);   \
-    else k_syrk<PPW, IPT, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS);            \
+    if (fz.decide) k_syrk<PPW, IPT, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);   \
+    else k_syrk<PPW, IPT, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);            \
   } while (0)
   // items per thread: (12C + 1) rows x FS frames over 256 threads -- 3 is enough up to 7 cameras at 8 frames per stage
   // (fewer prefetch registers: the kernel stays within 256 registers, two workgroups per CU, without scratch)

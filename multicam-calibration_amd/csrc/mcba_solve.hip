@@ -168,7 +168,7 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
   double gm = 0.0;
   for (int i = tid; i < npad; i += NTHREADS) {
     const bool in = i < n, fx = in && fixed && fixed[i];
-    const double du = in ? diagU[i] : 1.0;
+    const double du = in ? (a.dscale ? a.dscale[i] : diagU[i]) : 1.0;  // numeric x_scale: the caller's fixed D = 1 / x_scale^2
     damp[i] = du > 0.0 ? du : 1.0;  // scaled by lambda below (the state is not in LDS yet)
     if (in && !fx) gm = fmax(gm, fabs(gc[i]));
   }
@@ -187,7 +187,14 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
     lms[MCBA_LM_TICK] += 1.0;
     if (a.decide) {  // one-collective ticks: the decision is taken here, on the all-reduced trial scalars
       if (lms[MCBA_LM_SKIP] != 0.0) lm_mark_rebuild(lms);  // this tick only rebuilt the system (no trial)
-      else {
+      else if (a.timeout_word && *a.timeout_word == a.seq - 1.0 && a.seq > 1.0) {
+        // the previous tick's fused back-substitution gave up waiting: the trial point (and the speculative reduction built on
+        // it) is stale -- nothing is decided, the next tick rebuilds the system of the current point
+        lm_mark_rebuild(lms);
+        lms[MCBA_LM_SKIP] = 1.0;
+        lms[MCBA_LM_SOLVE_INFO] = 4.0;
+        mode = 3;
+      } else {
         const double lam_spec = lm_spec_lambda(lms[1], a.lam_min);  // what the Schur reduction before us assumed
         lm_decide(a.red + (size_t)n * n + 3 * n + 16, DecideArgs{2, 0.0, 0.0, 0.0, a.lam_min, a.lam_max, lms, a.ftol, a.xtol});
         if (!(lms[4] != 0.0 && lms[1] == lam_spec)) {  // rejected, or accepted with another damping: the system in the
@@ -590,8 +597,8 @@ int solve_backsub_set_lds_limit(int npad) {
 }
 
 void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const double* rec0, const double* rec1, const double* fbuf, double* x0, double* x1, double* bpart, int C, int F, int Fpad,
-                          const double* early_state, int max_polls, int spec) {
-  BacksubArgs b{sl, rec0, rec1, fbuf, x0, x1, bpart, C, F, Fpad, BacksubWait{early_state, a.flag, a.dc, nullptr, a.seq, max_polls, spec, a.lam_min}};
+                          const double* early_state, int max_polls, int spec, double* timeout_dev, double* timeout_host) {
+  BacksubArgs b{sl, rec0, rec1, fbuf, x0, x1, bpart, C, F, Fpad, BacksubWait{early_state, a.flag, a.dc, nullptr, a.seq, max_polls, spec, a.lam_min, timeout_dev, timeout_host}};
   const size_t lds = solve_lds_bytes(a.npad, 1);
   const dim3 grid(1 + Fpad / 64), block(64 * kBacksubWaves);
   if (a.npad <= 80) hipLaunchKernelGGL((k_solve_backsub<5>), grid, block, lds, st, a, b);

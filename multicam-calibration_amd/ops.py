@@ -23,6 +23,14 @@ SYMBOLS = [
     ("mcba_device_count", ctypes.c_int, [_ip]),
     ("mcba_create", ctypes.c_int, [ctypes.POINTER(_h), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("mcba_destroy", ctypes.c_int, [_h]),
+    ("mcba_pool_trim", ctypes.c_int, []),
+    ("mcba_set_x_scale", ctypes.c_int, [_h, _dp]),
+    ("mcba_residuals_detach", ctypes.c_int, [_h, ctypes.c_int, ctypes.POINTER(_h)]),
+    ("mcba_buffer_count", ctypes.c_size_t, [_h]),
+    ("mcba_buffer_download", ctypes.c_int, [_h, _dp]),
+    ("mcba_buffer_free", ctypes.c_int, [_h]),
+    ("mcba_error_histogram", ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_ulonglong, ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong)]),
+    ("mcba_lm_fuse_status", ctypes.c_int, [_h, _dp, _ip]),
     ("mcba_set_stream", ctypes.c_int, [_h, ctypes.c_void_p]),
     ("mcba_upload_observations", ctypes.c_int, [_h, _dp, _dp]),
     ("mcba_set_loss", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_double]),
@@ -118,6 +126,41 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+class DeviceArray:
+    """A float64 array that lives on the GPU and outlives the Problem that produced it (mcba_residuals_detach):
+    `download()` copies it to the host once and releases the device buffer; dropping the object releases it unread."""
+
+    def __init__(self, lib, handle, shape):
+        self.lib, self.handle, self.shape = lib, handle, tuple(shape)
+        self._host = None
+
+    def download(self):
+        if self._host is None:
+            out = np.empty(self.shape)
+            rc = self.lib.mcba_buffer_download(self.handle, _p(out))
+            if rc != OK:
+                raise McbaError(rc, self.lib.mcba_last_error().decode())
+            self._host = out
+            self.free()
+        return self._host
+
+    def free(self):
+        if self.handle:
+            self.lib.mcba_buffer_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pool_trim():
+    """Return every parked device / pinned buffer of destroyed handles to the driver (include/mcba.h: mcba_pool_trim)."""
+    load_library().mcba_pool_trim()
+
+
 class Problem:
     """One handle = one GPU = this process's shard of frames."""
 
@@ -163,6 +206,14 @@ class Problem:
         m = None if frame_mask is None else np.ascontiguousarray(frame_mask, dtype=np.uint8).tobytes()
         self._chk(self.lib.mcba_error_median(self.handle, m, ctypes.byref(med), ctypes.byref(cnt)))
         return med.value, int(cnt.value)
+
+    def error_histogram(self, frame_mask, prefix, pass_):
+        """One pass of the radix select over THIS handle's errors (frame-sharded pre-filter): 256 counts (uint64) of the next byte
+        among the values whose leading `pass_` bytes equal `prefix`; frame_mask None = the mask of the previous call."""
+        hist = np.zeros(256, dtype=np.uint64)
+        m = None if frame_mask is None else np.ascontiguousarray(frame_mask, dtype=np.uint8).tobytes()
+        self._chk(self.lib.mcba_error_histogram(self.handle, m, int(prefix), int(pass_), hist.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong))))
+        return hist
 
     def subset(self, frames, loss=None, f_scale=None):
         """A new Problem holding the observations of `frames` (indices into this one), gathered on the GPU."""
@@ -234,6 +285,31 @@ class Problem:
         r = np.empty((self.C, self.F, self.N, 2))
         self._chk(self.lib.mcba_residuals(self.handle, slot, _p(r)))
         return r
+
+    def residuals_detach(self, slot):
+        """The same array left on the GPU as a DeviceArray (no device-to-host copy until `.download()`)."""
+        buf = _h()
+        self._chk(self.lib.mcba_residuals_detach(self.handle, slot, ctypes.byref(buf)))
+        return DeviceArray(self.lib, buf, (self.C, self.F, self.N, 2))
+
+    def set_x_scale(self, x_scale):
+        """least_squares' numeric x_scale for this shard's parameter vector (nx positive numbers), or None for 'jac'."""
+        if x_scale is None:
+            self._chk(self.lib.mcba_set_x_scale(self.handle, None))
+            return
+        xs = _f64(x_scale)
+        if xs.shape != (self.nx,):
+            raise ValueError("Inconsistent shapes between `x_scale` and `x0`.")
+        rc = self.lib.mcba_set_x_scale(self.handle, _p(xs))
+        if rc == ERR_ARG:
+            raise ValueError(self.lib.mcba_last_error().decode())
+        self._chk(rc)
+
+    def fuse_status(self):
+        """(number of the last tick whose fused back-substitution gave up waiting for the solve -- 0: never --, fused launch still in use)."""
+        t, f = ctypes.c_double(), ctypes.c_int()
+        self._chk(self.lib.mcba_lm_fuse_status(self.handle, ctypes.byref(t), ctypes.byref(f)))
+        return t.value, bool(f.value)
 
     def jacobian_eval(self, slot, robust_scaled=False):
         self._chk(self.lib.mcba_jacobian_eval(self.handle, slot, int(bool(robust_scaled))))

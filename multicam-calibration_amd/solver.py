@@ -128,13 +128,17 @@ def make_comm(problem, device, group=None, direct=None):
         return HostStagedGloo(group)
     if direct is None:
         direct = os.environ.get("MCBA_DIRECT_RCCL", "1") != "0"
+    why = None
     if direct and hasattr(problem, "comm_init_from_torch"):
         try:
             return DirectRCCL(problem, group)
-        except Exception as e:  # noqa: BLE001 -- any failure: use the torch path
+        except Exception as e:  # noqa: BLE001 -- any failure: use the torch path, and say so in result.lm["collectives"]
+            why = str(e)
             print(f"[mcba] direct RCCL unavailable ({e}); using torch.distributed collectives", flush=True)
     problem.enable_collective(device)
-    return TorchDistributed(group)
+    comm = TorchDistributed(group)
+    comm.fallback_reason = why
+    return comm
 
 
 def _solve_spd(S, rhs):
@@ -158,10 +162,18 @@ class LevenbergMarquardt:
       host-driven (`iterate` itself): decision here as well -- what the CPU test double (tests/fake_problem.py) runs."""
 
     def __init__(self, problem, comm=None, free_cam_mask=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, lam0=1e-4, lam_min=1e-12, lam_max=1e12, speculative=True,
-                 reduced_solver=None, depth=2):
+                 reduced_solver=None, depth=2, x_scale=None):
         self.p = problem
         self.comm = comm or SingleProcess()
         n = problem.n
+        # least_squares' numeric x_scale (this shard's vector, cameras first): the fixed damping matrix D = 1 / x_scale^2 instead
+        # of Marquardt's diag(J^T J).  The backend applies it in the frame blocks and the device solve; the host solve needs D_c here.
+        self.Dc_fixed = None
+        if x_scale is not None:
+            problem.set_x_scale(x_scale)
+            self.Dc_fixed = 1.0 / np.asarray(x_scale, dtype=np.float64)[:n] ** 2
+        elif hasattr(problem, "set_x_scale"):
+            problem.set_x_scale(None)
         self.free = np.ones(n, dtype=bool) if free_cam_mask is None else np.asarray(free_cam_mask, dtype=bool)
         self.all_free = bool(self.free.all())
         self.ftol, self.xtol, self.gtol = ftol, xtol, gtol
@@ -297,7 +309,7 @@ class LevenbergMarquardt:
 
     def _solve_cameras(self, red, lam):
         diagU = red["diagU"]
-        Dc = np.where(diagU > 0, diagU, 1.0)
+        Dc = self.Dc_fixed if self.Dc_fixed is not None else np.where(diagU > 0, diagU, 1.0)
         S = red["S0"]  # damped in place: the buffer is rebuilt before it is used again
         S.flat[:: self.p.n + 1] += lam * Dc
         if red["scal"][2] != 0:  # a frame block failed to factorise
@@ -376,7 +388,7 @@ class LevenbergMarquardt:
             return self._iterate_device()
         lam = self.lam
         diagU = red["diagU"]
-        Dc = np.where(diagU > 0, diagU, 1.0)
+        Dc = self.Dc_fixed if self.Dc_fixed is not None else np.where(diagU > 0, diagU, 1.0)
         S = red["S0"]  # damped in place: the buffer is rebuilt by the next _refresh_system anyway
         S.flat[:: p.n + 1] += lam * Dc
         rhs = red["rhs"]
@@ -469,15 +481,20 @@ class LevenbergMarquardt:
         return OptimizeResult(
             x=x, cost=self.cost, optimality=self.g_inf, nfev=self.nfev, njev=self.njev, status=status, message=TERMINATION_MESSAGES[status],
             success=status > 0, active_mask=np.zeros_like(x),
-            lm=dict(iterations=self.iteration, steps=self.steps, lam=self.lam, slot=self.cur, history=self.history, rebuilds=getattr(self, "rebuilds", 0)),
+            lm=dict(iterations=self.iteration, steps=self.steps, lam=self.lam, slot=self.cur, history=self.history, rebuilds=getattr(self, "rebuilds", 0),
+                    # which collective backend the frame-sharded loop ran on (DirectRCCL, TorchDistributed [+ why direct RCCL was not
+                    # used], HostStagedGloo = rehearsal, SingleProcess) and where the reduced system was solved
+                    collectives=type(self.comm).__name__, collectives_fallback_reason=getattr(self.comm, "fallback_reason", None), world=self.comm.world,
+                    reduced_solver="device" if self.device_solve else "host",
+                    fuse_timeout_tick=(self.p.fuse_status()[0] if self.device_solve and hasattr(self.p, "fuse_status") else 0.0)),
         )
 
 
 def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=1e-4, max_iterations=None, speculative=True,
-             reduced_solver=None):
+             reduced_solver=None, x_scale=None):
     """Minimise the robust reprojection cost from x0 (this shard's flat vector, a7 layout of SURVEY.md).
     `fun` / `jac` / `grad` of the OptimizeResult are attached by api.bundle_adjust."""
-    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative, reduced_solver=reduced_solver)
+    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative, reduced_solver=reduced_solver, x_scale=x_scale)
     if max_nfev is None:
         max_nfev = 100 * np.size(x0)  # trf.py:437-438
     lm.max_nfev, lm.max_steps = max_nfev, max_iterations

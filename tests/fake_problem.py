@@ -9,8 +9,9 @@ from oracle import ba_oracle as orc
 
 
 class OracleProblem:
-    def __init__(self, uvs, objpoints, loss="soft_l1", f_scale=1.0, device=None):
+    def __init__(self, uvs, objpoints, loss="soft_l1", f_scale=1.0, device=None, stream=None):
         self.uvs, self.obj = np.asarray(uvs, float), np.asarray(objpoints, float)
+        self.x_scale = None
         self.C, self.F, self.N = self.uvs.shape[:3]
         self.n = 12 * self.C
         self.nx = self.n + 6 * self.F
@@ -43,6 +44,8 @@ class OracleProblem:
         U, gc, V, gf, W, cost = self.lin
         n = self.n
         Df2 = np.stack([np.where(np.diag(V[f]) > 0, np.diag(V[f]), 1.0) for f in range(self.F)])
+        if self.x_scale is not None:  # numeric x_scale: fixed D = 1 / x_scale^2
+            Df2 = 1.0 / self.x_scale[self.n:].reshape(self.F, 6) ** 2
         S, rhs = orc.schur_reduce(U, gc, V, gf, W, lam, np.zeros((self.C, 12)), Df2)
         r = self._red
         r[:] = 0
@@ -89,6 +92,53 @@ class OracleProblem:
 
     def close(self):
         pass
+
+    def set_x_scale(self, x_scale):
+        self.x_scale = None if x_scale is None else np.asarray(x_scale, float)
+
+    def set_loss(self, loss, f_scale=1.0):
+        self.loss, self.f_scale = loss, f_scale
+
+    # ---- the pre-filter interface of ops.Problem (api.select_frames), in numpy
+    def _errors(self, slot):
+        r = self.uvs - orc.predict_from_x(self.x[slot], self.C, self.obj)
+        return np.sqrt((r ** 2).sum(-1))  # NaN wherever either coordinate is missing, like np.linalg.norm(obs - pred)
+
+    def frame_errors(self, slot):
+        import warnings
+
+        self._err = self._errors(slot)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=RuntimeWarning)
+            mean = np.nanmean(self._err, axis=-1)
+        full = (~np.isnan(self.uvs).any(-1)).sum(-1).astype(float)
+        return mean, full
+
+    def error_median(self, frame_mask=None):
+        e = self._err if frame_mask is None else self._err[:, np.asarray(frame_mask, bool)]
+        v = e[~np.isnan(e)]
+        return (float(np.median(v)) if v.size else float("nan")), int(v.size)
+
+    def error_histogram(self, frame_mask, prefix, pass_):
+        if frame_mask is not None:
+            self._hmask = np.asarray(frame_mask, bool)
+        e = self._err[:, self._hmask]
+        keys = e[~np.isnan(e)].view(np.uint64)
+        if pass_ > 0:
+            keys = keys[(keys >> np.uint64(64 - 8 * pass_)) == np.uint64(prefix)]
+        return np.bincount(((keys >> np.uint64(56 - 8 * pass_)) & np.uint64(255)).astype(np.int64), minlength=256).astype(np.uint64)
+
+    def subset(self, frames, loss=None, f_scale=None):
+        return OracleProblem(self.uvs[:, np.asarray(frames, int)], self.obj, loss or self.loss, self.f_scale if f_scale is None else f_scale)
+
+    def residuals_detach(self, slot):
+        r = self.residuals(slot)
+
+        class _Host:
+            def download(self_inner):
+                return r
+
+        return _Host()
 
     def get_trial(self):
         return self._red[self.nsys :].copy()

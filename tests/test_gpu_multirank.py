@@ -211,3 +211,74 @@ def test_stop_by_max_nfev_after_a_mispredicted_tick_leaves_a_consistent_gradient
     assert abs(res.cost - float(r0["cost"])) <= 1e-12 * res.cost
     np.testing.assert_allclose(r0["x"], res.x, rtol=0, atol=1e-9 * np.abs(res.x).max())
     np.testing.assert_allclose(r0["grad"], res.grad, rtol=0, atol=1e-9 * np.abs(res.grad).max())
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] / configs[4] at (a quarter of) full size, frame-sharded
+def _full_worker(rank, world, port, out_dir, shape, n_frames):
+    sys.path.insert(0, ROOT)
+    import contextlib
+    import io
+    import time
+
+    import torch.distributed as dist
+
+    import multicam_calibration_amd as m
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    C, F, rows, cols = shape
+    p = m.synth.make_problem(C, F, rows=rows, cols=cols, seed=0)
+    np.random.seed(7)   # (rank 0's global RNG draws the subsample; the others' state must not matter)
+    buf = io.StringIO()
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(buf):
+        e, it, ps, use, res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=n_frames, device=0,
+                                              ftol=1e-13, xtol=1e-12, gtol=1e-8, max_nfev=60, verbose=0, distributed=True, return_jac=False)
+    dt = time.perf_counter() - t0
+    hist = np.array([(h[0], h[1], h[2], h[5]) for h in res.lm["history"]])   # nfev, cost before, trial cost, damping: the decisions
+    np.savez(os.path.join(out_dir, f"full{rank}.npz"), cam=res.x[: 12 * C], poses=ps, cost=res.cost, nfev=res.nfev, status=res.status, use=use, hist=hist,
+             printed=np.array(buf.getvalue()), seconds=dt, n_local=len(res.lm["frame_positions"]), collectives=np.array(res.lm["collectives"]), fun_size=res.fun.size)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tag,shape,world,n_frames", [
+    ("config4-6x100000x54", (6, 100000, 6, 9), 4, None),          # BASELINE configs[3]: every frame, four shards of 25 000
+    ("config4-subsample", (6, 100000, 6, 9), 4, 40000),           # the reference's random subsample (n_frames < usable frames): ragged, scattered shards
+    ("config5-24x12500x200", (24, 12500, 10, 20), 4, None),       # a quarter of BASELINE configs[4] (the frames two of its eight GPUs hold), 288 x 288 on-GPU solve
+])
+def test_full_size_frame_sharded_rehearsal(tmp_path, tag, shape, world, n_frames):
+    """SURVEY 7-1's pin for the sharded configs, as far as a one-GPU box allows: the whole problem solved as `world` gloo ranks
+    SHARING the GPU (each uploads and pre-filters only its slice of the frames; collectives host-staged) and as one process --
+    identical decisions on every rank, the same selection, the cost to 1e-10 and the intrinsics to 1e-6.
+    N > 1 RCCL ranks have still never executed (one GPU per box); this is the control flow and the arithmetic, not the fabric."""
+    import contextlib
+    import io
+
+    import torch.multiprocessing as mp
+
+    import multicam_calibration_amd as m
+
+    mp.spawn(_full_worker, args=(world, _free_port(), str(tmp_path), shape, n_frames), nprocs=world, join=True)
+    rs = [np.load(tmp_path / f"full{r}.npz") for r in range(world)]
+    for r in rs[1:]:   # every rank: the same decisions (trial costs and dampings to the bit), the same cameras, the same assembled poses
+        np.testing.assert_array_equal(r["hist"], rs[0]["hist"])
+        np.testing.assert_array_equal(r["cam"], rs[0]["cam"])
+        np.testing.assert_array_equal(r["poses"], rs[0]["poses"])
+        np.testing.assert_array_equal(r["use"], rs[0]["use"])
+        assert float(r["cost"]) == float(rs[0]["cost"]) and int(r["nfev"]) == int(rs[0]["nfev"]) and int(r["status"]) == int(rs[0]["status"])
+        assert str(r["printed"]) == ""
+    assert str(rs[0]["printed"]).startswith("Excluding ") and str(rs[0]["collectives"]) == "HostStagedGloo"
+    assert sum(int(r["n_local"]) for r in rs) == rs[0]["use"].size and all(int(r["n_local"]) > 0 for r in rs)
+    C, F, rows, cols = shape
+    assert all(int(r["fun_size"]) == 2 * C * rows * cols * int(r["n_local"]) for r in rs)   # result.fun covers the rank's own frames
+
+    p = m.synth.make_problem(C, F, rows=rows, cols=cols, seed=0)
+    np.random.seed(7)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=n_frames,
+                                              ftol=1e-13, xtol=1e-12, gtol=1e-8, max_nfev=60, verbose=0, return_jac=False)
+    np.testing.assert_array_equal(use, rs[0]["use"])   # same frames in the same (selection) order, incl. the random subsample
+    assert res.status > 0 and int(rs[0]["status"]) > 0
+    assert abs(res.cost - float(rs[0]["cost"])) <= 1e-10 * res.cost
+    cam_a, cam_b = rs[0]["cam"].reshape(C, 12), res.x[: 12 * C].reshape(C, 12)
+    assert (np.abs(cam_a[:, :6] - cam_b[:, :6]) / np.abs(cam_b[:, :6])).max() < 1e-6   # intrinsics + distortion: gauge-free
+    print(f"[{tag}] sharded {max(float(r['seconds']) for r in rs):.2f} s per rank, nfev {int(rs[0]['nfev'])}, cost {float(rs[0]['cost']):.9g}")

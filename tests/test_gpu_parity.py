@@ -512,7 +512,7 @@ def test_device_loop_max_nfev_and_verbose(mc, capsys):
 
 # ------------------------------------------------------------------ degenerate inputs: same answers as the oracle-driven LM
 @pytest.mark.parametrize("tag", ["blind_camera", "three_frames", "two_point_board", "unseen_frame", "nine_cameras", "ten_cameras"])
-def test_degenerate_inputs_match_oracle_driver(mc, tag):
+def test_degenerate_inputs_match_oracle_driver(mc, tag, monkeypatch):
     """Edge cases of the domain: a camera that never sees the board, fewer frames than a wavefront, a board
     with two points (rank-deficient frame blocks: only the damping keeps them solvable), a frame nobody sees, and the two
     sizes either side of the LDS-resident reduced solve.  Oracle = the same LM driver over the CPU test double."""
@@ -536,7 +536,9 @@ def test_degenerate_inputs_match_oracle_driver(mc, tag):
     kw = dict(n_frames=None, ftol=1e-10, xtol=1e-10, gtol=1e-8, verbose=0, max_nfev=80)
     with contextlib.redirect_stdout(io.StringIO()):
         e, it, ps, use, res = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], return_jac=False, **kw)
-        e2, it2, ps2, use2, ref = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], _backend=OracleProblem, **kw)
+        monkeypatch.setattr(mc.ops, "Problem", OracleProblem)   # the same call on the CPU test double (tests/fake_problem.py)
+        e2, it2, ps2, use2, ref = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], return_jac=False, **kw)
+        monkeypatch.undo()
     np.testing.assert_array_equal(use, use2)
     assert np.isfinite(res.x).all() and res.status > 0 and ref.status > 0
     assert abs(res.cost - ref.cost) <= 1e-8 * ref.cost

@@ -1,0 +1,185 @@
+"""GPU tests of the round-3 additions to the C ABI: buffer pool + lazily allocated solver buffers, the residual vector that stays on
+the device until `result.fun` is read, least_squares' numeric x_scale, the sharded radix select of the pre-filter, and the
+observable poll timeout of the fused back-substitution.  Run with `-m gpu` on an MI355X."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+from fake_problem import OracleProblem
+from oracle import ba_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mc():
+    import multicam_calibration_amd as m
+
+    m.ops.load_library()
+    return m
+
+
+@contextlib.contextmanager
+def env(**kv):
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update({k: str(v) for k, v in kv.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def quiet(f, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return f(*a, **k)
+
+
+# ------------------------------------------------------------------ result.fun: on the device until read; handles come from the pool
+def test_lazy_fun_outlives_the_handle_and_matches_the_oracle(mc):
+    p = mc.synth.make_problem(3, 70, seed=5, missing=0.2, scalar_nans=4)
+    kw = dict(n_frames=None, ftol=1e-10, verbose=0, return_jac=False)
+    e, it, ps, use, res = quiet(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], **kw)
+    assert isinstance(dict.get(res, "fun"), mc.api._Lazy)           # nothing downloaded yet; the Problem is closed by now
+    again = [quiet(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], **kw)[4] for _ in range(3)]   # pooled buffers are re-used
+    f = orc.residuals(res.x, p["uvs"][:, use], p["obj"])
+    np.testing.assert_allclose(res.fun, f, rtol=0, atol=1e-9)        # NaN scalars removed, (C,F,N,2) order
+    assert not isinstance(dict.get(res, "fun"), mc.api._Lazy)
+    for r in again:
+        np.testing.assert_array_equal(r.x, res.x)                     # recycled (not re-zeroed) buffers change nothing
+        np.testing.assert_array_equal(r.fun, res.fun)
+    full = quiet(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=1e-10, verbose=0)[4]
+    np.testing.assert_array_equal(full.fun, res.fun)                 # return_jac=True: the materialising kernel's residuals
+    mc.ops.pool_trim()
+    r2 = quiet(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], **kw)[4]
+    np.testing.assert_array_equal(r2.x, res.x)
+
+
+def test_prefilter_handle_allocates_no_solver_buffers(mc):
+    """a handle that only scores frames holds the observations, not 2 x F x C x 800 B of records."""
+    import torch
+
+    p = mc.synth.make_problem(6, 20000, seed=1)
+    mc.ops.pool_trim()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    prob = mc.ops.Problem(p["uvs"], p["obj"])
+    prob.set_params(0, mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"]))
+    mean, full = prob.frame_errors(0)
+    med = prob.error_median(None)[0]
+    used = free0 - torch.cuda.mem_get_info()[0]
+    obs = 2 * 6 * 20000 * 54 * 16
+    assert used < obs + 0.6 * obs, (used, obs)      # two observation layouts + the per-point errors; records alone would add 2 x 96 MB
+    assert np.isfinite(med) and mean.shape == (6, 20000)
+    prob.linearize(0)                                # the first solver call allocates the rest
+    assert free0 - torch.cuda.mem_get_info()[0] > used + 150e6
+    prob.close()
+
+
+# ------------------------------------------------------------------ sharded radix select == the single-handle median
+@pytest.mark.parametrize("shards", [2, 3])
+def test_error_histograms_of_frame_shards_give_the_exact_median(mc, shards):
+    p = mc.synth.make_problem(4, 333, seed=11, missing=0.25, scalar_nans=9)
+    x = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    mask = np.random.default_rng(3).uniform(size=333) < 0.7
+    whole = mc.ops.Problem(p["uvs"], p["obj"])
+    whole.set_params(0, x)
+    whole.frame_errors(0)
+    want = whole.error_median(mask)[0]
+    whole.close()
+    bounds = mc.api._split_bounds(333, shards)
+    probs = []
+    for r in range(shards):
+        lo, hi = bounds[r], bounds[r + 1]
+        q = mc.ops.Problem(p["uvs"][:, lo:hi], p["obj"])
+        q.set_params(0, np.concatenate([x[:48], x[48 + 6 * lo:48 + 6 * hi]]))
+        q.frame_errors(0)
+        probs.append((q, mask[lo:hi]))
+    first = {"v": True}
+
+    def hist(prefix, pas):
+        h = sum(q.error_histogram(m if first["v"] else None, prefix, pas).astype(np.int64) for q, m in probs)
+        first["v"] = False
+        return h
+
+    got = mc.api._median_from_histograms(hist)
+    for q, _ in probs:
+        q.close()
+    assert got == want                                # bit for bit: integer counts, whatever the sharding
+    err = np.sqrt(((p["uvs"] - orc.predict_from_x(x, 4, p["obj"])) ** 2).sum(-1))[:, mask]
+    assert abs(got - np.nanmedian(err)) <= 1e-10
+
+
+# ------------------------------------------------------------------ numeric x_scale: same iterates as the oracle-driven LM
+@pytest.mark.parametrize("reduced_solver", ["device", "host"])
+@pytest.mark.parametrize("scalar", [False, True])
+def test_numeric_x_scale_matches_the_oracle_driven_lm(mc, reduced_solver, scalar):
+    """least_squares' x_scale as a fixed damping matrix D = 1 / x_scale^2 (bundle_adjustment.py:301-304 forwards it): the GPU
+    loop against the same LM driver on the CPU oracle (tests/fake_problem.py) -- the same sequence of trial costs and dampings."""
+    C, F = 3, 40
+    p = mc.synth.make_problem(C, F, seed=21, missing=0.15)
+    x0 = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    if scalar:
+        xs = np.full(x0.size, 0.5)
+    else:
+        xs = np.concatenate([np.tile([100.0, 100.0, 50.0, 50.0, 0.05, 0.05, 0.01, 0.02, 0.01, 5.0, 4.0, 5.0], C), np.tile([0.01, 0.01, 0.02, 5.0, 5.0, 3.0], F)])
+    kw = dict(ftol=0.0, xtol=1e-13, gtol=1e-9, max_nfev=60, x_scale=xs)
+    ref = mc.solver.lm_solve(OracleProblem(p["uvs"], p["obj"]), x0, **kw)
+    prob = mc.ops.Problem(p["uvs"], p["obj"])
+    got = mc.solver.lm_solve(prob, x0, reduced_solver=reduced_solver, **kw)
+    jac = mc.solver.lm_solve(prob, x0, reduced_solver=reduced_solver, ftol=0.0, xtol=1e-13, gtol=1e-9, max_nfev=60)   # back to 'jac' on the same handle
+    prob.close()
+    ha, hb, hj = np.array(ref.lm["history"]), np.array(got.lm["history"]), np.array(jac.lm["history"])
+    n = min(len(ha), len(hb), 12)
+    assert n >= 5
+    np.testing.assert_allclose(hb[:n, 1:3], ha[:n, 1:3], rtol=1e-9)    # cost before / after every trial step
+    np.testing.assert_allclose(hb[:n, 5], ha[:n, 5], rtol=1e-6)        # the damping schedule (a function of the gain ratios)
+    assert not np.allclose(hj[:3, 2], hb[:3, 2], rtol=1e-6)            # ... and it is not the 'jac' path
+    assert abs(got.cost - ref.cost) <= 1e-9 * ref.cost and abs(jac.cost - ref.cost) <= 1e-9 * ref.cost
+
+
+def test_bundle_adjust_accepts_x_scale_like_scipy(mc):
+    p = mc.synth.make_problem(2, 30, seed=4)
+    kw = dict(n_frames=None, verbose=0, return_jac=False, ftol=1e-12, xtol=1e-12, outlier_threshold=1e9)
+    a = quiet(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], **kw)[4]
+    b = quiet(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], x_scale=2.0, **kw)[4]
+    assert abs(a.cost - b.cost) <= 1e-9 * a.cost
+    with pytest.raises(ValueError, match="positive numbers"):
+        quiet(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], x_scale=-1.0, **kw)
+    with pytest.raises(ValueError, match="Inconsistent shapes"):
+        quiet(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], x_scale=np.ones(7), **kw)
+
+
+# ------------------------------------------------------------------ a poll that runs out is observable and harmless
+@pytest.mark.parametrize("shape", [(6, 300, {}), (3, 130, dict(missing=0.2, outlier_frames=4))])
+def test_fused_backsub_poll_timeout_is_observable_and_harmless(mc, shape):
+    """MCBA_FUSE_MAX_POLLS=0: every back-substitution workgroup of k_solve_backsub that does not find the solve's word at its
+    first look gives up.  The stale trial points are discarded ON THE DEVICE (the next tick only rebuilds the system), the host
+    switches to the two-launch path, and the iterates are those of the unfused loop to the last bit."""
+    C, F, extra = shape
+    p = mc.synth.make_problem(C, F, seed=80 + C, **extra)
+    p["poses"][::7, 3:] += 40.0                                   # rejected steps and growing damping on the way
+    x0 = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    out = {}
+    for tag, e in (("timeout", dict(MCBA_FUSE_MAX_POLLS=0)), ("unfused", dict(MCBA_FUSE_BACKSUB=0)), ("fused", {})):
+        with env(**e):
+            prob = mc.ops.Problem(p["uvs"], p["obj"])
+            res = mc.solver.lm_solve(prob, x0, ftol=1e-12, xtol=1e-12, gtol=1e-9, max_nfev=120)
+            out[tag] = (res, prob.fuse_status())
+            prob.close()
+    (a, sa), (b, sb), (c, sc) = out["timeout"], out["unfused"], out["fused"]
+    assert sa[0] > 0 and sa[1] is False                           # it happened, it was seen, the handle left the fused path
+    assert sb == (0.0, False) and sc == (0.0, True)
+    assert a.lm["fuse_timeout_tick"] > 0 and c.lm["fuse_timeout_tick"] == 0
+    assert a.lm["rebuilds"] >= 1 and b.lm["rebuilds"] == 0        # the discarded trial points cost rebuild-only ticks, nothing else
+    assert a.status == b.status and a.nfev == b.nfev and a.lm["iterations"] == b.lm["iterations"]
+    np.testing.assert_array_equal(a.x, b.x)
+    assert a.cost == b.cost
+    np.testing.assert_array_equal(np.array(a.lm["history"]), np.array(b.lm["history"]))
+    np.testing.assert_array_equal(c.x, b.x)

@@ -127,12 +127,25 @@ def test_wrapper_serialization_and_structure(golden):
 
 
 # ------------------------------------------------------------------ explicit None tolerances (scipy: None -> 0 = test disabled)
-def test_none_tolerance_disables_the_test_like_scipy():
+def test_public_signature_has_no_private_hooks():
+    """the test double is injected by monkeypatching ops.Problem, not through the product's signature."""
+    import inspect
+
+    for fn in (api.bundle_adjust, api.select_frames):
+        assert not [n for n in inspect.signature(fn).parameters if n.startswith("_") or n == "backend"]
+    src = inspect.getsource(api)
+    assert "_backend=" not in src and "OracleProblem" not in src and "fake_problem" not in src
+
+
+def test_none_tolerance_disables_the_test_like_scipy(monkeypatch):
     import contextlib
     import io
 
+    from multicam_calibration_amd import ops
+
+    monkeypatch.setattr(ops, "Problem", OracleProblem)
     p = synth.make_problem(2, 12, seed=3)
-    kw = dict(n_frames=None, verbose=0, _backend=OracleProblem, max_nfev=60)
+    kw = dict(n_frames=None, verbose=0, return_jac=False, max_nfev=60)
     with contextlib.redirect_stdout(io.StringIO()):
         d = api.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], **kw)[4]               # reference default ftol = 1e-4
         n = api.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], ftol=None, **kw)[4]    # ftol test off
@@ -289,23 +302,28 @@ def _ba_worker(rank, world, port, out_dir):
 
     import torch.distributed as dist
 
+    from multicam_calibration_amd import ops
+
+    ops.Problem = OracleProblem   # this process only: the CPU test double stands in for libmcba
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     p = synth.make_problem(3, 41, seed=9, missing=0.15, outlier_frames=3)   # 41: ragged shards
     np.random.seed(100 + rank)   # different global RNG state per rank: only rank 0's may matter
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         e, it, ps, use, res = api.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=30,
-                                                 ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, distributed=True, _backend=OracleProblem)
+                                                 ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, distributed=True, return_jac=False)
     np.savez(os.path.join(out_dir, f"ba{rank}.npz"), ext=e, poses=ps, use=use, x=res.x, cost=res.cost, grad=res.grad, printed=np.array(buf.getvalue()),
              K=np.stack([k for k, _ in it]), dist=np.stack([d for _, d in it]))
     dist.destroy_process_group()
 
 
-def test_bundle_adjust_distributed_two_ranks(tmp_path):
+def test_bundle_adjust_distributed_two_ranks(tmp_path, monkeypatch):
     import contextlib
     import io
 
     import torch.multiprocessing as mp
+
+    from multicam_calibration_amd import ops
 
     port = _free_port()
     mp.spawn(_ba_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
@@ -317,11 +335,12 @@ def test_bundle_adjust_distributed_two_ranks(tmp_path):
     assert str(r0["printed"]).startswith("Excluding ") and str(r1["printed"]) == ""
     assert r0["use"].shape == (30,) and r0["poses"].shape == (30, 6) and r0["x"].shape == (36 + 180,)
     # the same call in one process with rank 0's RNG state selects the same frames and reaches the same optimum
+    monkeypatch.setattr(ops, "Problem", OracleProblem)
     p = synth.make_problem(3, 41, seed=9, missing=0.15, outlier_frames=3)
     np.random.seed(100)
     with contextlib.redirect_stdout(io.StringIO()):
         e, it, ps, use, res = api.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=30,
-                                                 ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, _backend=OracleProblem)
+                                                 ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, return_jac=False)
     np.testing.assert_array_equal(use, r0["use"])
     assert abs(res.cost - float(r0["cost"])) <= 1e-10 * res.cost
     pa = orc.predict_from_x(r0["x"], 3, p["obj"])
