@@ -32,17 +32,19 @@ def is_stale():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> multicam-calibration_amd/libmcba.so (cross-compiles without a GPU)."""
-    if not force and not is_stale():
+def build(force=False, verbose=False, out=None):
+    """hipcc --offload-arch=gfx950 -> multicam-calibration_amd/libmcba.so (cross-compiles without a GPU).
+    out: another output path (development: A/B builds for scripts/gram_ab.py, selected at run time with MCBA_LIB)."""
+    if out is None and not force and not is_stale():
         return LIB
     extra = os.environ.get("MCBA_HIPCC_FLAGS", "").split()  # development only (e.g. -DMCBA_SOLVE_TIMING, -save-temps)
-    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", LIB, "-ldl"] + SCHED_FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", out or LIB, "-ldl"] + SCHED_FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+    print(build(force="--force" in sys.argv, verbose=True, out=out))

@@ -110,6 +110,13 @@ __device__ __forceinline__ void post_state(const SolveArgs& a, const double* st,
 #define STAMP(k) do { } while (0)
 #endif
 
+// look-ahead panel products (LDS-resident factor): one more npad x 17 buffer -- there is room for it up to 8 cameras next to
+// k_solve_backsub's back-substitution scratch (160 KB per workgroup)
+#ifndef MCBA_SOLVE_LOOKAHEAD
+#define MCBA_SOLVE_LOOKAHEAD 1
+#endif
+__host__ __device__ inline bool solve_lookahead(int npad) { return MCBA_SOLVE_LOOKAHEAD && npad <= 96; }
+
 // Staging of the reduce buffer: thread (rr, cc) = (tid / 16, tid % 16) owns the elements (rr + RS a, cc + 16 b) --
 // all index arithmetic is incremental, every load is unconditional (clamped address) so none of them waits for another.
 // KS x KS elements per thread cover npad <= 16 KS with 256 threads (KS = 5: up to 6 cameras, KS = 7: up to 9).
@@ -134,6 +141,9 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
   double* W = LDSW ? (lst + MCBA_LMS) : a.work;        // npad rows, row-major: the factor L (lower part)
   const int ldw = LDSW ? npad + 1 : npad;              // odd row stride in LDS: rows land in different banks
   double* linv = W + (size_t)npad * ldw;               // LDSW: nblk x 16 x 17, the inverse transposes of the diagonal blocks of L
+  double* pnext = linv + (size_t)nblk * 16 * 17;       // LDSW, look-ahead: npad x 17, the next panel's products with the columns that are already final
+  constexpr int kLookWave = 2;                         // the wavefront that is idle in the diagonal phase (NW = 4, <= 7 tiles)
+  const bool lookahead = LDSW && NW == 4 && solve_lookahead(npad);
   double* Bs = lst + MCBA_LMS;                         // !LDSW: 16 x bst, the panel's own rows of L (the MFMA B operand)
   const int bst = npad + 2;                            // bst / 2 odd: conflict-free 16-byte LDS reads
 #ifdef MCBA_SOLVE_TIMING
@@ -284,12 +294,20 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
       const int r0 = 16 * k, ntile = nblk - k;
       if (k > 0) {
         if (LDSW) {
-          for (int t = wave; t < ntile; t += NW) {  // panel update, one 16x16 tile per wavefront pass
+          // panel update, one 16x16 tile per wavefront pass.  With look-ahead (below) only the K-chunk of the block column
+          // factorised LAST remains to be multiplied here: the products with all earlier columns were formed during that block's
+          // diagonal phase and wait in `pnext`.
+          const int p_lo = lookahead ? r0 - 16 : 0;
+          for (int t = wave; t < ntile; t += NW) {
             const int R = r0 + 16 * t;
             solve_d4 acc = {0.0, 0.0, 0.0, 0.0};
+            if (lookahead && k > 1) {
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) acc[reg] = pnext[(16 * t + 4 * reg + (lane >> 4)) * 17 + (lane & 15)];
+            }
             const double* pa = W + (size_t)(R + (lane & 15)) * ldw + (lane >> 4);
             const double* pb = W + (size_t)(r0 + (lane & 15)) * ldw + (lane >> 4);
-            for (int p = 0; p < r0; p += 16) {  // r0 is a multiple of 16: four operand pairs in flight
+            for (int p = p_lo; p < r0; p += 16) {  // r0 is a multiple of 16: four operand pairs in flight
               double av[4], bv[4];
 #pragma unroll
               for (int u = 0; u < 4; ++u) { av[u] = pa[p + 4 * u]; bv[u] = pb[p + 4 * u]; }
@@ -350,6 +368,26 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
       // the rows of the 16 x 16 IDENTITY through the same triangular solve: what comes out is L_kk^-T, which turns the
       // 16 sequential pivots of this block in the backward sweep into one 16-term dot product per row.
       const bool idrow = LDSW && wave == NW - 1 && lane >= 48;
+      if (lookahead && wave == kLookWave && k >= 1 && k + 1 < nblk) {
+        // LOOK-AHEAD: this wavefront has no rows in the diagonal phase (<= 7 tiles: wavefronts 0, 1 and the last one do) -- while
+        // wavefront 0 walks the 16 sequential pivots of block k it forms, for block k + 1, the products with every column that is
+        // already final (p < r0); after the barrier only the 16 columns of block k are missing (four MFMAs per tile, above)
+        const int r1 = r0 + 16;
+        const double* pb = W + (size_t)(r1 + (lane & 15)) * ldw + (lane >> 4);
+        for (int t = 0; t < ntile - 1; ++t) {
+          solve_d4 acc = {0.0, 0.0, 0.0, 0.0};
+          const double* pa = W + (size_t)(r1 + 16 * t + (lane & 15)) * ldw + (lane >> 4);
+          for (int p = 0; p < r0; p += 16) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = pa[p + 4 * u]; bv[u] = pb[p + 4 * u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) pnext[(16 * t + 4 * reg + (lane >> 4)) * 17 + (lane & 15)] = acc[reg];
+        }
+      }
       if (wave == 0 || 16 + 48 * wave < 16 * ntile || (LDSW && wave == NW - 1)) {  // wavefronts whose rows are all past the end sit this panel out
         const bool rv = q < 16 * ntile;
         double r[16];
@@ -369,6 +407,9 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
         double myinv = 1.0;
         // left-looking: column j of every row is finished at step j; L[r0+j][q'] (q' < j) is lane j's finished r[q'].
         // A non-positive pivot turns into NaN / inf here and surfaces as a non-finite step below.
+        // (Round 3, measured and withdrawn: lane j carrying its pivot-to-be a_jj - sum L[j][q]^2 as a running accumulator, so that
+        // only ONE broadcast sits on the dependent chain per pivot -- 23.2 k instead of 21.3 k cycles for this phase at 12C = 72:
+        // the stream is bound by its 616 instructions per block, 240 of them v_readlane, not by the chain.)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           double s0 = 0.0, s1 = 0.0;
@@ -567,7 +608,7 @@ int solve_threads(int npad) {
 
 size_t solve_lds_bytes(int npad, int use_lds) {
   size_t d = (size_t)npad * 17 + 4 * (size_t)npad + 72 + MCBA_LMS;
-  d += use_lds ? (size_t)npad * (npad + 1) + (size_t)(npad / 16) * 16 * 17 : (size_t)16 * (npad + 2);
+  d += use_lds ? (size_t)npad * (npad + 1) + (size_t)(npad / 16) * 16 * 17 + (solve_lookahead(npad) ? (size_t)npad * 17 : 0) : (size_t)16 * (npad + 2);
   return d * sizeof(double);
 }
 
