@@ -90,10 +90,7 @@ __global__ __launch_bounds__(256) void k_triangulate(const double2* __restrict__
     uy[c] = fma(y, fy, cy);
   }
   double X[NP], Y[NP], Z[NP];
-  // np.nanmedian drops NaN per coordinate (geometry.py:432): a pair whose null vector has x[3] == 0 gives NaN (0/0) or +-inf --
-  // the NaNs do not count, the infinities do.  Dropped entries sort to the end as +inf (ties with a real +inf are harmless: the
-  // value picked is +inf either way) and every coordinate has its own count.
-  int nx = 0, ny = 0, nz = 0;
+  int n = 0;
   {
     int k = 0;
 #pragma unroll
@@ -118,17 +115,19 @@ __global__ __launch_bounds__(256) void k_triangulate(const double2* __restrict__
         double x[4];
         null_vector4(a, x);
         const double iw = 1.0 / x[3];
-        const double big = __builtin_inf();
+        const double big = 1e300;  // invalid pairs sort to the end
+        // (a pair whose null vector has x[3] == 0 -- a point at infinity for that pair -- gives NaN or +-inf: such a pair does not
+        // count at all, in any coordinate; np.nanmedian drops the NaNs per coordinate, geometry.py:432)
         const double vx = x[0] * iw, vy = x[1] * iw, vz = x[2] * iw;
-        const bool kx = both && vx == vx, ky = both && vy == vy, kz = both && vz == vz;
-        X[k] = kx ? vx : big;
-        Y[k] = ky ? vy : big;
-        Z[k] = kz ? vz : big;
-        nx += kx ? 1 : 0; ny += ky ? 1 : 0; nz += kz ? 1 : 0;
+        const bool keep = both && fabs(vx) < big && fabs(vy) < big && fabs(vz) < big;
+        X[k] = keep ? vx : big;
+        Y[k] = keep ? vy : big;
+        Z[k] = keep ? vz : big;
+        n += keep ? 1 : 0;
       }
   }
   // per-coordinate nan-median: sort (odd-even transposition network, NP passes), pick the middle (or the mean of two)
-  auto median = [&](double (&v)[NP], int n) {
+  auto median = [&](double (&v)[NP]) {
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass)
 #pragma unroll
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(256) void k_triangulate(const double2* __restrict__
     for (int k = 0; k < NP; ++k) { m0 = k == i0 ? v[k] : m0; m1 = k == i1 ? v[k] : m1; }
     return n > 0 ? 0.5 * (m0 + m1) : __builtin_nan("");
   };
-  const double mx = median(X, nx), my = median(Y, ny), mz = median(Z, nz);
+  const double mx = median(X), my = median(Y), mz = median(Z);
   out[3 * p] = mx; out[3 * p + 1] = my; out[3 * p + 2] = mz;
 }
 
@@ -187,8 +186,8 @@ __global__ __launch_bounds__(256) void k_triangulate_wave(const double2* __restr
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  const double big = __builtin_inf();  // dropped entries (invalid pair, or a NaN coordinate: np.nanmedian) sort to the end
-  int nloc[3] = {0, 0, 0};
+  const double big = 1e300;  // invalid pairs sort to the end
+  int nloc = 0;
   for (int k = lane; k < NP; k += 64) {
     // pair k -> (i, j), i < j, in the order (0,1), (0,2), ..., (0,C-1), (1,2), ...
     int i = 0, rem = k;
@@ -214,27 +213,24 @@ __global__ __launch_bounds__(256) void k_triangulate_wave(const double2* __restr
     double xh[4];
     null_vector4(a, xh);
     const double iw = 1.0 / xh[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const double v = xh[d] * iw;
-      const bool keep = both && v == v;
-      XYZ[d * NP + k] = keep ? v : big;
-      nloc[d] += keep ? 1 : 0;
-    }
+    const double vx = xh[0] * iw, vy = xh[1] * iw, vz = xh[2] * iw;
+    const bool keep = both && fabs(vx) < big && fabs(vy) < big && fabs(vz) < big;   // (see k_triangulate: NaN / infinite results do not count)
+    XYZ[k] = keep ? vx : big;
+    XYZ[NP + k] = keep ? vy : big;
+    XYZ[2 * NP + k] = keep ? vz : big;
+    nloc += keep ? 1 : 0;
   }
+  int n = nloc;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) nloc[d] += __shfl_xor(nloc[d], off, 64);
-  }
+  for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off, 64);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int i0 = (n - 1) >> 1, i1 = n >> 1;
   double res[3];
   for (int d = 0; d < 3; ++d) {
-    const int n = nloc[d], i0 = (n - 1) >> 1, i1 = n >> 1;   // per coordinate: NaNs of this coordinate do not count
     const double* v = XYZ + d * NP;
-    if (lane < 2) mm[lane] = __builtin_nan("");
+    if (lane < 2) mm[lane] = __builtin_nan("");   // (never read stale: the two middle ranks exist whenever n > 0)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
