@@ -596,13 +596,14 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 constexpr int kSyrkSuper = 32;  // frames factorised per super-stage: 32 frames x 8 parts of their V / g_f entries = the 256 threads
 
-template <int PPW, int IPT, bool DECIDE>
+template <int PPW, int IPT, bool DECIDE, bool XS>
 __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse fz, const double* __restrict__ rec0, const double* __restrict__ rec1, double* __restrict__ fbuf, double* __restrict__ fpart,
                                               const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int sq, int sr, int FS,
                                               const double* __restrict__ dscale) {
   extern __shared__ __align__(16) double lds[];
   __shared__ double s_st[MCBA_LMS];
   __shared__ double s_sum[8];
+  __shared__ double s_tw;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: keeps the tile bookkeeping out of the exec mask
 #ifdef MCBA_SYRK_TIMING
@@ -610,6 +611,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
 #endif
   const bool have_state = sl.lms != nullptr;
   if (have_state && t < MCBA_LMS) s_st[t] = sl.lms[t];
+  if (DECIDE && t == MCBA_LMS) s_tw = fz.timeout_word ? *fz.timeout_word : -1.0;  // (in flight with the state: not a round trip of its own before the decision)
   if (DECIDE) {
     // trial scalars: wavefront 0 the robust cost of the trial point (BOTH linearisation buffers are summed -- which one holds
     // the trial point depends on the state, and a dependent round trip costs more than the few KB), wavefronts 1..3 the
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   if (DECIDE) {
     if (t == 0) {
       // (a back-substitution workgroup of the previous tick's k_solve_backsub gave up waiting: this tick's trial point is stale)
-      const bool stale = fz.timeout_word && *fz.timeout_word == fz.seq_prev && fz.seq_prev > 0.0;
+      const bool stale = s_tw == fz.seq_prev && fz.seq_prev > 0.0;
       if (s_st[MCBA_LM_SKIP] != 0.0 || stale) lm_mark_rebuild(s_st);  // the reduced solve had failed: this tick only rebuilds the system
       else {
         const bool trial1 = ((static_cast<int>(s_st[3]) ^ 1) & 1) != 0;  // the trial linearisation lives in the buffer that is not current
@@ -772,7 +774,9 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
       for (int k = 0; k < 6; ++k) {
         double d = V[tri6(k, k)];
         // Marquardt scaling D = diag(J^T J) (x_scale = 'jac'), or the caller's fixed D = 1 / x_scale^2 (numeric x_scale)
-        D[k] = dscale ? dscale[(size_t)12 * C + 6 * (size_t)(s0 + lane) + k] : (d > 0.0 ? d : 1.0);
+        // (XS is a template parameter because even a never-taken vector load here costs the default kernel 1.5 us: the wait
+        // for it is also a wait for the next stage's prefetched W rows -- vmcnt retires in order)
+        D[k] = XS ? dscale[(size_t)12 * C + 6 * (size_t)(s0 + lane) + k] : (d > 0.0 ? d : 1.0);
         V[tri6(k, k)] = d + lambda * D[k];
       }
       double Lp[21], id[6], z[6];
@@ -1285,8 +1289,10 @@ void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, 
 #define SYRK_GO(PPW, IPT, GY)                                                                                                                                   \
   do {                                                                                                                                                          \
     dim3 grid(G, GY);                                                                                                                                           \
-    if (fz.decide) k_syrk<PPW, IPT, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);   \
-    else k_syrk<PPW, IPT, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);            \
+    if (fz.decide && dscale) k_syrk<PPW, IPT, true, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);    \
+    else if (fz.decide) k_syrk<PPW, IPT, true, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);      \
+    else if (dscale) k_syrk<PPW, IPT, false, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);         \
+    else k_syrk<PPW, IPT, false, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);                    \
   } while (0)
   // items per thread: (12C + 1) rows x FS frames over 256 threads -- 3 is enough up to 7 cameras at 8 frames per stage
   // (fewer prefetch registers: the kernel stays within 256 registers, two workgroups per CU, without scratch)
@@ -1331,9 +1337,10 @@ void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs
 
 int syrk_set_lds_limit(size_t bytes) {
   int rc = 0;
-  const void* ks[] = {reinterpret_cast<const void*>(k_syrk<4, SYRK_IPT, false>), reinterpret_cast<const void*>(k_syrk<4, SYRK_IPT, true>),
-                      reinterpret_cast<const void*>(k_syrk<4, SYRK_IPT_SMALL, false>), reinterpret_cast<const void*>(k_syrk<4, SYRK_IPT_SMALL, true>),
-                      reinterpret_cast<const void*>(k_syrk<16, SYRK_IPT, false>), reinterpret_cast<const void*>(k_syrk<16, SYRK_IPT, true>)};
+#define SYRK_K(P, I) reinterpret_cast<const void*>(k_syrk<P, I, false, false>), reinterpret_cast<const void*>(k_syrk<P, I, true, false>), \
+                     reinterpret_cast<const void*>(k_syrk<P, I, false, true>), reinterpret_cast<const void*>(k_syrk<P, I, true, true>)
+  const void* ks[] = {SYRK_K(4, SYRK_IPT), SYRK_K(4, SYRK_IPT_SMALL), SYRK_K(16, SYRK_IPT)};
+#undef SYRK_K
   for (const void* k : ks) {
     int r = (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     rc = rc ? rc : r;

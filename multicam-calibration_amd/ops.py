@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libmcba.so")
+LIB_PATH = os.environ.get("MCBA_LIB") or os.path.join(PKG, "libmcba.so")   # MCBA_LIB: another build of the same ABI (development A/B runs)
 
 LOSSES = {"linear": 0, "soft_l1": 1, "huber": 2, "cauchy": 3, "arctan": 4}
 OK, ERR_HIP, ERR_ARG, ERR_NONFINITE, ERR_NODEVICE = 0, 1, 2, 3, 4

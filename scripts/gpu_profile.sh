@@ -1,17 +1,29 @@
 #!/bin/bash
-# Standard measurement set on the GPU box (run through gpurun from the repo root):
-#   scripts/gpu_profile.sh TAG   -> gpurun_out/TAG_bench.json, TAG_stats/ (rocprofv3 kernel stats of the default bench),
-#                                   TAG_pmc_{fetch,write,sq}/ (three separate counter passes), TAG_pmc_summary.json
+# The measurement set behind every number in DESIGN.md (run through gpurun from the repo root):
+#   scripts/gpu_profile.sh TAG   ->  gpurun_out/TAG_*  ; then  python3 scripts/store_profiles.py TAG roundN  copies the summaries to profiles/roundN/
+#   bench line (with end_to_end + roofline), rocprofv3 kernel stats of the SAME command, four separate counter passes over a fixed launch
+#   sequence (FETCH_SIZE; WRITE_SIZE; SQ busy / wait; FP64 instruction mix), the frame-sharded tick with a one-rank RCCL communicator,
+#   the user-level call's wall-clock breakdown, the other shapes DESIGN quotes.
 set -e -o pipefail
 TAG=${1:-run}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py --no-cpu-baseline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --no-cpu-baseline > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err
+echo "bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --no-cpu-baseline --no-end-to-end > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err
+echo "kernel stats done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 scripts/profile_kernels.py > $OUT/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 scripts/profile_kernels.py > $OUT/${TAG}_pmc_write.log 2>&1
+echo "hbm counters done"
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS --output-format csv -d $OUT/${TAG}_pmc_sq -- python3 scripts/profile_kernels.py > $OUT/${TAG}_pmc_sq.log 2>&1
-python3 scripts/pmc_summary.py $OUT/${TAG}_pmc_summary.json $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq > $OUT/${TAG}_pmc_summary.log
+rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/${TAG}_pmc_f64 -- python3 scripts/profile_kernels.py > $OUT/${TAG}_pmc_f64.log 2>&1
+echo "sq counters done"
+python3 scripts/pmc_summary.py $OUT/${TAG}_pmc_summary.json $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_f64 > $OUT/${TAG}_pmc_summary.log
 find $OUT/${TAG}_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
+MCBA_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_dist_stats -- python3 bench.py --no-cpu-baseline --no-end-to-end > $OUT/${TAG}_dist_bench.json 2> $OUT/${TAG}_dist.err
+find $OUT/${TAG}_dist_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_dist_kernel_stats.csv \;
+echo "forced-dist done"
+python3 scripts/e2e_breakdown.py > $OUT/${TAG}_e2e_breakdown.json 2> $OUT/${TAG}_e2e.err
+python3 scripts/other_shapes.py > $OUT/${TAG}_other_shapes.json 2> $OUT/${TAG}_shapes.err
 echo "profile set $TAG done"

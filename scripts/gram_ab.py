@@ -8,6 +8,11 @@ import sys, time
 sys.path.insert(0, ".")
 import multicam_calibration_amd as m
 m.ops.LIB_PATH = sys.argv[1]
+import ctypes
+_l = ctypes.CDLL(sys.argv[1])
+m.ops.SYMBOLS = [s for s in m.ops.SYMBOLS if hasattr(_l, s[0])]   # (an older build of the ABI: bind what it has)
+if not hasattr(_l, "mcba_set_x_scale"):
+    m.ops.Problem.set_x_scale = lambda self, x: None
 C, F = 6, 10000
 p = m.synth.make_problem(C, F, seed=0)
 x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])

@@ -1,10 +1,12 @@
-"""Copy one profile set of scripts/gpu_profile.sh from gpurun_out/ into profiles/roundN/ and derive profiles/pmc_traffic.json.
+"""Copy one profile set of scripts/gpu_profile.sh from gpurun_out/ into profiles/roundN/ and derive profiles/pmc_traffic.json
+and profiles/gram_flops.json (the two files bench.py reads).
 
-    python3 scripts/store_profiles.py TAG ROUND_DIR      e.g.  v14 round2
+    python3 scripts/store_profiles.py TAG ROUND_DIR      e.g.  v3 round3
 """
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,9 +16,13 @@ def main(tag, rnd):
     src = os.path.join(ROOT, "gpurun_out")
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
-    shutil.copy(os.path.join(src, f"{tag}_bench.json"), os.path.join(dst, f"bench_{tag}.json"))
-    shutil.copy(os.path.join(src, f"{tag}_kernel_stats.csv"), os.path.join(dst, f"bench_default_kernel_stats_{tag}.csv"))
-    shutil.copy(os.path.join(src, f"{tag}_pmc_summary.json"), os.path.join(dst, f"pmc_{tag}_summary.json"))
+    for a, b in ((f"{tag}_bench.json", f"bench_{tag}.json"), (f"{tag}_kernel_stats.csv", f"bench_default_kernel_stats_{tag}.csv"), (f"{tag}_pmc_summary.json", f"pmc_{tag}_summary.json"),
+                 (f"{tag}_dist_kernel_stats.csv", f"forced_dist_kernel_stats_{tag}.csv"), (f"{tag}_dist_bench.json", f"forced_dist_bench_{tag}.json"),
+                 (f"{tag}_e2e_breakdown.json", f"e2e_breakdown_{tag}.json"), (f"{tag}_other_shapes.json", f"other_shapes_{tag}.json")):
+        if os.path.exists(os.path.join(src, a)):
+            shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+        else:
+            print("missing:", a)
     summary = json.load(open(os.path.join(src, f"{tag}_pmc_summary.json")))
     keys = ("dispatches", "hbm_bytes_per_launch", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch")
     traffic = {k: {q: v[q] for q in keys if q in v} for k, v in summary.items()}
@@ -25,6 +31,8 @@ def main(tag, rnd):
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
         f.write("\n")
+    # FP64 instruction mix of k_gram: ISA of the CURRENT build + the FP64 counters of this profile set
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "gram_isa_mix.py"), os.path.join("profiles", rnd, f"pmc_{tag}_summary.json")], cwd=ROOT, stdout=subprocess.DEVNULL)
 
 
 if __name__ == "__main__":
