@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(420)]   # (a rank that hangs must fail the test, not the run: pytest-timeout here, faulthandler in the full-size workers)
 
 
 def _free_port():
@@ -217,8 +217,11 @@ def test_stop_by_max_nfev_after_a_mispredicted_tick_leaves_a_consistent_gradient
 def _full_worker(rank, world, port, out_dir, shape, n_frames):
     sys.path.insert(0, ROOT)
     import contextlib
+    import faulthandler
     import io
     import time
+
+    faulthandler.dump_traceback_later(int(os.environ.get("MCBA_TEST_WATCHDOG_S", "240")), exit=True)   # a hung rank reports where and ends: the test fails instead of hanging
 
     import torch.distributed as dist
 
