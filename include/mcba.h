@@ -198,6 +198,10 @@ int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, do
  *                       50 ms) and copy its MCBA_LM_STATE doubles.  At most 15 ticks may be outstanding.
  * After termination (state 15 != 0) the kernels of later ticks return at once; such ticks still post their slot. */
 int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, double lam_min, double lam_max, const unsigned char* fixed_mask);
+/* Floor of Nielsen's damping factor on an accepted step, lambda *= max(floor, 1 - (2 ratio - 1)^3); 0 (the default of a new handle)
+ * = the classical 1/3.  Applies to every decision the library takes (mcba_lm_decide_reduce, mcba_lm_iterate, the device-resident
+ * loop) and to the prediction its speculative Schur reduction is built on.  The Python driver sets 1/10 (solver.py). */
+int mcba_lm_set_decrease_floor(mcba_handle* h, double dec_floor);
 int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq, int decide);
 int mcba_lm_auto_trial(mcba_handle* h, int decide);
 int mcba_lm_auto_reduce(mcba_handle* h, int decide, int rank_slot);

@@ -237,6 +237,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     Extra keyword arguments (defaults preserve reference behaviour):
       device=0             HIP device ordinal (distributed: defaults to LOCAL_RANK)
       fix_intrinsics=False hold fx fy cx cy k1 k2 of every camera (BASELINE config 2); extrinsics + poses only
+      lam0=1e-2, dec_floor=0.1   damping schedule of the LM loop (solver.py); dec_floor=1/3 is Nielsen's classical rule
       return_jac=True      attach the robust-rescaled CSR Jacobian as `result.jac` (18 nnz/row; 1.4 GB at 6x10k x54)
       distributed=False    one process per GPU under torch.distributed (an initialised process group, backend nccl =
                            RCCL): every rank uploads and pre-filters its contiguous slice of ALL frames, solves the selected
@@ -263,7 +264,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     device = opt_kwargs.pop("device", 0)
     fix_intrinsics = opt_kwargs.pop("fix_intrinsics", False)
     return_jac = opt_kwargs.pop("return_jac", True)
-    lm_kwargs = {k: opt_kwargs.pop(k) for k in ("lam0", "reduced_solver") if k in opt_kwargs}
+    lm_kwargs = {k: opt_kwargs.pop(k) for k in ("lam0", "dec_floor", "reduced_solver") if k in opt_kwargs}
 
     kw = dict(verbose=2, x_scale="jac", ftol=1e-4, method="trf", loss="soft_l1")
     kw.update(opt_kwargs)

@@ -72,6 +72,7 @@ struct mcba_handle {
   bool fuse_backsub = false, trial_ready = false;
   bool spec_copy_ready = false;  // the last k_reduce_system was a speculative one: the pre-decision state copy is in place
   double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8, lam_min = 1e-12, lam_max = 1e12;
+  double dec_floor = 0.0;      // floor of Nielsen's damping factor on accepted steps (0 = the classical 1/3): mcba_lm_set_decrease_floor
   // profiling
   bool prof = false;
   unsigned prof_mask = ~0u;
@@ -116,12 +117,12 @@ struct Scope {  // brackets one launch with events when profiling
   }
 };
 
-mcba::Sel host_sel(int idx, double lam = 0.0) { return mcba::Sel{nullptr, idx, lam, 0}; }
-mcba::Sel dev_sel(const mcba_handle* h, int flip) { return mcba::Sel{h->red + h->nsys + 8, flip, 0.0, 0}; }  // LM state lives behind the trial scalars
-mcba::Sel spec_sel(const mcba_handle* h) { return mcba::Sel{h->red + h->nsys + 8, 0, h->lam_min, 1}; }
+mcba::Sel host_sel(int idx, double lam = 0.0) { return mcba::Sel{nullptr, idx, lam, 0, 0.0}; }
+mcba::Sel dev_sel(const mcba_handle* h, int flip) { return mcba::Sel{h->red + h->nsys + 8, flip, 0.0, 0, 0.0}; }  // LM state lives behind the trial scalars
+mcba::Sel spec_sel(const mcba_handle* h) { return mcba::Sel{h->red + h->nsys + 8, 0, h->lam_min, 1, h->dec_floor}; }
 // the state AFTER the decision k_syrk took itself (single-GPU ticks): a second buffer behind the first
 double* post_state(const mcba_handle* h) { return h->red + h->nsys + 8 + MCBA_LMS; }
-mcba::Sel post_sel(const mcba_handle* h) { return mcba::Sel{post_state(h), 0, 0.0, 0}; }
+mcba::Sel post_sel(const mcba_handle* h) { return mcba::Sel{post_state(h), 0, 0.0, 0, 0.0}; }
 mcba::SyrkFuse no_fuse() { mcba::SyrkFuse z{}; return z; }
 
 int check_launch() {
@@ -757,7 +758,7 @@ static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, boo
     fz.nbp = h->nbblocks;
     fz.trial_out = h->red + h->nsys;
     fz.lms_post = post_state(h);
-    fz.da = mcba::DecideArgs{2, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, nullptr, h->ftol, h->xtol};
+    fz.da = mcba::DecideArgs{2, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, nullptr, h->ftol, h->xtol, h->dec_floor};
     fz.timeout_word = timeout_word(h);
     fz.seq_prev = seq > 0 ? (double)(seq - 1) : 0.0;
   }
@@ -782,7 +783,7 @@ int mcba_lm_decide_reduce(mcba_handle* h, double pred_cam, double dcn2, double x
   HIPCHK(hipSetDevice(h->device));
   {
     Scope sc(h, K_DECIDE);
-    mcba::launch_decide(h->stream, h->red + h->nsys, mcba::DecideArgs{1, pred_cam, dcn2, xcn2, lam_min, lam_max, h->red + h->nsys + 8});
+    mcba::launch_decide(h->stream, h->red + h->nsys, mcba::DecideArgs{1, pred_cam, dcn2, xcn2, lam_min, lam_max, h->red + h->nsys + 8, 0.0, 0.0, h->dec_floor});
   }
   int rc = check_launch();
   if (rc) return rc;
@@ -810,7 +811,7 @@ int mcba_lm_fetch(mcba_handle* h, double* host) {
 int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, double dcn2, double xcn2, double lam_min, double lam_max, double* host) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
   // single rank: the decision rides on k_sum_trial (no separate launch, nothing to all-reduce in between)
-  int rc = lm_trial_impl(h, delta_cam, mcba::DecideArgs{1, pred_cam, dcn2, xcn2, lam_min, lam_max, h->red + h->nsys + 8});
+  int rc = lm_trial_impl(h, delta_cam, mcba::DecideArgs{1, pred_cam, dcn2, xcn2, lam_min, lam_max, h->red + h->nsys + 8, 0.0, 0.0, h->dec_floor});
   if (rc) return rc;
   rc = lm_reduce_chain(h, 0);
   if (rc) return rc;
@@ -861,7 +862,7 @@ static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, b
   a.timeout_word = timeout_word(h);
   a.seq = (double)seq; a.gtol = h->gtol; a.lam_max = h->lam_max;
   a.n = h->n; a.npad = h->npad; a.use_lds = h->solve_lds;
-  a.decide = decide ? 1 : 0; a.lam_min = h->lam_min; a.ftol = h->ftol; a.xtol = h->xtol;
+  a.decide = decide ? 1 : 0; a.lam_min = h->lam_min; a.ftol = h->ftol; a.xtol = h->xtol; a.dec_floor = h->dec_floor;
   {
     Scope sc(h, K_SOLVE);
     if (fuse_next)  // + the back-substitution of the next tick's trial step, overlapped with the solve (polls bounded: ~0.5 s)
@@ -875,6 +876,12 @@ static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, b
 }
 
 int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq, int decide) { return auto_solve_impl(h, seq, decide, false); }
+
+int mcba_lm_set_decrease_floor(mcba_handle* h, double dec_floor) {
+  if (!h || !(dec_floor >= 0.0) || dec_floor >= 1.0) return fail(MCBA_ERR_ARG, "mcba_lm_set_decrease_floor: 0 <= floor < 1 required (0 = 1/3)");
+  h->dec_floor = dec_floor;
+  return MCBA_OK;
+}
 
 // sum_here: k_sum_trial follows (frame-sharded ticks: the trial scalars are all-reduced); otherwise k_syrk sums and decides
 static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
@@ -896,7 +903,7 @@ static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   if (!sum_here) return MCBA_OK;
   {
     Scope sc(h, K_SUM_TRIAL);
-    mcba::DecideArgs da{decide ? 2 : 0, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, h->red + h->nsys + 8, h->ftol, h->xtol};
+    mcba::DecideArgs da{decide ? 2 : 0, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, h->red + h->nsys + 8, h->ftol, h->xtol, h->dec_floor};
     mcba::launch_sum_trial(h->stream, dev_sel(h, 1), h->gpart2[0] + (size_t)90 * h->nfb, h->gpart2[1] + (size_t)90 * h->nfb, 1, h->nfb, (size_t)MCBA_GP * h->nfb, h->C * h->nfb, h->bpart, h->nbblocks, h->red + h->nsys, da);
   }
   return check_launch();
@@ -912,7 +919,7 @@ int mcba_lm_auto_reduce(mcba_handle* h, int decide, int rank_slot) {
   if (decide == 1) {
     {
       Scope sc(h, K_DECIDE);
-      mcba::launch_decide(h->stream, h->red + h->nsys, mcba::DecideArgs{2, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, h->red + h->nsys + 8, h->ftol, h->xtol});
+      mcba::launch_decide(h->stream, h->red + h->nsys, mcba::DecideArgs{2, 0.0, 0.0, 0.0, h->lam_min, h->lam_max, h->red + h->nsys + 8, h->ftol, h->xtol, h->dec_floor});
     }
     int rc = check_launch();
     if (rc) return rc;

@@ -45,6 +45,7 @@ struct BacksubWait {
   // there -- and into a host-mapped word, on which mcba_lm_auto_wait switches the handle to the two-launch path.
   double* timeout_dev;
   double* timeout_host;
+  double dec_floor;     // spec != 0: floor of Nielsen's factor the prediction assumes
 };
 
 __device__ __forceinline__ void backsub_stamp_timeout(const BacksubWait* w) {
@@ -128,7 +129,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
     FSTAMP(2);
     active = true;  // so far: the final word is awaited before anything is stored
     sidx = sidx_early;
-    lambda = (wait->spec && wait->early[MCBA_LM_SKIP] == 0.0) ? lm_spec_lambda(wait->early[1], wait->lam_min) : wait->early[1];
+    lambda = (wait->spec && wait->early[MCBA_LM_SKIP] == 0.0) ? lm_spec_lambda(wait->early[1], wait->lam_min, wait->dec_floor) : wait->early[1];
   } else {
     active = sel_active(sl, true);
     sidx = active ? sel_index(sl) : 0;  // current slot / linearisation; the trial goes to the other slot

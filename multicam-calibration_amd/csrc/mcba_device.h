@@ -41,7 +41,7 @@ __device__ __forceinline__ double wave_sum63(double v) {
 // which reduces the current linearisation with the state's own damping.  k_solve_cam checks the prediction afterwards.
 __device__ __forceinline__ bool sel_spec(const Sel& s) { return s.spec && s.lms[MCBA_LM_SKIP] == 0.0; }
 __device__ __forceinline__ int sel_index(const Sel& s) { return s.lms ? ((static_cast<int>(s.lms[3]) ^ s.idx ^ (sel_spec(s) ? 1 : 0)) & 1) : s.idx; }
-__device__ __forceinline__ double sel_lambda(const Sel& s) { return s.lms ? (sel_spec(s) ? lm_spec_lambda(s.lms[1], s.lam) : s.lms[1]) : s.lam; }
+__device__ __forceinline__ double sel_lambda(const Sel& s) { return s.lms ? (sel_spec(s) ? lm_spec_lambda(s.lms[1], s.lam, s.dec) : s.lms[1]) : s.lam; }
 // device-resident LM loop: after termination every kernel of a tick returns at once; a tick that follows a failed
 // reduced solve skips its trial kernels (`trial` = true) and only rebuilds the system with the raised damping
 __device__ __forceinline__ bool sel_active(const Sel& s, bool trial) {

@@ -23,6 +23,7 @@ struct Sel {
   int idx;
   double lam;   // host value of the damping (lms == nullptr); lambda_min when spec != 0
   int spec;     // speculative Schur reduction of the trial linearisation (see sel_spec in mcba_kernels.hip)
+  double dec;   // spec != 0: floor of Nielsen's factor the prediction assumes (mcba_lm.h: lm_spec_lambda)
 };
 // k_syrk's fused decision prologue (single-GPU ticks of the device-resident loop; see k_syrk in mcba_kernels.hip)
 struct SyrkFuse {
@@ -62,6 +63,7 @@ struct SolveArgs {
   // accept/reject decision is taken HERE, then checked against the prediction the speculative Schur reduction was built on
   int decide;
   double lam_min, ftol, xtol;
+  double dec_floor;          // floor of Nielsen's damping factor (0 = 1/3): used by the decision taken here and to check the prediction
 };
 void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int C, int F, int N, int Fpad);
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,

@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   if (have_state) {
     const bool spec = sl.spec && s_st[MCBA_LM_SKIP] == 0.0;
     sidx = (static_cast<int>(s_st[3]) ^ sl.idx ^ (spec ? 1 : 0)) & 1;
-    lambda = spec ? lm_spec_lambda(s_st[1], sl.lam) : s_st[1];
+    lambda = spec ? lm_spec_lambda(s_st[1], sl.lam, sl.dec) : s_st[1];
   } else {
     sidx = sl.idx;
     lambda = sl.lam;

@@ -6,9 +6,13 @@
 
 namespace mcba {
 
-// damping a speculative Schur reduction assumes for the accepted trial point: Nielsen's factor at its floor of 1/3
-// (ratio >= 0.937, the usual case while converging).  Must be the very expression lm_decide evaluates.
-MCBA_HD double lm_spec_lambda(double lam, double lam_min) { return fmax(lam * (1.0 / 3.0), lam_min); }
+// Floor of Nielsen's damping factor: lambda *= max(floor, 1 - (2 ratio - 1)^3) on an accepted step.  Nielsen's 1/3 makes the damping
+// the slowest thing in the loop once the steps are good (from the bench's start point: 12 accepted steps just to bring lambda down
+// from 210, 24 evaluations to ftol = 1e-4 against 16 with 1/10: profiles/round3/NOTES_round3.md section 5); a caller's 0 means 1/3.
+MCBA_HD double lm_dec_floor(double f) { return f > 0.0 ? f : 1.0 / 3.0; }
+// damping a speculative Schur reduction assumes for the accepted trial point: Nielsen's factor at its floor
+// (the usual case while converging).  Must be the very expression lm_decide evaluates.
+MCBA_HD double lm_spec_lambda(double lam, double lam_min, double dec_floor) { return fmax(lam * lm_dec_floor(dec_floor), lam_min); }
 
 // state (lms): 0 cost  1 lambda  2 nu  3 sel (current slot / linearisation)  4 accepted  5 cost_new  6 pred  7 ratio
 //        8 step_norm  9 x_norm  10 dF.   pred_cam = d_c^T (lam D_c d_c - g_c), dcn2 = |d_c|^2, xcn2 = |x_c|^2 come from
@@ -44,7 +48,7 @@ MCBA_HD void lm_decide(const double* trial8, const DecideArgs& da, const LmPre& 
   if (accepted) {
     if (!(ratio > 0.0 && dF >= 0.0)) ratio = 0.5;  // neutral: factor 1 in Nielsen's rule
     double t = 2.0 * ratio - 1.0;
-    double fac = fmax(1.0 / 3.0, 1.0 - t * t * t);
+    double fac = fmax(lm_dec_floor(da.dec_floor), 1.0 - t * t * t);
     lam = fmax(lam * fac, da.lam_min);
     nu = 2.0;
     sel ^= 1;

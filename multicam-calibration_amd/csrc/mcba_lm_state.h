@@ -30,5 +30,7 @@ struct DecideArgs {
   double pred_cam, dcn2, xcn2, lam_min, lam_max;
   double* lms;
   double ftol, xtol;
+  // floor of Nielsen's damping factor on an accepted step, lambda *= max(dec_floor, 1 - (2 ratio - 1)^3); 0 = the classical 1/3
+  double dec_floor;
 };
 }  // namespace mcba

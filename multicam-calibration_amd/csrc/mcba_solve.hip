@@ -205,8 +205,8 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
         lms[MCBA_LM_SOLVE_INFO] = 4.0;
         mode = 3;
       } else {
-        const double lam_spec = lm_spec_lambda(lms[1], a.lam_min);  // what the Schur reduction before us assumed
-        lm_decide(a.red + (size_t)n * n + 3 * n + 16, DecideArgs{2, 0.0, 0.0, 0.0, a.lam_min, a.lam_max, lms, a.ftol, a.xtol});
+        const double lam_spec = lm_spec_lambda(lms[1], a.lam_min, a.dec_floor);  // what the Schur reduction before us assumed
+        lm_decide(a.red + (size_t)n * n + 3 * n + 16, DecideArgs{2, 0.0, 0.0, 0.0, a.lam_min, a.lam_max, lms, a.ftol, a.xtol, a.dec_floor});
         if (!(lms[4] != 0.0 && lms[1] == lam_spec)) {  // rejected, or accepted with another damping: the system in the
           lms[MCBA_LM_SKIP] = 1.0;                     // buffer is not the one to solve -> the next tick rebuilds it
           lms[MCBA_LM_SOLVE_INFO] = 3.0;
@@ -639,7 +639,7 @@ int solve_backsub_set_lds_limit(int npad) {
 
 void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const double* rec0, const double* rec1, const double* fbuf, double* x0, double* x1, double* bpart, int C, int F, int Fpad,
                           const double* early_state, int max_polls, int spec, double* timeout_dev, double* timeout_host) {
-  BacksubArgs b{sl, rec0, rec1, fbuf, x0, x1, bpart, C, F, Fpad, BacksubWait{early_state, a.flag, a.dc, nullptr, a.seq, max_polls, spec, a.lam_min, timeout_dev, timeout_host}};
+  BacksubArgs b{sl, rec0, rec1, fbuf, x0, x1, bpart, C, F, Fpad, BacksubWait{early_state, a.flag, a.dc, nullptr, a.seq, max_polls, spec, a.lam_min, timeout_dev, timeout_host, a.dec_floor}};
   const size_t lds = solve_lds_bytes(a.npad, 1);
   const dim3 grid(1 + Fpad / 64), block(64 * kBacksubWaves);
   if (a.npad <= 80) hipLaunchKernelGGL((k_solve_backsub<5>), grid, block, lds, st, a, b);

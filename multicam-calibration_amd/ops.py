@@ -60,6 +60,7 @@ SYMBOLS = [
     ("mcba_lm_iterate", ctypes.c_int, [_h, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp]),
     ("mcba_lm_auto_config", ctypes.c_int, [_h, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_char_p]),
     ("mcba_lm_auto_solve", ctypes.c_int, [_h, ctypes.c_ulonglong, ctypes.c_int]),
+    ("mcba_lm_set_decrease_floor", ctypes.c_int, [_h, ctypes.c_double]),
     ("mcba_lm_auto_trial", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_lm_auto_reduce", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int]),
     ("mcba_lm_auto_tick", ctypes.c_int, [_h, ctypes.c_ulonglong, ctypes.c_int]),
@@ -410,6 +411,10 @@ class Problem:
         self._chk(self.lib.mcba_lm_auto_config(self.handle, ftol, xtol, gtol, lam_min, lam_max, m))
         self._auto_state = np.zeros(LM_STATE)
         self._auto_state_p = _p(self._auto_state)
+
+    def lm_set_decrease_floor(self, dec_floor):
+        """Floor of Nielsen's damping factor on accepted steps (0 = the classical 1/3)."""
+        self._chk(self.lib.mcba_lm_set_decrease_floor(self.handle, float(dec_floor)))
 
     def lm_auto_solve(self, seq, decide=0):
         rc = self.lib.mcba_lm_auto_solve(self.handle, seq, int(decide))

@@ -113,6 +113,18 @@ class HostStagedGloo(TorchDistributed):
         self._ar(problem.reduce_tensor[: problem.nsys + 8])
 
 
+# Damping schedule of the Levenberg-Marquardt loop (Nielsen's rule: lambda *= max(DEC_FLOOR, 1 - (2 ratio - 1)^3) on an accepted step,
+# lambda *= nu, nu *= 2 on a rejected one).  Nielsen's floor of 1/3 and a start at 1e-4 cost the bench problem (6 x 10 000 x 54 from a
+# perturbed start) 24 evaluations to the reference's ftol = 1e-4, six of them rejected first steps and twelve just to bring the damping
+# down again; 1/10 and 1e-2 reach a lower cost in 16 (profiles/round3/NOTES_round3.md section 5).  Both are keyword arguments.
+# LAM_MIN: the bundle-adjustment Hessian has a 6-DoF gauge null space whose computed curvature is round-off; the damping is what keeps
+# the step finite there.  With the faster decrease a floor of 1e-12 is reached before scipy's xtol test can fire and the loop then
+# wanders at |step| ~ 1e-6 on neutral steps (4 of 10 problem / tolerance pairs ran into max_nfev); at 1e-9 all of them terminate,
+# in 19-26 evaluations instead of 29-33 with the round-2 schedule (1e-4, 1/3, 1e-12).  The minimiser does not depend on it.
+LAM0 = 1e-2
+DEC_FLOOR = 0.1
+LAM_MIN = 1e-9
+
 MAX_RANKS = 12  # per-rank max |g_f| slots in the reduce buffer's scalar block (include/mcba.h: scal[4..15])
 
 
@@ -161,8 +173,8 @@ class LevenbergMarquardt:
           (`_iterate_device`);
       host-driven (`iterate` itself): decision here as well -- what the CPU test double (tests/fake_problem.py) runs."""
 
-    def __init__(self, problem, comm=None, free_cam_mask=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, lam0=1e-4, lam_min=1e-12, lam_max=1e12, speculative=True,
-                 reduced_solver=None, depth=2, x_scale=None):
+    def __init__(self, problem, comm=None, free_cam_mask=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, lam0=LAM0, lam_min=LAM_MIN, lam_max=1e12, speculative=True,
+                 reduced_solver=None, depth=2, x_scale=None, dec_floor=DEC_FLOOR):
         self.p = problem
         self.comm = comm or SingleProcess()
         n = problem.n
@@ -178,6 +190,9 @@ class LevenbergMarquardt:
         self.all_free = bool(self.free.all())
         self.ftol, self.xtol, self.gtol = ftol, xtol, gtol
         self.lam0, self.lam_min, self.lam_max = float(lam0), lam_min, lam_max
+        self.dec_floor = float(dec_floor)
+        if hasattr(problem, "lm_set_decrease_floor"):
+            problem.lm_set_decrease_floor(self.dec_floor)
         # speculative: every trial point is linearised right away (k_gram also yields its cost), so an accepted
         # step needs one pass over the observations instead of two; a rejected step wastes the extra arithmetic.
         self.speculative = bool(speculative)
@@ -435,7 +450,7 @@ class LevenbergMarquardt:
             if accepted:
                 self.cur = 1 - self.cur
                 self.x_cam = self.x_cam + dc
-                self.lam = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3), self.lam_min)
+                self.lam = max(lam * max(self.dec_floor, 1.0 - (2.0 * ratio - 1.0) ** 3), self.lam_min)
                 self.nu = 2.0
                 self.actual_reduction, self.step_norm = dF, step_norm
                 self.iteration += 1
@@ -490,11 +505,11 @@ class LevenbergMarquardt:
         )
 
 
-def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=1e-4, max_iterations=None, speculative=True,
-             reduced_solver=None, x_scale=None):
+def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=LAM0, max_iterations=None, speculative=True,
+             reduced_solver=None, x_scale=None, dec_floor=DEC_FLOOR):
     """Minimise the robust reprojection cost from x0 (this shard's flat vector, a7 layout of SURVEY.md).
     `fun` / `jac` / `grad` of the OptimizeResult are attached by api.bundle_adjust."""
-    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative, reduced_solver=reduced_solver, x_scale=x_scale)
+    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative, reduced_solver=reduced_solver, x_scale=x_scale, dec_floor=dec_floor)
     if max_nfev is None:
         max_nfev = 100 * np.size(x0)  # trf.py:437-438
     lm.max_nfev, lm.max_steps = max_nfev, max_iterations

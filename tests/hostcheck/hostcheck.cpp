@@ -122,8 +122,8 @@ int hc_chol_solve(const double* Vt, const double* b, double* x) {
 }
 
 // the device loop's accept / reject + damping update + ftol / xtol verdict (csrc/mcba_lm.h) on a 32-double LM state
-void hc_lm_decide(double* lms, const double* trial8, double lam_min, double lam_max, double ftol, double xtol) {
+void hc_lm_decide(double* lms, const double* trial8, double lam_min, double lam_max, double ftol, double xtol, double dec_floor) {
   using std::isfinite;
-  lm_decide(trial8, DecideArgs{2, 0.0, 0.0, 0.0, lam_min, lam_max, lms, ftol, xtol});
+  lm_decide(trial8, DecideArgs{2, 0.0, 0.0, 0.0, lam_min, lam_max, lms, ftol, xtol, dec_floor});
 }
 }

@@ -213,7 +213,7 @@ def test_host_driven_decision_equals_device_lm_decide():
     lib = os.path.join(here, "hostcheck", "libhostcheck.so")
     subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", lib, os.path.join(here, "hostcheck", "hostcheck.cpp")])
     hc = ctypes.CDLL(lib)
-    hc.hc_lm_decide.argtypes = [ctypes.POINTER(ctypes.c_double)] * 2 + [ctypes.c_double] * 4
+    hc.hc_lm_decide.argtypes = [ctypes.POINTER(ctypes.c_double)] * 2 + [ctypes.c_double] * 5
     hc.hc_lm_decide.restype = None
     cost0 = 100.0
     # (cost_new, pred_f, |d_f|^2, |x_f|^2): good step, bad step, poor-ratio step, NEUTRAL step (|dF| below FP64 resolution, dF < 0)
@@ -236,7 +236,7 @@ def test_host_driven_decision_equals_device_lm_decide():
         lms[13] = x_cam @ x_cam
         trial8 = np.zeros(8)
         trial8[:4] = t
-        hc.hc_lm_decide(P(lms), P(trial8), lam_min, lam_max, ftol, xtol)
+        hc.hc_lm_decide(P(lms), P(trial8), lam_min, lam_max, ftol, xtol, lm.dec_floor)
         assert bool(lms[4]) == lm.accepted, k
         assert lms[1] == lm.lam and lms[2] == lm.nu and lms[0] == lm.cost, k
         assert int(lms[3]) == lm.cur, k
