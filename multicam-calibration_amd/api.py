@@ -238,13 +238,15 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
       device=0             HIP device ordinal (distributed: defaults to LOCAL_RANK)
       fix_intrinsics=False hold fx fy cx cy k1 k2 of every camera (BASELINE config 2); extrinsics + poses only
       lam0=1e-2, dec_floor=0.1   damping schedule of the LM loop (solver.py); dec_floor=1/3 is Nielsen's classical rule
-      return_jac=True      attach the robust-rescaled CSR Jacobian as `result.jac` (18 nnz/row; 1.4 GB at 6x10k x54)
+      return_jac=True      attach the robust-rescaled CSR Jacobian as `result.jac` (18 nnz/row; 1.4 GB at 6x10k x54) -- lazily: it is
+                           produced when the field is first read; until then the result keeps the GPU handle alive
+                           (return_jac=False releases it at once)
       distributed=False    one process per GPU under torch.distributed (an initialised process group, backend nccl =
                            RCCL): every rank uploads and pre-filters its contiguous slice of ALL frames, solves the selected
                            frames of that slice, every LM iteration all-reduces the reduced camera system, and every rank
                            returns the full 5-tuple (poses gathered in selection order).  `result.fun` / `result.jac` then
                            cover the calling rank's frames only (`result.lm["frame_positions"]` = their places in use_frames).
-    `result.fun` is downloaded from the GPU when it is first read (LazyOptimizeResult).  `result.lm` carries the solver's own
+    `result.fun` and `result.jac` are produced when they are first read (LazyOptimizeResult).  `result.lm` carries the solver's own
     record: iterations, damping history, which collective backend and reduced solver ran.
     """
     distributed = opt_kwargs.pop("distributed", False)
@@ -345,26 +347,35 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
                                  max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, x_scale=x_scale, **lm_kwargs)
         result = LazyOptimizeResult(result)
 
-        # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560)
+        # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560).  `fun` and `jac` are LAZY: the residual
+        # vector stays on the GPU as a detached buffer, and the robust-rescaled CSR Jacobian (116.6 M non-zeros = 1.4 GB on the host at
+        # 6 x 10 000 x 54, 0.58 s to materialise, download and index) is produced when `result.jac` is first read -- from the handle,
+        # which the result then keeps alive (observations + parameters, ~0.4 GB of HBM at that size) until the field has been
+        # read or the result is dropped.  return_jac=False releases the handle at once.
         slot = result.lm["slot"]
         need_mask = not all_seen  # (every selected detection complete -- the pre-filter counted them on the GPU: no NaN mask to apply)
+        src, frames = (all_calib_uvs, use_frames) if need_mask else (None, None)
+        vec = prob.residuals_detach(slot)
+
+        def fun(vec=vec, src=src, frames=frames):
+            r = vec.download()
+            return r.ravel() if src is None else r[~np.isnan(src[:, frames])]
+
+        dict.__setitem__(result, "fun", _Lazy(fun))
         if return_jac:
-            uvs = all_calib_uvs[:, use_frames]
-            idx, indptr, shape, mask = jacobian_structure(uvs)  # CSR indices: 0.25 s of numpy at 6 x 10k x 54 -- only when asked for
-            prob.jacobian_eval(slot, robust_scaled=kw["loss"] != "linear")
-            jac, res = prob.jacobian_download()
-            result.jac = sp.csr_matrix((jac[mask].ravel(), idx, indptr), shape=shape)
-            result.fun = res[mask]
-            del jac
-        else:
-            vec = prob.residuals_detach(slot)   # stays on the GPU until result.fun is read
-            src, frames = (all_calib_uvs, use_frames) if need_mask else (None, None)
+            jprob, robust, shape3 = prob, kw["loss"] != "linear", (n_cameras, use_frames.size, all_calib_uvs.shape[2])
 
-            def fun(vec=vec, src=src, frames=frames):
-                r = vec.download()
-                return r.ravel() if src is None else r[~np.isnan(src[:, frames])]
+            def jac(jprob=jprob, src=src, frames=frames):
+                try:
+                    uvs = np.zeros(shape3 + (2,)) if src is None else src[:, frames]
+                    idx, indptr, shape, mask = jacobian_structure(uvs)  # CSR indices: 0.25 s of numpy at 6 x 10k x 54 -- only when asked for
+                    jprob.jacobian_eval(slot, robust_scaled=robust)
+                    data, _ = jprob.jacobian_download(want_res=False)
+                    return sp.csr_matrix((data[mask].ravel(), idx, indptr), shape=shape)
+                finally:
+                    jprob.close()
 
-            dict.__setitem__(result, "fun", _Lazy(fun))
+            dict.__setitem__(result, "jac", _Lazy(jac))
         red = prob.get_reduced()
         grad = np.concatenate([red["gc"], prob.frame_gradient().ravel()])
         if free is not None:
@@ -382,6 +393,8 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             result.optimality = float(np.abs(grad).max())
             result.lm["frame_positions"] = positions
         result.grad = grad
+        if return_jac:
+            prob = None   # owned by the lazy `jac` field now (closed when that field is produced, or with the result)
     finally:
         if prob_all is not None:
             prob_all.close()

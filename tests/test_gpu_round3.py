@@ -55,7 +55,16 @@ def test_lazy_fun_outlives_the_handle_and_matches_the_oracle(mc):
         np.testing.assert_array_equal(r.x, res.x)                     # recycled (not re-zeroed) buffers change nothing
         np.testing.assert_array_equal(r.fun, res.fun)
     full = quiet(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=1e-10, verbose=0)[4]
-    np.testing.assert_allclose(full.fun, res.fun, rtol=0, atol=1e-11)  # return_jac=True: the materialising kernel's residuals (another instruction order)
+    assert isinstance(dict.get(full, "jac"), mc.api._Lazy)          # the default call (return_jac=True) does not pay for the Jacobian either ...
+    np.testing.assert_array_equal(full.fun, res.fun)                 # ... and reading `fun` does not produce it
+    assert isinstance(dict.get(full, "jac"), mc.api._Lazy)
+    J = full.jac                                                     # produced now, from the handle the result kept alive
+    assert J.shape == (res.fun.size, res.x.size) and J.nnz == 18 * res.fun.size
+    z = res.fun ** 2
+    rho1 = (1 + z) ** -0.5                                           # soft_l1: rho' ; scipy's row scaling js = sqrt(rho' + 2 rho'' f^2) = (1 + z)^-3/4
+    js = (1 + z) ** -0.75
+    np.testing.assert_allclose(J.T @ (rho1 * res.fun / js), full.grad, rtol=0, atol=1e-8 * max(1.0, np.abs(full.grad).max()) + 1e-7)
+    assert full.jac is J                                             # an ordinary field from here on
     mc.ops.pool_trim()
     r2 = quiet(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], **kw)[4]
     np.testing.assert_array_equal(r2.x, res.x)
