@@ -168,10 +168,11 @@ def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             dist.all_gather_object(parts, (mean_cf, full_cf), group=group)
             mean_cf = np.concatenate([p[0] for p in parts], axis=1)
             full_cf = np.concatenate([p[1] for p in parts], axis=1)
-        use_frames = np.nonzero((full_cf == N).sum(0) > 1)[0]                     # complete in at least two cameras (:266)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore", category=RuntimeWarning)
-            worst_mean_err = np.nanmax(mean_cf[:, use_frames], axis=0) if use_frames.size else np.empty(0)   # (:279)
+        complete_cf = full_cf == N
+        use_frames = np.nonzero(complete_cf.sum(0) > 1)[0]                        # complete in at least two cameras (:266)
+        every = use_frames.size == F_all                                          # (no fancy-index copies in the common case)
+        # np.nanmax over the cameras (:279) = fmax-reduction: NaN only where every camera is NaN, and no warning for it
+        worst_mean_err = np.fmax.reduce(mean_cf if every else mean_cf[:, use_frames], axis=0) if use_frames.size else np.empty(0)
         if outlier_threshold is None:                                             # 5 * np.nanmedian(err)  (:281-282)
             mask = np.zeros(hi - lo, dtype=np.uint8)
             mask[use_frames[(use_frames >= lo) & (use_frames < hi)] - lo] = 1
@@ -205,7 +206,7 @@ def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         dist.broadcast_object_list(box, src=0, group=group)
         use_frames = box[0]
     if keep_problem:  # + whether every selected detection is complete (then no NaN mask is needed for result.fun / result.jac)
-        complete = bool(np.all(full_cf[:, use_frames] == N))
+        complete = bool(complete_cf.all()) or bool(complete_cf[:, use_frames].all())
         return use_frames, prob, complete, lo
     if prob is not None:
         prob.close()

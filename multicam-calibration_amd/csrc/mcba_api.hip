@@ -1023,7 +1023,7 @@ static int ensure_diag(mcba_handle* h) {
   if (!h->err && (rc = dalloc(h, &h->err, (size_t)h->C * h->N * h->Fpad))) return rc;
   if (!h->dmean && (rc = dalloc(h, &h->dmean, std::max<size_t>((size_t)h->C * h->F, 8)))) return rc;
   if (!h->dfull && (rc = dalloc(h, &h->dfull, (size_t)h->C * h->F))) return rc;
-  if (!h->sel && (rc = dalloc(h, &h->sel, mcba::select_state_bytes(h->C)))) return rc;
+  if (!h->sel && (rc = dalloc(h, &h->sel, mcba::select_state_bytes(2 * h->C)))) return rc;
   if (!h->fmask && (rc = dalloc(h, &h->fmask, (size_t)h->Fpad))) return rc;
   return MCBA_OK;
 }
@@ -1046,20 +1046,18 @@ int mcba_frame_errors(mcba_handle* h, int slot, double* mean_cf, double* full_cf
 // nan-median (exact order statistics) of `groups` equal slices of h->err restricted to the frames of h->fmask
 static int median_of_err(mcba_handle* h, size_t per_group, int groups, bool use_mask, double* median, double* count) {
   struct Sel { unsigned long long prefix, rank, count, value; unsigned int hist[256]; };
-  std::vector<Sel> lo(groups), hi(groups);
-  for (int upper = 0; upper < 2; ++upper) {
-    mcba::launch_select(h->stream, h->err, use_mask ? h->fmask : nullptr, per_group, groups, h->Fpad, h->sel, upper);
-    int rc = check_launch();
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync((upper ? hi : lo).data(), h->sel, (size_t)groups * sizeof(Sel), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-  }
+  std::vector<Sel> both(2 * (size_t)groups);  // state 2 g: rank (n - 1) / 2, state 2 g + 1: rank n / 2 -- found in the same eight passes
+  mcba::launch_select(h->stream, h->err, use_mask ? h->fmask : nullptr, per_group, groups, h->Fpad, h->sel, 2);
+  int rc = check_launch();
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(both.data(), h->sel, both.size() * sizeof(Sel), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   for (int g = 0; g < groups; ++g) {
     double a, b;
-    memcpy(&a, &lo[g].value, 8);
-    memcpy(&b, &hi[g].value, 8);
-    median[g] = lo[g].count ? 0.5 * (a + b) : NAN;  // np.median / np.nanmedian: mean of the two middle values
-    if (count) count[g] = (double)lo[g].count;
+    memcpy(&a, &both[2 * g].value, 8);
+    memcpy(&b, &both[2 * g + 1].value, 8);
+    median[g] = both[2 * g].count ? 0.5 * (a + b) : NAN;  // np.median / np.nanmedian: mean of the two middle values
+    if (count) count[g] = (double)both[2 * g].count;
   }
   return MCBA_OK;
 }
@@ -1070,8 +1068,7 @@ int mcba_error_median(mcba_handle* h, const unsigned char* frame_mask, double* m
   HIPCHK(hipSetDevice(h->device));
   if (frame_mask) {
     HIPCHK(hipMemsetAsync(h->fmask, 0, (size_t)h->Fpad, h->stream));
-    HIPCHK(hipMemcpyAsync(h->fmask, frame_mask, (size_t)h->F, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(h->fmask, frame_mask, (size_t)h->F, hipMemcpyHostToDevice, h->stream));  // (pageable source: staged before the call returns)
   }
   return median_of_err(h, (size_t)h->C * h->N * h->Fpad, 1, frame_mask != nullptr, median, count);
 }

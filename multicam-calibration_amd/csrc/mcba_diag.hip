@@ -104,14 +104,15 @@ struct SelState {
 
 // values: [groups][stride] doubles with the frame index = i % Fpad; mask (per frame) may be nullptr; group g selects the
 // slice [g * per_group, (g + 1) * per_group) (per-camera medians) -- blockIdx.y = group, one SelState per group
-__global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ v, const unsigned char* __restrict__ fmask, size_t per_group, int Fpad, SelState* __restrict__ sts, int pass) {
+// dual != 0: two states per group (2 g: the lower middle rank, 2 g + 1: the upper one) walk the same slice in the same passes
+__global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ v, const unsigned char* __restrict__ fmask, size_t per_group, int Fpad, SelState* __restrict__ sts, int pass, int dual) {
   __shared__ unsigned int s_h[256];
   SelState* st = sts + blockIdx.y;
   s_h[threadIdx.x] = 0;
   __syncthreads();
   const unsigned long long prefix = st->prefix;
   const int shift_hi = 64 - 8 * pass, shift = 56 - 8 * pass;
-  const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(v) + (size_t)blockIdx.y * per_group;
+  const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(v) + (size_t)(dual ? blockIdx.y >> 1 : blockIdx.y) * per_group;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per_group; i += (size_t)gridDim.x * 256) {
     const unsigned long long k = keys[i];
     const double d = __longlong_as_double((long long)k);
@@ -125,9 +126,10 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ v, 
 }
 
 // one thread per group: which byte holds the wanted rank; upper == 0 selects rank (n-1)/2, upper == 1 rank n/2
-__global__ void k_sel_pick(SelState* __restrict__ sts, int pass, int upper) {
+__global__ void k_sel_pick(SelState* __restrict__ sts, int pass, int upper, int dual) {
   SelState* st = sts + blockIdx.x;
   if (threadIdx.x != 0) return;
+  if (dual) upper = blockIdx.x & 1;
   unsigned long long total = 0;
   for (int b = 0; b < 256; ++b) total += st->hist[b];
   if (pass == 0) {
@@ -404,13 +406,16 @@ size_t select_state_bytes(int groups) { return (size_t)groups * sizeof(SelState)
 
 // median(s) of `groups` equal slices of v (per_group doubles each, frame = index % Fpad): after the call sel[g].count and
 // sel[g].value (bit pattern of the order statistic) are valid.  16 tiny launches per call, no host synchronisation.
+// upper = 0 / 1: one order statistic per group; upper = 2: BOTH middle ranks in the same eight passes (states 2 g and 2 g + 1:
+// `sel` must hold 2 x groups states) -- half the launches and one host synchronisation instead of two for a median
 void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int groups, int Fpad, void* sel, int upper) {
   SelState* s = static_cast<SelState*>(sel);
-  (void)hipMemsetAsync(s, 0, select_state_bytes(groups), st);
+  const int dual = upper == 2 ? 1 : 0, nst = dual ? 2 * groups : groups;
+  (void)hipMemsetAsync(s, 0, select_state_bytes(nst), st);
   const unsigned bx = (unsigned)std::min<size_t>((per_group + 255) / 256, 1024);
   for (int pass = 0; pass < 8; ++pass) {
-    k_sel_hist<<<dim3(bx, groups), dim3(256), 0, st>>>(v, fmask, per_group, Fpad, s, pass);
-    k_sel_pick<<<dim3(groups), dim3(64), 0, st>>>(s, pass, upper);
+    k_sel_hist<<<dim3(bx, nst), dim3(256), 0, st>>>(v, fmask, per_group, Fpad, s, pass, dual);
+    k_sel_pick<<<dim3(nst), dim3(64), 0, st>>>(s, pass, upper, dual);
   }
 }
 
@@ -422,7 +427,7 @@ int launch_select_hist(hipStream_t st, const double* v, const unsigned char* fma
   init.prefix = prefix;
   if (hipMemcpyAsync(s, &init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
   const unsigned bx = (unsigned)std::min<size_t>((per_group + 255) / 256, 1024);
-  k_sel_hist<<<dim3(bx, 1), dim3(256), 0, st>>>(v, fmask, per_group, Fpad, s, pass);
+  k_sel_hist<<<dim3(bx, 1), dim3(256), 0, st>>>(v, fmask, per_group, Fpad, s, pass, 0);
   if (hipMemcpyAsync(hist256, s->hist, 256 * sizeof(unsigned int), hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
   return hipStreamSynchronize(st) == hipSuccess ? 0 : 1;
 }
