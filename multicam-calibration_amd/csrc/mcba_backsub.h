@@ -118,7 +118,17 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
         }
         __builtin_amdgcn_s_sleep(4);
       }
+      // Reader side of the release word: every datum read after the poll -- the camera step here, DONE / SKIP of the
+      // state below -- is fetched with agent-scope atomic loads (load_coherent: they bypass the per-XCD L2, which is not coherent
+      // across XCDs), so nothing stale can be served from a cache and no invalidation is needed; the compiler barrier keeps the
+      // fetches behind the poll, the hardware issues them in order.  The formally complete alternative -- an agent-scope acquire
+      // fence in this ONE polling wavefront per workgroup, -DMCBA_POLL_ACQUIRE -- invalidates the L2 157 times per launch and was
+      // measured at +2.5 us per iteration (k_solve_backsub 28.3 -> 31.0 us, three alternations on one box): not the default.
+#ifdef MCBA_POLL_ACQUIRE
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
       asm volatile("" ::: "memory");  // (compiler: the fetches below stay behind the poll; the hardware issues in order)
+#endif
       if (got) {
         for (int i = lane; i < n; i += 64) mail[8 + i] = load_coherent(wait->dc + i);
       }
@@ -201,7 +211,11 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
       if (++polls > wait->max_polls) { posted = false; break; }
       __builtin_amdgcn_s_sleep(4);
     }
+#ifdef MCBA_POLL_ACQUIRE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
     asm volatile("" ::: "memory");
+#endif
     if (!posted && lane == 0) backsub_stamp_timeout(wait);
     if (!posted || load_coherent(sl.lms + MCBA_LM_DONE) != 0.0 || load_coherent(sl.lms + MCBA_LM_SKIP) != 0.0) return;
   }
