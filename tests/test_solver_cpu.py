@@ -294,7 +294,7 @@ def test_two_rank_frame_sharding_matches_single_process(tmp_path):
 
 
 # ------------------------------------------------------------------ bundle_adjust(distributed=True), world_size 2 over gloo
-def _ba_worker(rank, world, port, out_dir):
+def _ba_worker(rank, world, port, out_dir, variant="ragged"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import contextlib
@@ -306,18 +306,26 @@ def _ba_worker(rank, world, port, out_dir):
 
     ops.Problem = OracleProblem   # this process only: the CPU test double stands in for libmcba
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    p = synth.make_problem(3, 41, seed=9, missing=0.15, outlier_frames=3)   # 41: ragged shards
+    p = _ba_problem(variant)
     np.random.seed(100 + rank)   # different global RNG state per rank: only rank 0's may matter
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         e, it, ps, use, res = api.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=30,
                                                  ftol=0.0, xtol=1e-12, gtol=1e-10, max_nfev=100, verbose=0, distributed=True, return_jac=False)
     np.savez(os.path.join(out_dir, f"ba{rank}.npz"), ext=e, poses=ps, use=use, x=res.x, cost=res.cost, grad=res.grad, printed=np.array(buf.getvalue()),
-             K=np.stack([k for k, _ in it]), dist=np.stack([d for _, d in it]))
+             K=np.stack([k for k, _ in it]), dist=np.stack([d for _, d in it]), positions=res.lm["frame_positions"], fun_size=res.fun.size)
     dist.destroy_process_group()
 
 
-def test_bundle_adjust_distributed_two_ranks(tmp_path, monkeypatch):
+def _ba_problem(variant):
+    p = synth.make_problem(3, 41, seed=9, missing=0.15, outlier_frames=3)   # 41: ragged shards
+    if variant == "empty_slice":   # no usable frame in the second rank's slice of ALL frames: the shards are cut from the selection instead
+        p["uvs"][1:, 21:] = np.nan
+    return p
+
+
+@pytest.mark.parametrize("variant", ["ragged", "empty_slice"])
+def test_bundle_adjust_distributed_two_ranks(tmp_path, monkeypatch, variant):
     import contextlib
     import io
 
@@ -326,17 +334,26 @@ def test_bundle_adjust_distributed_two_ranks(tmp_path, monkeypatch):
     from multicam_calibration_amd import ops
 
     port = _free_port()
-    mp.spawn(_ba_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_ba_worker, args=(2, port, str(tmp_path), variant), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "ba0.npz"), np.load(tmp_path / "ba1.npz")
+    n_sel = 30 if variant == "ragged" else int(r0["use"].size)
+    # the two ranks' frames partition the selection; locality sharding (each rank solves the selected frames of its own slice of all
+    # frames) unless a slice holds none of them
+    assert sorted(np.concatenate([r0["positions"], r1["positions"]]).tolist()) == list(range(n_sel))
+    bound = 21   # array_split(41, 2): rank 0 holds frames 0..20
+    if variant == "ragged":
+        assert (r0["use"][r0["positions"]] < bound).all() and (r1["use"][r1["positions"]] >= bound).all()
+    else:
+        assert (r0["use"] < bound).all() and r1["positions"].size > 0
     # every rank returns the same full result; only rank 0 printed the reference's "Excluding ..." line
     for k in ("ext", "poses", "use", "x", "K", "dist", "grad"):
         np.testing.assert_array_equal(r0[k], r1[k])
     assert float(r0["cost"]) == float(r1["cost"])
     assert str(r0["printed"]).startswith("Excluding ") and str(r1["printed"]) == ""
-    assert r0["use"].shape == (30,) and r0["poses"].shape == (30, 6) and r0["x"].shape == (36 + 180,)
+    assert r0["use"].shape == (n_sel,) and r0["poses"].shape == (n_sel, 6) and r0["x"].shape == (36 + 6 * n_sel,)
     # the same call in one process with rank 0's RNG state selects the same frames and reaches the same optimum
     monkeypatch.setattr(ops, "Problem", OracleProblem)
-    p = synth.make_problem(3, 41, seed=9, missing=0.15, outlier_frames=3)
+    p = _ba_problem(variant)
     np.random.seed(100)
     with contextlib.redirect_stdout(io.StringIO()):
         e, it, ps, use, res = api.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=30,
