@@ -3,6 +3,7 @@ through libmcba.so -- trial kernels -> all-reduce of the trial scalars -> decisi
 all-reduce of the reduced system -> k_solve_cam -- against the single-process run on the same data.
 RCCL refuses two ranks on one device, so the collectives here are host-staged gloo all-reduces of the very same
 buffers (solver.HostStagedGloo, chosen by solver.make_comm for a gloo group on a CUDA device); the RCCL plumbing itself is exercised by the single-rank `nccl` runs of bench.py (MCBA_BENCH_FORCE_DIST=1)."""
+import datetime
 import os
 import socket
 import sys
@@ -44,7 +45,7 @@ def _worker(rank, world, port, out_dir, mode):
 
     import multicam_calibration_amd as m
 
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))   # a lost rank fails the collectives instead of blocking them for 30 minutes
 
     # gloo group + CUDA device: solver.make_comm picks HostStagedGloo (host-staged all-reduces of the library's reduce buffer)
     p = _problem(m)
@@ -227,7 +228,7 @@ def _full_worker(rank, world, port, out_dir, shape, n_frames):
 
     import multicam_calibration_amd as m
 
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))   # a lost rank fails the collectives instead of blocking them for 30 minutes
     C, F, rows, cols = shape
     p = m.synth.make_problem(C, F, rows=rows, cols=cols, seed=0)
     np.random.seed(7)   # (rank 0's global RNG draws the subsample; the others' state must not matter)

@@ -1,6 +1,7 @@
 """Host-side LM / Schur driver (multicam-calibration_amd/solver.py) exercised on the CPU through an
 oracle-backed test double of ops.Problem: convergence to the reference's tight optimum, fixed
 intrinsics, termination codes, and the world_size-2 frame-sharded path over gloo."""
+import datetime
 import os
 import socket
 import sys
@@ -258,7 +259,7 @@ def _worker(rank, world, port, out_dir):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
 
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))   # a lost rank fails the collectives instead of blocking them for 30 minutes
     p = synth.make_problem(3, 48, seed=8, missing=0.2)
     F = 48
     sl = slice(rank * F // world, (rank + 1) * F // world)
@@ -305,7 +306,7 @@ def _ba_worker(rank, world, port, out_dir, variant="ragged"):
     from multicam_calibration_amd import ops
 
     ops.Problem = OracleProblem   # this process only: the CPU test double stands in for libmcba
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))   # a lost rank fails the collectives instead of blocking them for 30 minutes
     p = _ba_problem(variant)
     np.random.seed(100 + rank)   # different global RNG state per rank: only rank 0's may matter
     buf = io.StringIO()
