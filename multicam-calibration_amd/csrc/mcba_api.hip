@@ -978,6 +978,7 @@ int mcba_debug_gram_stamps(mcba_handle* h, double* host) {  // development only 
 int mcba_get_cam_step(mcba_handle* h, double* host) {
   if (!h || !host) return fail(MCBA_ERR_ARG, "mcba_get_cam_step: bad argument");
   HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
   HIPCHK(hipMemcpyAsync(host, h->dcbuf, (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return MCBA_OK;
@@ -1283,6 +1284,7 @@ int mcba_comm_init(mcba_handle* h, const unsigned char* id128, int rank, int wor
 
 int mcba_comm_allreduce(mcba_handle* h, size_t offset, size_t count) {
   if (!h || !h->comm) return fail(MCBA_ERR_ARG, "mcba_comm_allreduce: no communicator (call mcba_comm_init)");
+  NEED_SOLVER(h);   // (the reduce buffer belongs to the lazily allocated solver set)
   if (offset + count > h->nsys + 8 + MCBA_LMS) return fail(MCBA_ERR_ARG, "mcba_comm_allreduce: range outside the reduce buffer");
   ncclResult_t r = g_rccl.AllReduce(h->red + offset, h->red + offset, count, ncclDouble, ncclSum, h->comm, h->stream);
   if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
