@@ -177,6 +177,15 @@ def cpu_baseline(sample_frames=500, max_nfev=12):
     from scipy.optimize import least_squares
     from scipy.optimize._numdiff import approx_derivative, group_columns
 
+    # One thread: the path is sequential (sparse finite differences, LSMR); left alone, the BLAS / OpenMP pools behind numpy spin
+    # on every core of the host (round 2 reported "14.9 cores busy" of 256 for what the survey measured as 1.6-1.8 cores of work).
+    limiter = None
+    try:
+        from threadpoolctl import threadpool_limits
+
+        limiter = threadpool_limits(limits=1)
+    except Exception:  # noqa: BLE001 -- threadpoolctl missing: report what is observed
+        pass
     p = synth.make_problem(C, sample_frames, rows=ROWS, cols=COLS, seed=0)
     x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
     t0 = time.perf_counter()
@@ -192,14 +201,17 @@ def cpu_baseline(sample_frames=500, max_nfev=12):
     dt = time.perf_counter() - t0
     c1 = os.times()
     cores = ((c1.user - c0.user) + (c1.system - c0.system)) / dt
+    if limiter is not None:
+        limiter.restore_original_limits()
     iters = max(res.njev - 1, 1)  # accepted iterations = Jacobian evaluations after the first
     it_per_s_sample = iters / dt
     scale = sample_frames / F_PER_GPU
     return {
-        "value": it_per_s_sample * scale, "unit": "it/s", "cores": round(cores, 2), "kind": "port",
+        "value": it_per_s_sample * scale, "unit": "it/s", "cores": 1 if limiter is not None else round(cores, 2), "kind": "port",
         "config": {"cameras": C, "frames": sample_frames, "points": ROWS * COLS, "trf_iterations": iters, "nfev": int(res.nfev), "njev": int(res.njev), "seconds": dt,
                    "it_per_s_on_sample": it_per_s_sample, "scale_to_workload": scale, "scaling_rule": "cost per iteration linear in frames (BASELINE.md section 2)",
-                   "host_cpu_count": os.cpu_count(), "cores_busy_observed": round(cores, 2), "cores_note": "os.times / wall: BLAS threads spinning, the path is single-threaded (SURVEY: 1.6-1.8 cores)"},
+                   "host_cpu_count": os.cpu_count(), "cores_busy_observed": round(cores, 2), "threads": 1 if limiter is not None else None,
+                   "cores_note": "thread pools limited to 1 (threadpoolctl); cores_busy_observed = os.times / wall of the least_squares call"},
         "sample": f"{C}x{sample_frames}x{ROWS * COLS} sample of the workload, {iters} TRF iterations (nfev {res.nfev}, njev {res.njev}) in {dt:.1f}s = {it_per_s_sample:.3f} it/s on the sample; "
                   f"scaled x{scale:g} to 10k frames (cost per iteration is linear in frames: BASELINE.md section 2); sparsity pattern {t_pat:.2f}s + colouring excluded; "
                   f"observed {cores:.2f} cores busy of os.cpu_count()={os.cpu_count()}",
