@@ -167,7 +167,7 @@ def end_to_end(m, p, reps=5):
             "note": "result.fun stays on the GPU until first read (LazyOptimizeResult); its download is timed separately above and is not part of `ms`; default_call_ms = the same call without return_jac=False (result.jac lazy, the result holds the handle)"}
 
 
-def cpu_baseline(sample_frames=500, max_nfev=12):
+def cpu_baseline(sample_frames=1000, max_nfev=12):
     """the oracle's CPU path (vectorised numpy residual + the reference's own scipy.least_squares call:
     trf, soft_l1, x_scale='jac', ftol=1e-4, 2-point finite differences through jac_sparsity) on a bounded sample of the
     same workload, plus one timed `approx_derivative(..., sparsity=(A, groups))` = the CPU "Jacobian-eval", with the
