@@ -52,6 +52,8 @@ struct mcba_handle {
   int planar = 0;              // every board point has z = 0 exactly (the fused k_gram then runs its planar instance)
   int *tile_i = nullptr, *tile_j = nullptr;
   int NT = 0, NP = 0, G = 0, sq = 0, sr = 0, FS = 0, ppw = 4, nfblocks = 0, nbblocks = 0, nch = 1;  // k_syrk: G workgroups, sq stages of FS frames each, the first sr one more
+  int gram_nchunk = 0;  // gram_split == 3: point chunks per (camera, frame block) of the tail
+  double* gchunk = nullptr;  // ... and their raw sums
   int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD (few frames)
   size_t nx = 0, nsys = 0;
   double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
@@ -301,8 +303,23 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
     // more than one round with a short last round: fused for the whole rounds + split roles for the tail (mode 2)
     // (measured 24 x 6250 x 200, 2.3 rounds: 536 us vs 561 us fused, 612 us split; at 1.15 rounds plain split roles win)
     if (items > 2048 && (items % 1024) > 0 && (items % 1024) <= 512) h->gram_split = 2;
+    // Round 3: more than one round with a short last round -> whole rounds fused + the tail's POINTS in chunks over the idle SIMDs
+    // (mode 3; measured 24 x 6250 x 200: k_gram 381 -> 360 us -- profiles/round3/NOTES_round3.md section 6)
+    if (items > 1024) {
+      const int fba = ((items / 1024) * 1024 / C) & ~3, tail = C * (h->nfb - fba);
+      // (worth it for large boards only: the chunk launch + the combine launch cost ~25 us whatever the board, the split-role
+      //  tail 0.73 of a fused pass -- break-even near 90 points; 6 x 12500 x 54: 88 us against 79 us with plain split roles)
+      if (fba > 0 && tail > 0 && tail <= 512 && N >= 128) {
+        const int nch = std::min(std::min(8, 1024 / tail), N / 8);
+        if (nch >= 2) { h->gram_split = 3; h->gram_nchunk = nch; }
+      }
+    }
   }
-  if (const char* e = getenv("MCBA_GRAM_SPLIT")) h->gram_split = std::max(0, std::min(2, atoi(e)));  // 0 fused, 1 split roles, 2 fused + split tail
+  if (const char* e = getenv("MCBA_GRAM_SPLIT")) {  // 0 fused, 1 split roles, 2 fused + split-role tail, 3 fused + point-chunk tail
+    h->gram_split = std::max(0, std::min(3, atoi(e)));
+    if (h->gram_split == 3 && h->gram_nchunk < 2) h->gram_nchunk = std::max(2, std::min(4, N / 8));
+  }
+  if (const char* e = getenv("MCBA_GRAM_NCHUNK")) h->gram_nchunk = std::max(2, std::min(8, atoi(e)));
   // k_cost: split the board points so that ~4 waves per SIMD (1024 SIMDs) are in flight
   h->nch = std::max(1, std::min(std::min(8, N / 8), (4096 + C * h->nfb - 1) / (C * h->nfb)));
   h->nfblocks = h->G;  // (kept: k_syrk's workgroups factorise their own frames: one (max |g_f|, #failures) pair each)
@@ -346,6 +363,7 @@ static int ensure_solver(mcba_handle* h) {
   DA(swork, h->solve_lds ? 16 : (size_t)h->npad * h->npad);
   DA(fixed, (size_t)h->n);
   DA(dscale, h->nx);
+  if (h->gram_split == 3) DA(gchunk, mcba::gram_chunk_doubles(C, h->nfb, h->gram_nchunk));
 #undef DA
   if (mcba::solve_set_lds_limit(h->npad, h->solve_lds) != 0) return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_solve_cam");
   h->fuse_backsub = h->solve_lds != 0;
@@ -570,7 +588,7 @@ int mcba_linearize(mcba_handle* h, int slot) {
   NEED_SOLVER(h);
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk);
   }
   int rc = check_launch();
   if (rc) return rc;
@@ -649,7 +667,7 @@ int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, 
   const int alt = 1 - h->lin;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -725,7 +743,7 @@ static int lm_trial_impl(mcba_handle* h, const double* delta_cam, const mcba::De
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);  // trial point = the OTHER slot / buffer
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -897,7 +915,7 @@ static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk);
   }
   if ((rc = check_launch())) return rc;
   if (!sum_here) return MCBA_OK;

@@ -67,7 +67,9 @@ struct SolveArgs {
 };
 void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int C, int F, int N, int Fpad);
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,
-                 int planar = 0);  // planar: every board point has z = 0 exactly (with f_scale = 1 the fused kernel's FAST instance runs)
+                 int planar = 0,   // planar: every board point has z = 0 exactly (with f_scale = 1 the fused kernel's FAST instance runs)
+                 double* chunk = nullptr, int nchunk = 0);  // split == 3: scratch for the point-chunk tail (gram_chunk_doubles) and the number of chunks
+size_t gram_chunk_doubles(int C, int nfb, int nchunk);   // doubles of that scratch for C cameras x nfb frame blocks
 void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch);
 size_t syrk_lds_bytes(int C, int FS);
 void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int sq, int sr, int FS, int ppw,

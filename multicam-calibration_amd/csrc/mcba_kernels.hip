@@ -139,10 +139,18 @@ __global__ void k_transpose_obs(const double2* __restrict__ raw, double2* __rest
 // hide each other's FP64 / memory latency; the roles never exchange data.
 // FAST (fused variant only): planar board (every z = 0) and f_scale = 1 -- the reference's own set-up -- known at compile time:
 // seven FP64 instructions per point-observation less (products with 0.0 / 1.0 dropped; results equal to round-off).
-template <int LOSS, int ROLE, bool FAST = false>
+// MODE (fused variant only; round 3): 0 the whole linearisation of one (camera, frame block); 1 POINT CHUNK -- the points [p_lo, p_hi)
+// only, and instead of the expansion the 88 raw per-lane sums (local Gram accumulators, cost, data flag) go to `chunk` --; 2 COMBINE --
+// no point loop: the sums of `nchunk` chunks are added up in chunk order and expanded.  1 + 2 replace the split-role tail launch of
+// shards that are not a whole number of rounds of the 1 024 wavefront slots: the remainder's POINTS are spread over the idle SIMDs.
+constexpr int kGramRaw = 88;  // ee 21 | he 6 | cost | ii 17 | ie 36 | hi 6 | any
+template <int LOSS, int ROLE, bool FAST = false, int MODE = 0>
 __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
                                           double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2,
-                                          const double (&pz0)[6], const double2 (&pre)[4], double* s_cost, int nrun) {
+                                          const double (&pz0)[6], const double2 (&pre)[4], double* s_cost, int nrun, int p_lo = 0, int p_hi = -1, double2* chunk = nullptr, int nchunk = 1,
+                                          size_t chunk_stride = 0) {
+  if (p_hi < 0) p_hi = N;
+  static_assert(MODE == 0 || (ROLE == 2 && MCBA_GRAM_PIPE), "point chunks exist for the fused, pipelined loop only");
   // pz0: this lane's frame pose, pre: its first four observations -- loaded by the kernel before the camera constants were
   // staged (those loads, the LM state and the camera rows are all in flight together: one memory round trip at the start)
   const int f = fb * 64 + lane;
@@ -222,7 +230,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     double x4[RD][3];
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
-      const int pj = min(j, N - 1);
+      const int pj = min(p_lo + j, p_hi - 1);
       r4[j] = pre[j];
       x4[j][0] = obj[3 * pj]; x4[j][1] = obj[3 * pj + 1]; x4[j][2] = obj[3 * pj + 2];
     }
@@ -251,8 +259,9 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
         gram_add_row<1>(gb, E, wv2, gv, q.b * q.d, l4, l4 * q.s);
       }
     };
-    int p = 0;
-    for (; p + RD <= N; p += RD) {
+    int p = p_lo;
+    if constexpr (MODE != 2)
+    for (; p + RD <= p_hi; p += RD) {
 #pragma unroll
       for (int j = 0; j < RD; ++j) {
         const int jn = (j + 1) % RD;
@@ -260,16 +269,17 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
         obs_lead<true, FAST>(pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));  // point p + j + 1 (clamped duplicate at the very end)
         const double2 o2 = r4[j];
         const double Xo[3] = {x4[j][0], x4[j][1], x4[j][2]};
-        const int pn = min(p + j + RD, N - 1);
+        const int pn = min(p + j + RD, p_hi - 1);
         r4[j] = op[(size_t)pn * Fpad];
         x4[j][0] = obj[3 * pn]; x4[j][1] = obj[3 * pn + 1]; x4[j][2] = obj[3 * pn + 2];
         accumulate(o2, Xo, qc);
         qc = qn;
       }
     }
+    if constexpr (MODE != 2)
 #pragma unroll
     for (int j = 0; j < RD; ++j) {  // remainder (N not a multiple of 4): same rotation of the ring, no refill
-      if (p + j < N) {
+      if (p + j < p_hi) {
         const int jn = (j + 1) % RD;
         ObsLead qn;
         obs_lead<true, FAST>(pc, x4[jn], qn, is_num(r4[jn].x) || is_num(r4[jn].y));
@@ -298,6 +308,56 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #ifdef MCBA_GRAM_TIMING
   const long long gt2 = clock64();
 #endif
+  if constexpr (MODE == 1) {  // point chunk: the raw sums, [k / 2][lane] double2 rows (1 KiB each), nothing else
+    double raw[kGramRaw];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) raw[i] = ga.ee[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { raw[21 + i] = ga.he[i]; raw[81 + i] = gb.hi[i]; }
+    raw[27] = cost;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) raw[28 + i] = gb.ii[i];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) raw[45 + i] = gb.ie[i];
+    raw[87] = any ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < kGramRaw; k += 2) chunk[(k >> 1) * 64] = make_double2(raw[k], raw[k + 1]);
+    return;
+  }
+  if constexpr (MODE == 2) {
+    // combine: chunk sums in chunk order, THREE chunks (132 double2 rows of 1 KiB) in flight per round trip -- a dependent global
+    // round trip costs ~2 us here, the data next to nothing
+    constexpr int HR = kGramRaw / 2, CB = 3;
+    double acc[kGramRaw];
+#pragma unroll
+    for (int k = 0; k < kGramRaw; ++k) acc[k] = 0.0;
+    for (int c0 = 0; c0 < nchunk; c0 += CB) {
+      double2 v[CB][HR];
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        const double2* src = chunk + (size_t)min(c0 + j, nchunk - 1) * chunk_stride;  // (clamped duplicates are not added)
+#pragma unroll
+        for (int k = 0; k < HR; ++k) v[j][k] = src[k * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (c0 + j < nchunk) {
+#pragma unroll
+          for (int k = 0; k < HR; ++k) { acc[2 * k] += v[j][k].x; acc[2 * k + 1] += v[j][k].y; }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 21; ++i) ga.ee[i] = acc[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { ga.he[i] = acc[21 + i]; gb.hi[i] = acc[81 + i]; }
+    cost = acc[27];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) gb.ii[i] = acc[28 + i];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) gb.ie[i] = acc[45 + i];
+    any = acc[87] != 0.0;
+  }
   // ---- expand once per (c,f): this role's part of W, V, g_f (record) and of U, g_c (reduced over the wave)
   ChainConst ch;
   {
@@ -421,11 +481,12 @@ struct GramStart {
   bool run;
 };
 __device__ __forceinline__ void gram_start(GramStart& g, CamConst& s_cam, const double2* __restrict__ obs_t, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1, double* rec0, double* rec1,
-                                           double* gp0, double* gp1, int C, int N, int Fpad, int fb0, int fb1) {
+                                           double* gp0, double* gp1, int C, int N, int Fpad, int fb0, int fb1, int p_lo = 0, int p_hi = -1) {
+  if (p_hi < 0) p_hi = N;
   const int c = blockIdx.y;
   const int wave = threadIdx.x >> 6;
   g.lane = threadIdx.x & 63;
-  g.fb = fb0 + blockIdx.x * 4 + wave;  // this launch covers the frame blocks [fb0, fb1)
+  g.fb = fb0 + blockIdx.x * (blockDim.x >> 6) + wave;  // this launch covers the frame blocks [fb0, fb1), one per wavefront
   const bool have = g.fb < fb1;
   const int fbc = have ? g.fb : fb1 - 1;
   double st3 = 0.0, st14 = 0.0, st15 = 0.0;
@@ -440,7 +501,7 @@ __device__ __forceinline__ void gram_start(GramStart& g, CamConst& s_cam, const 
   }
   const double2* op = obs_t + (size_t)c * N * Fpad + (size_t)fbc * 64 + g.lane;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) g.pre[j] = op[(size_t)min(j, N - 1) * Fpad];
+  for (int j = 0; j < 4; ++j) g.pre[j] = op[(size_t)min(p_lo + j, p_hi - 1) * Fpad];
   // ---- the state has arrived: sel_active(sl, true) / sel_index(sl)
   const bool active = !sl.lms || (st15 == 0.0 && st14 == 0.0);
   const bool spec = sl.spec && st14 == 0.0;
@@ -489,6 +550,40 @@ __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t,
   if (!g.run) return;
   const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));  // wavefronts of this workgroup that have a frame block
   gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun);
+}
+
+// Point-chunk tail (gram_body MODE 1 / 2).  k_gram_chunk: grid (frame blocks, C, nchunk) of ONE-wavefront workgroups (with four
+// wavefronts per workgroup a tail of 14 frame blocks x 24 cameras x 3 chunks is 288 workgroups on 256 CUs: 32 CUs carry two, i.e.
+// two wavefronts per SIMD, and the launch takes twice as long -- measured 96.8 us against 5x us), blockIdx.z = chunk of the board's
+// points [z ppc, (z + 1) ppc); raw sums -> chunk[((camera * ntb + tail block) * nchunk + z)][44][64] double2.  k_gram_combine: grid
+// (ceil(frame blocks / 4), C): sums the chunks of its (camera, frame block) and finishes it exactly as k_gram does.
+template <int LOSS, bool FAST>
+__global__ __launch_bounds__(64) void k_gram_chunk(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
+                                                       double2* __restrict__ chunk, int C, int N, int Fpad, int nfb, int fb0, int fb1, double fs2, double ifs2, int ppc, int nchunk) {
+  __shared__ CamConst s_cam;
+  __shared__ double s_cost[8];
+  const int p_lo = (int)blockIdx.z * ppc, p_hi = min(N, p_lo + ppc);
+  GramStart g;
+  gram_start(g, s_cam, obs_t, sl, x0, x1, nullptr, nullptr, nullptr, nullptr, C, N, Fpad, fb0, fb1, p_lo, p_hi);
+  if (!g.run) return;
+  const int ntb = fb1 - fb0;
+  double2* dst = chunk + ((((size_t)blockIdx.y * ntb + (g.fb - fb0)) * nchunk + blockIdx.z) * (kGramRaw / 2)) * 64 + g.lane;
+  gram_body<LOSS, 2, FAST, 1>(s_cam, obs_t, obj, g.x, nullptr, nullptr, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, 0, p_lo, p_hi, dst);
+}
+template <int LOSS, bool FAST>
+__global__ __launch_bounds__(256) void k_gram_combine(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
+                                                         double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, const double2* __restrict__ chunk,
+                                                         int C, int N, int Fpad, int nfb, int fb0, int fb1, double fs2, double ifs2, int nchunk) {
+  __shared__ CamConst s_cam;
+  __shared__ double s_cost[8];
+  GramStart g;
+  gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1);
+  if (!g.run) return;
+  const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));
+  const int ntb = fb1 - fb0;
+  const double2* src = chunk + (((size_t)blockIdx.y * ntb + (g.fb - fb0)) * nchunk * (kGramRaw / 2)) * 64 + g.lane;
+  gram_body<LOSS, 2, FAST, 2>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun, 0, N, const_cast<double2*>(src), nchunk,
+                              (size_t)(kGramRaw / 2) * 64);
 }
 
 // ---------------------------------------------------------------- k_cost: robust cost only (trial points), optional residual vector
@@ -1234,7 +1329,7 @@ void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int 
 }
 
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,
-                 int planar) {
+                 int planar, double* chunk, int nchunk) {
   const int nfb = Fpad / 64;
   dim3 block(256);
   const double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
@@ -1252,6 +1347,30 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
     DISPATCH_LOSS(loss, (k_gram_split<L><<<grid, block, 0, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)));
   };
   if (split == 1) { roles(0, nfb); return; }
+  if (split == 3) {
+    // whole rounds of the 1 024 wavefront slots fused; the last, short round as POINT CHUNKS: nchunk wavefronts per (camera, frame
+    // block), each over 1 / nchunk of the board's points (ppc a multiple of the loop's four), + one combine launch
+    const int items3 = C * nfb;
+    const int fba3 = ((items3 / 1024) * 1024 / C) & ~3;
+    if (fba3 > 0 && fba3 < nfb && chunk && nchunk >= 2) {
+      fused(0, fba3);
+      const int ppc = ((N + nchunk - 1) / nchunk + 3) & ~3;
+      const int nch = (N + ppc - 1) / ppc;
+      dim3 gridc(nfb - fba3, C, nch), gridm((nfb - fba3 + 3) / 4, C, 1);
+      double2* ck = reinterpret_cast<double2*>(chunk);
+      const bool fast = planar && f_scale == 1.0;
+      if (fast) {
+        DISPATCH_LOSS(loss, (k_gram_chunk<L, true><<<gridc, dim3(64), 0, st>>>(o2, obj, s, x0, x1, ck, C, N, Fpad, nfb, fba3, nfb, fs2, ifs2, ppc, nch)));
+        DISPATCH_LOSS(loss, (k_gram_combine<L, true><<<gridm, block, 0, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, ck, C, N, Fpad, nfb, fba3, nfb, fs2, ifs2, nch)));
+      } else {
+        DISPATCH_LOSS(loss, (k_gram_chunk<L, false><<<gridc, dim3(64), 0, st>>>(o2, obj, s, x0, x1, ck, C, N, Fpad, nfb, fba3, nfb, fs2, ifs2, ppc, nch)));
+        DISPATCH_LOSS(loss, (k_gram_combine<L, false><<<gridm, block, 0, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, ck, C, N, Fpad, nfb, fba3, nfb, fs2, ifs2, nch)));
+      }
+      return;
+    }
+    fused(0, nfb);
+    return;
+  }
   // split == 2: whole rounds of the 1024 wavefront slots with the fused variant, the (short) last round with the split
   // roles -- their wavefronts are lighter, so a tail of r items costs ~0.55 of a fused pass instead of a whole one
   const int items = C * nfb;
@@ -1262,6 +1381,11 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
   } else {
     fused(0, nfb);
   }
+}
+
+size_t gram_chunk_doubles(int C, int nfb, int nchunk) {
+  const int items = C * nfb, fba = ((items / 1024) * 1024 / C) & ~3;
+  return (size_t)C * (nfb - fba) * nchunk * kGramRaw * 64;
 }
 
 void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch) {

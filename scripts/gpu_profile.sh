@@ -3,7 +3,7 @@
 #   scripts/gpu_profile.sh TAG   ->  gpurun_out/TAG_*  ; then  python3 scripts/store_profiles.py TAG roundN  copies the summaries to profiles/roundN/
 #   bench line (with end_to_end + roofline), rocprofv3 kernel stats of the SAME command, four separate counter passes over a fixed launch
 #   sequence (FETCH_SIZE; WRITE_SIZE; SQ busy / wait; FP64 instruction mix), the frame-sharded tick with a one-rank RCCL communicator,
-#   the user-level call's wall-clock breakdown, the other shapes DESIGN quotes.
+#   the user-level call's wall-clock breakdown, the other shapes DESIGN quotes, kernel stats of the config-5 shard (24 x 6 250 x 200).
 set -e -o pipefail
 TAG=${1:-run}
 OUT=gpurun_out
@@ -26,4 +26,6 @@ find $OUT/${TAG}_dist_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_di
 echo "forced-dist done"
 python3 scripts/e2e_breakdown.py > $OUT/${TAG}_e2e_breakdown.json 2> $OUT/${TAG}_e2e.err
 python3 scripts/other_shapes.py > $OUT/${TAG}_other_shapes.json 2> $OUT/${TAG}_shapes.err
+MCBA_SHAPES="24,6250,10,20" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_shard5_stats -- python3 scripts/other_shapes.py > $OUT/${TAG}_shard5.json 2> $OUT/${TAG}_shard5.err
+find $OUT/${TAG}_shard5_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_shard5_kernel_stats.csv \;
 echo "profile set $TAG done"

@@ -8,8 +8,13 @@ import time
 sys.path.insert(0, ".")
 import multicam_calibration_amd as m
 
+import os
+
 out = {}
-for C, F, rows, cols in ((6, 1000, 6, 9), (6, 10000, 6, 9), (6, 12500, 6, 9), (24, 6250, 10, 20), (6, 100000, 6, 9)):
+SHAPES = ((6, 1000, 6, 9), (6, 10000, 6, 9), (6, 12500, 6, 9), (24, 6250, 10, 20), (6, 100000, 6, 9))
+if os.environ.get("MCBA_SHAPES"):  # e.g. MCBA_SHAPES="6,12500,6,9;24,6250,10,20" (under rocprofv3: one shape per run)
+    SHAPES = tuple(tuple(int(v) for v in sh.split(",")) for sh in os.environ["MCBA_SHAPES"].split(";"))
+for C, F, rows, cols in SHAPES:
     p = m.synth.make_problem(C, F, rows=rows, cols=cols, seed=0)
     x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
     prob = m.ops.Problem(p["uvs"], p["obj"])

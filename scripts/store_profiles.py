@@ -18,7 +18,8 @@ def main(tag, rnd):
     os.makedirs(dst, exist_ok=True)
     for a, b in ((f"{tag}_bench.json", f"bench_{tag}.json"), (f"{tag}_kernel_stats.csv", f"bench_default_kernel_stats_{tag}.csv"), (f"{tag}_pmc_summary.json", f"pmc_{tag}_summary.json"),
                  (f"{tag}_dist_kernel_stats.csv", f"forced_dist_kernel_stats_{tag}.csv"), (f"{tag}_dist_bench.json", f"forced_dist_bench_{tag}.json"),
-                 (f"{tag}_e2e_breakdown.json", f"e2e_breakdown_{tag}.json"), (f"{tag}_other_shapes.json", f"other_shapes_{tag}.json")):
+                 (f"{tag}_e2e_breakdown.json", f"e2e_breakdown_{tag}.json"), (f"{tag}_other_shapes.json", f"other_shapes_{tag}.json"),
+                 (f"{tag}_shard5_kernel_stats.csv", f"shard5_kernel_stats_{tag}.csv")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, b))
         else:

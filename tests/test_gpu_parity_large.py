@@ -1,7 +1,7 @@
 """GPU parity above toy size (run with `-m gpu` on an MI355X):
   * converged parameters against reference-certified tight optima at 6 cameras x 1000 frames x 54 points, all parameters
     free and with the intrinsics frozen (BASELINE configs[1]) -- tests/golden/make_golden_tight_large.py;
-  * every k_gram launch variant (fused / split roles / fused rounds + split tail) against the oracle's normal equations
+  * every k_gram launch variant (fused / split roles / fused rounds + split tail / fused rounds + point-chunk tail) against the oracle's normal equations
     on a problem big enough for the two-launch variant to split (24 cameras x 2880 frames);
   * size-independent properties at the shard shapes of BASELINE configs[3] (6 x 12 500 x 54) and configs[4]
     (24 x 6 250 x 200), which no oracle run can reach."""
@@ -58,13 +58,15 @@ def test_solution_matches_tight_reference_optimum_large(mc, golden, size, mode):
 
 
 # ------------------------------------------------------------------ every k_gram launch variant against the oracle
-@pytest.mark.parametrize("split", [0, 1, 2])
-def test_gram_variants_vs_oracle(mc, split):
+@pytest.mark.parametrize("split,board", [(0, (2, 2)), (1, (2, 2)), (2, (2, 2)), (3, (2, 2)), (3, (3, 5)), (3, (2, 5))])
+def test_gram_variants_vs_oracle(mc, split, board):
     """MCBA_GRAM_SPLIT (read in mcba_create): 0 fused (one wavefront per SIMD), 1 split roles (two per SIMD), 2 whole
-    rounds fused + the tail with the split roles in a second launch over the frame blocks [fb0, fb1).  24 cameras x 45
-    frame blocks = 1080 wavefront items: variant 2 launches fused(0..40) + roles(40..45).  2 x 2 board: small enough
-    for the oracle's dense normal equations."""
-    p = mc.synth.make_problem(24, 2880 - 7, rows=2, cols=2, pitch=60.0, seed=41, missing=0.15)   # ragged last frame block
+    rounds fused + the tail with the split roles in a second launch over the frame blocks [fb0, fb1), 3 whole rounds fused + the
+    tail as POINT CHUNKS (k_gram_chunk: 2 chunks of the board's points per (camera, frame block), k_gram_combine sums and expands them).
+    24 cameras x 45 frame blocks = 1080 wavefront items: variants 2 / 3 launch fused(0..40) + tail(40..45).  Boards small enough for
+    the oracle's dense normal equations: 2 x 2 (one chunk: the degenerate case), 3 x 5 (chunks of 8 + 7 points: a remainder inside a
+    chunk), 2 x 5 (8 + 2)."""
+    p = mc.synth.make_problem(24, 2880 - 7, rows=board[0], cols=board[1], pitch=60.0 if board == (2, 2) else 25.0, seed=41, missing=0.15)   # ragged last frame block
     C, F = p["uvs"].shape[:2]
     x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
     old = os.environ.get("MCBA_GRAM_SPLIT")
@@ -98,7 +100,7 @@ def test_gram_variants_vs_oracle(mc, split):
 
 # ------------------------------------------------------------------ shard shapes of BASELINE configs[3] and configs[4]
 @pytest.mark.parametrize("C,F,rows,cols,tag", [(6, 12500, 6, 9, "config-4 shard: 1176 wavefront items, split roles at 1.15 rounds"),
-                                                (24, 6250, 10, 20, "config-5 shard: 2352 items, fused rounds + split tail, 288x288 solve on the GPU")])
+                                                (24, 6250, 10, 20, "config-5 shard: 2352 items, fused rounds + point-chunk tail (3 chunks; 6 in the half shards), 288x288 solve on the GPU")])
 def test_shard_shape_properties(mc, C, F, rows, cols, tag):
     """What the driver's 8-GPU runs execute per rank, checked through size-independent properties:
     (i) k_cost and k_gram agree on the robust cost, and the oracle agrees on a 64-frame sample of the residuals;
