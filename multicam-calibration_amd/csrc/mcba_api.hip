@@ -360,7 +360,7 @@ static int ensure_solver(mcba_handle* h) {
   DA(tile_i, (size_t)h->NP);
   DA(tile_j, (size_t)h->NP);
   DA(dcbuf, (size_t)h->n + 8);  // + the word k_solve_backsub's solve releases, + the poll-timeout stamp
-  DA(swork, h->solve_lds ? 16 : (size_t)h->npad * h->npad);
+  DA(swork, h->solve_lds ? 16 : 2 * (size_t)h->npad * h->npad + 64 * (size_t)h->npad);  // two sets of 16 x 16 tiles of the lower triangle (mcba_solve.hip, right-looking variant)
   DA(fixed, (size_t)h->n);
   DA(dscale, h->nx);
   if (h->gram_split == 3) DA(gchunk, mcba::gram_chunk_doubles(C, h->nfb, h->gram_nchunk));

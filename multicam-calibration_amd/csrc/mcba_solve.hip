@@ -117,6 +117,337 @@ __device__ __forceinline__ void post_state(const SolveArgs& a, const double* st,
 #endif
 __host__ __device__ inline bool solve_lookahead(int npad) { return MCBA_SOLVE_LOOKAHEAD && npad <= 96; }
 
+// =====================================================================================================================
+// RIGHT-LOOKING variant for systems that do not fit LDS (> 9 cameras; config 5: 12C = 288), 8 wavefronts.
+//
+// The left-looking form above reads, per block column, rows of the factor that grow with the column index from an L2-resident
+// scratch: every block step pays several dependent global round trips (B rows -> LDS, A rows, the diagonal rows, the write
+// back) -- 10.8 us per block step at 12C = 288 against 2.4 us with the factor in LDS.  Here every 16 x 16 tile of the trailing
+// matrix is read and written ONCE per block step, in the MFMA accumulator layout (32 contiguous bytes per lane), the panel of
+// the current step never leaves the workgroup (registers + LDS), and the next panel is produced first (look-ahead), so that the
+// 16 sequential pivots of block k + 1 (wavefront 0) run while the other wavefronts finish the trailing update of block k.
+//
+// Tile layout: element (i, c) of a tile lives in lane i + 16 (c >> 2), register c & 3 -- a lane holds four CONTIGUOUS columns of
+// its row, so a tile of the row-major reduce buffer is one aligned 32-byte load per lane.  The same registers are
+//   * an MFMA B operand of the tile as it stands (lane (i, kk), K-step s  <->  column 4 kk + s: any K order serves as long as
+//     both operands use it) and, read back from LDS with the lane's two 2-bit fields swapped (rl_pi), its A operand,
+//   * the accumulator of the TRANSPOSED tile under that row permutation: D row 4 r + g of lane (i, g) is column 4 g + r,
+// so  C^T -= L_J L_I^T  keeps the layout and a finished tile of the factor is an operand without any shuffle.  Per block step k
+// (two barriers):
+//   A  wavefront 0: the 16 pivots of the diagonal block, with the 16 identity rows riding in lanes 16..31 (-> L_kk^-T);
+//      wavefronts 1-3, 5-7 (the SIMDs wavefront 0 is not on): trailing update with panel k - 1 of every tile right of column k,
+//      a ring of tiles in flight, branch-free; at k = 0 they bring the tiles from the reduce buffer into the scratch instead;
+//      wavefront 4 (same SIMD as the pivots, so no MFMAs): panel k - 1 from LDS to the tiles of the backward sweep
+//   B  every wavefront, its tile rows I = wave, wave + 8, ...:  L_(I,k) = Z L_kk^-T  as four MFMAs on the registers the
+//      look-ahead left (result to LDS: operands of A's updates), then at once the look-ahead -- its tiles of column k + 1
+//      updated with panel k: the one operand it does not own, L_(k+1,k), every wavefront forms for itself; the diagonal tile
+//      goes to LDS as rows for the pivots, the others stay in registers
+// The backward sweep uses the inverse diagonal blocks; its rows of the factor are requested one step ahead.
+// Measured (scripts/solve_time.py, one box): 12C = 120 / 192 / 288 / 480: 43 / 79 / 150 / 424 us against 117.6 (192) / 205 / 578 us
+// left-looking; what is left at 288: ~45 k cycles of first touch (0.66 MB of cold reads by ONE CU), B at ~4.5 k per step
+// (a global round trip for the look-ahead tiles inside it), the updates at 2 x their MFMA time.
+#ifndef MCBA_SOLVE_RL
+#define MCBA_SOLVE_RL 1
+#endif
+#ifndef MCBA_RL_NB
+#define MCBA_RL_NB 4
+#endif
+// a barrier that orders LDS traffic only: global loads issued before it stay in flight (__syncthreads waits for them)
+__device__ __forceinline__ void rl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ size_t rl_tile(int I, int J) { return ((size_t)(I * (I + 1) / 2 + J)) << 8; }
+// lane a of an A operand carries row pi(a) of the tile (the 4 x 4 transpose of the lane's two 2-bit fields), see above
+__device__ __forceinline__ int rl_pi(int lane) { return ((lane & 3) << 2) | ((lane >> 2) & 3) | (lane & 48); }
+
+// tile (I, J), I >= J, of the augmented damped matrix straight from the reduce buffer (both triangles are there: k_reduce_system
+// mirrors on write): lane (i, g) = row 16 I + i, columns 16 J + 4 g .. + 3 -- one aligned 32-byte load (n = 12 C: a group of four
+// columns is either inside the matrix or past it)
+__device__ __forceinline__ solve_d4 rl_system_load(const double* __restrict__ S0, int n, int I, int J, int lane) {
+  const int row = 16 * I + (lane & 15), c0 = 16 * J + 4 * (lane >> 4);
+  const bool in = row <= n && c0 < n;  // (row n of the stride-n array is the right-hand side)
+  return *reinterpret_cast<const solve_d4*>(S0 + (in ? (size_t)row * n + c0 : 0));
+}
+// ... and what is not in the buffer: the damping on the diagonal, 1 at (n, n), the identity padding, parameters held fixed.
+// (Kept apart from the load so that a caller can have many tiles in flight: the rare-path branch below ends the compiler's
+//  static wait counts.)
+__device__ __forceinline__ solve_d4 rl_system_fixup(solve_d4 v, const double* damp, const unsigned char* fixed, int n, int I, int J, int lane) {
+  const int row = 16 * I + (lane & 15), c0 = 16 * J + 4 * (lane >> 4);
+  const bool in = row <= n && c0 < n;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = c0 + r;
+    double x = in ? v[r] : ((row == c) ? 1.0 : 0.0);
+    if (in && row == c) x += damp[row];
+    v[r] = x;
+  }
+  if (fixed) {  // identity row and column, zero right-hand side
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = c0 + r, rr = max(row, c), cc = min(row, c);
+      if ((rr < n && fixed[rr]) || (cc < n && fixed[cc])) v[r] = (row == c) ? 1.0 : 0.0;
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ solve_d4 rl_tile_from_system(const double* __restrict__ S0, const double* damp, const unsigned char* fixed, int n, int I, int J, int lane) {
+  return rl_system_fixup(rl_system_load(S0, n, I, J, lane), damp, fixed, n, I, J, lane);
+}
+
+// C^T -= L_J L_I^T on one tile: `pj` is the panel's tile of rows J read as an A operand (rl_pi), `pi` its tile of rows I as it stands
+__device__ __forceinline__ solve_d4 rl_update(solve_d4 c, const solve_d4 pj, const solve_d4 pi) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-pj[s], pi[s], c, 0, 0, 0);
+  return c;
+}
+
+// flat index t of a lower-triangular enumeration (row-major) -> (row, column)
+__device__ __forceinline__ void rl_unflatten(int t, int& Ir, int& Jr) {
+  Ir = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((Ir + 1) * (Ir + 2) / 2 <= t) ++Ir;
+  while (Ir * (Ir + 1) / 2 > t) --Ir;
+  Jr = t - Ir * (Ir + 1) / 2;
+}
+
+template <int NTHREADS>
+__device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const double* __restrict__ S0, const unsigned char* fixed, const double* damp, double* yv, double* dv, double* invd,
+                                                    double* linv /* npad x 17 */, double* Pop /* npad x 16 */, double* dtile /* 16 x 17 */, double* znext /* 2 x 256 */, double* tstamp) {
+  constexpr int NW = NTHREADS / 64, SL = 32 / NW;  // tile row I is owned by wavefront I mod NW (<= 32 tile rows: 40 cameras)
+  static_assert(NW == 8, "8 wavefronts: 256 VGPRs each");
+  constexpr int NWK = NW - NW / 4;                // trailing-update workers: the wavefronts that do not share a SIMD with wavefront 0 (the pivots)
+  const int n = a.n, npad = a.npad, nblk = npad >> 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform, and the compiler knows it: tile indices and addresses stay in SGPRs)
+  const bool worker = (wave & 3) != 0;
+  const int wk = wave - 1 - (wave >> 2);                      // worker index 0 .. NWK - 1
+  const int li = lane & 15, lg = lane >> 4, lpi = rl_pi(lane);
+  double* T1 = a.work;                                        // trailing tiles
+  double* T2 = a.work + rl_tile(nblk, 0);                     // the factor, column-major tiles (backward sweep)
+  for (int j = tid; j < npad; j += NTHREADS) yv[j] = 0.0;
+  solve_d4 Zp[SL];                                            // my tiles of the current panel (rows wave, wave + NW, ...)
+#pragma unroll
+  for (int sl = 0; sl < SL; ++sl) {
+    const int I = wave + NW * sl;
+    Zp[sl] = solve_d4{0.0, 0.0, 0.0, 0.0};
+    if (I >= 1 && I < nblk) Zp[sl] = rl_tile_from_system(S0, damp, fixed, n, I, 0, lane);
+    if (I == 1 && I < nblk) *reinterpret_cast<solve_d4*>(znext + 4 * lane) = Zp[sl];  // tile (k + 1, k) of the coming step, for everybody
+  }
+  if (wave == 0) {
+    const solve_d4 v = rl_tile_from_system(S0, damp, fixed, n, 0, 0, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dtile[li * 17 + 4 * lg + r] = v[r];
+  }
+  __syncthreads();
+#ifdef MCBA_SOLVE_TIMING
+  long long t_a = 0, t_b = 0;
+#endif
+  for (int k = 0; k < nblk; ++k) {
+    const int r0 = 16 * k;
+#ifdef MCBA_SOLVE_TIMING
+    const long long t0 = clock64();
+#endif
+    // ---- A: pivots of block k (wavefront 0)  ||  the others: trailing update with panel k - 1 of the columns >= k + 1
+    if (wave == 0) {
+      double r[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) r[c] = lane < 16 ? dtile[li * 17 + c] : ((lane < 32 && c == li) ? 1.0 : 0.0);
+      double myinv = 1.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int qq = 0; qq < j; ++qq) {
+          const double ljq = lane_bcast(r[qq], j);
+          if (qq & 1) s1 = fma(r[qq], ljq, s1); else s0 = fma(r[qq], ljq, s0);
+        }
+        r[j] -= s0 + s1;
+        double pj = lane_bcast(r[j], j);
+        if (r0 + j == n) pj = 1.0;  // right-hand-side row: not a pivot
+        const double inv = rsqrt_cubic(pj);
+        r[j] *= inv;
+        myinv = lane == j ? inv : myinv;
+      }
+      if (lane < 16) {
+        invd[r0 + lane] = myinv;
+        if (r0 + lane == n) {  // the right-hand-side row ends in this block: y for the block's columns left of it
+#pragma unroll
+          for (int c = 0; c < 16; ++c) if (c < lane) yv[r0 + c] = r[c];
+        }
+      } else if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) linv[(r0 + li) * 17 + c] = r[c];
+      }
+    } else if (!worker) {
+      // wavefront 4 (shares its SIMD with the pivots, so no MFMA work here): the finished panel k - 1, still in Pop, to the tiles
+      // of the backward sweep -- four 8-byte LDS reads and one 32-byte store per tile and lane (lane (c, g): rows 4 g .. + 3)
+      if (k > 0) {
+        for (int I = k; I < nblk; ++I) {
+          solve_d4 x;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = Pop[256 * I + 4 * ((4 * lg + r) + 16 * (li >> 2)) + (li & 3)];
+          *reinterpret_cast<solve_d4*>(T2 + rl_tile(I, k - 1) + 64 * lg + 4 * li) = x;  // [row quad][column][row in quad]: threads of one column group read 32-byte neighbours
+        }
+      }
+    } else if (k == 0) {
+      // first touch: while wavefront 0 does the first 16 pivots the six others bring every tile right of column 0 from the reduce buffer
+      // (written by other XCDs: a long round trip) into the tile scratch, eight aligned 32-byte loads in flight per lane
+      const int M = nblk * (nblk + 1) / 2 - nblk;  // tiles (I, J), 1 <= J <= I
+      const int t_begin = (int)(((long long)M * wk) / NWK), ntile = (int)(((long long)M * (wk + 1)) / NWK) - t_begin;
+      int Ir, Jr;
+      rl_unflatten(t_begin, Ir, Jr);
+      for (int done = 0; done < ntile; done += 8) {
+        solve_d4 v[8];
+        double* dstp[8];
+        int Is[8], Js[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = done + j < ntile;
+          Is[j] = ok ? Ir + 1 : nblk - 1; Js[j] = ok ? Jr + 1 : nblk - 1;
+          dstp[j] = ok ? T1 + rl_tile(Is[j], Js[j]) : a.work + 2 * rl_tile(nblk, 0) + 256 * wave;
+          v[j] = rl_system_load(S0, n, Is[j], Js[j], lane);
+          if (++Jr > Ir) { ++Ir; Jr = 0; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<solve_d4*>(dstp[j] + 4 * lane) = rl_system_fixup(v[j], damp, fixed, n, Is[j], Js[j], lane);
+      }
+    } else if (k + 1 < nblk) {
+      const int J0 = k + 1, m = nblk - J0;        // panel k - 1 is in Pop; tiles (I, J), J0 <= J <= I < nblk: m (m + 1) / 2 of them
+      const int M = m * (m + 1) / 2;
+      const int t_begin = (int)(((long long)M * wk) / NWK), ntile = (int)(((long long)M * (wk + 1)) / NWK) - t_begin;
+      if (ntile > 0) {
+        // A ring of R tiles, branch-free: slot j multiplies and stores its tile, then requests the tile R places further on into the
+        // same registers -- R - 1 tile updates (~300 cycles each) cover the round trip.  Past the end of this wavefront's run the
+        // slots work on a dummy tile of its own (harmless operands, a scratch destination), so that every wait count is static.
+        constexpr int R = MCBA_RL_NB;
+        double* const dummy = a.work + 2 * rl_tile(nblk, 0) + 256 * wave;
+        int Ir, Jr, issued = 0;
+        rl_unflatten(t_begin, Ir, Jr);
+        solve_d4 cin[R];
+        int It[R], Jt[R];
+        double* dst[R];
+        auto request = [&](int j) {
+          const bool ok = issued < ntile;
+          It[j] = ok ? Ir + J0 : nblk - 1; Jt[j] = ok ? Jr + J0 : nblk - 1;
+          double* tp = T1 + rl_tile(It[j], Jt[j]);
+          dst[j] = ok ? tp : dummy;
+          cin[j] = *reinterpret_cast<const solve_d4*>(tp + 4 * lane);
+          ++issued;
+          if (++Jr > Ir) { ++Ir; Jr = 0; }
+        };
+#pragma unroll
+        for (int j = 0; j < R; ++j) request(j);
+        for (int done = 0; done < ntile; done += R) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            const solve_d4 pi = *reinterpret_cast<const solve_d4*>(Pop + 256 * It[j] + 4 * lane);
+            const solve_d4 pj = *reinterpret_cast<const solve_d4*>(Pop + 256 * Jt[j] + 4 * lpi);
+            const solve_d4 out = rl_update(cin[j], pj, pi);
+            *reinterpret_cast<solve_d4*>(dst[j] + 4 * lane) = out;
+            request(j);
+          }
+        }
+      }
+    }
+    __syncthreads();
+#ifdef MCBA_SOLVE_TIMING
+    const long long t1 = clock64();
+    if (k == (int)a.seq - 1) t_a = t1 - t0;
+#endif
+    // ---- B: my tiles of panel k:  L_(I,k) = Z L_kk^-T,  then the look-ahead at once: my tiles of column k + 1 updated with panel k.
+    // The one operand that is not mine -- L_(k+1,k) -- every wavefront forms for itself (four MFMAs on the tile its owner left in
+    // LDS a step ago, read with the A operand's lane order): no barrier between the two.
+    {
+      solve_d4 cpre[SL];
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        const int I = wave + NW * sl;
+        cpre[sl] = solve_d4{0.0, 0.0, 0.0, 0.0};
+        if (I >= k + 1 && I < nblk) cpre[sl] = *reinterpret_cast<const solve_d4*>(T1 + rl_tile(I, k + 1) + 4 * lane);
+      }
+      solve_d4 lv;  // A operand of  X^T = L_kk^-1 Z^T : lane (a, kk), register s:  L_kk^-1[pi(a)][4 kk + s] = L_kk^-T[4 kk + s][pi(a)]
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) lv[s2] = linv[(r0 + 4 * lg + s2) * 17 + (lpi & 15)];
+      solve_d4 pja = {0.0, 0.0, 0.0, 0.0};  // L_(k+1,k) as an A operand
+      if (k + 1 < nblk) {
+        const solve_d4 zn = *reinterpret_cast<const solve_d4*>(znext + 256 * (k & 1) + 4 * lpi);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) pja = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[s2], zn[s2], pja, 0, 0, 0);
+      }
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        const int I = wave + NW * sl;
+        if (I > k && I < nblk) {
+          solve_d4 xo = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) xo = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[s2], Zp[sl][s2], xo, 0, 0, 0);
+          *reinterpret_cast<solve_d4*>(Pop + 256 * I + 4 * lane) = xo;
+          if (16 * I + li == n) {  // the right-hand-side row: y for this block's columns
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[r0 + 4 * lg + r] = xo[r];
+          }
+          const solve_d4 c = rl_update(cpre[sl], pja, xo);   // tile (I, k + 1)
+          if (I == k + 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dtile[li * 17 + 4 * lg + r] = c[r];
+          } else {
+            Zp[sl] = c;
+            if (I == k + 2) *reinterpret_cast<solve_d4*>(znext + 256 * ((k + 1) & 1) + 4 * lane) = c;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#ifdef MCBA_SOLVE_TIMING
+    if (k == (int)a.seq - 1) t_b = clock64() - t1;
+#endif
+  }
+  // (the last panel has no tiles below its diagonal block: nothing is left in Pop to bring to T2)
+#ifdef MCBA_SOLVE_TIMING
+  const long long t_sw = clock64();
+#endif
+  // ---- backward sweep  L^T d = y  with the inverse diagonal blocks; thread j owns column j.  The rows of the factor a step needs
+  // (block row k, column j) are requested one step ahead: a round trip to the scratch costs more than the step's arithmetic.
+  {
+    solve_d4 wc[4], wn[4];  // wc[q][r] = L[16 k + 4 q + r][tid]
+    auto fetch = [&](int kk, solve_d4 (&w)[4]) {
+      const bool ok = kk >= 1 && tid < 16 * kk;
+      const double* src = T2 + rl_tile(ok ? kk : 1, ok ? (tid >> 4) : 0) + 4 * (tid & 15);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const solve_d4*>(src + 64 * q);
+    };
+    auto step = [&](int k, solve_d4 (&w)[4], solve_d4 (&wnext)[4]) {  // block step k with its rows in `w`; requests step k - 1 into `wnext`
+      const int r0 = 16 * k;
+      fetch(k - 1, wnext);
+      if (tid < 16) {
+        const double* lr = linv + (r0 + tid) * 17;
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s4[c & 3] = fma(lr[c], yv[r0 + c], s4[c & 3]);
+        dv[r0 + tid] = (r0 + tid < n) ? (s4[0] + s4[1]) + (s4[2] + s4[3]) : 0.0;
+      }
+      rl_lds_barrier();
+      if (tid < r0) {
+        double s0 = yv[tid], s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          s0 = fma(-w[q][0], dv[r0 + 4 * q], s0);
+          s1 = fma(-w[q][1], dv[r0 + 4 * q + 1], s1);
+          s0 = fma(-w[q][2], dv[r0 + 4 * q + 2], s0);
+          s1 = fma(-w[q][3], dv[r0 + 4 * q + 3], s1);
+        }
+        yv[tid] = s0 + s1;
+      }
+      rl_lds_barrier();
+    };
+    fetch(nblk - 1, wc);
+    for (int k = nblk - 1; k >= 0; k -= 2) {  // two steps per trip: the two register sets swap roles without a copy
+      step(k, wc, wn);
+      if (k >= 1) step(k - 1, wn, wc);
+    }
+  }
+#ifdef MCBA_SOLVE_TIMING
+  if (tid == 0) { tstamp[29] = (double)t_a; tstamp[30] = (double)t_b; tstamp[27] = (double)(clock64() - t_sw); }  // of block step k = seq - 1: 29 interval A, 30 interval B; 27 the backward sweep
+#endif
+}
+
 // Staging of the reduce buffer: thread (rr, cc) = (tid / 16, tid % 16) owns the elements (rr + RS a, cc + 16 b) --
 // all index arithmetic is incremental, every load is unconditional (clamped address) so none of them waits for another.
 // KS x KS elements per thread cover npad <= 16 KS with 256 threads (KS = 5: up to 6 cameras, KS = 7: up to 9).
@@ -239,6 +570,10 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
     //   rows < n: S0 + lambda D_c on the diagonal,  row n: the right-hand side, 1 on the diagonal,  rows > n: identity
     for (int i = tid; i < npad; i += NTHREADS) damp[i] *= lambda;
     __syncthreads();
+    if constexpr (!LDSW && NTHREADS == 512 && MCBA_SOLVE_RL) {
+      STAMP(1);
+      solve_right_looking<NTHREADS>(a, S0, fixed, damp, yv, dv, invd, panel, Bs, Bs + (size_t)16 * bst, Bs + (size_t)16 * bst + 16 * 17, lst);
+    } else {
     if (LDSW) {
 #pragma unroll
       for (int ia = 0; ia < kStage; ++ia) {
@@ -529,6 +864,7 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
         __syncthreads();
       }
     }
+    }
   }
 
   STAMP(3);
@@ -601,14 +937,14 @@ __global__ __launch_bounds__(64 * kBacksubWaves) void k_solve_backsub(SolveArgs 
 
 // rows a launch can hold: 16 diagonal rows + 48 per wavefront
 int solve_threads(int npad) {
-  int t = npad <= 16 + 4 * 48 ? 256 : npad <= 16 + 8 * 48 ? 512 : 1024;
+  int t = MCBA_SOLVE_RL ? 512 : npad <= 16 + 4 * 48 ? 256 : npad <= 16 + 8 * 48 ? 512 : 1024;  // (the right-looking variant: 8 wavefronts, 256 VGPRs each)
   if (const char* e = getenv("MCBA_SOLVE_THREADS")) { int v = atoi(e); if ((v == 512 || v == 1024) && v > t) t = v; }  // tuning knob
   return t;
 }
 
 size_t solve_lds_bytes(int npad, int use_lds) {
   size_t d = (size_t)npad * 17 + 4 * (size_t)npad + 72 + MCBA_LMS;
-  d += use_lds ? (size_t)npad * (npad + 1) + (size_t)(npad / 16) * 16 * 17 + (solve_lookahead(npad) ? (size_t)npad * 17 : 0) : (size_t)16 * (npad + 2);
+  d += use_lds ? (size_t)npad * (npad + 1) + (size_t)(npad / 16) * 16 * 17 + (solve_lookahead(npad) ? (size_t)npad * 17 : 0) : (size_t)16 * (npad + 2) + 16 * 17 + 2 * 256;  // (+ the diagonal tile and two panel tiles of the right-looking variant)
   return d * sizeof(double);
 }
 

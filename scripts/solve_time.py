@@ -21,9 +21,13 @@ for C in [int(a) for a in sys.argv[1:]] or [6, 24]:
     prob.lm_set_state(float(red["scal"][0]), 1e-3, 2.0, 0)
     prob.lm_auto_config(0.0, 0.0, 0.0, 1e-12, 1e12, None)
     prob.profile_enable(True)
-    for s in range(1, 12):
+    per_launch = []
+    for s in range(1, int(os.environ.get("MCBA_SOLVE_LAUNCHES", "12"))):
         prob.lm_auto_solve(s)
         st = prob.lm_auto_wait(s).copy()
+        per_launch.append((int(st[27]), int(st[29]), int(st[30])))
+    if os.environ.get("MCBA_SOLVE_LAUNCHES"):
+        print("per launch (slots 27, 29, 30):", per_launch)
     prof = prob.profile_read()
     ms, n = prof["k_solve_cam"]
     print("C=%d n=%d: k_solve_cam %.2f us avg; stamps (cycles): %s" % (C, 12 * C, 1e3 * ms / n, np.array2string(st[25:31], precision=6)))
