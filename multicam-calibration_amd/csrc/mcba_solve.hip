@@ -5,22 +5,22 @@
 // no host round trip at all (solver.py `reduced_solver="device"`).  It replaces the host LAPACK call of
 // solver._solve_spd, which itself stands where the reference calls LSMR (scipy/optimize/_lsq/trf.py:479-480).
 //
-// Algorithm: left-looking blocked Cholesky, block 16, of the matrix augmented with the right-hand side as ROW n
+// Algorithm: blocked Cholesky, block 16, of the matrix augmented with the right-hand side as ROW n
 //            [ S   . ]        L y = rhs falls out of the factorisation as row n of the factor (no forward sweep)
 //            [ rhs 1 ]
+// Up to 9 cameras the factor lives in LDS (odd row stride) -- LEFT-LOOKING: the whole lower triangle is put in flight before
+// anything else, because a dependent global round trip costs ~2 us here;
 //   per block column k:   panel  = A[16k:, 16k:16k+16] - L[16k:, :16k] L[16k:16k+16, :16k]^T     v_mfma_f64_16x16x4, one
 //                                                                                               wave per 16-row tile
 //                         diagonal block AND the rows below it in ONE instruction stream: lanes 0..15 of every wavefront
 //                         hold the 16 diagonal rows (redundantly), lanes 16..63 hold 48 further panel rows; finished
 //                         entries of the diagonal rows are broadcast with v_readlane (left-looking inside the block), so
 //                         there is no barrier between "factor" and "triangular solve"; pivots: v_rsq_f64 + one cubic step
-//   backward sweep L^T d = y block by block.  Factor in LDS: the identity's 16 rows ride through every diagonal block's
-//   triangular solve in otherwise idle lanes, which leaves L_kk^-T -- the sweep's 16 sequential pivots per block become
-//   one 16-term dot product per row (measured at 12 C = 72: 10.6 k -> 6.1 k cycles).  Factor in global memory: each
-//   step's operands in flight while wavefront 0 does the 16 pivots.
-// The factor lives in LDS (odd row stride) when it fits (<= 9 cameras) -- then the whole lower triangle is put in flight
-// before anything else, because a dependent global round trip costs ~2 us here; otherwise in an L2-resident scratch,
-// with the panel's own rows staged in LDS and the A rows streamed 32 B per lane, one work item ahead.
+//   backward sweep L^T d = y block by block: the identity's 16 rows ride through every diagonal block's triangular solve
+//   in otherwise idle lanes, which leaves L_kk^-T -- the sweep's 16 sequential pivots per block become one 16-term dot
+//   product per row (measured at 12 C = 72: 10.6 k -> 6.1 k cycles).
+// Beyond that (12 C + 1 > 112 rows) the trailing matrix lives in an L2-resident scratch as 16 x 16 tiles in the MFMA
+// accumulator layout -- RIGHT-LOOKING with a look-ahead panel: solve_right_looking below.
 // k_solve_backsub (single-GPU ticks, factor in LDS) runs the back-substitution of the NEXT trial step in the same launch, in
 // workgroups that wait for two words this workgroup releases (mcba_backsub.h).
 // The same launch evaluates first-order optimality, applies the termination verdict (pending from k_sum_trial / k_decide,
@@ -144,17 +144,27 @@ __host__ __device__ inline bool solve_lookahead(int npad) { return MCBA_SOLVE_LO
 //      goes to LDS as rows for the pivots, the others stay in registers
 // The backward sweep uses the inverse diagonal blocks; its rows of the factor are requested one step ahead.
 // Measured (scripts/solve_time.py, one box): 12C = 120 / 192 / 288 / 480: 43 / 79 / 150 / 424 us against 117.6 (192) / 205 / 578 us
-// left-looking; what is left at 288: ~45 k cycles of first touch (0.66 MB of cold reads by ONE CU), B at ~4.5 k per step
-// (a global round trip for the look-ahead tiles inside it), the updates at 2 x their MFMA time.
-#ifndef MCBA_SOLVE_RL
-#define MCBA_SOLVE_RL 1
-#endif
+// left-looking; what is left at 288 (of ~340 k cycles): ~38 k of first touch (0.66 MB of cold reads by ONE CU), B at ~4.5 k per step
+// (a global round trip for the look-ahead tiles inside it: interleaving its MFMA chains changed nothing), the updates at 2 x their
+// MFMA time -- they are bound by the tile traffic of one CU (~30 B per cycle: with the MFMAs removed the interval is as long, with
+// the loads and stores removed it shrinks to the pivots' 4.5 k), the backward sweep 30 k.
 #ifndef MCBA_RL_NB
 #define MCBA_RL_NB 4
 #endif
 // a barrier that orders LDS traffic only: global loads issued before it stay in flight (__syncthreads waits for them)
 __device__ __forceinline__ void rl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ size_t rl_tile(int I, int J) { return ((size_t)(I * (I + 1) / 2 + J)) << 8; }
+// a tile in the scratch: registers (0, 1) of all lanes, then registers (2, 3) -- each 16-byte access of a wavefront is 1 KB of
+// whole cache lines (with 32 contiguous bytes per lane every instruction touched half of 16 lines: first touch 45 k -> 38 k cycles)
+typedef double solve_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ solve_d4 rl_tile_load(const double* t, int lane) {
+  const solve_d2 lo = *reinterpret_cast<const solve_d2*>(t + 2 * lane), hi = *reinterpret_cast<const solve_d2*>(t + 128 + 2 * lane);
+  return solve_d4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ void rl_tile_store(double* t, int lane, const solve_d4 v) {
+  *reinterpret_cast<solve_d2*>(t + 2 * lane) = solve_d2{v[0], v[1]};
+  *reinterpret_cast<solve_d2*>(t + 128 + 2 * lane) = solve_d2{v[2], v[3]};
+}
 // lane a of an A operand carries row pi(a) of the tile (the 4 x 4 transpose of the lane's two 2-bit fields), see above
 __device__ __forceinline__ int rl_pi(int lane) { return ((lane & 3) << 2) | ((lane >> 2) & 3) | (lane & 48); }
 
@@ -306,7 +316,7 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
           if (++Jr > Ir) { ++Ir; Jr = 0; }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<solve_d4*>(dstp[j] + 4 * lane) = rl_system_fixup(v[j], damp, fixed, n, Is[j], Js[j], lane);
+        for (int j = 0; j < 8; ++j) rl_tile_store(dstp[j], lane, rl_system_fixup(v[j], damp, fixed, n, Is[j], Js[j], lane));
       }
     } else if (k + 1 < nblk) {
       const int J0 = k + 1, m = nblk - J0;        // panel k - 1 is in Pop; tiles (I, J), J0 <= J <= I < nblk: m (m + 1) / 2 of them
@@ -328,7 +338,7 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
           It[j] = ok ? Ir + J0 : nblk - 1; Jt[j] = ok ? Jr + J0 : nblk - 1;
           double* tp = T1 + rl_tile(It[j], Jt[j]);
           dst[j] = ok ? tp : dummy;
-          cin[j] = *reinterpret_cast<const solve_d4*>(tp + 4 * lane);
+          cin[j] = rl_tile_load(tp, lane);
           ++issued;
           if (++Jr > Ir) { ++Ir; Jr = 0; }
         };
@@ -340,7 +350,7 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
             const solve_d4 pi = *reinterpret_cast<const solve_d4*>(Pop + 256 * It[j] + 4 * lane);
             const solve_d4 pj = *reinterpret_cast<const solve_d4*>(Pop + 256 * Jt[j] + 4 * lpi);
             const solve_d4 out = rl_update(cin[j], pj, pi);
-            *reinterpret_cast<solve_d4*>(dst[j] + 4 * lane) = out;
+            rl_tile_store(dst[j], lane, out);
             request(j);
           }
         }
@@ -360,7 +370,7 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
       for (int sl = 0; sl < SL; ++sl) {
         const int I = wave + NW * sl;
         cpre[sl] = solve_d4{0.0, 0.0, 0.0, 0.0};
-        if (I >= k + 1 && I < nblk) cpre[sl] = *reinterpret_cast<const solve_d4*>(T1 + rl_tile(I, k + 1) + 4 * lane);
+        if (I >= k + 1 && I < nblk) cpre[sl] = rl_tile_load(T1 + rl_tile(I, k + 1), lane);
       }
       solve_d4 lv;  // A operand of  X^T = L_kk^-1 Z^T : lane (a, kk), register s:  L_kk^-1[pi(a)][4 kk + s] = L_kk^-T[4 kk + s][pi(a)]
 #pragma unroll
@@ -469,14 +479,14 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
   double* s_red = damp + npad;                         // 4 x 16 + 8
   int* s_flag = reinterpret_cast<int*>(s_red + 64);    // [0] mode
   double* lst = s_red + 72;                            // MCBA_LMS : the LM state, worked on in LDS
-  double* W = LDSW ? (lst + MCBA_LMS) : a.work;        // npad rows, row-major: the factor L (lower part)
-  const int ldw = LDSW ? npad + 1 : npad;              // odd row stride in LDS: rows land in different banks
+  double* W = lst + MCBA_LMS;                          // LDSW: npad rows, row-major: the factor L (lower part)
+  const int ldw = npad + 1;                            // odd row stride in LDS: rows land in different banks
   double* linv = W + (size_t)npad * ldw;               // LDSW: nblk x 16 x 17, the inverse transposes of the diagonal blocks of L
   double* pnext = linv + (size_t)nblk * 16 * 17;       // LDSW, look-ahead: npad x 17, the next panel's products with the columns that are already final
   constexpr int kLookWave = 2;                         // the wavefront that is idle in the diagonal phase (NW = 4, <= 7 tiles)
   const bool lookahead = LDSW && NW == 4 && solve_lookahead(npad);
-  double* Bs = lst + MCBA_LMS;                         // !LDSW: 16 x bst, the panel's own rows of L (the MFMA B operand)
-  const int bst = npad + 2;                            // bst / 2 odd: conflict-free 16-byte LDS reads
+  double* Bs = lst + MCBA_LMS;                         // !LDSW: the right-looking variant's LDS (16 (npad + 2) doubles: the panel as MFMA operands; + 16 x 17 + 2 x 256 behind)
+  const int bst = npad + 2;
 #ifdef MCBA_SOLVE_TIMING
   const long long t_begin = clock64();
 #endif
@@ -570,11 +580,12 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
     //   rows < n: S0 + lambda D_c on the diagonal,  row n: the right-hand side, 1 on the diagonal,  rows > n: identity
     for (int i = tid; i < npad; i += NTHREADS) damp[i] *= lambda;
     __syncthreads();
-    if constexpr (!LDSW && NTHREADS == 512 && MCBA_SOLVE_RL) {
+    if constexpr (!LDSW) {
+      static_assert(NTHREADS == 512, "the right-looking variant is written for 8 wavefronts");
       STAMP(1);
       solve_right_looking<NTHREADS>(a, S0, fixed, damp, yv, dv, invd, panel, Bs, Bs + (size_t)16 * bst, Bs + (size_t)16 * bst + 16 * 17, lst);
     } else {
-    if (LDSW) {
+    {
 #pragma unroll
       for (int ia = 0; ia < kStage; ++ia) {
         const int i = rr + RS * ia;
@@ -582,23 +593,6 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
         for (int b = 0; b < kStage; ++b) {
           const int j = cc + 16 * b;
           if (i <= n && j < n && j <= i) W[i * ldw + j] = stage[ia * kStage + b] + ((i == j) ? damp[i] : 0.0);
-        }
-      }
-    } else {
-      for (int i0 = 0; i0 <= n; i0 += RS) {
-        const int i = i0 + rr;
-        for (int j0 = 0; j0 < n && j0 <= i0 + RS - 1; j0 += 16 * 8) {  // 8 loads in flight
-          double v[8];
-#pragma unroll
-          for (int b = 0; b < 8; ++b) {
-            const int j = j0 + cc + 16 * b;
-            v[b] = S0[(i <= n && j < n && j <= i) ? (size_t)i * n + j : 0];
-          }
-#pragma unroll
-          for (int b = 0; b < 8; ++b) {
-            const int j = j0 + cc + 16 * b;
-            if (i <= n && j < n && j <= i) W[(size_t)i * ldw + j] = v[b] + ((i == j) ? damp[i] : 0.0);
-          }
         }
       }
     }
@@ -628,7 +622,7 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
     for (int k = 0; k < nblk; ++k) {
       const int r0 = 16 * k, ntile = nblk - k;
       if (k > 0) {
-        if (LDSW) {
+        {
           // panel update, one 16x16 tile per wavefront pass.  With look-ahead (below) only the K-chunk of the block column
           // factorised LAST remains to be multiplied here: the products with all earlier columns were formed during that block's
           // diagonal phase and wait in `pnext`.
@@ -651,49 +645,6 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
             }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) panel[(16 * t + 4 * reg + (lane >> 4)) * 17 + (lane & 15)] = acc[reg];
-          }
-        } else {
-          // factor in (L2-resident) global memory: a dependent load costs ~1-2k cycles, so the panel's own 16 rows -- the
-          // B operand of every tile -- are staged in LDS once, and each wavefront streams its A rows 32 B per lane
-          // (lane (i, kk) owns K indices P + 4 kk .. + 3 of a 16-wide chunk: any K order is fine as long as A and B agree)
-          for (int e = tid; e < 4 * r0; e += NTHREADS) {  // 16 rows x r0 / 4 double4
-            const int row = e / (r0 >> 2), c4 = e - row * (r0 >> 2);
-            const solve_d4 v = *reinterpret_cast<const solve_d4*>(W + (size_t)(r0 + row) * ldw + 4 * c4);
-            *reinterpret_cast<solve_d4*>(Bs + row * bst + 4 * c4) = v;
-          }
-          __syncthreads();
-          constexpr int CH = 2;  // chunks of 16 K indices per work item (measured at 12C = 288: 2 -> 239k cycles for this phase, 1 -> 274k, 4 -> 259k, 6 -> 287k); the next item's A rows load while this one computes
-          const int ngrp = (r0 + 16 * CH - 1) / (16 * CH);
-          const int nitems = ((ntile - wave + NW - 1) / NW) * ngrp;
-          const double* pb = Bs + (lane & 15) * bst + 4 * (lane >> 4);
-          solve_d4 cur[CH], nxt[CH];
-          auto load_item = [&](int it, solve_d4 (&dst)[CH]) {
-            const int tl = it / ngrp, p = (it - tl * ngrp) * 16 * CH;
-            const double* pa = W + (size_t)(r0 + 16 * (wave + NW * tl) + (lane & 15)) * ldw + 4 * (lane >> 4);
-#pragma unroll
-            for (int u = 0; u < CH; ++u) dst[u] = *reinterpret_cast<const solve_d4*>(pa + min(p + 16 * u, r0 - 16));
-          };
-          if (nitems > 0) load_item(0, cur);
-          solve_d4 acc = {0.0, 0.0, 0.0, 0.0};
-          for (int it = 0; it < nitems; ++it) {
-            if (it + 1 < nitems) load_item(it + 1, nxt);
-            const int tl = it / ngrp, g = it - tl * ngrp, p = g * 16 * CH;
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-              if (p + 16 * u < r0) {
-                const solve_d4 bv = *reinterpret_cast<const solve_d4*>(pb + p + 16 * u);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u][c], bv[c], acc, 0, 0, 0);
-              }
-            }
-            if (g == ngrp - 1) {
-              const int t = wave + NW * tl;
-#pragma unroll
-              for (int reg = 0; reg < 4; ++reg) panel[(16 * t + 4 * reg + (lane >> 4)) * 17 + (lane & 15)] = acc[reg];
-              acc = solve_d4{0.0, 0.0, 0.0, 0.0};
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) cur[u] = nxt[u];
           }
         }
         __syncthreads();
@@ -783,7 +734,7 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
     // ---- backward sweep  L^T d = y,  y = row n of the factor
     for (int j = tid; j < npad; j += NTHREADS) yv[j] = j < n ? W[(size_t)n * ldw + j] : 0.0;
     __syncthreads();
-    if constexpr (LDSW) {
+    {
       // d_k = L_kk^-T y_k: row i of the inverse transpose (zero left of the diagonal) times the block's right-hand side; y
       // beyond row n is zero, so the right-hand-side row and the padding drop out.  Then y_j -= sum_t L[r0+t][j] d[r0+t].
       for (int k = nblk - 1; k >= 0; --k) {
@@ -810,56 +761,6 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
             for (int t = 0; t < 16; t += 2) { s0 = fma(-wc[(size_t)t * ldw], dv[r0 + t], s0); s1 = fma(-wc[(size_t)(t + 1) * ldw], dv[r0 + t + 1], s1); }
           }
           yv[j] = s0 + s1;
-        }
-        __syncthreads();
-      }
-    } else {
-      // Every step's loads are issued at its top: the off-diagonal rows it needs after the barrier, and (wavefront 0) the
-      // diagonal block of the NEXT step -- both are in flight while wavefront 0 does the 16 sequential pivots.
-      double col[16];   // wavefront 0: col[l] = L[r0 + l][r0 + row] of the block being solved
-      {
-        const int r0 = 16 * (nblk - 1);
-#pragma unroll
-        for (int l = 0; l < 16; ++l) col[l] = W[(size_t)(r0 + l) * ldw + r0 + (lane & 15)];
-      }
-      for (int k = nblk - 1; k >= 0; --k) {
-        const int r0 = 16 * k;
-        double wcur[16];  // wcur[t] = L[r0 + t][j] for this thread's column j = tid (first pass over j)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) wcur[t] = W[(size_t)(r0 + t) * ldw + min(tid, npad - 1)];
-        if (wave == 0) {
-          const int row = lane & 15;
-          double cnx[16];
-          if (k > 0) {
-#pragma unroll
-            for (int l = 0; l < 16; ++l) cnx[l] = W[(size_t)(r0 - 16 + l) * ldw + r0 - 16 + row];
-          }
-          double y = yv[r0 + row];
-          const double iv = invd[r0 + row];
-#pragma unroll
-          for (int l = 15; l >= 0; --l) {
-            const double dl = lane_bcast(y * iv, l);
-            if (row == l) y = dl;
-            else if (row < l) y = fma(-col[l], dl, y);
-          }
-          if (lane < 16) dv[r0 + row] = (r0 + row < n) ? y : 0.0;
-          if (k > 0) {
-#pragma unroll
-            for (int l = 0; l < 16; ++l) col[l] = cnx[l];
-          }
-        }
-        __syncthreads();
-        for (int j = tid; j < r0; j += NTHREADS) {
-          double s = yv[j];
-          if (j == tid) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) s = fma(-wcur[t], dv[r0 + t], s);
-          } else {
-            const double* wc = W + (size_t)r0 * ldw + j;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) s = fma(-wc[(size_t)t * ldw], dv[r0 + t], s);
-          }
-          yv[j] = s;
         }
         __syncthreads();
       }
@@ -935,13 +836,6 @@ __global__ __launch_bounds__(64 * kBacksubWaves) void k_solve_backsub(SolveArgs 
   backsub_body<DevStep>(b.sl, b.rec0, b.rec1, b.fbuf, DevStep{a.dc}, b.x0, b.x1, b.bpart, b.C, b.F, b.Fpad, (int)blockIdx.x - 1, b.C < kBacksubWaves ? b.C : kBacksubWaves, s_t, &b.wait);
 }
 
-// rows a launch can hold: 16 diagonal rows + 48 per wavefront
-int solve_threads(int npad) {
-  int t = MCBA_SOLVE_RL ? 512 : npad <= 16 + 4 * 48 ? 256 : npad <= 16 + 8 * 48 ? 512 : 1024;  // (the right-looking variant: 8 wavefronts, 256 VGPRs each)
-  if (const char* e = getenv("MCBA_SOLVE_THREADS")) { int v = atoi(e); if ((v == 512 || v == 1024) && v > t) t = v; }  // tuning knob
-  return t;
-}
-
 size_t solve_lds_bytes(int npad, int use_lds) {
   size_t d = (size_t)npad * 17 + 4 * (size_t)npad + 72 + MCBA_LMS;
   d += use_lds ? (size_t)npad * (npad + 1) + (size_t)(npad / 16) * 16 * 17 + (solve_lookahead(npad) ? (size_t)npad * 17 : 0) : (size_t)16 * (npad + 2) + 16 * 17 + 2 * 256;  // (+ the diagonal tile and two panel tiles of the right-looking variant)
@@ -953,11 +847,7 @@ int solve_fits_lds(int npad) { return npad <= 16 * kStageMax && solve_lds_bytes(
 
 static const void* solve_kernel(int npad, int use_lds) {
   if (use_lds) return npad <= 80 ? reinterpret_cast<const void*>(&k_solve_cam<256, true, 5>) : reinterpret_cast<const void*>(&k_solve_cam<256, true, kStageMax>);
-  switch (solve_threads(npad)) {
-    case 256: return reinterpret_cast<const void*>(&k_solve_cam<256, false, 1>);
-    case 512: return reinterpret_cast<const void*>(&k_solve_cam<512, false, 1>);
-    default: return reinterpret_cast<const void*>(&k_solve_cam<1024, false, 1>);
-  }
+  return reinterpret_cast<const void*>(&k_solve_cam<512, false, 1>);
 }
 
 int solve_set_lds_limit(int npad, int use_lds) {
@@ -989,11 +879,7 @@ void launch_solve_cam(hipStream_t st, const SolveArgs& a) {
     else hipLaunchKernelGGL((k_solve_cam<256, true, kStageMax>), dim3(1), dim3(256), lds, st, a);
     return;
   }
-  switch (solve_threads(a.npad)) {
-    case 256: hipLaunchKernelGGL((k_solve_cam<256, false, 1>), dim3(1), dim3(256), lds, st, a); break;
-    case 512: hipLaunchKernelGGL((k_solve_cam<512, false, 1>), dim3(1), dim3(512), lds, st, a); break;
-    default: hipLaunchKernelGGL((k_solve_cam<1024, false, 1>), dim3(1), dim3(1024), lds, st, a);
-  }
+  hipLaunchKernelGGL((k_solve_cam<512, false, 1>), dim3(1), dim3(512), lds, st, a);
 }
 
 }  // namespace mcba
