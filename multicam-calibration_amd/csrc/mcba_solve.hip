@@ -192,8 +192,9 @@ __device__ __forceinline__ solve_d4 rl_system_fixup(solve_d4 v, const double* da
   if (fixed) {  // identity row and column, zero right-hand side
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int c = c0 + r, rr = max(row, c), cc = min(row, c);
-      if ((rr < n && fixed[rr]) || (cc < n && fixed[cc])) v[r] = (row == c) ? 1.0 : 0.0;
+      const int c = c0 + r;
+      const bool fr = row < n && fixed[min(row, n - 1)] != 0, fc = c < n && fixed[min(c, n - 1)] != 0;
+      if (fr || fc) v[r] = (row == c) ? 1.0 : 0.0;
     }
   }
   return v;

@@ -402,11 +402,12 @@ def test_full_size_properties(mc):
 
 
 # ------------------------------------------------------------------ reduced camera system solved on the GPU (k_solve_cam)
-@pytest.mark.parametrize("C,fixed", [(2, False), (6, False), (6, True), (7, False), (10, False), (24, False)])
+@pytest.mark.parametrize("C,fixed", [(2, False), (6, False), (6, True), (7, False), (9, False), (10, False), (10, True), (13, False), (24, False), (24, True), (40, False), (40, True)])
 def test_device_reduced_solve_matches_lapack(mc, C, fixed):
     """k_solve_cam (blocked FP64 Cholesky, one workgroup) against LAPACK on the SAME reduced system.
-    C = 2, 6, 7: factor in LDS (npad 32 / 80 / 96); C = 10: 256 threads, factor in the L2 scratch (npad 128);
-    C = 24: 1024 threads (npad 304, BASELINE configs[4]).  `fixed`: intrinsics held fixed (configs[1])."""
+    C = 2, 6, 7, 9: factor in LDS, left-looking (npad 32 / 80 / 96 / 112); C >= 10: right-looking on 16 x 16 tiles in the L2 scratch
+    (npad 128, 160 (13 cameras: the right-hand-side row opens a tile row of its own), 304 = BASELINE configs[4], 496 = the largest
+    system the library takes).  `fixed`: intrinsics held fixed (configs[1]) -- identity rows / columns in the system."""
     import scipy.linalg as sla
 
     p = mc.synth.make_problem(C, 40, seed=60 + C, missing=0.1)
