@@ -72,6 +72,7 @@ struct mcba_handle {
   // k_solve_backsub (single-GPU ticks, factor in LDS): the solve's launch also runs the back-substitution of the NEXT trial step;
   // trial_ready = the last tick did so, the next one must not back-substitute again.  The flag word sits behind the camera step.
   bool fuse_backsub = false, trial_ready = false;
+  int ncu = 256, lds_optin = 160 * 1024;  // compute units and the LDS a workgroup may ask for (hipGetDeviceProperties at create; MI355X: 256 / 160 KiB)
   bool spec_copy_ready = false;  // the last k_reduce_system was a speculative one: the pre-decision state copy is in place
   double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8, lam_min = 1e-12, lam_max = 1e12;
   double dec_floor = 0.0;      // floor of Nielsen's damping factor on accepted steps (0 = the classical 1/3): mcba_lm_set_decrease_floor
@@ -251,6 +252,15 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   HIPCHK(hipSetDevice(device));
   mcba_handle* h = new mcba_handle();
   h->C = C; h->F = F; h->N = N; h->device = device;
+  {  // the launch geometry below is derived from the device, not from MI355X constants (a part with fewer CUs or less LDS gets its own deal)
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      if (prop.multiProcessorCount > 0) h->ncu = prop.multiProcessorCount;
+      if (prop.sharedMemPerBlockOptin > 0) h->lds_optin = (int)std::min<size_t>(prop.sharedMemPerBlockOptin, 160 * 1024);
+    }
+  }
+  const int ncu = h->ncu, slots = 4 * h->ncu;  // wavefront slots at one wavefront per SIMD
+  mcba::gram_set_slots(slots);
   h->Fpad = (F + 63) / 64 * 64;
   h->nfb = h->Fpad / 64;
   h->n = 12 * C;
@@ -264,16 +274,16 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   h->FS = 8;  // (measured at 6 x 10k: 8 frames per stage and up to 512 workgroups -- two per CU, one building Y while the
               //  other is in its MFMA phase -- 24.2 us; 16 frames / 256 workgroups 27.4 us)
   if (const char* e = getenv("MCBA_SYRK_FS")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) h->FS = v; }  // tuning knob
-  while (h->FS > 2 && (mcba::syrk_lds_bytes(C, h->FS) > 96 * 1024 || (h->n + 1) * h->FS > 256 * mcba::syrk_items_per_thread())) h->FS /= 2;
+  while (h->FS > 2 && (mcba::syrk_lds_bytes(C, h->FS) > (size_t)h->lds_optin * 3 / 5 || (h->n + 1) * h->FS > 256 * mcba::syrk_items_per_thread())) h->FS /= 2;
   if ((h->n + 1) * h->FS > 256 * mcba::syrk_items_per_thread()) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for k_syrk's per-thread item budget"); }
-  if (mcba::syrk_lds_bytes(C, h->FS) > 160 * 1024) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for the LDS staging of k_syrk"); }
+  if (mcba::syrk_lds_bytes(C, h->FS) > (size_t)h->lds_optin) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for the LDS staging of k_syrk"); }
   {
     int nstage = (F + h->FS - 1) / h->FS;
     // the 16-tile variant (> 13 cameras) runs ONE workgroup per CU and grid.y = ceil(NP / 64) of them share a set of frames:
     // one round of the 256 CUs, every workgroup as many stages as that allows -- 24 x 6250 x 200: 83 x 3 workgroups of 19 stages
     // 776 us per tick (33 MB of partial tiles) against 839 us for 391 x 3 of 4 stages (152 MB), 806 / 796 / 822 / 809 / 874 us
     // for G = 256 / 171 / 128 / 64 / 43
-    int gmax = h->ppw == 4 ? 512 : std::max(1, 256 / ((h->NP + 63) / 64));
+    int gmax = h->ppw == 4 ? std::min(512, 2 * ncu) : std::max(1, ncu / ((h->NP + 63) / 64));
     if (const char* e = getenv("MCBA_SYRK_G")) gmax = std::max(1, std::min(512, atoi(e)));  // tuning knob (k_reduce_system holds <= 512 / 16 partial rows per wavefront)
     int g = std::min(nstage, gmax);
     // Two workgroups per CU (ppw == 4: <= 10 cameras): deal the stages out evenly over g workgroups -- measured at 6 x 10 000:
@@ -299,18 +309,18 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   // share SIMDs and fill the tail better (measured 6 x 12500 x 54: 102 us split vs 132 us fused; equal at 1.84 and 2.3 rounds).
   {
     const int items = C * h->nfb;
-    h->gram_split = items < 768 || (items > 1024 && items <= 1536);
+    h->gram_split = items < 3 * slots / 4 || (items > slots && items <= 3 * slots / 2);
     // more than one round with a short last round: fused for the whole rounds + split roles for the tail (mode 2)
     // (measured 24 x 6250 x 200, 2.3 rounds: 536 us vs 561 us fused, 612 us split; at 1.15 rounds plain split roles win)
-    if (items > 2048 && (items % 1024) > 0 && (items % 1024) <= 512) h->gram_split = 2;
+    if (items > 2 * slots && (items % slots) > 0 && (items % slots) <= slots / 2) h->gram_split = 2;
     // Round 3: more than one round with a short last round -> whole rounds fused + the tail's POINTS in chunks over the idle SIMDs
     // (mode 3; measured 24 x 6250 x 200: k_gram 381 -> 360 us -- profiles/round3/NOTES_round3.md section 6)
-    if (items > 1024) {
-      const int fba = ((items / 1024) * 1024 / C) & ~3, tail = C * (h->nfb - fba);
+    if (items > slots) {
+      const int fba = ((items / slots) * slots / C) & ~3, tail = C * (h->nfb - fba);
       // (worth it for large boards only: the chunk launch + the combine launch cost ~25 us whatever the board, the split-role
       //  tail 0.73 of a fused pass -- break-even near 90 points; 6 x 12500 x 54: 88 us against 79 us with plain split roles)
-      if (fba > 0 && tail > 0 && tail <= 512 && N >= 128) {
-        const int nch = std::min(std::min(8, 1024 / tail), N / 8);
+      if (fba > 0 && tail > 0 && tail <= slots / 2 && N >= 128) {
+        const int nch = std::min(std::min(8, slots / tail), N / 8);
         if (nch >= 2) { h->gram_split = 3; h->gram_nchunk = nch; }
       }
     }
@@ -321,10 +331,10 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   }
   if (const char* e = getenv("MCBA_GRAM_NCHUNK")) h->gram_nchunk = std::max(2, std::min(8, atoi(e)));
   // k_cost: split the board points so that ~4 waves per SIMD (1024 SIMDs) are in flight
-  h->nch = std::max(1, std::min(std::min(8, N / 8), (4096 + C * h->nfb - 1) / (C * h->nfb)));
+  h->nch = std::max(1, std::min(std::min(8, N / 8), (4 * slots + C * h->nfb - 1) / (C * h->nfb)));
   h->nfblocks = h->G;  // (kept: k_syrk's workgroups factorise their own frames: one (max |g_f|, #failures) pair each)
   h->npad = 16 * h->NT;
-  h->solve_lds = mcba::solve_fits_lds(h->npad);
+  h->solve_lds = mcba::solve_fits_lds(h->npad, h->lds_optin);
   int rc;
 #define DA(p, cnt, zero) if ((rc = dalloc(h, &h->p, (cnt), zero)) != MCBA_OK) { mcba_destroy(h); return rc; }
   // what every handle needs (a pre-filter handle needs nothing else): the two observation layouts, the board, the parameter slots

@@ -82,7 +82,8 @@ void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad);
 void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const double* dc_dev, double* x0, double* x1, double* bpart, int C, int F, int Fpad);
 size_t solve_lds_bytes(int npad, int use_lds);
-int solve_fits_lds(int npad);
+int solve_fits_lds(int npad, int lds_limit);
+void gram_set_slots(int slots);  // wavefront slots of the device (4 x CUs): where k_gram's launch variants cut a shard into rounds
 int solve_set_lds_limit(int npad, int use_lds);
 void launch_solve_cam(hipStream_t st, const SolveArgs& a);
 // solve + the back-substitution of the next trial step in one launch (a.use_lds variants, a.flag set); early_state = the LM state

@@ -1328,6 +1328,10 @@ void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int 
   k_transpose_obs<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(raw), reinterpret_cast<double2*>(obs_t), C, F, N, Fpad);
 }
 
+// wavefront slots of the device at one wavefront per SIMD (4 x compute units; mcba_create sets it from the device properties)
+static int g_gram_slots = 1024;
+void gram_set_slots(int slots) { if (slots >= 64) g_gram_slots = slots; }
+
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,
                  int planar, double* chunk, int nchunk) {
   const int nfb = Fpad / 64;
@@ -1351,7 +1355,7 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
     // whole rounds of the 1 024 wavefront slots fused; the last, short round as POINT CHUNKS: nchunk wavefronts per (camera, frame
     // block), each over 1 / nchunk of the board's points (ppc a multiple of the loop's four), + one combine launch
     const int items3 = C * nfb;
-    const int fba3 = ((items3 / 1024) * 1024 / C) & ~3;
+    const int fba3 = ((items3 / g_gram_slots) * g_gram_slots / C) & ~3;
     if (fba3 > 0 && fba3 < nfb && chunk && nchunk >= 2) {
       fused(0, fba3);
       const int ppc = ((N + nchunk - 1) / nchunk + 3) & ~3;
@@ -1374,7 +1378,7 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
   // split == 2: whole rounds of the 1024 wavefront slots with the fused variant, the (short) last round with the split
   // roles -- their wavefronts are lighter, so a tail of r items costs ~0.55 of a fused pass instead of a whole one
   const int items = C * nfb;
-  const int fba = split == 2 ? (((items / 1024) * 1024 / C) & ~3) : nfb;
+  const int fba = split == 2 ? (((items / g_gram_slots) * g_gram_slots / C) & ~3) : nfb;
   if (split == 2 && fba > 0 && fba < nfb) {
     fused(0, fba);
     roles(fba, nfb);
@@ -1384,7 +1388,7 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
 }
 
 size_t gram_chunk_doubles(int C, int nfb, int nchunk) {
-  const int items = C * nfb, fba = ((items / 1024) * 1024 / C) & ~3;
+  const int items = C * nfb, fba = ((items / g_gram_slots) * g_gram_slots / C) & ~3;
   return (size_t)C * (nfb - fba) * nchunk * kGramRaw * 64;
 }
 

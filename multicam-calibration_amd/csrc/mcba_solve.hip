@@ -850,7 +850,7 @@ size_t solve_lds_bytes(int npad, int use_lds) {
 }
 
 // the factor fits LDS (and the register staging of the 256-thread variant covers it)
-int solve_fits_lds(int npad) { return npad <= 16 * kStageMax && solve_lds_bytes(npad, 1) <= 150 * 1024; }
+int solve_fits_lds(int npad, int lds_limit) { return npad <= 16 * kStageMax && solve_lds_bytes(npad, 1) <= (size_t)lds_limit - 10 * 1024; }  // (k_solve_backsub's static scratch rides along)
 
 static const void* solve_kernel(int npad, int use_lds) {
   if (use_lds) return npad <= 80 ? reinterpret_cast<const void*>(&k_solve_cam<256, true, 5>) : reinterpret_cast<const void*>(&k_solve_cam<256, true, kStageMax>);
