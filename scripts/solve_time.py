@@ -1,4 +1,7 @@
-"""k_solve_cam phase stamps (build with MCBA_HIPCC_FLAGS=-DMCBA_SOLVE_TIMING) and launch time."""
+"""k_solve_cam phase stamps (build with MCBA_HIPCC_FLAGS=-DMCBA_SOLVE_TIMING) and launch time.
+usage: python scripts/solve_time.py [cameras ...]      (MCBA_LIB = an alternative build)
+Beyond 9 cameras (right-looking variant) the stamps of slots 27 / 29 / 30 are the backward sweep and intervals A / B of block step
+k = launch number - 1: MCBA_SOLVE_LAUNCHES=N prints them for the first N - 1 launches."""
 import sys
 import time
 
