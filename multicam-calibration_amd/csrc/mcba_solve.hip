@@ -286,22 +286,29 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
 #pragma unroll
         for (int c = 0; c < 16; ++c) linv[(r0 + li) * 17 + c] = r[c];
       }
-    } else if (!worker) {
-      // wavefront 4 (shares its SIMD with the pivots, so no MFMA work here): the finished panel k - 1, still in Pop, to the tiles
-      // of the backward sweep -- four 8-byte LDS reads and one 32-byte store per tile and lane (lane (c, g): rows 4 g .. + 3)
-      if (k > 0) {
-        for (int I = k; I < nblk; ++I) {
-          solve_d4 x;
+    } else {
+    // wavefront 4 (shares its SIMD with the pivots): first the finished panel k - 1, still in Pop, to the tiles of the backward
+    // sweep -- four 8-byte LDS reads and one 32-byte store per tile and lane (lane (c, g): rows 4 g .. + 3) --, then, while the
+    // updates are the longer side of the interval anyway, a seventh share of them (its MFMAs slow the pivots down, which then
+    // does not matter); on the short steps it leaves the SIMD to the pivots
+    const int mleft = nblk - k - 1;
+    const int nwk = k == 0 || mleft * (mleft + 1) / 2 >= 48 ? NWK + 1 : NWK;
+    const int wq = worker ? wk : NWK;  // this wavefront's share
+    if (!worker && k > 0) {
+      for (int I = k; I < nblk; ++I) {
+        solve_d4 x;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) x[r] = Pop[256 * I + 4 * ((4 * lg + r) + 16 * (li >> 2)) + (li & 3)];
-          *reinterpret_cast<solve_d4*>(T2 + rl_tile(I, k - 1) + 64 * lg + 4 * li) = x;  // [row quad][column][row in quad]: threads of one column group read 32-byte neighbours
-        }
+        for (int r = 0; r < 4; ++r) x[r] = Pop[256 * I + 4 * ((4 * lg + r) + 16 * (li >> 2)) + (li & 3)];
+        *reinterpret_cast<solve_d4*>(T2 + rl_tile(I, k - 1) + 64 * lg + 4 * li) = x;  // [row quad][column][row in quad]: threads of one column group read 32-byte neighbours
       }
+    }
+    if (wq >= nwk) {
+      // (wavefront 4 on a short step)
     } else if (k == 0) {
       // first touch: while wavefront 0 does the first 16 pivots the six others bring every tile right of column 0 from the reduce buffer
       // (written by other XCDs: a long round trip) into the tile scratch, eight aligned 32-byte loads in flight per lane
       const int M = nblk * (nblk + 1) / 2 - nblk;  // tiles (I, J), 1 <= J <= I
-      const int t_begin = (int)(((long long)M * wk) / NWK), ntile = (int)(((long long)M * (wk + 1)) / NWK) - t_begin;
+      const int t_begin = (int)(((long long)M * wq) / nwk), ntile = (int)(((long long)M * (wq + 1)) / nwk) - t_begin;
       int Ir, Jr;
       rl_unflatten(t_begin, Ir, Jr);
       for (int done = 0; done < ntile; done += 8) {
@@ -322,7 +329,7 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
     } else if (k + 1 < nblk) {
       const int J0 = k + 1, m = nblk - J0;        // panel k - 1 is in Pop; tiles (I, J), J0 <= J <= I < nblk: m (m + 1) / 2 of them
       const int M = m * (m + 1) / 2;
-      const int t_begin = (int)(((long long)M * wk) / NWK), ntile = (int)(((long long)M * (wk + 1)) / NWK) - t_begin;
+      const int t_begin = (int)(((long long)M * wq) / nwk), ntile = (int)(((long long)M * (wq + 1)) / nwk) - t_begin;
       if (ntile > 0) {
         // A ring of R tiles, branch-free: slot j multiplies and stores its tile, then requests the tile R places further on into the
         // same registers -- R - 1 tile updates (~300 cycles each) cover the round trip.  Past the end of this wavefront's run the
@@ -362,6 +369,7 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
           }
         }
       }
+    }
     }
     __syncthreads();
 #ifdef MCBA_SOLVE_TIMING
