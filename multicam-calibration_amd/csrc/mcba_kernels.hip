@@ -1022,76 +1022,93 @@ __device__ __forceinline__ double run_sum(const double* __restrict__ p, int coun
   return wave_sum63(s);
 }
 
+template <int RR>
 __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __restrict__ gp0, const double* __restrict__ gp1, const double* __restrict__ spart, const double* __restrict__ fpart,
                                                         const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ red, int C, int nfb, int G, int NT, int NP,
                                                         int nfblocks, int rank_slot, const double* __restrict__ bpart, int nbp, double* __restrict__ state_copy) {
   const int n = 12 * C;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __shared__ double s_part[16][64];
-  __shared__ double s_u[64];
+  __shared__ double s_part[RR][16][64];
+  __shared__ double s_u[RR][16];
   const size_t camstride = (size_t)MCBA_GP * nfb;
-  if ((int)blockIdx.x < 16 * NP) {
-    // One block per (tile pair q, accumulator register reg, row rr of the register's four): 16 elements = one 128-byte
+  constexpr int BPQ = 16 / RR;  // blocks per tile pair
+  if ((int)blockIdx.x < BPQ * NP) {
+    // RR == 1: one block per (tile pair q, accumulator register reg, row rr of the register's four): 16 elements = one 128-byte
     // segment of every k_syrk partial -- four times as many blocks as one per (q, reg), so that the 16 MB of partials are
-    // pulled by (almost) every CU instead of 60 of them.  Wavefront s sums slice s (the partials g = s, s + 16, ...): lane
-    // (rg, el) = (lane >> 4, lane & 15) takes every fourth row of the slice for element el.
-    const int q = blockIdx.x >> 4, reg = (blockIdx.x >> 2) & 3, rr = blockIdx.x & 3;
+    // pulled by (almost) every CU instead of 60 of them (6 cameras: 15 pairs).  RR == 4 (many tile pairs: 24 cameras = 171): one
+    // block per (q, reg) does the four rows with all their loads in flight at once -- 684 blocks instead of 2 736, each as long
+    // as one of those was (a block is a chain of round trips, and only two 1024-thread blocks fit a CU): 21.6 -> 19.2 us by rocprofv3
+    // at 24 x 6 250 x 200.
+    // Wavefront s sums slice s (the partials g = s, s + 16, ...): lane (rg, el) = (lane >> 4, lane & 15) takes every fourth row
+    // of the slice for element el.
+    const int q = blockIdx.x / BPQ, reg = RR == 1 ? (blockIdx.x >> 2) & 3 : blockIdx.x & 3, rr0 = RR == 1 ? blockIdx.x & 3 : 0;
     const int ti = tile_i[q], tj = tile_j[q];
     const int rg = lane >> 4, el = lane & 15;
     // ---- the partials do not depend on the LM state: all of this lane's rows (G <= 512 -> at most 8) go in flight before
     // anything waits for the state, which rides along
-    double pv[8];
-    {
-      const double* p = spart + (size_t)(4 * q + reg) * G * 64 + 16 * rr + el;
+    constexpr int NK = RR == 1 ? 8 : 2;  // (RR == 4 is chosen for G <= 128 only: two rows per lane and slice)
+    double pv[RR][NK];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { const int g = wave + 16 * (rg + 4 * k); pv[k] = g < G ? p[(size_t)g * 64] : 0.0; }
+    for (int r = 0; r < RR; ++r) {
+      const double* p = spart + (size_t)(4 * q + reg) * G * 64 + 16 * (rr0 + r) + el;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) { const int g = wave + 16 * (rg + 4 * k); pv[r][k] = g < G ? p[(size_t)g * 64] : 0.0; }
     }
     if (!sel_active(sl, false)) return;
     const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
-    // ---- U_c / g_c term of element `wave` of this block's 16, if it needs one: one wavefront task
-    const double* up = nullptr;
-    {
-      const int row = 16 * ti + rr + 4 * reg, col = 16 * tj + wave;
+    // ---- U_c / g_c term of element `wave` of each of this block's 16-element rows, if it needs one: one wavefront task each
+    // (the loads of all RR rows in flight together)
+    const double* up[RR];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      up[r] = nullptr;
+      const int row = 16 * ti + (rr0 + r) + 4 * reg, col = 16 * tj + wave;
       if (row < n && col < n && row / 12 == col / 12) {
         int cam = row / 12, li = row - 12 * cam, lj = col - 12 * cam;
         int a = li <= lj ? li : lj, b2 = li <= lj ? lj : li;
-        up = gpart + cam * camstride + (size_t)tri12(a, b2) * nfb;
+        up[r] = gpart + cam * camstride + (size_t)tri12(a, b2) * nfb;
       } else if (col == n && row < n) {
         int cam = row / 12, li = row - 12 * cam;
-        up = gpart + cam * camstride + (size_t)(78 + li) * nfb;
+        up[r] = gpart + cam * camstride + (size_t)(78 + li) * nfb;
       }
     }
-    double us = 0.0;
-    for (int base = 0; base < nfb; base += 256) {
-      double w[4];
+    double us[RR];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { const int i = base + lane + 64 * k; w[k] = (up && i < nfb) ? up[i] : 0.0; }
-      us += (w[0] + w[1]) + (w[2] + w[3]);
+    for (int r = 0; r < RR; ++r) us[r] = 0.0;
+    for (int base = 0; base < nfb; base += 256) {
+      double w[RR][4];
+#pragma unroll
+      for (int r = 0; r < RR; ++r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = base + lane + 64 * k; w[r][k] = (up[r] && i < nfb) ? up[r][i] : 0.0; }
+      }
+#pragma unroll
+      for (int r = 0; r < RR; ++r) us[r] += (w[r][0] + w[r][1]) + (w[r][2] + w[r][3]);
     }
-    {
-      const double u = wave_sum63(us);
-      if (lane == 63) s_u[wave] = u;
-    }
-    {
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      const double u = wave_sum63(us[r]);
+      if (lane == 63) s_u[r][wave] = u;
       double sum = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sum += pv[k];
-      s_part[wave][lane] = sum;
+      for (int k = 0; k < NK; ++k) sum += pv[r][k];
+      s_part[r][wave][lane] = sum;
     }
     __syncthreads();
-    if (wave == 0) {
+    if (wave < RR) {
+      const int r = wave;
       double t = 0.0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) t += s_part[k][lane];  // the 16 slices in order, per (row group, element)
+      for (int k = 0; k < 16; ++k) t += s_part[r][k][lane];  // the 16 slices in order, per (row group, element)
       const double v = (__shfl(t, el, 64) + __shfl(t, el + 16, 64)) + (__shfl(t, el + 32, 64) + __shfl(t, el + 48, 64));  // the four row groups
       if (lane < 16) {
-        const int row = 16 * ti + rr + 4 * reg, col = 16 * tj + el;
+        const int row = 16 * ti + (rr0 + r) + 4 * reg, col = 16 * tj + el;
         if (row < n && col < n) {
-          double out = s_u[el] - v;  // S0 = blockdiag(U) - sum Y Y^T
+          double out = s_u[r][el] - v;  // S0 = blockdiag(U) - sum Y Y^T
           red[(size_t)row * n + col] = out;
           if (ti != tj) red[(size_t)col * n + row] = out;
         } else if (col == n && row < n) {
-          red[(size_t)n * n + row] = v - s_u[el];  // rhs = sum Y z - g_c
+          red[(size_t)n * n + row] = v - s_u[r][el];  // rhs = sum Y z - g_c
         }
       }
     }
@@ -1100,7 +1117,7 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
   // ---- diag(U), g_c, scalars: task id per wavefront
   if (!sel_active(sl, false)) return;
   const double* __restrict__ gpart = sel_index(sl) ? gp1 : gp0;
-  const int task = ((int)blockIdx.x - 16 * NP) * 16 + wave;
+  const int task = ((int)blockIdx.x - BPQ * NP) * 16 + wave;
   double* tail = red + (size_t)n * n + n;
   if (task < n) {  // diag U
     int cam = task / 12, l = task - 12 * cam;
@@ -1440,7 +1457,9 @@ void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double
                           const double* bpart, int nbp, double* state_copy) {
   int n = 12 * C;
   int tail_blocks = (2 * n + 16 + (bpart ? 9 : 0) + 15) / 16;
-  k_reduce_system<<<dim3(16 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy);
+  // many tile pairs and few partials per pair (the 16-tile k_syrk: one workgroup per CU): one block per (pair, register) instead of four
+  if (NP >= 64 && G <= 128) k_reduce_system<4><<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy);
+  else k_reduce_system<1><<<dim3(16 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy);
 }
 
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {
