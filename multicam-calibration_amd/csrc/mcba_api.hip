@@ -72,6 +72,7 @@ struct mcba_handle {
   // k_solve_backsub (single-GPU ticks, factor in LDS): the solve's launch also runs the back-substitution of the NEXT trial step;
   // trial_ready = the last tick did so, the next one must not back-substitute again.  The flag word sits behind the camera step.
   bool fuse_backsub = false, trial_ready = false;
+  unsigned long long solve_launches = 0;  // k_solve_cam launches so far (SolveArgs.stage_tag)
   int ncu = 256, lds_optin = 160 * 1024;  // compute units and the LDS a workgroup may ask for (hipGetDeviceProperties at create; MI355X: 256 / 160 KiB)
   bool spec_copy_ready = false;  // the last k_reduce_system was a speculative one: the pre-decision state copy is in place
   double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8, lam_min = 1e-12, lam_max = 1e12;
@@ -889,6 +890,7 @@ static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, b
   a.flag = fuse_next ? h->dcbuf + h->n : nullptr;
   a.timeout_word = timeout_word(h);
   a.seq = (double)seq; a.gtol = h->gtol; a.lam_max = h->lam_max;
+  a.stage_tag = (double)(++h->solve_launches);
   a.n = h->n; a.npad = h->npad; a.use_lds = h->solve_lds;
   a.decide = decide ? 1 : 0; a.lam_min = h->lam_min; a.ftol = h->ftol; a.xtol = h->xtol; a.dec_floor = h->dec_floor;
   {

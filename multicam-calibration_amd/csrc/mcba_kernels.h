@@ -64,6 +64,7 @@ struct SolveArgs {
   int decide;
   double lam_min, ftol, xtol;
   double dec_floor;          // floor of Nielsen's damping factor (0 = 1/3): used by the decision taken here and to check the prediction
+  double stage_tag;          // > 9 cameras: this launch's number in the handle's life (never repeats: the stager workgroups release it, workgroup 0 waits for it)
 };
 void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int C, int F, int N, int Fpad);
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,

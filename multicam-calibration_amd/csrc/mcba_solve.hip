@@ -27,6 +27,7 @@
 // or taken here on the all-reduced trial scalars: one-collective ticks), handles a failed factorisation (more damping,
 // next tick rebuild-only) and posts the LM state to a host-mapped ring slot.
 #include <stdlib.h>
+#include <algorithm>
 #include "mcba_kernels.h"
 #include "mcba_lm.h"
 #include "mcba_math.h"
@@ -218,9 +219,53 @@ __device__ __forceinline__ void rl_unflatten(int t, int& Ir, int& Jr) {
   Jr = t - Ir * (Ir + 1) / 2;
 }
 
+// ---- stager workgroups (blockIdx.x >= 1 of the right-looking variant's launch).  The reduce buffer was written by other XCDs and
+// ONE compute unit pulls it at ~45 GB/s (0.66 MB at 24 cameras: 38 k cycles, 2 MB at 40 cameras: 99 k -- more tiles in flight per
+// wavefront change nothing), so the OFF-DIAGONAL tiles right of column 0 -- no damping in them, nothing that depends on the LM
+// state -- are brought into the tile scratch by NS other workgroups, a tile or two per wavefront, while workgroup 0 reads its
+// state, takes its decision and does the first 16 pivots.  Each stager releases a word carrying the launch's number in the handle's life (SolveArgs.stage_tag; the scratch is zero at allocation);
+// workgroup 0 acquires all of them before it touches the scratch (bounded polls: if a stager does not show up it stages the
+// tiles itself -- the values are the same, so a late stager does no harm).
+constexpr int kRlMaxStagers = 32;
+__host__ __device__ inline int rl_stagers(int npad) { const int nblk = npad >> 4, moff = (nblk - 1) * (nblk - 2) / 2; return min(kRlMaxStagers, max(1, moff / 8)); }
+__device__ __forceinline__ double* rl_stage_flags(const SolveArgs& a, int nblk) { return a.work + 2 * rl_tile(nblk, 0) + 256 * 8; }
+__device__ __forceinline__ void rl_stage_offdiag(const SolveArgs& a, int part, int nparts, int lane, int wave) {  // tiles (I, J), 1 <= J < I, share `part` of `nparts`
+  const int n = a.n, nblk = a.npad >> 4, m = nblk - 2;
+  if (m <= 0) return;
+  const int M = m * (m + 1) / 2;
+  const int t_begin = (int)(((long long)M * part) / nparts), ntile = (int)(((long long)M * (part + 1)) / nparts) - t_begin;
+  const double* __restrict__ S0 = a.red;
+  double* T1 = a.work;
+  int Ir, Jr;
+  rl_unflatten(t_begin, Ir, Jr);
+  for (int done = 0; done < ntile; done += 8) {
+    solve_d4 v[8];
+    double* dstp[8];
+    int Is[8], Js[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = done + j < ntile;
+      Is[j] = ok ? Ir + 2 : nblk - 1; Js[j] = ok ? Jr + 1 : nblk - 2;
+      dstp[j] = ok ? T1 + rl_tile(Is[j], Js[j]) : a.work + 2 * rl_tile(nblk, 0) + 256 * wave;
+      v[j] = rl_system_load(S0, n, Is[j], Js[j], lane);
+      if (++Jr > Ir) { ++Ir; Jr = 0; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rl_tile_store(dstp[j], lane, rl_system_fixup(v[j], nullptr, a.fixed, n, Is[j], Js[j], lane));  // (no diagonal entry in these tiles: no damping)
+  }
+}
+__device__ __forceinline__ void rl_stager(const SolveArgs& a, int b, int ns) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  // (the dummy tile of a wavefront past its run: the stagers share workgroup 0's eight -- harmless, nobody reads them)
+  rl_stage_offdiag(a, b * nw + wave, ns * nw, lane, wave & 7);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(rl_stage_flags(a, a.npad >> 4) + b, a.stage_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int NTHREADS>
 __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const double* __restrict__ S0, const unsigned char* fixed, const double* damp, double* yv, double* dv, double* invd,
-                                                    double* linv /* npad x 17 */, double* Pop /* npad x 16 */, double* dtile /* 16 x 17 */, double* znext /* 2 x 256 */, double* tstamp) {
+                                                    double* linv /* npad x 17 */, double* Pop /* npad x 16 */, double* dtile /* 16 x 17 */, double* znext /* 2 x 256 */, int* stage_miss /* LDS word */, double* tstamp) {
   constexpr int NW = NTHREADS / 64, SL = 32 / NW;  // tile row I is owned by wavefront I mod NW (<= 32 tile rows: 40 cameras)
   static_assert(NW == 8, "8 wavefronts: 256 VGPRs each");
   constexpr int NWK = NW - NW / 4;                // trailing-update workers: the wavefronts that do not share a SIMD with wavefront 0 (the pivots)
@@ -305,26 +350,33 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
     if (wq >= nwk) {
       // (wavefront 4 on a short step)
     } else if (k == 0) {
-      // first touch: while wavefront 0 does the first 16 pivots the six others bring every tile right of column 0 from the reduce buffer
-      // (written by other XCDs: a long round trip) into the tile scratch, eight aligned 32-byte loads in flight per lane
-      const int M = nblk * (nblk + 1) / 2 - nblk;  // tiles (I, J), 1 <= J <= I
-      const int t_begin = (int)(((long long)M * wq) / nwk), ntile = (int)(((long long)M * (wq + 1)) / nwk) - t_begin;
-      int Ir, Jr;
-      rl_unflatten(t_begin, Ir, Jr);
-      for (int done = 0; done < ntile; done += 8) {
-        solve_d4 v[8];
-        double* dstp[8];
-        int Is[8], Js[8];
+      // first touch: the DIAGONAL tiles right of column 0 (they carry the damping) from the reduce buffer into the tile scratch, while
+      // wavefront 0 does the first 16 pivots; the off-diagonal ones come from the stager workgroups (rl_stager)
+      {
+        solve_d4 v[4];
+        int Id[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bool ok = done + j < ntile;
-          Is[j] = ok ? Ir + 1 : nblk - 1; Js[j] = ok ? Jr + 1 : nblk - 1;
-          dstp[j] = ok ? T1 + rl_tile(Is[j], Js[j]) : a.work + 2 * rl_tile(nblk, 0) + 256 * wave;
-          v[j] = rl_system_load(S0, n, Is[j], Js[j], lane);
-          if (++Jr > Ir) { ++Ir; Jr = 0; }
+        for (int j = 0; j < 4; ++j) {
+          Id[j] = 1 + wq + nwk * j;
+          v[j] = rl_system_load(S0, n, min(Id[j], nblk - 1), min(Id[j], nblk - 1), lane);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rl_tile_store(dstp[j], lane, rl_system_fixup(v[j], damp, fixed, n, Is[j], Js[j], lane));
+        for (int j = 0; j < 4; ++j) {
+          if (Id[j] < nblk) rl_tile_store(T1 + rl_tile(Id[j], Id[j]), lane, rl_system_fixup(v[j], damp, fixed, n, Id[j], Id[j], lane));
+        }
+        for (int Ix = 1 + wq + nwk * 4; Ix < nblk; Ix += nwk)  // (more than 29 tile rows: the rest one at a time)
+          rl_tile_store(T1 + rl_tile(Ix, Ix), lane, rl_tile_from_system(S0, damp, fixed, n, Ix, Ix, lane));
+      }
+      if (wave == 1) {  // ... and one wavefront waits for the stagers' words (lane b: stager b), bounded
+        const int ns = (int)gridDim.x - 1;
+        const double* fl = rl_stage_flags(a, nblk);
+        bool ok = lane >= ns;
+        for (int polls = 0; polls < 40000 && !__all(ok); ++polls) {
+          if (!ok) ok = __hip_atomic_load(fl + min(lane, kRlMaxStagers - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.stage_tag;
+          if (!__all(ok)) __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the stagers wrote is visible to this CU from here on
+        if (lane == 0) *stage_miss = __all(ok) ? 0 : 1;
       }
     } else if (k + 1 < nblk) {
       const int J0 = k + 1, m = nblk - J0;        // panel k - 1 is in Pop; tiles (I, J), J0 <= J <= I < nblk: m (m + 1) / 2 of them
@@ -372,6 +424,10 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
     }
     }
     __syncthreads();
+    if (k == 0 && ((int)gridDim.x == 1 || *stage_miss)) {  // no stagers in this launch, or one did not show up in time: the same tiles, by this workgroup
+      rl_stage_offdiag(a, wave, NW, lane, wave);
+      __syncthreads();
+    }
 #ifdef MCBA_SOLVE_TIMING
     const long long t1 = clock64();
     if (k == (int)a.seq - 1) t_a = t1 - t0;
@@ -598,7 +654,7 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
     if constexpr (!LDSW) {
       static_assert(NTHREADS == 512, "the right-looking variant is written for 8 wavefronts");
       STAMP(1);
-      solve_right_looking<NTHREADS>(a, S0, fixed, damp, yv, dv, invd, panel, Bs, Bs + (size_t)16 * bst, Bs + (size_t)16 * bst + 16 * 17, lst);
+      solve_right_looking<NTHREADS>(a, S0, fixed, damp, yv, dv, invd, panel, Bs, Bs + (size_t)16 * bst, Bs + (size_t)16 * bst + 16 * 17, s_flag + 2, lst);
     } else {
     {
 #pragma unroll
@@ -824,6 +880,9 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
 
 template <int NTHREADS, bool LDSW, int KS>
 __global__ __launch_bounds__(NTHREADS) void k_solve_cam(SolveArgs a) {
+  if constexpr (!LDSW) {
+    if (blockIdx.x > 0) { rl_stager(a, (int)blockIdx.x - 1, (int)gridDim.x - 1); return; }
+  }
   solve_cam_body<NTHREADS, LDSW, KS>(a);
 }
 
@@ -894,7 +953,9 @@ void launch_solve_cam(hipStream_t st, const SolveArgs& a) {
     else hipLaunchKernelGGL((k_solve_cam<256, true, kStageMax>), dim3(1), dim3(256), lds, st, a);
     return;
   }
-  hipLaunchKernelGGL((k_solve_cam<512, false, 1>), dim3(1), dim3(512), lds, st, a);
+  int ns = rl_stagers(a.npad);
+  if (const char* e = getenv("MCBA_SOLVE_STAGERS")) ns = std::max(0, std::min(kRlMaxStagers, atoi(e)));  // 0: workgroup 0 brings the tiles in itself (the path a missing stager falls back to)
+  hipLaunchKernelGGL((k_solve_cam<512, false, 1>), dim3(1 + ns), dim3(512), lds, st, a);  // workgroup 0 solves, the others bring the system's tiles in
 }
 
 }  // namespace mcba

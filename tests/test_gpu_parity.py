@@ -401,6 +401,39 @@ def test_full_size_properties(mc):
     assert abs(acc["scal"][0] - full["scal"][0]) <= 1e-12 * full["scal"][0]
 
 
+
+def test_right_looking_solve_is_the_same_with_and_without_stagers(mc, monkeypatch):
+    """> 9 cameras: workgroups 1.. of the launch bring the system's off-diagonal tiles into the scratch and release a word each;
+    workgroup 0 falls back to doing it itself if one is missing (MCBA_SOLVE_STAGERS=0 launches none: that path).  The values are
+    the same either way, so the camera step must be identical to the bit -- also on a second launch of the same handle."""
+    C = 24
+    p = mc.synth.make_problem(C, 40, seed=77, missing=0.1)
+    x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    steps = {}
+    for ns in ("default", "0", "3"):
+        if ns == "default":
+            monkeypatch.delenv("MCBA_SOLVE_STAGERS", raising=False)
+        else:
+            monkeypatch.setenv("MCBA_SOLVE_STAGERS", ns)
+        prob = mc.ops.Problem(p["uvs"], p["obj"])
+        prob.set_params(0, x)
+        prob.linearize(0)
+        out = []
+        for s, lam in ((1, 2e-3), (2, 5e-2)):
+            prob.build_reduced(lam, rank_slot=0)
+            red = prob.get_reduced()
+            prob.lm_set_state(float(red["scal"][0]), lam, 2.0, 0)
+            prob.lm_auto_config(1e-8, 1e-8, 1e-8, 1e-12, 1e12, None)
+            prob.lm_auto_solve(s)
+            st = prob.lm_auto_wait(s).copy()
+            assert st[15] == 0
+            out.append(prob.cam_step().copy())
+        prob.close()
+        steps[ns] = out
+    for ns in ("0", "3"):
+        for a, b in zip(steps["default"], steps[ns]):
+            np.testing.assert_array_equal(a, b)
+
 # ------------------------------------------------------------------ reduced camera system solved on the GPU (k_solve_cam)
 @pytest.mark.parametrize("C,fixed", [(2, False), (6, False), (6, True), (7, False), (9, False), (10, False), (10, True), (13, False), (24, False), (24, True), (40, False), (40, True)])
 def test_device_reduced_solve_matches_lapack(mc, C, fixed):
