@@ -144,8 +144,8 @@ __host__ __device__ inline bool solve_lookahead(int npad) { return MCBA_SOLVE_LO
 //      updated with panel k: the one operand it does not own, L_(k+1,k), every wavefront forms for itself; the diagonal tile
 //      goes to LDS as rows for the pivots, the others stay in registers
 // The backward sweep uses the inverse diagonal blocks; its rows of the factor are requested one step ahead.
-// Measured (scripts/solve_time.py, one box): 12C = 120 / 192 / 288 / 480: 44 / 78 / 142 / 380 us against 117.6 (192) / 205 / 578 us
-// left-looking; what is left at 288 (of ~340 k cycles): ~38 k of first touch (0.66 MB of cold reads by ONE CU), B at ~4.5 k per step
+// Measured (scripts/solve_time.py, one box): 12C = 120 / 192 / 288 / 480: 44 / 78 / 131 / 342 us against 117.6 (192) / 205 / 578 us
+// left-looking; what is left at 288 (of ~300 k cycles; the first touch went to stager workgroups, rl_stager): B at ~4.5 k per step
 // (a global round trip for the look-ahead tiles inside it: interleaving its MFMA chains changed nothing), the updates at 2 x their
 // MFMA time -- they are bound by the tile traffic of one CU (~30 B per cycle: with the MFMAs removed the interval is as long, with
 // the loads and stores removed it shrinks to the pivots' 4.5 k), the backward sweep 30 k.
