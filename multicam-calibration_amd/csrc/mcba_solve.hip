@@ -147,8 +147,8 @@ __host__ __device__ inline bool solve_lookahead(int npad) { return MCBA_SOLVE_LO
 // Measured (scripts/solve_time.py, one box): 12C = 120 / 192 / 288 / 480: 44 / 78 / 131 / 342 us against 117.6 (192) / 205 / 578 us
 // left-looking; what is left at 288 (of ~300 k cycles; the first touch went to stager workgroups, rl_stager): B at ~4.5 k per step
 // (a global round trip for the look-ahead tiles inside it: interleaving its MFMA chains changed nothing), the updates at 2 x their
-// MFMA time -- they are bound by the tile traffic of one CU (~30 B per cycle: with the MFMAs removed the interval is as long, with
-// the loads and stores removed it shrinks to the pivots' 4.5 k), the backward sweep 30 k.
+// MFMA time (stamped per tile and wavefront: ~250 cycles of LDS operand reads, ~200 of MFMAs, ~160 of stores + the next request;
+// with the MFMAs removed the interval is almost as long), the backward sweep 30 k.
 #ifndef MCBA_RL_NB
 #define MCBA_RL_NB 4
 #endif
