@@ -255,6 +255,7 @@ __device__ __forceinline__ void rl_stage_offdiag(const SolveArgs& a, int part, i
   }
 }
 __device__ __forceinline__ void rl_stager(const SolveArgs& a, int b, int ns) {
+  if (a.stage_tag < 0.0) return;  // (MCBA_SOLVE_STAGERS=-1, tests: stagers that never show up -- workgroup 0 must time out and do the work itself)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   // (the dummy tile of a wavefront past its run: the stagers share workgroup 0's eight -- harmless, nobody reads them)
   rl_stage_offdiag(a, b * nw + wave, ns * nw, lane, wave & 7);
@@ -372,7 +373,7 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
         const double* fl = rl_stage_flags(a, nblk);
         bool ok = lane >= ns;
         for (int polls = 0; polls < 40000 && !__all(ok); ++polls) {
-          if (!ok) ok = __hip_atomic_load(fl + min(lane, kRlMaxStagers - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.stage_tag;
+          if (!ok) ok = __hip_atomic_load(fl + min(lane, kRlMaxStagers - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fabs(a.stage_tag);
           if (!__all(ok)) __builtin_amdgcn_s_sleep(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the stagers wrote is visible to this CU from here on
@@ -954,8 +955,12 @@ void launch_solve_cam(hipStream_t st, const SolveArgs& a) {
     return;
   }
   int ns = rl_stagers(a.npad);
-  if (const char* e = getenv("MCBA_SOLVE_STAGERS")) ns = std::max(0, std::min(kRlMaxStagers, atoi(e)));  // 0: workgroup 0 brings the tiles in itself (the path a missing stager falls back to)
-  hipLaunchKernelGGL((k_solve_cam<512, false, 1>), dim3(1 + ns), dim3(512), lds, st, a);  // workgroup 0 solves, the others bring the system's tiles in
+  SolveArgs b = a;
+  if (const char* e = getenv("MCBA_SOLVE_STAGERS")) {  // 0: workgroup 0 brings the tiles in itself; -1 (tests): stagers are launched but do nothing, so workgroup 0's bounded wait runs out
+    const int v = atoi(e);
+    if (v < 0) b.stage_tag = -b.stage_tag; else ns = std::min(kRlMaxStagers, v);
+  }
+  hipLaunchKernelGGL((k_solve_cam<512, false, 1>), dim3(1 + ns), dim3(512), lds, st, b);  // workgroup 0 solves, the others bring the system's tiles in
 }
 
 }  // namespace mcba
