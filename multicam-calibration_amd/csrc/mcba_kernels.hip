@@ -694,7 +694,29 @@ constexpr int kSyrkSuper = 32;  // frames factorised per super-stage: 32 frames 
 template <int PPW, int IPT, bool DECIDE, bool XS>
 __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse fz, const double* __restrict__ rec0, const double* __restrict__ rec1, double* __restrict__ fbuf, double* __restrict__ fpart,
                                               const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int sq, int sr, int FS,
-                                              const double* __restrict__ dscale) {
+                                              const double* __restrict__ dscale, int xg, int yg) {
+  // Workgroup coordinates: (frame set, tile-pair group).  With more than one pair group (the 16-tile variant: 24 cameras = 3) the
+  // groups of one frame set read the SAME W rows; launched as (G, 3) they land on three different XCDs (workgroups go round the
+  // XCDs by linear id) and each pulls the rows from HBM: 465 MB per launch by the counters against ~150 MB of rows.  xg > 0: a
+  // 1-D launch decoded so that the yg siblings of a frame set have the same id modulo 8 --
+  // the same XCD, the same L2 -- and follow each other in dispatch order.
+  int bx = blockIdx.x, by = blockIdx.y, gx = gridDim.x;
+  if (xg > 0) {
+    // whole groups of eight frame sets: set (8 q + xcd), its yg siblings in consecutive slots of that XCD; the xg % 8 sets left over
+    // are dealt out one workgroup at a time (their siblings may part) -- an XCD must not get more workgroups than it has CUs, or its
+    // last one waits for a whole workgroup to finish (first attempt: 33 on three XCDs, 239 us instead of 139 us)
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3, nfull = xg >> 3;
+    gx = xg;
+    if (slot < nfull * yg) {
+      by = slot % yg;
+      bx = (slot / yg) * 8 + xcd;
+    } else {
+      const int e = (slot - nfull * yg) * 8 + xcd;
+      bx = 8 * nfull + e / yg;
+      by = e % yg;
+      if (bx >= xg) return;
+    }
+  }
   extern __shared__ __align__(16) double lds[];
   __shared__ double s_st[MCBA_LMS];
   __shared__ double s_sum[8];
@@ -740,7 +762,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   const long long t_summed = clock64();
 #endif
   if (have_state && s_st[MCBA_LM_DONE] != 0.0) {  // terminated: nothing left to do (uniform) -- but the rest of the tick reads
-    if (DECIDE && blockIdx.x == 0 && blockIdx.y == 0 && t < MCBA_LMS) fz.lms_post[t] = s_st[t];  // the state from the second buffer
+    if (DECIDE && bx == 0 && by == 0 && t < MCBA_LMS) fz.lms_post[t] = s_st[t];  // the state from the second buffer
     return;
   }
   if (DECIDE) {
@@ -759,7 +781,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
       }
     }
     __syncthreads();
-    if (blockIdx.x == 0 && blockIdx.y == 0) {  // publish: later kernels of the tick read the state from here
+    if (bx == 0 && by == 0) {  // publish: later kernels of the tick read the state from here
       if (t < MCBA_LMS) fz.lms_post[t] = s_st[t];
       if (t < 4) fz.trial_out[t] = s_sum[t];
     }
@@ -787,7 +809,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   mfma_d4 acc[PPW];
 #pragma unroll
   for (int k = 0; k < PPW; ++k) {
-    int q = blockIdx.y * (4 * PPW) + wave + 4 * k;
+    int q = by * (4 * PPW) + wave + 4 * k;
     qi[k] = q < NP ? q : -1;  // a missing pair still multiplies tile (0,0) -- branch-free MFMA loop -- but is never stored
     // tile pair q -> (ti, tj), ti <= tj, rows of NT - ti pairs each (the order of the host's table tile_i / tile_j): computed --
     // q is wave-uniform, a few scalar instructions -- because a load here is a dependent global round trip on the critical
@@ -804,7 +826,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   }
   for (int i = t; i < (NT * 16 - (n + 1)) * RS; i += 256) s_y[(size_t)(n + 1) * RS + i] = 0.0;  // padding rows stay zero
 
-  const int f0 = ((int)blockIdx.x * sq + min((int)blockIdx.x, sr)) * FS, f1 = min(F, f0 + (sq + ((int)blockIdx.x < sr ? 1 : 0)) * FS);
+  const int f0 = (bx * sq + min(bx, sr)) * FS, f1 = min(F, f0 + (sq + (bx < sr ? 1 : 0)) * FS);
   double wreg[IPT][6];
 
   // thread = (frame b of the stage, row group): its IPT items are rows r0, r0 + 256/FS, ... of the SAME frame, so that
@@ -884,7 +906,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
 #pragma unroll
       for (int k = 0; k < 6; ++k) { row[21 + k] = id[k]; row[27 + k] = z[k]; gmax = fmax(gmax, fabs(gf[k])); }
       nfail += ok ? 0.0 : 1.0;
-      if (blockIdx.y == 0) {
+      if (by == 0) {
         double o[40];
 #pragma unroll
         for (int k = 0; k < 21; ++k) o[k] = Lp[k];
@@ -977,21 +999,21 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
 #ifdef MCBA_SYRK_TIMING
   const long long t_loop_end = clock64();
 #endif
-  if (wave == 0 && blockIdx.y == 0) {
+  if (wave == 0 && by == 0) {
     const double wm = wave_max(gmax), wn = wave_sum63(nfail);
-    if (lane == 63) { fpart[2 * blockIdx.x] = wm; fpart[2 * blockIdx.x + 1] = wn; }
+    if (lane == 63) { fpart[2 * bx] = wm; fpart[2 * bx + 1] = wn; }
   }
 #pragma unroll
   for (int k = 0; k < PPW; ++k) {
     if (qi[k] >= 0) {
-      const size_t G = gridDim.x;
-      double* o = spart + ((size_t)(4 * qi[k]) * G + blockIdx.x) * 64 + lane;
+      const size_t G = gx;
+      double* o = spart + ((size_t)(4 * qi[k]) * G + bx) * 64 + lane;
       o[0] = acc[k][0]; o[G * 64] = acc[k][1]; o[2 * G * 64] = acc[k][2]; o[3 * G * 64] = acc[k][3];
     }
   }
 #ifdef MCBA_SYRK_TIMING
-  if (t == 0 && blockIdx.y == 0) {  // per workgroup, shader cycles: entry -> trial scalars summed -> decided -> stages; V sums, factor, Y build, MFMA, barrier, tile store
-    double* dbg = spart + (size_t)gridDim.x * NP * 256 + 64 + 12 * (size_t)blockIdx.x;
+  if (t == 0 && by == 0) {  // per workgroup, shader cycles: entry -> trial scalars summed -> decided -> stages; V sums, factor, Y build, MFMA, barrier, tile store
+    double* dbg = spart + (size_t)gx * NP * 256 + 64 + 12 * (size_t)bx;
     dbg[0] = (double)(t_summed - t_entry); dbg[1] = (double)(t_decided - t_summed); dbg[2] = (double)(tstart - t_decided);
     dbg[3] = (double)tacc[4]; dbg[4] = (double)tacc[0]; dbg[5] = (double)tacc[1]; dbg[6] = (double)tacc[2]; dbg[7] = (double)tacc[3];
     dbg[8] = (double)(clock64() - t_loop_end);
@@ -1428,16 +1450,19 @@ size_t syrk_lds_bytes(int C, int FS) {
 #define SYRK_IPT 5  // (12C+1)*FS <= 256*SYRK_IPT is guaranteed by the choice of FS in mcba_create
 #define SYRK_IPT_SMALL 3
 
+static bool g_syrk_xcd_remap = [] { const char* e = getenv("MCBA_SYRK_XCD"); return !e || atoi(e) != 0; }();  // (0: the plain (G, groups) launch, for A/B)
 void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int sq, int sr, int FS, int ppw,
                  const double* dscale) {
   size_t lds = syrk_lds_bytes(C, FS);
 #define SYRK_GO(PPW, IPT, GY)                                                                                                                                   \
   do {                                                                                                                                                          \
-    dim3 grid(G, GY);                                                                                                                                           \
-    if (fz.decide && dscale) k_syrk<PPW, IPT, true, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);    \
-    else if (fz.decide) k_syrk<PPW, IPT, true, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);      \
-    else if (dscale) k_syrk<PPW, IPT, false, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);         \
-    else k_syrk<PPW, IPT, false, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale);                    \
+    const bool remap = (GY) > 1 && g_syrk_xcd_remap;                                                                                                            \
+    dim3 grid(remap ? 8 * ((G / 8) * (GY) + ((G % 8) * (GY) + 7) / 8) : G, remap ? 1 : (GY));                                                                   \
+    const int xg = remap ? G : 0, yg = remap ? (GY) : 0;                                                                                                        \
+    if (fz.decide && dscale) k_syrk<PPW, IPT, true, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);    \
+    else if (fz.decide) k_syrk<PPW, IPT, true, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);      \
+    else if (dscale) k_syrk<PPW, IPT, false, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);         \
+    else k_syrk<PPW, IPT, false, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);                    \
   } while (0)
   // items per thread: (12C + 1) rows x FS frames over 256 threads -- 3 is enough up to 7 cameras at 8 frames per stage
   // (fewer prefetch registers: the kernel stays within 256 registers, two workgroups per CU, without scratch)

@@ -1,4 +1,5 @@
-"""Fixed launch sequence for rocprofv3 counter passes: 12 LM steps + 6 Jacobian evaluations at 6x10kx54.
+"""Fixed launch sequence for rocprofv3 counter passes: 12 LM steps + 6 Jacobian evaluations at 6x10kx54
+   (MCBA_SHAPE="C,F,rows,cols", e.g. "24,6250,10,20": another shape, reduced system solved on the GPU, no Jacobian evaluations).
    rocprofv3 --pmc <counters> --output-format csv -d <dir> -- python3 scripts/profile_kernels.py"""
 import os
 import sys
@@ -8,15 +9,18 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multicam_calibration_amd as m
 
-C, F = 6, 10000
-p = m.synth.make_problem(C, F, seed=0)
+C, F, rows, cols = 6, 10000, 6, 9
+shape = os.environ.get("MCBA_SHAPE")
+if shape:
+    C, F, rows, cols = (int(v) for v in shape.split(","))
+p = m.synth.make_problem(C, F, rows=rows, cols=cols, seed=0)
 x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
 prob = m.ops.Problem(p["uvs"], p["obj"])
-lm = m.solver.LevenbergMarquardt(prob, ftol=0.0, xtol=0.0, gtol=0.0)
+lm = m.solver.LevenbergMarquardt(prob, ftol=0.0, xtol=0.0, gtol=0.0, **(dict(reduced_solver="device", depth=2) if shape else {}))
 lm.start(x0)
 for _ in range(12):
     lm.iterate(always_linearize=True)
-for _ in range(6):
+for _ in range(0 if shape else 6):
     prob.jacobian_eval(lm.cur, robust_scaled=True)
 prob.synchronize()
 print("done cost", lm.cost)
