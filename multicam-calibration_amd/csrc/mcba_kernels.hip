@@ -117,19 +117,28 @@ __device__ __forceinline__ void obs_weights(double r, bool valid, double fs2, do
 }
 
 // ---------------------------------------------------------------- observation re-layout
-// raw (C,F,N,2) -> obs_t [C][N][Fpad] (u,v); frames f >= F are NaN (= missing, contribute nothing)
-__global__ void k_transpose_obs(const double2* __restrict__ raw, double2* __restrict__ obs_t, int C, int F, int N, int Fpad) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)C * N * Fpad;
-  if (i >= total) return;
-  int f = (int)(i % Fpad);
-  size_t cp = i / Fpad;
-  int p = (int)(cp % N);
-  int c = (int)(cp / N);
-  double2 v;
-  v.x = v.y = __builtin_nan("");
-  if (f < F) v = raw[((size_t)c * F + f) * N + p];
-  obs_t[i] = v;
+// raw (C,F,N,2) -> obs_t [C][N][Fpad] (u,v); frames f >= F are NaN (= missing, contribute nothing).
+// Through an LDS tile of 64 frames x 16 points: reads are 256 contiguous bytes per frame (16 points), writes 1 KB per point (64
+// frames).  (One thread per output element, as it was, read 16 bytes at a stride of 16 N: 326 MB fetched for the 52 MB array at
+// 6 x 10 000 x 54 by FETCH_SIZE, 2.16 GB for 482 MB at 24 x 6 250 x 200.)
+__global__ __launch_bounds__(256) void k_transpose_obs(const double2* __restrict__ raw, double2* __restrict__ obs_t, int C, int F, int N, int Fpad) {
+  __shared__ double2 tile[64][17];
+  const int fb = blockIdx.x, c = blockIdx.y, p0 = 16 * blockIdx.z;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double2 nanv;
+  nanv.x = nanv.y = __builtin_nan("");
+#pragma unroll
+  for (int fr = 0; fr < 4; ++fr) {
+    const int f = fb * 64 + fr * 16 + ty, p = p0 + tx;
+    tile[fr * 16 + ty][tx] = (f < F && p < N) ? raw[((size_t)c * F + f) * N + p] : nanv;
+  }
+  __syncthreads();
+  const int fl = threadIdx.x & 63, pp = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = p0 + pp + 4 * k;
+    if (p < N) obs_t[((size_t)c * N + p) * Fpad + fb * 64 + fl] = tile[fl][pp + 4 * k];
+  }
 }
 
 // ---------------------------------------------------------------- k_gram: linearise
@@ -1363,8 +1372,7 @@ __global__ __launch_bounds__(64) void k_jacobian(const double2* __restrict__ obs
   }
 
 void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int C, int F, int N, int Fpad) {
-  size_t total = (size_t)C * N * Fpad;
-  k_transpose_obs<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(raw), reinterpret_cast<double2*>(obs_t), C, F, N, Fpad);
+  k_transpose_obs<<<dim3(Fpad / 64, C, (N + 15) / 16), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(raw), reinterpret_cast<double2*>(obs_t), C, F, N, Fpad);
 }
 
 // wavefront slots of the device at one wavefront per SIMD (4 x compute units; mcba_create sets it from the device properties)
