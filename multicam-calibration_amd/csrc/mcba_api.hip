@@ -54,7 +54,9 @@ struct mcba_handle {
   int NT = 0, NP = 0, G = 0, sq = 0, sr = 0, FS = 0, ppw = 4, nfblocks = 0, nbblocks = 0, nch = 1;  // k_syrk: G workgroups, sq stages of FS frames each, the first sr one more
   int gram_nchunk = 0;  // gram_split == 3: point chunks per (camera, frame block) of the tail
   double* gchunk = nullptr;  // ... and their raw sums
-  int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD (few frames)
+  int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD (few frames); 2 / 3: fused rounds + split-role / point-chunk tail;
+                       // 4: point split inside the workgroup (gram_npw wavefronts per (camera, frame block)); 5: fused rounds + point-split tail
+  int gram_npw = 4;
   size_t nx = 0, nsys = 0;
   double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
   ncclComm_t comm = nullptr;  // direct RCCL communicator (optional)
@@ -326,9 +328,28 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
       }
     }
   }
-  if (const char* e = getenv("MCBA_GRAM_SPLIT")) {  // 0 fused, 1 split roles, 2 fused + split-role tail, 3 fused + point-chunk tail
-    h->gram_split = std::max(0, std::min(3, atoi(e)));
-    if (h->gram_split == 3 && h->gram_nchunk < 2) h->gram_nchunk = std::max(2, std::min(4, N / 8));
+  // Round 4: point split INSIDE the workgroup (k_gram_psplit: the 4 or 2 wavefronts of a (camera, frame block) take a part of the board's
+  // points each and meet in LDS) -- for shards with at most half a round of items, and for a short last round behind whole fused rounds.
+  {
+    static bool ps_ready[64] = {};  // the dynamic-LDS limit of its instances is raised once per device
+    bool ps_ok = (size_t)h->lds_optin >= mcba::gram_psplit_lds_bytes(4) + 2048;
+    if (ps_ok && !ps_ready[device & 63]) { ps_ok = mcba::gram_psplit_set_lds_limit() == 0; ps_ready[device & 63] = ps_ok; (void)hipGetLastError(); }
+    const int items = C * h->nfb;
+    if (ps_ok) {
+      if (items <= slots / 4) { h->gram_split = 4; h->gram_npw = 4; }
+      else if (items <= slots / 2) { h->gram_split = 4; h->gram_npw = 2; }
+      else if (items > slots) {
+        const int fba = mcba::gram_round_blocks(C, h->nfb), tail = C * (h->nfb - fba);
+        if (fba > 0 && tail > 0 && tail <= slots / 4) { h->gram_split = 5; h->gram_npw = 4; }
+        else if (fba > 0 && tail > 0 && tail <= slots / 2 && h->gram_split != 3) { h->gram_split = 5; h->gram_npw = 2; }
+      }
+    }
+    if (const char* e = getenv("MCBA_GRAM_SPLIT")) {  // 0 fused, 1 split roles, 2 fused + split-role tail, 3 fused + point-chunk tail, 4 point split, 5 fused + point-split tail
+      h->gram_split = std::max(0, std::min(5, atoi(e)));
+      if (h->gram_split == 3 && h->gram_nchunk < 2) h->gram_nchunk = std::max(2, std::min(4, N / 8));
+      if (h->gram_split >= 4 && !ps_ok) { delete h; return fail(MCBA_ERR_ARG, "MCBA_GRAM_SPLIT=4/5: this device cannot give k_gram_psplit its LDS"); }
+    }
+    if (const char* e = getenv("MCBA_GRAM_NPW")) h->gram_npw = atoi(e) == 2 ? 2 : 4;
   }
   if (const char* e = getenv("MCBA_GRAM_NCHUNK")) h->gram_nchunk = std::max(2, std::min(8, atoi(e)));
   // k_cost: split the board points so that ~4 waves per SIMD (1024 SIMDs) are in flight
@@ -599,7 +620,7 @@ int mcba_linearize(mcba_handle* h, int slot) {
   NEED_SOLVER(h);
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw);
   }
   int rc = check_launch();
   if (rc) return rc;
@@ -678,7 +699,7 @@ int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, 
   const int alt = 1 - h->lin;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -754,7 +775,7 @@ static int lm_trial_impl(mcba_handle* h, const double* delta_cam, const mcba::De
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);  // trial point = the OTHER slot / buffer
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -779,10 +800,17 @@ static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, boo
     fz.decide = 1;
     fz.cp0 = h->gpart2[0] + (size_t)90 * h->nfb;
     fz.cp1 = h->gpart2[1] + (size_t)90 * h->nfb;
-    fz.cstride = 4;  // k_gram: per-workgroup sums in every fourth frame block's slot
+    fz.cstride = 4;  // k_gram: per-workgroup sums in every fourth frame block's slot ...
     fz.cinner = (h->nfb + 3) / 4;
+    fz.cdense = 1 << 30;
+    // ... except where its point-split variant ran (one frame block per wavefront group: every slot holds its own cost)
+    if (h->gram_split == 4) { fz.cdense = 0; fz.cinner = h->nfb; }
+    else if (h->gram_split == 5) {
+      const int fba = mcba::gram_round_blocks(h->C, h->nfb);
+      if (fba > 0 && fba < h->nfb) { fz.cdense = fba / 4; fz.cinner = fba / 4 + (h->nfb - fba); }
+    }
     fz.couter = (size_t)MCBA_GP * h->nfb;
-    fz.ncp = h->C * ((h->nfb + 3) / 4);
+    fz.ncp = h->C * fz.cinner;
     fz.bpart = h->bpart;
     fz.nbp = h->nbblocks;
     fz.trial_out = h->red + h->nsys;
@@ -927,7 +955,7 @@ static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw);
   }
   if ((rc = check_launch())) return rc;
   if (!sum_here) return MCBA_OK;
@@ -995,13 +1023,13 @@ int mcba_debug_fuse_stamps(mcba_handle* h, double* host8) {  // development only
   return MCBA_OK;
 }
 
-int mcba_debug_gram_stamps(mcba_handle* h, double* host) {  // development only (MCBA_GRAM_TIMING builds): [C][nfb][8]
+int mcba_debug_gram_stamps(mcba_handle* h, double* host) {  // development only (MCBA_GRAM_TIMING builds): [C][nfb][32] (the fused kernel fills 8 per wavefront, the point split 8 per part)
   if (!h || !host) return fail(MCBA_ERR_ARG, "bad argument");
   HIPCHK(hipDeviceSynchronize());
   for (int c = 0; c < h->C; ++c)
     for (int fb = 0; fb < h->nfb; ++fb)
-      HIPCHK(hipMemcpy2D(host + ((size_t)c * h->nfb + fb) * 8, sizeof(double), h->rec2[h->lin] + ((size_t)c * h->nfb + fb) * (MCBA_REC * 64) + (size_t)(49 * 64) * 2 + 1, 2 * sizeof(double),
-                         sizeof(double), 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy2D(host + ((size_t)c * h->nfb + fb) * 32, sizeof(double), h->rec2[h->lin] + ((size_t)c * h->nfb + fb) * (MCBA_REC * 64) + (size_t)(49 * 64) * 2 + 1, 2 * sizeof(double),
+                         sizeof(double), 32, hipMemcpyDeviceToHost));
   return MCBA_OK;
 }
 

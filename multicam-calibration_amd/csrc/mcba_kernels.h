@@ -32,6 +32,7 @@ struct SyrkFuse {
   const double* cp1;
   int cinner;          // ... element idx of `ncp` lives at (idx / cinner) * couter + (idx % cinner) * cstride
   int cstride;         // 4: k_gram leaves the cost of a whole workgroup (four frame blocks) in its first wavefront's slot, zeros in the others
+  int cdense;          // ... up to idx % cinner == cdense; from there on every slot holds a value (k_gram_psplit ran on those frame blocks): slot = cdense cstride + (idx % cinner - cdense)
   size_t couter;
   int ncp;
   const double* bpart; // k_backsub's per-block sums (3 per block)
@@ -69,7 +70,11 @@ struct SolveArgs {
 void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int C, int F, int N, int Fpad);
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,
                  int planar = 0,   // planar: every board point has z = 0 exactly (with f_scale = 1 the fused kernel's FAST instance runs)
-                 double* chunk = nullptr, int nchunk = 0);  // split == 3: scratch for the point-chunk tail (gram_chunk_doubles) and the number of chunks
+                 double* chunk = nullptr, int nchunk = 0,   // split == 3: scratch for the point-chunk tail (gram_chunk_doubles) and the number of chunks
+                 int npw = 4);                              // split == 4 / 5 (point split inside the workgroup): wavefronts per (camera, frame block), 4 or 2
+int gram_round_blocks(int C, int nfb);       // frame blocks (a multiple of 4) that whole rounds of the wavefront slots cover; split 2 / 3 / 5 handle the rest as a tail
+size_t gram_psplit_lds_bytes(int npw);       // dynamic LDS of k_gram_psplit
+int gram_psplit_set_lds_limit();             // raises the dynamic-LDS limit of its instances (0 = ok)
 size_t gram_chunk_doubles(int C, int nfb, int nchunk);   // doubles of that scratch for C cameras x nfb frame blocks
 void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch);
 size_t syrk_lds_bytes(int C, int FS);

@@ -152,14 +152,21 @@ __global__ __launch_bounds__(256) void k_transpose_obs(const double2* __restrict
 // only, and instead of the expansion the 88 raw per-lane sums (local Gram accumulators, cost, data flag) go to `chunk` --; 2 COMBINE --
 // no point loop: the sums of `nchunk` chunks are added up in chunk order and expanded.  1 + 2 replace the split-role tail launch of
 // shards that are not a whole number of rounds of the 1 024 wavefront slots: the remainder's POINTS are spread over the idle SIMDs.
+// MODE 3 (round 4): POINT SPLIT INSIDE THE WORKGROUP -- the NPW wavefronts of one (camera, frame block) each run the fused loop over
+// 1 / NPW of the board's points, then meet in LDS: the role-A sums (ee, he, cost, data flag: 29 per lane) of the others go to the
+// group's wavefront 0, the role-B sums (ii, ie, hi: 59) to its wavefront 1, each adds them IN PART ORDER and runs its role's half of
+// the expansion (the two halves are independent, see mcba_math.h) -- no second launch and no trip of the raw sums through HBM.  For
+// every shape that is not a whole number of rounds of the 1 024 wavefront slots: few (camera, frame block) items, or a short last round.
 constexpr int kGramRaw = 88;  // ee 21 | he 6 | cost | ii 17 | ie 36 | hi 6 | any
-template <int LOSS, int ROLE, bool FAST = false, int MODE = 0>
+constexpr int kGramRawA = 29, kGramRawB = 59;  // what role A / role B of the expansion needs of them
+template <int LOSS, int ROLE, bool FAST = false, int MODE = 0, int NPW = 1>
 __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
                                           double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2,
                                           const double (&pz0)[6], const double2 (&pre)[4], double* s_cost, int nrun, int p_lo = 0, int p_hi = -1, double2* chunk = nullptr, int nchunk = 1,
                                           size_t chunk_stride = 0) {
   if (p_hi < 0) p_hi = N;
   static_assert(MODE == 0 || (ROLE == 2 && MCBA_GRAM_PIPE), "point chunks exist for the fused, pipelined loop only");
+  static_assert(MODE == 3 ? (NPW == 2 || NPW == 4) : NPW == 1, "NPW wavefronts share a (camera, frame block) in MODE 3 only");
   // pz0: this lane's frame pose, pre: its first four observations -- loaded by the kernel before the camera constants were
   // staged (those loads, the LM state and the camera rows are all in flight together: one memory round trip at the start)
   const int f = fb * 64 + lane;
@@ -239,7 +246,8 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     double x4[RD][3];
 #pragma unroll
     for (int j = 0; j < RD; ++j) {
-      const int pj = min(p_lo + j, p_hi - 1);
+      int pj = min(p_lo + j, p_hi - 1);
+      if constexpr (MODE == 3) pj = max(pj, 0);  // (a piece of a board with fewer points than wavefronts may be empty)
       r4[j] = pre[j];
       x4[j][0] = obj[3 * pj]; x4[j][1] = obj[3 * pj + 1]; x4[j][2] = obj[3 * pj + 2];
     }
@@ -367,101 +375,281 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     for (int i = 0; i < 36; ++i) gb.ie[i] = acc[45 + i];
     any = acc[87] != 0.0;
   }
-  // ---- expand once per (c,f): this role's part of W, V, g_f (record) and of U, g_c (reduced over the wave)
-  ChainConst ch;
-  {
-    double pz[6], Rf[9], Jrf[9], Jrc[9];
+  if constexpr (MODE == 3) {
+    // ---- the wavefronts of the group meet in LDS (see the head of this function): xs = [group][A: NPW - 1 sources][29][64] then
+    // [group][B: NPW - 1 sources][59][64] doubles; every access is 64 consecutive doubles (conflict-free ds_*_b64)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), part = wv % NPW, grp = wv / NPW;
+#ifdef MCBA_GRAM_TIMING
+    long long gt2b = 0;
+#endif
+    if constexpr (NPW == 4) {
+      // FOUR finishing roles, one per wavefront, so that the expansion and the cross-lane reduction of the 92 per-wavefront sums --
+      // about a third of this kernel's time on a 54-point board when one or two wavefronts do it -- are spread over the four SIMDs:
+      //   part 0: role A -> U rows 6..11, g_c[6..12), cost, pairs with data (29 sums, reduced over the lanes)
+      //   part 3: role A -> the record's W rows 6..11, V, g_f (no reduction)
+      //   part 1: role B, intrinsics rows 0..2 -> U rows 0..2, g_c[0..3) (36 sums), W rows 0..2
+      //   part 2: role B, intrinsics rows 3..5 -> U rows 3..5, g_c[3..6) (27 sums), W rows 3..5
+      // LDS: A sums [4 parts][29][64] (both readers add all four in part order), B-low (ii 0..10, ie rows 0..2, hi 0..2: 32) from
+      // parts 0, 2, 3 and B-high (ii 11..16, ie rows 3..5, hi 3..5: 27) from parts 0, 1, 3 -- 150 016 bytes.
+      constexpr int NBL = 32, NBH = 27;
+      double* xA = reinterpret_cast<double*>(chunk) + lane;
+      double* xL = xA + 4 * kGramRawA * 64;
+      double* xH = xL + 3 * NBL * 64;
+      {
+        double* d = xA + part * (kGramRawA * 64);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) pz[i] = pose[i];
-    rot_and_jr(pz, Rf, Jrf, abc);
+        for (int i = 0; i < 21; ++i) d[i * 64] = ga.ee[i];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) Jrc[i] = uni(s_cam.Jr[i]);
-    make_chain_const(Rc, Jrc, Rf, Jrf, pz + 3, ch);
-    chain_to_cam_rows(pc.Rcf, ch);  // the point loop accumulated camera-frame rows [A~ | P]
-  }
-  // records are wave tiles rec[camera][frame block][k/2 = 0..49][lane][2]: every store below is one 1 KiB dwordx4 row
-  double2* r2 = reinterpret_cast<double2*>(rec + ((size_t)c * nfb + fb) * (MCBA_REC * 64)) + lane;
-  // per-wavefront sums of U_c (78), g_c (12), the cost and the number of pairs with data: all of them are reduced over the
-  // lanes TOGETHER (wave_reduce_scatter) and leave as three values per lane, stored [camera][k = 0..91][frame block] so that
-  // the second stage reads contiguous runs.  Compact index j of this role's values -> row k:
-  //   both roles (fused): j = k;   role A: j < 21 -> 57 + j (U rows 6..11), else 63 + j (g_c 6..11, cost, pairs);
-  //   role B: j < 57 -> j (U rows 0..5), else 21 + j (g_c 0..5)
-  constexpr int KR = (ROLE == 0) ? 48 : 96;
-  double red[KR];
+        for (int i = 0; i < 6; ++i) d[(21 + i) * 64] = ga.he[i];
+        d[27 * 64] = cost;
+        d[28 * 64] = any ? 1.0 : 0.0;
+      }
+      if (part != 1) {
+        double* d = xL + (part == 0 ? 0 : part - 1) * (NBL * 64);
 #pragma unroll
-  for (int i = 0; i < KR; ++i) red[i] = 0.0;
-  if constexpr (DO_A) {
-    double U[78], gc[12], W[72], V[21], gf[6];
-    gram_expand(ga, ch, U, gc, W, V, gf);
-    {
+        for (int i = 0; i < 11; ++i) d[i * 64] = gb.ii[i];
 #pragma unroll
-      for (int i = 36; i < 72; i += 2) r2[(i >> 1) * 64] = make_double2(W[i], W[i + 1]);
+        for (int i = 0; i < 18; ++i) d[(11 + i) * 64] = gb.ie[i];
 #pragma unroll
-      for (int i = 0; i < 20; i += 2) r2[(36 + (i >> 1)) * 64] = make_double2(V[i], V[i + 1]);
-      r2[46 * 64] = make_double2(V[20], gf[0]);
-      r2[47 * 64] = make_double2(gf[1], gf[2]);
-      r2[48 * 64] = make_double2(gf[3], gf[4]);
-      r2[49 * 64] = make_double2(gf[5], 0.0);
+        for (int i = 0; i < 3; ++i) d[(29 + i) * 64] = gb.hi[i];
+      }
+      if (part != 2) {
+        double* d = xH + (part == 3 ? 2 : part) * (NBH * 64);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i * 64] = gb.ii[11 + i];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) d[(6 + i) * 64] = gb.ie[18 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) d[(24 + i) * 64] = gb.hi[3 + i];
+      }
+      double pz[6];  // the frame's pose again (not kept over the point loop): requested before the barrier, needed after it
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pz[i] = pose[i];
+      __syncthreads();
+#ifdef MCBA_GRAM_TIMING
+      gt2b = clock64();
+#endif
+      ChainConst ch;
+      {
+        double Rf[9], Jrf[9], Jrc[9];
+        rot_and_jr(pz, Rf, Jrf, abc);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Jrc[i] = uni(s_cam.Jr[i]);
+        make_chain_const(Rc, Jrc, Rf, Jrf, pz + 3, ch);
+        chain_to_cam_rows(pc.Rcf, ch);
+      }
+      double2* r2 = reinterpret_cast<double2*>(rec + ((size_t)c * nfb + fb) * (MCBA_REC * 64)) + lane;
+      double red[48];
+#pragma unroll
+      for (int i = 0; i < 48; ++i) red[i] = 0.0;
+      int kofs_lo = 0, kofs_hi = 0, nlo = 0, nown = 0;  // compact index j of this part's sums -> row k of gpart: j < nlo ? kofs_lo + j : kofs_hi + j
+      if (part == 0 || part == 3) {
+        GramA gs;
+#pragma unroll
+        for (int i = 0; i < 21; ++i) gs.ee[i] = xA[i * 64];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gs.he[i] = xA[(21 + i) * 64];
+        double cs = xA[27 * 64];
+        bool an = xA[28 * 64] != 0.0;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+          const double* sA = xA + j * (kGramRawA * 64);
+#pragma unroll
+          for (int i = 0; i < 21; ++i) gs.ee[i] += sA[i * 64];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) gs.he[i] += sA[(21 + i) * 64];
+          cs += sA[27 * 64];
+          an = an || sA[28 * 64] != 0.0;
+        }
+        double U[78], gc[12], W[72], V[21], gf[6];
+        gram_expand(gs, ch, U, gc, W, V, gf);
+        if (part == 3) {
+#pragma unroll
+          for (int i = 36; i < 72; i += 2) r2[(i >> 1) * 64] = make_double2(W[i], W[i + 1]);
+#pragma unroll
+          for (int i = 0; i < 20; i += 2) r2[(36 + (i >> 1)) * 64] = make_double2(V[i], V[i + 1]);
+          r2[46 * 64] = make_double2(V[20], gf[0]);
+          r2[47 * 64] = make_double2(gf[1], gf[2]);
+          r2[48 * 64] = make_double2(gf[3], gf[4]);
+          r2[49 * 64] = make_double2(gf[5], 0.0);
+        } else {
+#pragma unroll
+          for (int a = 6; a < 12; ++a) {
+#pragma unroll
+            for (int b = a; b < 12; ++b) red[tri12(a, b) - 57] = U[tri12(a, b)];
+            red[78 + a - 63] = gc[a];
+          }
+          red[27] = cs;
+          red[28] = an ? 1.0 : 0.0;
+          kofs_lo = 57; kofs_hi = 63; nlo = 21; nown = 29;
+        }
+      } else {
+        GramB gs;
+        gram_zero(gs);
+        if (part == 1) {  // ((part 0 + own) + part 2) + part 3
+#pragma unroll
+          for (int i = 0; i < 11; ++i) gs.ii[i] = xL[i * 64] + gb.ii[i];
+#pragma unroll
+          for (int i = 0; i < 18; ++i) gs.ie[i] = xL[(11 + i) * 64] + gb.ie[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) gs.hi[i] = xL[(29 + i) * 64] + gb.hi[i];
+#pragma unroll
+          for (int j = 1; j < 3; ++j) {
+            const double* sB = xL + j * (NBL * 64);
+#pragma unroll
+            for (int i = 0; i < 11; ++i) gs.ii[i] += sB[i * 64];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) gs.ie[i] += sB[(11 + i) * 64];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gs.hi[i] += sB[(29 + i) * 64];
+          }
+        } else {  // ((part 0 + part 1) + own) + part 3
+#pragma unroll
+          for (int i = 0; i < 6; ++i) gs.ii[11 + i] = ((xH[i * 64] + xH[(NBH + i) * 64]) + gb.ii[11 + i]) + xH[(2 * NBH + i) * 64];
+#pragma unroll
+          for (int i = 0; i < 18; ++i) gs.ie[18 + i] = ((xH[(6 + i) * 64] + xH[(NBH + 6 + i) * 64]) + gb.ie[18 + i]) + xH[(2 * NBH + 6 + i) * 64];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) gs.hi[3 + i] = ((xH[(24 + i) * 64] + xH[(NBH + 24 + i) * 64]) + gb.hi[3 + i]) + xH[(2 * NBH + 24 + i) * 64];
+        }
+        double U[78], gc[12], W[72];
+        gram_expand(gs, ch, U, gc, W);
+        if (part == 1) {
+#pragma unroll
+          for (int i = 0; i < 18; i += 2) r2[(i >> 1) * 64] = make_double2(W[i], W[i + 1]);
+#pragma unroll
+          for (int j = 0; j < 33; ++j) red[j] = U[j];  // rows 0..2 of the upper triangle are its first 33 entries
+#pragma unroll
+          for (int a = 0; a < 3; ++a) red[33 + a] = gc[a];
+          kofs_lo = 0; kofs_hi = 78 - 33; nlo = 33; nown = 36;
+        } else {
+#pragma unroll
+          for (int i = 18; i < 36; i += 2) r2[(i >> 1) * 64] = make_double2(W[i], W[i + 1]);
+#pragma unroll
+          for (int j = 0; j < 24; ++j) red[j] = U[33 + j];  // rows 3..5: entries 33..56
+#pragma unroll
+          for (int a = 0; a < 3; ++a) red[24 + a] = gc[3 + a];
+          kofs_lo = 33; kofs_hi = 81 - 24; nlo = 24; nown = 27;
+        }
+      }
+      if (part != 3) {
+        double o3[3];
+        wave_reduce_scatter<48>(red, o3, lane);
+        if ((lane & 3) == 0) {  // lanes that share lane >> 2 hold copies: the first of them stores
+          double* gp = gpart + (size_t)c * MCBA_GP * nfb + fb;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int j = 3 * (lane >> 2) + r;
+            if (j < nown) gp[(size_t)(j < nlo ? kofs_lo + j : kofs_hi + j) * nfb] = o3[r];
+          }
+        }
+      }
+    } else {
+    double* xa = reinterpret_cast<double*>(chunk) + (size_t)grp * ((NPW - 1) * kGramRaw * 64) + lane;
+    double* xb = xa + (NPW - 1) * kGramRawA * 64;
+    if (part != 0) {  // role-A sums -> the group's wavefront 0 (source slot part - 1)
+      double* d = xa + (part - 1) * (kGramRawA * 64);
+#pragma unroll
+      for (int i = 0; i < 21; ++i) d[i * 64] = ga.ee[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d[(21 + i) * 64] = ga.he[i];
+      d[27 * 64] = cost;
+      d[28 * 64] = any ? 1.0 : 0.0;
     }
-    constexpr int OFF = ROLE == 0 ? 57 : 0, OFG = ROLE == 0 ? 63 : 0;
+    if (part != 1) {  // role-B sums -> the group's wavefront 1 (source slots: part 0 -> 0, part j >= 2 -> j - 1)
+      double* d = xb + (part == 0 ? 0 : part - 1) * (kGramRawB * 64);
 #pragma unroll
-    for (int a = 6; a < 12; ++a) {
+      for (int i = 0; i < 17; ++i) d[i * 64] = gb.ii[i];
 #pragma unroll
-      for (int b = a; b < 12; ++b) red[tri12(a, b) - OFF] = U[tri12(a, b)];
-      red[78 + a - OFG] = gc[a];
+      for (int i = 0; i < 36; ++i) d[(17 + i) * 64] = gb.ie[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d[(53 + i) * 64] = gb.hi[i];
     }
-    red[90 - OFG] = cost;
-    red[91 - OFG] = any ? 1.0 : 0.0;
-  }
-  if constexpr (DO_B) {
-    double U[78], gc[12], W[72];
-    gram_expand(gb, ch, U, gc, W);
-    {
+    __syncthreads();  // (wavefronts past the last frame block have ended: the barrier does not wait for them)
+#ifdef MCBA_GRAM_TIMING
+    gt2b = clock64();
+#endif
+    if (part == 0) {  // parts 0, 1, 2, ... in order
 #pragma unroll
-      for (int i = 0; i < 36; i += 2) r2[(i >> 1) * 64] = make_double2(W[i], W[i + 1]);
-    }
-    constexpr int OFG = ROLE == 1 ? 21 : 0;
+      for (int j = 1; j < NPW; ++j) {
+        const double* sA = xa + (j - 1) * (kGramRawA * 64);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
+        for (int i = 0; i < 21; ++i) ga.ee[i] += sA[i * 64];
 #pragma unroll
-      for (int b = a; b < 12; ++b) red[tri12(a, b)] = U[tri12(a, b)];
-      red[78 + a - OFG] = gc[a];
-    }
-  }
-  {
-    double o3[3];
-    wave_reduce_scatter<KR>(red, o3, lane);
-    constexpr int SH = KR == 96 ? 1 : 2;  // lanes that share lane >> SH hold copies: the first of them stores
-    if constexpr (DO_A) {
-      // The cost and the pair count (k = 90, 91) of the workgroup's wavefronts are summed HERE, in wavefront order, and stored
-      // by wavefront 0 (the others store zeros): k_syrk's decision prologue -- on the critical path of every one of its
-      // workgroups -- then reads a quarter of the entries (every fourth frame block) instead of all of them.
-      constexpr int LQ = ROLE == 0 ? 9 : 30;  // lane >> SH that holds the values k = 90 (r = 0) and 91 (r = 1)
-      const int wv = threadIdx.x >> 6;
-      const bool holder = (lane >> SH) == LQ && (lane & ((1 << SH) - 1)) == 0;
-      if (holder) { s_cost[2 * wv] = o3[0]; s_cost[2 * wv + 1] = o3[1]; }
-      __syncthreads();  // (wavefronts past the last frame block have ended: the barrier does not wait for them)
-      if (holder) {
-        double a = 0.0, b = 0.0;
-        if (wv == 0)
-          for (int w = 0; w < nrun; ++w) { a += s_cost[2 * w]; b += s_cost[2 * w + 1]; }
-        o3[0] = a; o3[1] = b;
+        for (int i = 0; i < 6; ++i) ga.he[i] += sA[(21 + i) * 64];
+        cost += sA[27 * 64];
+        any = any || sA[28 * 64] != 0.0;
+      }
+      {
+#define GF_ROLE 0
+#define GF_A true
+#define GF_B false
+#define GF_PRESUM false
+#include "mcba_gram_finish.inc"
+#undef GF_ROLE
+#undef GF_A
+#undef GF_B
+#undef GF_PRESUM
+      }
+    } else if (part == 1) {
+      {  // part 0 + own, then parts 2, 3: the same order of additions as above
+        const double* sB = xb;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) gb.ii[i] = sB[i * 64] + gb.ii[i];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) gb.ie[i] = sB[(17 + i) * 64] + gb.ie[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gb.hi[i] = sB[(53 + i) * 64] + gb.hi[i];
+      }
+#pragma unroll
+      for (int j = 2; j < NPW; ++j) {
+        const double* sB = xb + (j - 1) * (kGramRawB * 64);
+#pragma unroll
+        for (int i = 0; i < 17; ++i) gb.ii[i] += sB[i * 64];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) gb.ie[i] += sB[(17 + i) * 64];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gb.hi[i] += sB[(53 + i) * 64];
+      }
+      {
+#define GF_ROLE 1
+#define GF_A false
+#define GF_B true
+#define GF_PRESUM false
+#include "mcba_gram_finish.inc"
+#undef GF_ROLE
+#undef GF_A
+#undef GF_B
+#undef GF_PRESUM
       }
     }
-    if ((lane & ((1 << SH) - 1)) == 0) {
-      double* gp = gpart + (size_t)c * MCBA_GP * nfb + fb;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const int j = 3 * (lane >> SH) + r;
-        int k;
-        bool own;
-        if constexpr (ROLE == 0) { own = j < 29; k = j < 21 ? 57 + j : 63 + j; }
-        else if constexpr (ROLE == 1) { own = j < 63; k = j < 57 ? j : 21 + j; }
-        else { own = j < MCBA_GP; k = j; }
-        if (own) gp[(size_t)k * nfb] = o3[r];
+    }
+#ifdef MCBA_GRAM_TIMING
+    {  // every wavefront of the group: set-up, point loop, LDS exchange + barrier, finish (shader cycles), begin / end (100 MHz), where it ran
+      double* s_stamp = reinterpret_cast<double*>(chunk) + (NPW == 4 ? (4 * kGramRawA + 3 * 32 + 3 * 27) * 64 : (4 / NPW) * (NPW - 1) * kGramRaw * 64);  // behind the exchange area
+      const long long gt3 = clock64(), gw3 = wall_clock64();
+      if (lane == 0) {
+        double* d = s_stamp + 8 * wv;
+        d[0] = (double)(gt1 - gt0); d[1] = (double)(gt2 - gt1); d[2] = (double)(gt2b - gt2); d[3] = (double)(gt3 - gt2b); d[4] = (double)gw0; d[5] = (double)gw3;
+        d[6] = s_stamp[32 + wv]; d[7] = (double)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // [6]: the kernel's entry (100 MHz)
+      }
+      __syncthreads();
+      if (part == 0 && lane < 8 * NPW) {
+        double2* r2 = reinterpret_cast<double2*>(rec + ((size_t)c * nfb + fb) * (MCBA_REC * 64)) + lane;
+        r2[49 * 64].y = s_stamp[8 * (wv / NPW) * NPW + lane];  // pad slot of the record
       }
     }
+#endif
+    return;
   }
+#define GF_ROLE ROLE
+#define GF_A DO_A
+#define GF_B DO_B
+#define GF_PRESUM true
+#include "mcba_gram_finish.inc"
+#undef GF_ROLE
+#undef GF_A
+#undef GF_B
+#undef GF_PRESUM
 #ifdef MCBA_GRAM_TIMING
   if (lane < 8) {  // every wavefront: phase lengths in shader cycles, begin / end on the 100 MHz wall clock, where it ran
     const long long gt3 = clock64();
@@ -490,12 +678,12 @@ struct GramStart {
   bool run;
 };
 __device__ __forceinline__ void gram_start(GramStart& g, CamConst& s_cam, const double2* __restrict__ obs_t, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1, double* rec0, double* rec1,
-                                           double* gp0, double* gp1, int C, int N, int Fpad, int fb0, int fb1, int p_lo = 0, int p_hi = -1) {
+                                           double* gp0, double* gp1, int C, int N, int Fpad, int fb0, int fb1, int p_lo = 0, int p_hi = -1, int npw = 1) {
   if (p_hi < 0) p_hi = N;
   const int c = blockIdx.y;
   const int wave = threadIdx.x >> 6;
   g.lane = threadIdx.x & 63;
-  g.fb = fb0 + blockIdx.x * (blockDim.x >> 6) + wave;  // this launch covers the frame blocks [fb0, fb1), one per wavefront
+  g.fb = fb0 + blockIdx.x * ((blockDim.x >> 6) / npw) + wave / npw;  // this launch covers the frame blocks [fb0, fb1), one per wavefront (point split: per npw wavefronts)
   const bool have = g.fb < fb1;
   const int fbc = have ? g.fb : fb1 - 1;
   double st3 = 0.0, st14 = 0.0, st15 = 0.0;
@@ -559,6 +747,26 @@ __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t,
   if (!g.run) return;
   const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));  // wavefronts of this workgroup that have a frame block
   gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun);
+}
+
+// Point split inside the workgroup (gram_body MODE 3): the workgroup's four wavefronts are 4 / NPW (camera, frame block) items of
+// NPW wavefronts each, wavefront part = wave % NPW over the points [N part / NPW, N (part + 1) / NPW).  Dynamic LDS: gram_psplit_lds_bytes.
+template <int LOSS, bool FAST, int NPW>
+__global__ __launch_bounds__(256) void k_gram_psplit(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
+                                                        double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, int fb0, int fb1,
+                                                        double fs2, double ifs2) {
+  __shared__ CamConst s_cam;
+  __shared__ double s_cost[8];
+  extern __shared__ __align__(16) double s_xch[];
+  const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) % NPW;
+  const int p_lo = (int)(((long long)N * part) / NPW), p_hi = (int)(((long long)N * (part + 1)) / NPW);
+#ifdef MCBA_GRAM_TIMING
+  if ((threadIdx.x & 63) == 0) s_xch[(NPW == 4 ? (4 * kGramRawA + 3 * 32 + 3 * 27) * 64 : (4 / NPW) * (NPW - 1) * kGramRaw * 64) + 32 + (threadIdx.x >> 6)] = (double)wall_clock64();
+#endif
+  GramStart g;
+  gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1, p_lo, max(p_hi, p_lo + 1), NPW);  // (an empty piece -- fewer points than wavefronts -- still prefetches a valid point)
+  if (!g.run) return;
+  gram_body<LOSS, 2, FAST, 3, NPW>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, 0, p_lo, p_hi, reinterpret_cast<double2*>(s_xch));
 }
 
 // Point-chunk tail (gram_body MODE 1 / 2).  k_gram_chunk: grid (frame blocks, C, nchunk) of ONE-wavefront workgroups (with four
@@ -745,7 +953,8 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
     const double *pa, *pb;
     int stride = 1, count, inner = 1 << 30;
     size_t outer = 0;
-    if (wave == 0) { pa = fz.cp0; pb = fz.cp1; count = fz.ncp; inner = fz.cinner; outer = fz.couter; stride = fz.cstride; }
+    int dense = 1 << 30;
+    if (wave == 0) { pa = fz.cp0; pb = fz.cp1; count = fz.ncp; inner = fz.cinner; outer = fz.couter; stride = fz.cstride; dense = fz.cdense; }
     else { pa = pb = fz.bpart + (wave - 1); stride = 3; count = fz.nbp; }
     const bool two = pa != pb;  // wave-uniform
     double sa = 0.0, sb = 0.0;
@@ -755,7 +964,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
       for (int k = 0; k < 8; ++k) {
         const int idx = base + lane + 64 * k;
         const int hi = idx / inner, lo = idx - hi * inner;
-        const size_t at = (size_t)hi * outer + (size_t)lo * stride;
+        const size_t at = (size_t)hi * outer + (size_t)(lo < dense ? lo * stride : dense * stride + (lo - dense));
         va[k] = idx < count ? pa[at] : 0.0;
         vb[k] = (two && idx < count) ? pb[at] : 0.0;
       }
@@ -1379,8 +1588,17 @@ void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int 
 static int g_gram_slots = 1024;
 void gram_set_slots(int slots) { if (slots >= 64) g_gram_slots = slots; }
 
+int gram_round_blocks(int C, int nfb) { return std::min(nfb, (((C * nfb) / g_gram_slots) * g_gram_slots / C) & ~3); }
+size_t gram_psplit_lds_bytes(int npw) {
+  size_t b = npw == 4 ? (size_t)(4 * kGramRawA + 3 * 32 + 3 * 27) * 64 * sizeof(double) : (size_t)(4 / npw) * (npw - 1) * kGramRaw * 64 * sizeof(double);
+#ifdef MCBA_GRAM_TIMING
+  b += 40 * sizeof(double);
+#endif
+  return b;
+}
+
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,
-                 int planar, double* chunk, int nchunk) {
+                 int planar, double* chunk, int nchunk, int npw) {
   const int nfb = Fpad / 64;
   dim3 block(256);
   const double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
@@ -1397,6 +1615,27 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
     dim3 grid((fb1 - fb0 + 3) / 4, C, 2);
     DISPATCH_LOSS(loss, (k_gram_split<L><<<grid, block, 0, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)));
   };
+  // point split inside the workgroup: npw = 4 / 2 wavefronts per (camera, frame block), 1 / 2 of them per workgroup
+  auto psplit = [&](int fb0, int fb1) {
+    const int per = npw == 4 ? 1 : 2;
+    dim3 grid((fb1 - fb0 + per - 1) / per, C, 1);
+    const size_t lds = gram_psplit_lds_bytes(npw == 4 ? 4 : 2);
+    const bool fast = planar && f_scale == 1.0;
+#define PS_GO(FASTV, NPWV) DISPATCH_LOSS(loss, (k_gram_psplit<L, FASTV, NPWV><<<grid, block, lds, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)))
+    if (npw == 4) {
+      if (fast) { PS_GO(true, 4); } else { PS_GO(false, 4); }
+    } else {
+      if (fast) { PS_GO(true, 2); } else { PS_GO(false, 2); }
+    }
+#undef PS_GO
+  };
+  if (split == 4) { psplit(0, nfb); return; }
+  if (split == 5) {  // whole rounds of the wavefront slots fused, the short last round point-split
+    const int fba5 = gram_round_blocks(C, nfb);
+    if (fba5 > 0 && fba5 < nfb) { fused(0, fba5); psplit(fba5, nfb); }
+    else fused(0, nfb);
+    return;
+  }
   if (split == 1) { roles(0, nfb); return; }
   if (split == 3) {
     // whole rounds of the 1 024 wavefront slots fused; the last, short round as POINT CHUNKS: nchunk wavefronts per (camera, frame
@@ -1513,6 +1752,19 @@ void launch_decide(hipStream_t st, const double* trial8, DecideArgs da) {
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust) {
   double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
   DISPATCH_LOSS(loss, (k_jacobian<L><<<dim3(F, C), dim3(64), 0, st>>>(reinterpret_cast<const double2*>(obs_raw), obj, x, jac, res, C, F, N, Fpad, robust, fs2, ifs2)));
+}
+
+int gram_psplit_set_lds_limit() {
+  int rc = 0;
+#define PS_K(L) reinterpret_cast<const void*>(k_gram_psplit<L, true, 4>), reinterpret_cast<const void*>(k_gram_psplit<L, false, 4>), \
+                reinterpret_cast<const void*>(k_gram_psplit<L, true, 2>), reinterpret_cast<const void*>(k_gram_psplit<L, false, 2>)
+  const void* ks[] = {PS_K(LOSS_LINEAR), PS_K(LOSS_SOFT_L1), PS_K(LOSS_HUBER), PS_K(LOSS_CAUCHY), PS_K(LOSS_ARCTAN)};
+#undef PS_K
+  for (const void* k : ks) {
+    int r = (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_psplit_lds_bytes(4));
+    rc = rc ? rc : r;
+  }
+  return rc;
 }
 
 int syrk_set_lds_limit(size_t bytes) {

@@ -58,26 +58,35 @@ def test_solution_matches_tight_reference_optimum_large(mc, golden, size, mode):
 
 
 # ------------------------------------------------------------------ every k_gram launch variant against the oracle
-@pytest.mark.parametrize("split,board", [(0, (2, 2)), (1, (2, 2)), (2, (2, 2)), (3, (2, 2)), (3, (3, 5)), (3, (2, 5))])
-def test_gram_variants_vs_oracle(mc, split, board):
+@pytest.mark.parametrize("split,board,npw", [(0, (2, 2), 0), (1, (2, 2), 0), (2, (2, 2), 0), (3, (2, 2), 0), (3, (3, 5), 0), (3, (2, 5), 0),
+                                             (4, (2, 2), 4), (4, (2, 5), 4), (4, (3, 5), 4), (4, (1, 3), 4), (4, (1, 1), 4), (4, (3, 5), 2), (4, (1, 1), 2),
+                                             (5, (2, 2), 4), (5, (3, 5), 4), (5, (2, 5), 2), (5, (1, 3), 4)])
+def test_gram_variants_vs_oracle(mc, split, board, npw):
     """MCBA_GRAM_SPLIT (read in mcba_create): 0 fused (one wavefront per SIMD), 1 split roles (two per SIMD), 2 whole
     rounds fused + the tail with the split roles in a second launch over the frame blocks [fb0, fb1), 3 whole rounds fused + the
-    tail as POINT CHUNKS (k_gram_chunk: 2 chunks of the board's points per (camera, frame block), k_gram_combine sums and expands them).
-    24 cameras x 45 frame blocks = 1080 wavefront items: variants 2 / 3 launch fused(0..40) + tail(40..45).  Boards small enough for
-    the oracle's dense normal equations: 2 x 2 (one chunk: the degenerate case), 3 x 5 (chunks of 8 + 7 points: a remainder inside a
-    chunk), 2 x 5 (8 + 2)."""
+    tail as POINT CHUNKS (k_gram_chunk: 2 chunks of the board's points per (camera, frame block), k_gram_combine sums and expands them),
+    4 (round 4) the POINT SPLIT INSIDE THE WORKGROUP (k_gram_psplit: MCBA_GRAM_NPW = 4 or 2 wavefronts per (camera, frame block), each
+    over its part of the points, raw sums combined in LDS in part order), 5 whole rounds fused + the tail point-split.
+    24 cameras x 45 frame blocks = 1080 wavefront items: variants 2 / 3 / 5 launch fused(0..40) + tail(40..45).  Boards small enough for
+    the oracle's dense normal equations: 2 x 2 (one chunk: the degenerate case; one point per wavefront of a 4-way split), 3 x 5 (chunks
+    of 8 + 7 points: a remainder inside a chunk; parts of 3 + 4 + 4 + 4), 2 x 5 (8 + 2; parts of 2 + 3 + 2 + 3), 1 x 3 and 1 x 1 (fewer
+    points than wavefronts: empty parts)."""
     p = mc.synth.make_problem(24, 2880 - 7, rows=board[0], cols=board[1], pitch=60.0 if board == (2, 2) else 25.0, seed=41, missing=0.15)   # ragged last frame block
     C, F = p["uvs"].shape[:2]
     x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
-    old = os.environ.get("MCBA_GRAM_SPLIT")
-    os.environ["MCBA_GRAM_SPLIT"] = str(split)
+    env = {"MCBA_GRAM_SPLIT": str(split)}
+    if npw:
+        env["MCBA_GRAM_NPW"] = str(npw)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         prob = mc.ops.Problem(p["uvs"], p["obj"])
     finally:
-        if old is None:
-            del os.environ["MCBA_GRAM_SPLIT"]
-        else:
-            os.environ["MCBA_GRAM_SPLIT"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     prob.set_params(0, x)
     prob.linearize(0)
     lam = 5e-3
@@ -96,6 +105,35 @@ def test_gram_variants_vs_oracle(mc, split, board):
     assert abs(red["scal"][0] - cost) <= 1e-12 * cost and abs(cost_k - cost) <= 1e-12 * cost
     assert red["scal"][1] == (~np.isnan(p["uvs"]).all((-1, -2))).sum()            # (camera, frame) pairs with data
     assert np.abs(gfd - gf).max() <= 1e-10 * np.abs(gf).max()
+
+
+@pytest.mark.parametrize("C,F,board,split,npw", [(6, 1000, (6, 9), 4, 4), (6, 1000, (6, 9), 4, 2), (2, 50, (6, 9), 4, 4), (24, 2873, (3, 5), 5, 4), (24, 2873, (3, 5), 5, 2)])
+def test_point_split_lm_loop_matches_fused(mc, C, F, board, split, npw):
+    """The device-resident LM loop on the point-split k_gram against the same loop on the fused kernel: k_syrk's decision prologue
+    reads the trial cost from a different slot pattern there (every frame block's own slot instead of every fourth: SyrkFuse.cdense),
+    so a wrong pattern shows as a different sequence of trial costs.  Same decisions, trial costs to 1e-11, the same optimum."""
+    p = mc.synth.make_problem(C, F, rows=board[0], cols=board[1], pitch=12.5 if board == (6, 9) else 25.0, seed=3, missing=0.1)
+    kw = dict(n_frames=None, ftol=1e-13, xtol=1e-13, gtol=1e-9, verbose=0, max_nfev=14, return_jac=False)
+    out = []
+    for env in ({"MCBA_GRAM_SPLIT": "0"}, {"MCBA_GRAM_SPLIT": str(split), "MCBA_GRAM_NPW": str(npw)}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                out.append(mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], **kw)[4])
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+    a, b = out
+    ha, hb = np.array(a.lm["history"]), np.array(b.lm["history"])
+    assert ha.shape == hb.shape and len(ha) >= 8
+    np.testing.assert_allclose(hb[:, 2], ha[:, 2], rtol=1e-11)      # trial costs
+    np.testing.assert_allclose(hb[:, 5], ha[:, 5], rtol=1e-6)       # dampings: the same accept / reject sequence
+    assert abs(a.cost - b.cost) <= 1e-11 * a.cost
+    assert np.abs(a.x - b.x).max() <= 1e-8 * np.abs(a.x).max()
 
 
 # ------------------------------------------------------------------ shard shapes of BASELINE configs[3] and configs[4]
