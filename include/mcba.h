@@ -73,6 +73,18 @@ int mcba_upload_observations(mcba_handle* h, const double* uvs, const double* ob
 /* Robust loss and f_scale of least_squares (default soft_l1, 1.0: bundle_adjustment.py:301-303). */
 int mcba_set_loss(mcba_handle* h, int loss, double f_scale);
 
+/* Camera block width (round 4, ABI 5).  12 (default): all 12 parameters of every camera are variables, as in the reference
+ * (bundle_adjustment.py:113,121-122,149-155).  6: the intrinsics (fx fy cx cy k1 k2) of EVERY camera are held fixed -- BASELINE
+ * configs[1] ("intrinsics fixed: extrinsics + points only"; SURVEY section 8c-8: the reference has no entry point for it, its oracle is
+ * a wrapper fun(y) = residuals(scatter(y, frozen intrinsics))).  With 6 the linearisation accumulates the (rho, t) blocks alone,
+ * the reduced camera system is 6C x 6C -- row i is parameter 6 + i % 6 of camera i / 6 -- and EVERY camera-system quantity of this
+ * ABI has 6 entries per camera: mcba_reduced_size / mcba_get_reduced (n = 6C), the camera step of mcba_step* / mcba_lm_* /
+ * mcba_get_cam_step, the `fixed` flags of mcba_lm_auto_config.  The parameter vector x keeps the reference's layout (12 per camera;
+ * the intrinsics are copied unchanged into every trial point).  Must be called before the first solver entry point of the handle
+ * (MCBA_ERR_ARG afterwards, and for width 6 with more than 26 cameras: hold those with the `fixed` flags instead). */
+int mcba_set_camera_block(mcba_handle* h, int width);
+int mcba_get_camera_block(const mcba_handle* h);
+
 /* least_squares' numeric `x_scale` (forwarded verbatim by the reference: bundle_adjustment.py:301-313; scipy least_squares.py
  * :243, trf.py:415-420): 12C + 6F positive doubles in the layout of x -> the FIXED damping matrix D = diag(1 / x_scale^2) replaces
  * Marquardt's D = diag(J^T J) (which is x_scale = 'jac', the reference's default) in the frame blocks, the camera block and the

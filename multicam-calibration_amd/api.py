@@ -12,6 +12,7 @@ What differs: the optimiser is Levenberg-Marquardt with an
 exact Schur solve instead of scipy's TRF/LSMR on a finite-difference Jacobian.  It minimises the same robust
 cost, so it converges to the same minimiser (gauge aside); the iterate sequence is not reproduced.
 """
+import os
 import warnings
 
 import numpy as np
@@ -253,7 +254,6 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     distributed = opt_kwargs.pop("distributed", False)
     rank, world, dist, group = 0, 1, None, None
     if distributed:
-        import os
         import torch
         import torch.distributed as dist
 
@@ -330,14 +330,16 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         if prob_all is not None:
             prob_all.close()
             prob_all = None
+        # fix_intrinsics (BASELINE configs[1]): the library's 6-wide camera block -- role A of the linearisation alone, a 6C x 6C
+        # camera system -- where it serves the rig (before anything allocates the solver buffers); otherwise flags on the 12-wide one
+        free = None
+        if fix_intrinsics and not (os.environ.get("MCBA_FIXED_COMPACT", "1") != "0" and hasattr(prob, "set_camera_block") and prob.set_camera_block(6)):
+            free = np.tile(np.r_[np.zeros(6, bool), np.ones(6, bool)], n_cameras)
         comm = None
         if distributed:
             import torch
 
             comm = solver.make_comm(prob, torch.device(f"cuda:{device}"))
-        free = None
-        if fix_intrinsics:
-            free = np.tile(np.r_[np.zeros(6, bool), np.ones(6, bool)], n_cameras)
         # an explicit None disables that test, as scipy's check_tolerance does (least_squares.py: None -> 0); the device loop
         # treats a zero tolerance as "never satisfied".  A missing key keeps the reference's / scipy's defaults.
         tol = lambda name, default: 0.0 if kw.get(name, default) is None else float(kw.get(name, default))
@@ -378,7 +380,9 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
 
             dict.__setitem__(result, "jac", _Lazy(jac))
         red = prob.get_reduced()
-        grad = np.concatenate([red["gc"], prob.frame_gradient().ravel()])
+        gcam = np.zeros(12 * n_cameras)
+        gcam[prob.cam_index if hasattr(prob, "cam_index") else slice(None)] = red["gc"]   # (6-wide camera block: the gradient entries of the intrinsics held fixed are 0, as with flags)
+        grad = np.concatenate([gcam, prob.frame_gradient().ravel()])
         if free is not None:
             grad[: 12 * n_cameras][~free] = 0.0
         if distributed:

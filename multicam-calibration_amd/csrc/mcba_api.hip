@@ -57,6 +57,7 @@ struct mcba_handle {
   int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD (few frames); 2 / 3: fused rounds + split-role / point-chunk tail;
                        // 4: point split inside the workgroup (gram_npw wavefronts per (camera, frame block)); 5: fused rounds + point-split tail
   int gram_npw = 4;
+  int cw = 12;         // camera block width: 12, or 6 = the intrinsics of every camera are held fixed (mcba_set_camera_block; BASELINE configs[1]): n = cw C
   size_t nx = 0, nsys = 0;
   double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
   ncclComm_t comm = nullptr;  // direct RCCL communicator (optional)
@@ -234,40 +235,14 @@ static int rccl_fail(const char* what, ncclResult_t r) {
   return MCBA_ERR_HIP;
 }
 
-extern "C" {
-
-int mcba_abi_version(void) { return 4; }  // 4: buffer pool, detachable residuals, x_scale, sharded select, fuse status (round 3)
-const char* mcba_last_error(void) { return g_err.c_str(); }
-const char* mcba_profile_names(void) { return kKernelNames; }
-
-int mcba_device_count(int* count) {
-  if (!count) return fail(MCBA_ERR_ARG, "count is NULL");
-  hipError_t e = hipGetDeviceCount(count);
-  if (e != hipSuccess) { *count = 0; g_err = hipGetErrorString(e); return MCBA_ERR_NODEVICE; }
-  return MCBA_OK;
-}
-
-int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
-  if (!out || C < 1 || F < 1 || N < 1 || C > 40) return fail(MCBA_ERR_ARG, "mcba_create: need 1 <= C <= 40, F >= 1, N >= 1");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MCBA_ERR_NODEVICE, "no HIP device visible");
-  if (device < 0 || device >= ndev) return fail(MCBA_ERR_ARG, "device ordinal out of range");
-  HIPCHK(hipSetDevice(device));
-  mcba_handle* h = new mcba_handle();
-  h->C = C; h->F = F; h->N = N; h->device = device;
-  {  // the launch geometry below is derived from the device, not from MI355X constants (a part with fewer CUs or less LDS gets its own deal)
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
-      if (prop.multiProcessorCount > 0) h->ncu = prop.multiProcessorCount;
-      if (prop.sharedMemPerBlockOptin > 0) h->lds_optin = (int)std::min<size_t>(prop.sharedMemPerBlockOptin, 160 * 1024);
-    }
-  }
+// Launch geometry of the solver kernels, derived from the problem's shape, the device and the camera block width (h->cw): called by
+// mcba_create and again by mcba_set_camera_block.
+static int derive_geometry(mcba_handle* h) {
+  const int C = h->C, F = h->F, N = h->N, device = h->device;
+  (void)N;
   const int ncu = h->ncu, slots = 4 * h->ncu;  // wavefront slots at one wavefront per SIMD
   mcba::gram_set_slots(slots);
-  h->Fpad = (F + 63) / 64 * 64;
-  h->nfb = h->Fpad / 64;
-  h->n = 12 * C;
-  h->nx = (size_t)12 * C + (size_t)6 * h->Fpad;
+  h->n = h->cw * C;
   h->nsys = (size_t)h->n * h->n + 3 * h->n + 16;
   // k_syrk geometry: (12C + 1) rows of [Y ; z^T] padded to NT tiles of 16, NP tile pairs (ti <= tj);
   // FS frames per LDS stage (a divisor of 64; <= 96 KiB so that two workgroups fit a CU when C is small)
@@ -277,9 +252,9 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   h->FS = 8;  // (measured at 6 x 10k: 8 frames per stage and up to 512 workgroups -- two per CU, one building Y while the
               //  other is in its MFMA phase -- 24.2 us; 16 frames / 256 workgroups 27.4 us)
   if (const char* e = getenv("MCBA_SYRK_FS")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) h->FS = v; }  // tuning knob
-  while (h->FS > 2 && (mcba::syrk_lds_bytes(C, h->FS) > (size_t)h->lds_optin * 3 / 5 || (h->n + 1) * h->FS > 256 * mcba::syrk_items_per_thread())) h->FS /= 2;
-  if ((h->n + 1) * h->FS > 256 * mcba::syrk_items_per_thread()) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for k_syrk's per-thread item budget"); }
-  if (mcba::syrk_lds_bytes(C, h->FS) > (size_t)h->lds_optin) { delete h; return fail(MCBA_ERR_ARG, "too many cameras for the LDS staging of k_syrk"); }
+  while (h->FS > 2 && (mcba::syrk_lds_bytes(C, h->FS, h->cw) > (size_t)h->lds_optin * 3 / 5 || (h->n + 1) * h->FS > 256 * mcba::syrk_items_per_thread())) h->FS /= 2;
+  if ((h->n + 1) * h->FS > 256 * mcba::syrk_items_per_thread()) { return fail(MCBA_ERR_ARG, "too many cameras for k_syrk's per-thread item budget"); }
+  if (mcba::syrk_lds_bytes(C, h->FS, h->cw) > (size_t)h->lds_optin) { return fail(MCBA_ERR_ARG, "too many cameras for the LDS staging of k_syrk"); }
   {
     int nstage = (F + h->FS - 1) / h->FS;
     // the 16-tile variant (> 13 cameras) runs ONE workgroup per CU and grid.y = ceil(NP / 64) of them share a set of frames:
@@ -347,16 +322,55 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
     if (const char* e = getenv("MCBA_GRAM_SPLIT")) {  // 0 fused, 1 split roles, 2 fused + split-role tail, 3 fused + point-chunk tail, 4 point split, 5 fused + point-split tail
       h->gram_split = std::max(0, std::min(5, atoi(e)));
       if (h->gram_split == 3 && h->gram_nchunk < 2) h->gram_nchunk = std::max(2, std::min(4, N / 8));
-      if (h->gram_split >= 4 && !ps_ok) { delete h; return fail(MCBA_ERR_ARG, "MCBA_GRAM_SPLIT=4/5: this device cannot give k_gram_psplit its LDS"); }
+      if (h->gram_split >= 4 && !ps_ok) { return fail(MCBA_ERR_ARG, "MCBA_GRAM_SPLIT=4/5: this device cannot give k_gram_psplit its LDS"); }
     }
     if (const char* e = getenv("MCBA_GRAM_NPW")) h->gram_npw = atoi(e) == 2 ? 2 : 4;
   }
+  if (h->cw == 6 && h->gram_split != 4) h->gram_split = 1;  // intrinsics held fixed: role A alone -- the point split (4), else the role-A half of the split roles
   if (const char* e = getenv("MCBA_GRAM_NCHUNK")) h->gram_nchunk = std::max(2, std::min(8, atoi(e)));
   // k_cost: split the board points so that ~4 waves per SIMD (1024 SIMDs) are in flight
   h->nch = std::max(1, std::min(std::min(8, N / 8), (4 * slots + C * h->nfb - 1) / (C * h->nfb)));
   h->nfblocks = h->G;  // (kept: k_syrk's workgroups factorise their own frames: one (max |g_f|, #failures) pair each)
   h->npad = 16 * h->NT;
   h->solve_lds = mcba::solve_fits_lds(h->npad, h->lds_optin);
+  return MCBA_OK;
+}
+
+extern "C" {
+
+int mcba_abi_version(void) { return 5; }  // 5: camera block width (intrinsics held fixed: 6C x 6C camera system), round 4
+const char* mcba_last_error(void) { return g_err.c_str(); }
+const char* mcba_profile_names(void) { return kKernelNames; }
+
+int mcba_device_count(int* count) {
+  if (!count) return fail(MCBA_ERR_ARG, "count is NULL");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) { *count = 0; g_err = hipGetErrorString(e); return MCBA_ERR_NODEVICE; }
+  return MCBA_OK;
+}
+
+int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
+  if (!out || C < 1 || F < 1 || N < 1 || C > 40) return fail(MCBA_ERR_ARG, "mcba_create: need 1 <= C <= 40, F >= 1, N >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MCBA_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(MCBA_ERR_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  mcba_handle* h = new mcba_handle();
+  h->C = C; h->F = F; h->N = N; h->device = device;
+  {  // the launch geometry below is derived from the device, not from MI355X constants (a part with fewer CUs or less LDS gets its own deal)
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      if (prop.multiProcessorCount > 0) h->ncu = prop.multiProcessorCount;
+      if (prop.sharedMemPerBlockOptin > 0) h->lds_optin = (int)std::min<size_t>(prop.sharedMemPerBlockOptin, 160 * 1024);
+    }
+  }
+  h->Fpad = (F + 63) / 64 * 64;
+  h->nfb = h->Fpad / 64;
+  h->nx = (size_t)12 * C + (size_t)6 * h->Fpad;
+  {
+    const int grc = derive_geometry(h);
+    if (grc != MCBA_OK) { delete h; return grc; }
+  }
   int rc;
 #define DA(p, cnt, zero) if ((rc = dalloc(h, &h->p, (cnt), zero)) != MCBA_OK) { mcba_destroy(h); return rc; }
   // what every handle needs (a pre-filter handle needs nothing else): the two observation layouts, the board, the parameter slots
@@ -401,7 +415,7 @@ static int ensure_solver(mcba_handle* h) {
   h->fuse_backsub = h->solve_lds != 0;
   if (const char* e = getenv("MCBA_FUSE_BACKSUB")) h->fuse_backsub = h->fuse_backsub && atoi(e) != 0;  // tuning knob
   // (a part whose LDS limit cannot be raised keeps the two-launch k_solve_cam + k_backsub path instead of failing)
-  if (h->fuse_backsub && mcba::solve_backsub_set_lds_limit(h->npad) != 0) h->fuse_backsub = false;
+  if (h->fuse_backsub && mcba::solve_backsub_set_lds_limit(h->npad, h->cw) != 0) h->fuse_backsub = false;
   h->fuse_max_polls = 200000;
   if (const char* e = getenv("MCBA_FUSE_MAX_POLLS")) h->fuse_max_polls = std::max(0, atoi(e));  // test knob: 0 forces every poll to time out
   {
@@ -420,7 +434,7 @@ static int ensure_solver(mcba_handle* h) {
   HIPCHK(hipMemcpyAsync(h->tile_j, cj.data(), cj.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   h->pinned_bytes = (h->nsys + 8 + MCBA_LMS + h->n) * sizeof(double);
   HIPCHK(pool_host_malloc(reinterpret_cast<void**>(&h->pinned), h->pinned_bytes, hipHostMallocDefault));
-  size_t lds = mcba::syrk_lds_bytes(C, h->FS);
+  size_t lds = mcba::syrk_lds_bytes(C, h->FS, h->cw);
   if (lds > 64 * 1024) {
     if (mcba::syrk_set_lds_limit(lds) != 0) return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_syrk");
   }
@@ -500,6 +514,31 @@ int mcba_set_loss(mcba_handle* h, int loss, double f_scale) {
   h->have_lin = h->have_red = false;
   return MCBA_OK;
 }
+
+// Camera block width: 12 (every camera parameter is a variable: the reference, bundle_adjustment.py:149-155) or 6 = the intrinsics
+// (fx fy cx cy k1 k2) of EVERY camera are held fixed -- BASELINE configs[1]; SURVEY section 8c-8's wrapper around the reference's
+// residuals().  With 6 the solver kernels run role A of the linearisation alone, the camera system is 6C x 6C (row i = parameter
+// 6 + i % 6 of camera i / 6: rho, t), every camera-system vector of this ABI (reduced system, camera step, `fixed` flags of
+// mcba_lm_auto_config) has 6 entries per camera; the parameter vector keeps the reference's layout.  Call it before the first
+// solver entry point of the handle (the solver buffers' geometry follows from it).  Partially frozen cameras: keep 12 and pass flags.
+int mcba_set_camera_block(mcba_handle* h, int width) {
+  if (!h || (width != 6 && width != 12)) return fail(MCBA_ERR_ARG, "mcba_set_camera_block: width 6 or 12");
+  if (width == h->cw) return MCBA_OK;
+  if (h->have_solver) return fail(MCBA_ERR_ARG, "mcba_set_camera_block: call it before the first solver entry point of the handle");
+  if (width == 6) {
+    const int nt = (6 * h->C + 1 + 15) / 16;
+    if (nt * (nt + 1) / 2 > 64) return fail(MCBA_ERR_ARG, "mcba_set_camera_block: more than 26 cameras -- hold the intrinsics with the flags of mcba_lm_auto_config instead");
+  }
+  const int old = h->cw;
+  h->cw = width;
+  HIPCHK(hipSetDevice(h->device));
+  const int rc = derive_geometry(h);
+  if (rc != MCBA_OK) { h->cw = old; (void)derive_geometry(h); return rc; }
+  h->have_lin = h->have_red = h->have_spec = false;
+  h->auto_ready = false;
+  return MCBA_OK;
+}
+int mcba_get_camera_block(const mcba_handle* h) { return h ? h->cw : 0; }
 
 static int slot_ok(mcba_handle* h, int slot) { return h && (slot == 0 || slot == 1); }
 
@@ -620,7 +659,7 @@ int mcba_linearize(mcba_handle* h, int slot) {
   NEED_SOLVER(h);
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
   }
   int rc = check_launch();
   if (rc) return rc;
@@ -637,12 +676,12 @@ int mcba_build_reduced(mcba_handle* h, double lambda, int rank_slot) {
   int rc;
   {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, host_sel(h->lin, lambda), no_fuse(), h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->sq, h->sr, h->FS, h->ppw, h->have_xscale ? h->dscale : nullptr);
+    mcba::launch_syrk(h->stream, host_sel(h->lin, lambda), no_fuse(), h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->sq, h->sr, h->FS, h->ppw, h->have_xscale ? h->dscale : nullptr, h->cw);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_REDUCE);
-    mcba::launch_reduce_system(h->stream, host_sel(h->lin), h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot);
+    mcba::launch_reduce_system(h->stream, host_sel(h->lin), h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot, nullptr, 0, nullptr, h->cw);
   }
   if ((rc = check_launch())) return rc;
   h->have_red = true;
@@ -675,7 +714,7 @@ static int step_common(mcba_handle* h, const double* delta_cam, double lambda, i
   {
     Scope sc(h, K_BACKSUB);
     // host-selected: 'current' operands are passed in position 0, the destination slot in position 1
-    mcba::launch_backsub(h->stream, host_sel(0, lambda), h->rec2[h->lin], h->rec2[h->lin], h->fbuf, cs, h->x[src], h->x[dst], h->bpart, h->C, h->F, h->Fpad);
+    mcba::launch_backsub(h->stream, host_sel(0, lambda), h->rec2[h->lin], h->rec2[h->lin], h->fbuf, cs, h->x[src], h->x[dst], h->bpart, h->C, h->F, h->Fpad, h->cw);
   }
   return check_launch();
 }
@@ -699,7 +738,7 @@ int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, 
   const int alt = 1 - h->lin;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -770,12 +809,12 @@ static int lm_trial_impl(mcba_handle* h, const double* delta_cam, const mcba::De
   int rc;
   {
     Scope sc(h, K_BACKSUB);
-    mcba::launch_backsub(h->stream, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, cs, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad);
+    mcba::launch_backsub(h->stream, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, cs, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad, h->cw);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);  // trial point = the OTHER slot / buffer
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -821,13 +860,13 @@ static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, boo
   }
   {
     Scope sc(h, K_SYRK);
-    mcba::launch_syrk(h->stream, sl, fz, h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->sq, h->sr, h->FS, h->ppw, h->have_xscale ? h->dscale : nullptr);
+    mcba::launch_syrk(h->stream, sl, fz, h->rec2[0], h->rec2[1], h->fbuf, h->fpart, h->tile_i, h->tile_j, h->spart, h->C, h->F, h->Fpad, h->NT, h->NP, h->G, h->sq, h->sr, h->FS, h->ppw, h->have_xscale ? h->dscale : nullptr, h->cw);
   }
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_REDUCE);
     mcba::launch_reduce_system(h->stream, decide_here ? post_sel(h) : sl, h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot,
-                               spec ? h->bpart : nullptr, h->nbblocks, spec ? post_state(h) : nullptr);
+                               spec ? h->bpart : nullptr, h->nbblocks, spec ? post_state(h) : nullptr, h->cw);
   }
   if ((rc = check_launch())) return rc;
   h->have_red = true;
@@ -919,7 +958,7 @@ static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, b
   a.timeout_word = timeout_word(h);
   a.seq = (double)seq; a.gtol = h->gtol; a.lam_max = h->lam_max;
   a.stage_tag = (double)(++h->solve_launches);
-  a.n = h->n; a.npad = h->npad; a.use_lds = h->solve_lds;
+  a.n = h->n; a.npad = h->npad; a.use_lds = h->solve_lds; a.cw = h->cw;
   a.decide = decide ? 1 : 0; a.lam_min = h->lam_min; a.ftol = h->ftol; a.xtol = h->xtol; a.dec_floor = h->dec_floor;
   {
     Scope sc(h, K_SOLVE);
@@ -949,13 +988,13 @@ static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   int rc;
   if (!h->trial_ready) {  // (else the previous tick's k_solve_backsub has already produced this trial step)
     Scope sc(h, K_BACKSUB);
-    mcba::launch_backsub_dev(h->stream, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->dcbuf, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad);
+    mcba::launch_backsub_dev(h->stream, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->dcbuf, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad, h->cw);
   }
   h->trial_ready = false;
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
   }
   if ((rc = check_launch())) return rc;
   if (!sum_here) return MCBA_OK;

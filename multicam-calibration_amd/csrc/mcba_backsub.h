@@ -55,10 +55,14 @@ __device__ __forceinline__ void backsub_stamp_timeout(const BacksubWait* w) {
 
 __device__ __forceinline__ double load_coherent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <class DcSrc>
+// CW: camera block width -- 12, or 6 = the intrinsics of every camera are held fixed: the camera step has 6 entries per camera
+// (rho, t), only the W rows 6..11 of a record are read (18 of its 36 double2 rows), the intrinsics are copied to the trial slot.
+template <class DcSrc, int CW = 12>
 __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const DcSrc dcs, double* __restrict__ x0,
                                              double* __restrict__ x1, double* __restrict__ bpart, int C, int F, int Fpad, int block, int nw, double (*s_t)[6][64], const BacksubWait* wait) {
-  const int n = 12 * C, nfb = Fpad >> 6;
+  const int n = 12 * C, nfb = Fpad >> 6;  // n: where the frame blocks start in x (the layout does not change with CW)
+  constexpr int NR = 3 * CW, R0 = 3 * (12 - CW);  // double2 rows of a record's W block that are read: R0 .. R0 + NR
+  const int nc = CW * C;                  // entries of the camera step
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave >= nw) return;  // (k_solve_backsub launches more wavefronts than a small rig has cameras)
   const int f = block * 64 + lane;
@@ -71,7 +75,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
 #else
 #define FSTAMP(k) do { } while (0)
 #endif
-  double2 v[36];
+  double2 v[NR];
   double xv[6], Lp[21], gf[6], D[6];
   int sidx_early = 0;
   if (wait) {
@@ -80,7 +84,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
     if (wave < C) {
       const double2* w2 = reinterpret_cast<const double2*>((sidx_early ? rec1 : rec0) + ((size_t)wave * nfb + block) * (MCBA_REC * 64)) + lane;
 #pragma unroll
-      for (int k = 0; k < 36; ++k) v[k] = w2[k * 64];
+      for (int k = 0; k < NR; ++k) v[k] = w2[(R0 + k) * 64];
     }
     if (fin) {
       const double* xf = (sidx_early ? x1 : x0) + n + 6 * (size_t)f;
@@ -130,7 +134,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
       asm volatile("" ::: "memory");  // (compiler: the fetches below stay behind the poll; the hardware issues in order)
 #endif
       if (got) {
-        for (int i = lane; i < n; i += 64) mail[8 + i] = load_coherent(wait->dc + i);
+        for (int i = lane; i < nc; i += 64) mail[8 + i] = load_coherent(wait->dc + i);
       }
       if (lane == 0) mail[0] = got ? 1.0 : 0.0;
     }
@@ -163,13 +167,13 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
     if (!(pre && c == wave)) {
       const double2* w2 = reinterpret_cast<const double2*>(rec + ((size_t)c * nfb + block) * (MCBA_REC * 64)) + lane;
 #pragma unroll
-      for (int k = 0; k < 36; ++k) v[k] = w2[k * 64];
+      for (int k = 0; k < NR; ++k) v[k] = w2[(R0 + k) * 64];
     }
-    double d[12];
+    double d[CW];
 #pragma unroll
-    for (int lr = 0; lr < 12; ++lr) d[lr] = dc(12 * c + lr);  // wave-uniform
+    for (int lr = 0; lr < CW; ++lr) d[lr] = dc(CW * c + lr);  // wave-uniform
 #pragma unroll
-    for (int lr = 0; lr < 12; ++lr) {
+    for (int lr = 0; lr < CW; ++lr) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) { t[2 * k] = fma(v[3 * lr + k].x, d[lr], t[2 * k]); t[2 * k + 1] = fma(v[3 * lr + k].y, d[lr], t[2 * k + 1]); }
     }
@@ -219,8 +223,16 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
     if (!posted && lane == 0) backsub_stamp_timeout(wait);
     if (!posted || load_coherent(sl.lms + MCBA_LM_DONE) != 0.0 || load_coherent(sl.lms + MCBA_LM_SKIP) != 0.0) return;
   }
-  if (block == 0)
-    for (int i = lane; i < n; i += 64) xd[i] = xs[i] + dc(i);
+  if (block == 0) {
+    if constexpr (CW == 12) {
+      for (int i = lane; i < n; i += 64) xd[i] = xs[i] + dc(i);
+    } else {
+      for (int i = lane; i < n; i += 64) {
+        const int cam = i / 12, l = i - 12 * cam;
+        xd[i] = l >= 12 - CW ? xs[i] + dc(CW * cam + l - (12 - CW)) : xs[i];
+      }
+    }
+  }
   if (fin) {
     double* xo = xd + n + 6 * (size_t)f;
 #pragma unroll

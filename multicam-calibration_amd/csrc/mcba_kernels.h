@@ -60,6 +60,7 @@ struct SolveArgs {
   double seq;
   double gtol, lam_max;
   int n, npad, use_lds;
+  int cw;                    // camera block width: 12, or 6 = the intrinsics of every camera are held fixed (row i of the system is parameter 6 + i % 6 of camera i / 6)
   // decide != 0 (frame-sharded ticks with one collective): the all-reduced trial scalars sit behind the system and the
   // accept/reject decision is taken HERE, then checked against the prediction the speculative Schur reduction was built on
   int decide;
@@ -71,22 +72,24 @@ void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int 
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,
                  int planar = 0,   // planar: every board point has z = 0 exactly (with f_scale = 1 the fused kernel's FAST instance runs)
                  double* chunk = nullptr, int nchunk = 0,   // split == 3: scratch for the point-chunk tail (gram_chunk_doubles) and the number of chunks
-                 int npw = 4);                              // split == 4 / 5 (point split inside the workgroup): wavefronts per (camera, frame block), 4 or 2
+                 int npw = 4,                               // split == 4 / 5 (point split inside the workgroup): wavefronts per (camera, frame block), 4 or 2
+                 int cw = 12);                              // camera block width: 12, or 6 = intrinsics held fixed (role A alone: split 4 = point split, anything else = the role-A half of the split roles)
 int gram_round_blocks(int C, int nfb);       // frame blocks (a multiple of 4) that whole rounds of the wavefront slots cover; split 2 / 3 / 5 handle the rest as a tail
-size_t gram_psplit_lds_bytes(int npw);       // dynamic LDS of k_gram_psplit
+size_t gram_psplit_lds_bytes(int npw, int cw = 12);  // dynamic LDS of k_gram_psplit
 int gram_psplit_set_lds_limit();             // raises the dynamic-LDS limit of its instances (0 = ok)
 size_t gram_chunk_doubles(int C, int nfb, int nchunk);   // doubles of that scratch for C cameras x nfb frame blocks
 void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch);
-size_t syrk_lds_bytes(int C, int FS);
+size_t syrk_lds_bytes(int C, int FS, int cw = 12);
 void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int sq, int sr, int FS, int ppw,
-                 const double* dscale = nullptr);  // dscale: D = 1 / x_scale^2 in the layout of x (numeric x_scale), nullptr: D = diag(J^T J)
+                 const double* dscale = nullptr,   // dscale: D = 1 / x_scale^2 in the layout of x (numeric x_scale), nullptr: D = diag(J^T J)
+                 int cw = 12);                     // camera block width (6: intrinsics held fixed; the 4-tile variant only)
 int syrk_items_per_thread();
 // bpart != nullptr (speculative frame-sharded ticks): the trial scalars are summed here as well (red + nsys .. + 8) and the LM
 // state is copied to state_copy (MCBA_LMS doubles)
 void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot,
-                          const double* bpart = nullptr, int nbp = 0, double* state_copy = nullptr);
-void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad);
-void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const double* dc_dev, double* x0, double* x1, double* bpart, int C, int F, int Fpad);
+                          const double* bpart = nullptr, int nbp = 0, double* state_copy = nullptr, int cw = 12);
+void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad, int cw = 12);
+void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const double* dc_dev, double* x0, double* x1, double* bpart, int C, int F, int Fpad, int cw = 12);
 size_t solve_lds_bytes(int npad, int use_lds);
 int solve_fits_lds(int npad, int lds_limit);
 void gram_set_slots(int slots);  // wavefront slots of the device (4 x CUs): where k_gram's launch variants cut a shard into rounds
@@ -94,9 +97,9 @@ int solve_set_lds_limit(int npad, int use_lds);
 void launch_solve_cam(hipStream_t st, const SolveArgs& a);
 // solve + the back-substitution of the next trial step in one launch (a.use_lds variants, a.flag set); early_state = the LM state
 // the tick's decision left (final as far as the slot bit goes), or -- spec != 0, the solve decides -- a copy of the state before it
-int solve_backsub_set_lds_limit(int npad);
+int solve_backsub_set_lds_limit(int npad, int cw = 12);
 void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const double* rec0, const double* rec1, const double* fbuf, double* x0, double* x1, double* bpart, int C, int F, int Fpad,
-                          const double* early_state, int max_polls, int spec, double* timeout_dev, double* timeout_host);
+                          const double* early_state, int max_polls, int spec, double* timeout_dev, double* timeout_host);  // (a.cw selects the camera block width)
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da);
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);

@@ -159,13 +159,17 @@ __global__ __launch_bounds__(256) void k_transpose_obs(const double2* __restrict
 // every shape that is not a whole number of rounds of the 1 024 wavefront slots: few (camera, frame block) items, or a short last round.
 constexpr int kGramRaw = 88;  // ee 21 | he 6 | cost | ii 17 | ie 36 | hi 6 | any
 constexpr int kGramRawA = 29, kGramRawB = 59;  // what role A / role B of the expansion needs of them
+// doubles of the LDS exchange area of a point-split workgroup (gram_body MODE 3): npw wavefronts per group, with / without role B
+__host__ __device__ constexpr int gram_xch_doubles(int npw, bool with_b) {
+  return npw == 4 ? (with_b ? (4 * kGramRawA + 3 * 32 + 3 * 27) * 64 : 4 * kGramRawA * 64) : (4 / npw) * (npw - 1) * (with_b ? kGramRaw : kGramRawA) * 64;
+}
 template <int LOSS, int ROLE, bool FAST = false, int MODE = 0, int NPW = 1>
 __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
                                           double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2,
                                           const double (&pz0)[6], const double2 (&pre)[4], double* s_cost, int nrun, int p_lo = 0, int p_hi = -1, double2* chunk = nullptr, int nchunk = 1,
                                           size_t chunk_stride = 0) {
   if (p_hi < 0) p_hi = N;
-  static_assert(MODE == 0 || (ROLE == 2 && MCBA_GRAM_PIPE), "point chunks exist for the fused, pipelined loop only");
+  static_assert(MODE == 0 || ((ROLE == 2 || (MODE == 3 && ROLE == 0)) && MCBA_GRAM_PIPE), "point chunks exist for the pipelined loop only (both roles; role A alone in MODE 3: intrinsics held fixed)");
   static_assert(MODE == 3 ? (NPW == 2 || NPW == 4) : NPW == 1, "NPW wavefronts share a (camera, frame block) in MODE 3 only");
   // pz0: this lane's frame pose, pre: its first four observations -- loaded by the kernel before the camera constants were
   // staged (those loads, the LM state and the camera rows are all in flight together: one memory round trip at the start)
@@ -236,7 +240,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #ifdef MCBA_GRAM_TIMING
   const long long gt1 = clock64();
 #endif
-  if constexpr (ROLE == 2 && MCBA_GRAM_PIPE) {
+  if constexpr ((ROLE == 2 || MODE == 3) && MCBA_GRAM_PIPE) {
     // Software-pipelined, branch-free point loop (fused variant, one wavefront per SIMD): the projection of point p + 1 --
     // a serial chain (rotate, reciprocal, distortion polynomial) -- is issued next to the 180 independent accumulator
     // updates of point p, which is what fills the FP64 pipe when no second wavefront is there to do it.  Lanes without
@@ -265,15 +269,19 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
         double E[6];
         obs_row_cam<0>(q, E);
         gram_add_row<0>(ga, E, wu2, gu);
+        if constexpr (DO_B) {
         double l4 = q.fa * q.s;
         gram_add_row<0>(gb, E, wu2, gu, q.a * q.d, l4, l4 * q.s);
+        }
       }
       {
         double E[6];
         obs_row_cam<1>(q, E);
         gram_add_row<1>(ga, E, wv2, gv);
+        if constexpr (DO_B) {
         double l4 = q.fb * q.s;
         gram_add_row<1>(gb, E, wv2, gv, q.b * q.d, l4, l4 * q.s);
+        }
       }
     };
     int p = p_lo;
@@ -404,7 +412,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
         d[27 * 64] = cost;
         d[28 * 64] = any ? 1.0 : 0.0;
       }
-      if (part != 1) {
+      if (DO_B && part != 1) {
         double* d = xL + (part == 0 ? 0 : part - 1) * (NBL * 64);
 #pragma unroll
         for (int i = 0; i < 11; ++i) d[i * 64] = gb.ii[i];
@@ -413,7 +421,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #pragma unroll
         for (int i = 0; i < 3; ++i) d[(29 + i) * 64] = gb.hi[i];
       }
-      if (part != 2) {
+      if (DO_B && part != 2) {
         double* d = xH + (part == 3 ? 2 : part) * (NBH * 64);
 #pragma unroll
         for (int i = 0; i < 6; ++i) d[i * 64] = gb.ii[11 + i];
@@ -429,6 +437,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #ifdef MCBA_GRAM_TIMING
       gt2b = clock64();
 #endif
+      if (!DO_B && (part == 1 || part == 2)) return;  // intrinsics held fixed: role A alone (no timing stamps from these two)
       ChainConst ch;
       {
         double Rf[9], Jrf[9], Jrc[9];
@@ -483,7 +492,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
           red[28] = an ? 1.0 : 0.0;
           kofs_lo = 57; kofs_hi = 63; nlo = 21; nown = 29;
         }
-      } else {
+      } else if constexpr (DO_B) {
         GramB gs;
         gram_zero(gs);
         if (part == 1) {  // ((part 0 + own) + part 2) + part 3
@@ -544,7 +553,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
         }
       }
     } else {
-    double* xa = reinterpret_cast<double*>(chunk) + (size_t)grp * ((NPW - 1) * kGramRaw * 64) + lane;
+    double* xa = reinterpret_cast<double*>(chunk) + (size_t)grp * ((NPW - 1) * (DO_B ? kGramRaw : kGramRawA) * 64) + lane;
     double* xb = xa + (NPW - 1) * kGramRawA * 64;
     if (part != 0) {  // role-A sums -> the group's wavefront 0 (source slot part - 1)
       double* d = xa + (part - 1) * (kGramRawA * 64);
@@ -555,7 +564,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       d[27 * 64] = cost;
       d[28 * 64] = any ? 1.0 : 0.0;
     }
-    if (part != 1) {  // role-B sums -> the group's wavefront 1 (source slots: part 0 -> 0, part j >= 2 -> j - 1)
+    if (DO_B && part != 1) {  // role-B sums -> the group's wavefront 1 (source slots: part 0 -> 0, part j >= 2 -> j - 1)
       double* d = xb + (part == 0 ? 0 : part - 1) * (kGramRawB * 64);
 #pragma unroll
       for (int i = 0; i < 17; ++i) d[i * 64] = gb.ii[i];
@@ -590,7 +599,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #undef GF_B
 #undef GF_PRESUM
       }
-    } else if (part == 1) {
+    } else if (DO_B && part == 1) {
       {  // part 0 + own, then parts 2, 3: the same order of additions as above
         const double* sB = xb;
 #pragma unroll
@@ -625,7 +634,7 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     }
 #ifdef MCBA_GRAM_TIMING
     {  // every wavefront of the group: set-up, point loop, LDS exchange + barrier, finish (shader cycles), begin / end (100 MHz), where it ran
-      double* s_stamp = reinterpret_cast<double*>(chunk) + (NPW == 4 ? (4 * kGramRawA + 3 * 32 + 3 * 27) * 64 : (4 / NPW) * (NPW - 1) * kGramRaw * 64);  // behind the exchange area
+      double* s_stamp = reinterpret_cast<double*>(chunk) + gram_xch_doubles(NPW, DO_B);  // behind the exchange area
       const long long gt3 = clock64(), gw3 = wall_clock64();
       if (lane == 0) {
         double* d = s_stamp + 8 * wv;
@@ -751,7 +760,9 @@ __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t,
 
 // Point split inside the workgroup (gram_body MODE 3): the workgroup's four wavefronts are 4 / NPW (camera, frame block) items of
 // NPW wavefronts each, wavefront part = wave % NPW over the points [N part / NPW, N (part + 1) / NPW).  Dynamic LDS: gram_psplit_lds_bytes.
-template <int LOSS, bool FAST, int NPW>
+// ROLE 0: the intrinsics of every camera are held fixed (BASELINE configs[1]; camera block 6 wide): role A alone -- 28 accumulators
+// instead of 87, no W rows / U rows / g_c of the intrinsics.
+template <int LOSS, bool FAST, int NPW, int ROLE = 2>
 __global__ __launch_bounds__(256) void k_gram_psplit(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
                                                         double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, int fb0, int fb1,
                                                         double fs2, double ifs2) {
@@ -761,12 +772,12 @@ __global__ __launch_bounds__(256) void k_gram_psplit(const double2* __restrict__
   const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) % NPW;
   const int p_lo = (int)(((long long)N * part) / NPW), p_hi = (int)(((long long)N * (part + 1)) / NPW);
 #ifdef MCBA_GRAM_TIMING
-  if ((threadIdx.x & 63) == 0) s_xch[(NPW == 4 ? (4 * kGramRawA + 3 * 32 + 3 * 27) * 64 : (4 / NPW) * (NPW - 1) * kGramRaw * 64) + 32 + (threadIdx.x >> 6)] = (double)wall_clock64();
+  if ((threadIdx.x & 63) == 0) s_xch[gram_xch_doubles(NPW, ROLE != 0) + 32 + (threadIdx.x >> 6)] = (double)wall_clock64();
 #endif
   GramStart g;
   gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1, p_lo, max(p_hi, p_lo + 1), NPW);  // (an empty piece -- fewer points than wavefronts -- still prefetches a valid point)
   if (!g.run) return;
-  gram_body<LOSS, 2, FAST, 3, NPW>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, 0, p_lo, p_hi, reinterpret_cast<double2*>(s_xch));
+  gram_body<LOSS, ROLE, FAST, 3, NPW>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, 0, p_lo, p_hi, reinterpret_cast<double2*>(s_xch));
 }
 
 // Point-chunk tail (gram_body MODE 1 / 2).  k_gram_chunk: grid (frame blocks, C, nchunk) of ONE-wavefront workgroups (with four
@@ -908,7 +919,7 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 constexpr int kSyrkSuper = 32;  // frames factorised per super-stage: 32 frames x 8 parts of their V / g_f entries = the 256 threads
 
-template <int PPW, int IPT, bool DECIDE, bool XS>
+template <int PPW, int IPT, bool DECIDE, bool XS, int CW = 12>
 __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse fz, const double* __restrict__ rec0, const double* __restrict__ rec1, double* __restrict__ fbuf, double* __restrict__ fpart,
                                               const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ spart, int C, int F, int Fpad, int NT, int NP, int sq, int sr, int FS,
                                               const double* __restrict__ dscale, int xg, int yg) {
@@ -1018,7 +1029,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
     lambda = sl.lam;
   }
   const double* __restrict__ rec = sidx ? rec1 : rec0;
-  const int n = 12 * C, nfb = Fpad >> 6;
+  const int n = CW * C, nfb = Fpad >> 6;  // CW = 6: the intrinsics of every camera are held fixed -- the rows of (rho, t) alone: W rows 6..11 of each record
   const int RS = 6 * FS + 2;
   double* s_y = lds;                          // [NT*16][RS]
   double* s_L = lds + (size_t)NT * 16 * RS;   // [kSyrkSuper][34]: L(21) 1/diag(6) z(6) pad, one super-stage of frames; behind it [kSyrkSuper][28] sums
@@ -1055,7 +1066,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
     for (int it = 0; it < IPT; ++it) {
       int row = tr0 + rstep * it, b = tb, f = fb + b;
       if (row < n) {
-        int c = row / 12, lr = row - 12 * c;
+        int c = row / CW, lr = row - CW * c + (12 - CW);
         const double2* w2 = reinterpret_cast<const double2*>(rec + ((size_t)c * nfb + (f >> 6)) * (MCBA_REC * 64)) + (size_t)(3 * lr) * 64 + (f & 63);
 #pragma unroll
         for (int k = 0; k < 3; ++k) { double2 v = w2[k * 64]; wreg[it][2 * k] = v.x; wreg[it][2 * k + 1] = v.y; }
@@ -1265,8 +1276,8 @@ __device__ __forceinline__ double run_sum(const double* __restrict__ p, int coun
 template <int RR>
 __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __restrict__ gp0, const double* __restrict__ gp1, const double* __restrict__ spart, const double* __restrict__ fpart,
                                                         const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ red, int C, int nfb, int G, int NT, int NP,
-                                                        int nfblocks, int rank_slot, const double* __restrict__ bpart, int nbp, double* __restrict__ state_copy) {
-  const int n = 12 * C;
+                                                        int nfblocks, int rank_slot, const double* __restrict__ bpart, int nbp, double* __restrict__ state_copy, int cw) {
+  const int n = cw * C, coff = 12 - cw;  // cw = 6: intrinsics held fixed -- row i of the system is parameter coff + i % cw of camera i / cw
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ double s_part[RR][16][64];
   __shared__ double s_u[RR][16];
@@ -1303,12 +1314,12 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
     for (int r = 0; r < RR; ++r) {
       up[r] = nullptr;
       const int row = 16 * ti + (rr0 + r) + 4 * reg, col = 16 * tj + wave;
-      if (row < n && col < n && row / 12 == col / 12) {
-        int cam = row / 12, li = row - 12 * cam, lj = col - 12 * cam;
+      if (row < n && col < n && row / cw == col / cw) {
+        int cam = row / cw, li = row - cw * cam + coff, lj = col - cw * cam + coff;
         int a = li <= lj ? li : lj, b2 = li <= lj ? lj : li;
         up[r] = gpart + cam * camstride + (size_t)tri12(a, b2) * nfb;
       } else if (col == n && row < n) {
-        int cam = row / 12, li = row - 12 * cam;
+        int cam = row / cw, li = row - cw * cam + coff;
         up[r] = gpart + cam * camstride + (size_t)(78 + li) * nfb;
       }
     }
@@ -1360,11 +1371,11 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
   const int task = ((int)blockIdx.x - BPQ * NP) * 16 + wave;
   double* tail = red + (size_t)n * n + n;
   if (task < n) {  // diag U
-    int cam = task / 12, l = task - 12 * cam;
+    int cam = task / cw, l = task - cw * cam + coff;
     double v = run_sum(gpart + cam * camstride + (size_t)tri12(l, l) * nfb, nfb, lane);
     if (lane == 63) tail[task] = v;
   } else if (task < 2 * n) {  // g_c
-    int jj = task - n, cam = jj / 12, l = jj - 12 * cam;
+    int jj = task - n, cam = jj / cw, l = jj - cw * cam + coff;
     double v = run_sum(gpart + cam * camstride + (size_t)(78 + l) * nfb, nfb, lane);
     if (lane == 63) tail[n + jj] = v;
   } else if (task < 2 * n + 16) {
@@ -1430,11 +1441,11 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
 }
 
 // ---------------------------------------------------------------- k_backsub: frame steps + trial parameters (body: mcba_backsub.h)
-template <class DcSrc>
+template <class DcSrc, int CW>
 __global__ __launch_bounds__(64 * kBacksubWaves) void k_backsub(Sel sl, const double* __restrict__ rec0, const double* __restrict__ rec1, const double* __restrict__ fbuf, const DcSrc dcs,
                                                                 double* __restrict__ x0, double* __restrict__ x1, double* __restrict__ bpart, int C, int F, int Fpad) {
   __shared__ double s_t[kBacksubWaves][6][64];
-  backsub_body<DcSrc>(sl, rec0, rec1, fbuf, dcs, x0, x1, bpart, C, F, Fpad, (int)blockIdx.x, (int)(blockDim.x >> 6), s_t, nullptr);
+  backsub_body<DcSrc, CW>(sl, rec0, rec1, fbuf, dcs, x0, x1, bpart, C, F, Fpad, (int)blockIdx.x, (int)(blockDim.x >> 6), s_t, nullptr);
 }
 
 // trial scalars: [cost, pred_f, dn2_f, xn2_f, n_residuals, 0, 0, 0].  One block of 512 threads: wavefront w
@@ -1589,8 +1600,8 @@ static int g_gram_slots = 1024;
 void gram_set_slots(int slots) { if (slots >= 64) g_gram_slots = slots; }
 
 int gram_round_blocks(int C, int nfb) { return std::min(nfb, (((C * nfb) / g_gram_slots) * g_gram_slots / C) & ~3); }
-size_t gram_psplit_lds_bytes(int npw) {
-  size_t b = npw == 4 ? (size_t)(4 * kGramRawA + 3 * 32 + 3 * 27) * 64 * sizeof(double) : (size_t)(4 / npw) * (npw - 1) * kGramRaw * 64 * sizeof(double);
+size_t gram_psplit_lds_bytes(int npw, int cw) {
+  size_t b = (size_t)gram_xch_doubles(npw == 4 ? 4 : 2, cw != 6) * sizeof(double);
 #ifdef MCBA_GRAM_TIMING
   b += 40 * sizeof(double);
 #endif
@@ -1598,7 +1609,7 @@ size_t gram_psplit_lds_bytes(int npw) {
 }
 
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,
-                 int planar, double* chunk, int nchunk, int npw) {
+                 int planar, double* chunk, int nchunk, int npw, int cw) {
   const int nfb = Fpad / 64;
   dim3 block(256);
   const double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
@@ -1619,16 +1630,30 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
   auto psplit = [&](int fb0, int fb1) {
     const int per = npw == 4 ? 1 : 2;
     dim3 grid((fb1 - fb0 + per - 1) / per, C, 1);
-    const size_t lds = gram_psplit_lds_bytes(npw == 4 ? 4 : 2);
+    const size_t lds = gram_psplit_lds_bytes(npw == 4 ? 4 : 2, cw);
     const bool fast = planar && f_scale == 1.0;
-#define PS_GO(FASTV, NPWV) DISPATCH_LOSS(loss, (k_gram_psplit<L, FASTV, NPWV><<<grid, block, lds, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)))
-    if (npw == 4) {
-      if (fast) { PS_GO(true, 4); } else { PS_GO(false, 4); }
+#define PS_GO(FASTV, NPWV, ROLEV) DISPATCH_LOSS(loss, (k_gram_psplit<L, FASTV, NPWV, ROLEV><<<grid, block, lds, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)))
+    if (cw == 6) {
+      if (npw == 4) {
+        if (fast) { PS_GO(true, 4, 0); } else { PS_GO(false, 4, 0); }
+      } else {
+        if (fast) { PS_GO(true, 2, 0); } else { PS_GO(false, 2, 0); }
+      }
+    } else if (npw == 4) {
+      if (fast) { PS_GO(true, 4, 2); } else { PS_GO(false, 4, 2); }
     } else {
-      if (fast) { PS_GO(true, 2); } else { PS_GO(false, 2); }
+      if (fast) { PS_GO(true, 2, 2); } else { PS_GO(false, 2, 2); }
     }
 #undef PS_GO
   };
+  if (cw == 6) {
+    // intrinsics held fixed (camera block 6 wide): role A alone -- the point split for shards of at most half a round of the wavefront
+    // slots, otherwise the role-A half of the split-role kernel (grid.z = 1: two wavefronts per SIMD)
+    if (split == 4) { psplit(0, nfb); return; }
+    dim3 grid((nfb + 3) / 4, C, 1);
+    DISPATCH_LOSS(loss, (k_gram_split<L><<<grid, block, 0, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, 0, nfb, fs2, ifs2)));
+    return;
+  }
   if (split == 4) { psplit(0, nfb); return; }
   if (split == 5) {  // whole rounds of the wavefront slots fused, the short last round point-split
     const int fba5 = gram_round_blocks(C, nfb);
@@ -1689,8 +1714,8 @@ void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, 
   }
 }
 
-size_t syrk_lds_bytes(int C, int FS) {
-  int NT = (12 * C + 1 + 15) / 16;
+size_t syrk_lds_bytes(int C, int FS, int cw) {
+  int NT = (cw * C + 1 + 15) / 16;
   return ((size_t)NT * 16 * (6 * FS + 2) + (size_t)kSyrkSuper * (34 + 28)) * sizeof(double);
 }
 
@@ -1699,26 +1724,29 @@ size_t syrk_lds_bytes(int C, int FS) {
 
 static bool g_syrk_xcd_remap = [] { const char* e = getenv("MCBA_SYRK_XCD"); return !e || atoi(e) != 0; }();  // (0: the plain (G, groups) launch, for A/B)
 void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int sq, int sr, int FS, int ppw,
-                 const double* dscale) {
-  size_t lds = syrk_lds_bytes(C, FS);
-#define SYRK_GO(PPW, IPT, GY)                                                                                                                                   \
+                 const double* dscale, int cw) {
+  size_t lds = syrk_lds_bytes(C, FS, cw);
+#define SYRK_GO(PPW, IPT, GY, CWV)                                                                                                                              \
   do {                                                                                                                                                          \
     const bool remap = (GY) > 1 && g_syrk_xcd_remap;                                                                                                            \
     dim3 grid(remap ? 8 * ((G / 8) * (GY) + ((G % 8) * (GY) + 7) / 8) : G, remap ? 1 : (GY));                                                                   \
     const int xg = remap ? G : 0, yg = remap ? (GY) : 0;                                                                                                        \
-    if (fz.decide && dscale) k_syrk<PPW, IPT, true, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);    \
-    else if (fz.decide) k_syrk<PPW, IPT, true, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);      \
-    else if (dscale) k_syrk<PPW, IPT, false, true><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);         \
-    else k_syrk<PPW, IPT, false, false><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);                    \
+    if (fz.decide && dscale) k_syrk<PPW, IPT, true, true, CWV><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);    \
+    else if (fz.decide) k_syrk<PPW, IPT, true, false, CWV><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);      \
+    else if (dscale) k_syrk<PPW, IPT, false, true, CWV><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);         \
+    else k_syrk<PPW, IPT, false, false, CWV><<<grid, dim3(256), lds, st>>>(s, fz, rec0, rec1, fbuf, fpart, tile_i, tile_j, spart, C, F, Fpad, NT, NP, sq, sr, FS, dscale, xg, yg);                    \
   } while (0)
   // items per thread: (12C + 1) rows x FS frames over 256 threads -- 3 is enough up to 7 cameras at 8 frames per stage
   // (fewer prefetch registers: the kernel stays within 256 registers, two workgroups per CU, without scratch)
-  const bool small = (12 * C + 1) * FS <= 256 * SYRK_IPT_SMALL;
-  if (ppw <= 4) {
-    if (small) SYRK_GO(4, SYRK_IPT_SMALL, (NP + 15) / 16);
-    else SYRK_GO(4, SYRK_IPT, (NP + 15) / 16);
+  const bool small = (cw * C + 1) * FS <= 256 * SYRK_IPT_SMALL;
+  if (cw == 6) {  // intrinsics held fixed: rows of (rho, t) alone; mcba_set_camera_block admits it only where the 4-tile variant serves (<= 64 tile pairs)
+    if (small) SYRK_GO(4, SYRK_IPT_SMALL, (NP + 15) / 16, 6);
+    else SYRK_GO(4, SYRK_IPT, (NP + 15) / 16, 6);
+  } else if (ppw <= 4) {
+    if (small) SYRK_GO(4, SYRK_IPT_SMALL, (NP + 15) / 16, 12);
+    else SYRK_GO(4, SYRK_IPT, (NP + 15) / 16, 12);
   } else {
-    SYRK_GO(16, SYRK_IPT, (NP + 63) / 64);
+    SYRK_GO(16, SYRK_IPT, (NP + 63) / 64, 12);
   }
 #undef SYRK_GO
 }
@@ -1726,19 +1754,21 @@ void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, 
 int syrk_items_per_thread() { return SYRK_IPT; }
 
 void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot,
-                          const double* bpart, int nbp, double* state_copy) {
-  int n = 12 * C;
+                          const double* bpart, int nbp, double* state_copy, int cw) {
+  int n = cw * C;
   int tail_blocks = (2 * n + 16 + (bpart ? 9 : 0) + 15) / 16;
   // many tile pairs and few partials per pair (the 16-tile k_syrk: one workgroup per CU): one block per (pair, register) instead of four
-  if (NP >= 64 && G <= 128) k_reduce_system<4><<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy);
-  else k_reduce_system<1><<<dim3(16 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy);
+  if (NP >= 64 && G <= 128) k_reduce_system<4><<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy, cw);
+  else k_reduce_system<1><<<dim3(16 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy, cw);
 }
 
-void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {
-  k_backsub<CamStep><<<dim3(Fpad / 64), dim3(64 * std::min(C, kBacksubWaves)), 0, st>>>(s, rec0, rec1, fbuf, dc, x0, x1, bpart, C, F, Fpad);
+void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad, int cw) {
+  if (cw == 6) k_backsub<CamStep, 6><<<dim3(Fpad / 64), dim3(64 * std::min(C, kBacksubWaves)), 0, st>>>(s, rec0, rec1, fbuf, dc, x0, x1, bpart, C, F, Fpad);
+  else k_backsub<CamStep, 12><<<dim3(Fpad / 64), dim3(64 * std::min(C, kBacksubWaves)), 0, st>>>(s, rec0, rec1, fbuf, dc, x0, x1, bpart, C, F, Fpad);
 }
-void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const double* dc_dev, double* x0, double* x1, double* bpart, int C, int F, int Fpad) {
-  k_backsub<DevStep><<<dim3(Fpad / 64), dim3(64 * std::min(C, kBacksubWaves)), 0, st>>>(s, rec0, rec1, fbuf, DevStep{dc_dev}, x0, x1, bpart, C, F, Fpad);
+void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const double* dc_dev, double* x0, double* x1, double* bpart, int C, int F, int Fpad, int cw) {
+  if (cw == 6) k_backsub<DevStep, 6><<<dim3(Fpad / 64), dim3(64 * std::min(C, kBacksubWaves)), 0, st>>>(s, rec0, rec1, fbuf, DevStep{dc_dev}, x0, x1, bpart, C, F, Fpad);
+  else k_backsub<DevStep, 12><<<dim3(Fpad / 64), dim3(64 * std::min(C, kBacksubWaves)), 0, st>>>(s, rec0, rec1, fbuf, DevStep{dc_dev}, x0, x1, bpart, C, F, Fpad);
 }
 
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da) {
@@ -1756,12 +1786,12 @@ void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs
 
 int gram_psplit_set_lds_limit() {
   int rc = 0;
-#define PS_K(L) reinterpret_cast<const void*>(k_gram_psplit<L, true, 4>), reinterpret_cast<const void*>(k_gram_psplit<L, false, 4>), \
-                reinterpret_cast<const void*>(k_gram_psplit<L, true, 2>), reinterpret_cast<const void*>(k_gram_psplit<L, false, 2>)
+#define PS_K(L) reinterpret_cast<const void*>(k_gram_psplit<L, true, 4, 2>), reinterpret_cast<const void*>(k_gram_psplit<L, false, 4, 2>), \
+                reinterpret_cast<const void*>(k_gram_psplit<L, true, 2, 2>), reinterpret_cast<const void*>(k_gram_psplit<L, false, 2, 2>)
   const void* ks[] = {PS_K(LOSS_LINEAR), PS_K(LOSS_SOFT_L1), PS_K(LOSS_HUBER), PS_K(LOSS_CAUCHY), PS_K(LOSS_ARCTAN)};
 #undef PS_K
   for (const void* k : ks) {
-    int r = (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_psplit_lds_bytes(4));
+    int r = (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_psplit_lds_bytes(4, 12));
     rc = rc ? rc : r;
   }
   return rc;
@@ -1769,9 +1799,9 @@ int gram_psplit_set_lds_limit() {
 
 int syrk_set_lds_limit(size_t bytes) {
   int rc = 0;
-#define SYRK_K(P, I) reinterpret_cast<const void*>(k_syrk<P, I, false, false>), reinterpret_cast<const void*>(k_syrk<P, I, true, false>), \
-                     reinterpret_cast<const void*>(k_syrk<P, I, false, true>), reinterpret_cast<const void*>(k_syrk<P, I, true, true>)
-  const void* ks[] = {SYRK_K(4, SYRK_IPT), SYRK_K(4, SYRK_IPT_SMALL), SYRK_K(16, SYRK_IPT)};
+#define SYRK_K(P, I, W) reinterpret_cast<const void*>(k_syrk<P, I, false, false, W>), reinterpret_cast<const void*>(k_syrk<P, I, true, false, W>), \
+                        reinterpret_cast<const void*>(k_syrk<P, I, false, true, W>), reinterpret_cast<const void*>(k_syrk<P, I, true, true, W>)
+  const void* ks[] = {SYRK_K(4, SYRK_IPT, 12), SYRK_K(4, SYRK_IPT_SMALL, 12), SYRK_K(16, SYRK_IPT, 12), SYRK_K(4, SYRK_IPT, 6), SYRK_K(4, SYRK_IPT_SMALL, 6)};
 #undef SYRK_K
   for (const void* k : ks) {
     int r = (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

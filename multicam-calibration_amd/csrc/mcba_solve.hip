@@ -591,7 +591,7 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
   double gm = 0.0;
   for (int i = tid; i < npad; i += NTHREADS) {
     const bool in = i < n, fx = in && fixed && fixed[i];
-    const double du = in ? (a.dscale ? a.dscale[i] : diagU[i]) : 1.0;  // numeric x_scale: the caller's fixed D = 1 / x_scale^2
+    const double du = in ? (a.dscale ? a.dscale[a.cw == 12 ? i : 12 * (i / 6) + 6 + i % 6] : diagU[i]) : 1.0;  // numeric x_scale: the caller's fixed D = 1 / x_scale^2 (in the layout of x)
     damp[i] = du > 0.0 ? du : 1.0;  // scaled by lambda below (the state is not in LDS yet)
     if (in && !fx) gm = fmax(gm, fabs(gc[i]));
   }
@@ -845,7 +845,7 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
   double sums[4] = {0.0, 0.0, 0.0, 0.0};  // pred_cam, |d_c|^2, |x_c|^2, non-finite entries
   if (mode == 0) {
     for (int i = tid; i < n; i += NTHREADS) {
-      const double d = dv[i], xv = xc[i];
+      const double d = dv[i], xv = xc[a.cw == 12 ? i : 12 * (i / 6) + 6 + i % 6];  // (camera block 6 wide: the system's row i is parameter 6 + i % 6 of camera i / 6)
       a.dc[i] = d;
       sums[3] += (fabs(d) < 1e300) ? 0.0 : 1.0;
       sums[0] += d * (damp[i] * d - gc[i]);
@@ -899,16 +899,16 @@ struct BacksubArgs {
   int C, F, Fpad;
   BacksubWait wait;
 };
-template <int KS>
+template <int KS, int CW = 12>
 __global__ __launch_bounds__(64 * kBacksubWaves) void k_solve_backsub(SolveArgs a, BacksubArgs b) {
   __shared__ double s_t[kBacksubWaves][6][64];
-  __shared__ double s_mail[8 + 12 * 9];  // (the LDS-resident solve serves at most 9 cameras)
+  __shared__ double s_mail[8 + 12 * 9];  // (the LDS-resident solve serves at most 9 cameras 12 wide, 18 cameras 6 wide: 112 rows)
   if (blockIdx.x == 0) {
     if (threadIdx.x < 256) solve_cam_body<256, true, KS>(a);
     return;
   }
   b.wait.mail = s_mail;
-  backsub_body<DevStep>(b.sl, b.rec0, b.rec1, b.fbuf, DevStep{a.dc}, b.x0, b.x1, b.bpart, b.C, b.F, b.Fpad, (int)blockIdx.x - 1, b.C < kBacksubWaves ? b.C : kBacksubWaves, s_t, &b.wait);
+  backsub_body<DevStep, CW>(b.sl, b.rec0, b.rec1, b.fbuf, DevStep{a.dc}, b.x0, b.x1, b.bpart, b.C, b.F, b.Fpad, (int)blockIdx.x - 1, b.C < kBacksubWaves ? b.C : kBacksubWaves, s_t, &b.wait);
 }
 
 size_t solve_lds_bytes(int npad, int use_lds) {
@@ -931,10 +931,11 @@ int solve_set_lds_limit(int npad, int use_lds) {
   return hipFuncSetAttribute(solve_kernel(npad, use_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : 1;
 }
 
-int solve_backsub_set_lds_limit(int npad) {
+int solve_backsub_set_lds_limit(int npad, int cw) {
   const size_t bytes = solve_lds_bytes(npad, 1) + sizeof(double) * (kBacksubWaves * 6 * 64 + 8 + 12 * 9);
   if (bytes <= 64 * 1024) return 0;
-  const void* k = npad <= 80 ? reinterpret_cast<const void*>(&k_solve_backsub<5>) : reinterpret_cast<const void*>(&k_solve_backsub<kStageMax>);
+  const void* k = cw == 6 ? (npad <= 80 ? reinterpret_cast<const void*>(&k_solve_backsub<5, 6>) : reinterpret_cast<const void*>(&k_solve_backsub<kStageMax, 6>))
+                          : (npad <= 80 ? reinterpret_cast<const void*>(&k_solve_backsub<5>) : reinterpret_cast<const void*>(&k_solve_backsub<kStageMax>));
   return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes(npad, 1)) == hipSuccess ? 0 : 1;
 }
 
@@ -943,7 +944,10 @@ void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const doub
   BacksubArgs b{sl, rec0, rec1, fbuf, x0, x1, bpart, C, F, Fpad, BacksubWait{early_state, a.flag, a.dc, nullptr, a.seq, max_polls, spec, a.lam_min, timeout_dev, timeout_host, a.dec_floor}};
   const size_t lds = solve_lds_bytes(a.npad, 1);
   const dim3 grid(1 + Fpad / 64), block(64 * kBacksubWaves);
-  if (a.npad <= 80) hipLaunchKernelGGL((k_solve_backsub<5>), grid, block, lds, st, a, b);
+  if (a.cw == 6) {
+    if (a.npad <= 80) hipLaunchKernelGGL((k_solve_backsub<5, 6>), grid, block, lds, st, a, b);
+    else hipLaunchKernelGGL((k_solve_backsub<kStageMax, 6>), grid, block, lds, st, a, b);
+  } else if (a.npad <= 80) hipLaunchKernelGGL((k_solve_backsub<5>), grid, block, lds, st, a, b);
   else hipLaunchKernelGGL((k_solve_backsub<kStageMax>), grid, block, lds, st, a, b);
 }
 

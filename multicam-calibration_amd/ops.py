@@ -34,6 +34,8 @@ SYMBOLS = [
     ("mcba_set_stream", ctypes.c_int, [_h, ctypes.c_void_p]),
     ("mcba_upload_observations", ctypes.c_int, [_h, _dp, _dp]),
     ("mcba_set_loss", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_double]),
+    ("mcba_set_camera_block", ctypes.c_int, [_h, ctypes.c_int]),
+    ("mcba_get_camera_block", ctypes.c_int, [_h]),
     ("mcba_set_params", ctypes.c_int, [_h, ctypes.c_int, _dp]),
     ("mcba_get_params", ctypes.c_int, [_h, ctypes.c_int, _dp]),
     ("mcba_copy_params", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int]),
@@ -172,6 +174,7 @@ class Problem:
         if uvs.ndim != 4 or uvs.shape[3] != 2 or objpoints.shape != (uvs.shape[2], 3):
             raise ValueError("uvs must be (C,F,N,2) and objpoints (N,3)")
         self.C, self.F, self.N = uvs.shape[:3]
+        self.cw = 12
         self.n = 12 * self.C
         self.nx = 12 * self.C + 6 * self.F
         self.handle = _h()
@@ -222,7 +225,7 @@ class Problem:
         new = Problem.__new__(Problem)
         new.lib = self.lib
         new.C, new.N, new.F = self.C, self.N, int(idx.size)
-        new.n = self.n
+        new.cw, new.n = 12, 12 * self.C
         new.nx = 12 * new.C + 6 * new.F
         new.handle = _h()
         self._chk(self.lib.mcba_create_subset(ctypes.byref(new.handle), self.handle, idx.ctypes.data_as(_ip), int(idx.size)))
@@ -256,6 +259,27 @@ class Problem:
             self.close()
         except Exception:
             pass
+
+    def set_camera_block(self, width):
+        """Camera block width (include/mcba.h: mcba_set_camera_block): 12 = every camera parameter is a variable (the reference);
+        6 = the intrinsics of every camera are held fixed (BASELINE configs[1]) -- the camera system, the camera step and every other
+        camera-system vector then have 6 entries per camera (rho, t).  Before the first solver call of the handle.  Returns False
+        (and changes nothing) if the library declines the width for this rig (more than 26 cameras: hold them with flags instead)."""
+        rc = self.lib.mcba_set_camera_block(self.handle, int(width))
+        if rc == ERR_ARG and int(width) == 6 and "26 cameras" in self.lib.mcba_last_error().decode():
+            return False
+        self._chk(rc)
+        self.cw = int(width)
+        self.n = self.cw * self.C
+        self._init_host_views()
+        return True
+
+    @property
+    def cam_index(self):
+        """Positions in the parameter vector x of the camera system's variables, in the system's order."""
+        if self.cw == 12:
+            return np.arange(12 * self.C)
+        return (12 * np.arange(self.C)[:, None] + 6 + np.arange(6)[None, :]).ravel()
 
     def set_loss(self, loss, f_scale=1.0):
         if loss not in LOSSES:

@@ -177,13 +177,15 @@ class LevenbergMarquardt:
                  reduced_solver=None, depth=2, x_scale=None, dec_floor=DEC_FLOOR):
         self.p = problem
         self.comm = comm or SingleProcess()
-        n = problem.n
+        n = problem.n   # size of the camera system: 12 C, or 6 C when the problem holds every camera's intrinsics fixed (ops.Problem.set_camera_block)
+        # where the camera system's variables sit in the parameter vector
+        self.cam_index = np.asarray(problem.cam_index) if hasattr(problem, "cam_index") else np.arange(n)
         # least_squares' numeric x_scale (this shard's vector, cameras first): the fixed damping matrix D = 1 / x_scale^2 instead
         # of Marquardt's diag(J^T J).  The backend applies it in the frame blocks and the device solve; the host solve needs D_c here.
         self.Dc_fixed = None
         if x_scale is not None:
             problem.set_x_scale(x_scale)
-            self.Dc_fixed = 1.0 / np.asarray(x_scale, dtype=np.float64)[:n] ** 2
+            self.Dc_fixed = 1.0 / np.asarray(x_scale, dtype=np.float64)[self.cam_index] ** 2
         elif hasattr(problem, "set_x_scale"):
             problem.set_x_scale(None)
         self.free = np.ones(n, dtype=bool) if free_cam_mask is None else np.asarray(free_cam_mask, dtype=bool)
@@ -218,7 +220,7 @@ class LevenbergMarquardt:
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         self.cur = 0
         self.p.set_params(0, x0)
-        self.x_cam = x0[: self.p.n].copy()
+        self.x_cam = x0[self.cam_index].copy()
         self.p.linearize(0)
         self.nfev, self.njev = 1, 1
         self.lam, self.nu = self.lam0, 2.0

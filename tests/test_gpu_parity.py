@@ -689,3 +689,121 @@ def test_inner_seam_scipy_least_squares_over_the_c_abi(golden):
     # and the saving: the reference's path evaluates residuals() nfev + 18 njev times (18 colour groups per Jacobian)
     assert calls["fun"] == res.nfev and calls["jac"] == res.njev
     assert calls["fun"] < (int(z["nfev"]) + 18 * int(z["njev"])) / 10
+
+
+# ------------------------------------------------------------------ camera block 6 wide: BASELINE configs[1] (intrinsics held fixed) as its own instance
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("kw,loss,env", [
+    (dict(n_cameras=3, n_frames=20, seed=23, missing=0.25, scalar_nans=9), "soft_l1", {}),                        # point split, four wavefronts per (camera, frame block), role A alone
+    (dict(n_cameras=2, n_frames=130, seed=24), "cauchy", {"MCBA_GRAM_NPW": "2"}),                                 # ... two wavefronts
+    (dict(n_cameras=7, n_frames=75, seed=25, missing=0.3), "soft_l1", {"MCBA_GRAM_SPLIT": "1"}),                  # the role-A half of the split-role kernel
+    (dict(n_cameras=13, n_frames=9, seed=26, missing=0.2, rows=2, cols=3), "huber", {}),                          # 79 rows: five tiles of 16, 15 tile pairs
+    (dict(n_cameras=20, n_frames=5, seed=27, rows=1, cols=3), "soft_l1", {}),                                     # 121 rows; fewer points than wavefronts
+])
+def test_camera_block6_reduced_system_and_step_vs_oracle(mc, kw, loss, env):
+    """mcba_set_camera_block(6): role A of the linearisation alone, rows of (rho, t) in the Schur product, a 6C x 6C reduced system
+    -- against the oracle's dense normal equations with the intrinsics' rows and columns struck out (the variables of
+    BASELINE configs[1] are extrinsics + poses)."""
+    p = mc.synth.make_problem(**kw)
+    C, F = p["uvs"].shape[:2]
+    x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+
+    def run():
+        prob = mc.ops.Problem(p["uvs"], p["obj"], loss=loss)
+        assert prob.set_camera_block(6) and prob.n == 6 * C
+        return prob
+
+    prob = _with_env(env, run)
+    prob.set_params(0, x)
+    prob.linearize(0)
+    lam = 3e-3
+    prob.build_reduced(lam, rank_slot=1)
+    red = {k: v.copy() for k, v in prob.get_reduced().items()}
+    U, gc, V, gf, W, cost = orc.normal_equations(x, p["uvs"], p["obj"], loss)
+    keep = prob.cam_index
+    Df2 = np.stack([np.where(np.diag(V[f]) > 0, np.diag(V[f]), 1.0) for f in range(F)])
+    S, rhs = orc.schur_reduce(U, gc, V, gf, W, lam, np.zeros((C, 12)), Df2)
+    S, rhs = S[np.ix_(keep, keep)], rhs[keep]
+    scale = np.abs(S).max()
+    assert red["S0"].shape == (6 * C, 6 * C)
+    assert np.abs(red["S0"] - S).max() <= 1e-10 * scale
+    assert np.abs(red["rhs"] - rhs).max() <= 1e-10 * np.abs(rhs).max()
+    dU = np.concatenate([np.diag(U[c]) for c in range(C)])[keep]
+    np.testing.assert_allclose(red["diagU"], dU, rtol=1e-11)
+    assert np.abs(red["gc"] - gc.ravel()[keep]).max() <= 1e-10 * np.abs(gc).max()
+    assert abs(red["scal"][0] - cost) <= 1e-12 * cost
+    assert np.abs(prob.frame_gradient() - gf).max() <= 1e-10 * np.abs(gf).max()
+    # one damped step: 6 entries per camera in, intrinsics copied to the trial slot unchanged
+    dc = np.linalg.solve(S + lam * np.diag(np.where(dU > 0, dU, 1.0)), rhs)
+    dfull = np.zeros(12 * C)
+    dfull[keep] = dc
+    df = orc.back_substitute(dfull, V, gf, W, lam, Df2)
+    prob.step(dc, lam, 0, 1)
+    t = prob.get_trial()
+    x1 = prob.get_params(1)
+    want = x + np.concatenate([dfull, df.ravel()])
+    assert np.abs(x1 - want).max() <= 1e-9 * np.abs(np.concatenate([dc, df.ravel()])).max() + 1e-13 * np.abs(x).max()
+    np.testing.assert_array_equal(x1[:12 * C].reshape(C, 12)[:, :6], x[:12 * C].reshape(C, 12)[:, :6])
+    assert abs(t[0] - orc.robust_cost(orc.residuals(want, p["uvs"], p["obj"]), loss)) <= 1e-10 * t[0]
+    # the device solve on the same system (6C x 6C, no flags) against LAPACK
+    prob.lm_set_state(float(red["scal"][0]), lam, 2.0, 0)
+    prob.lm_auto_config(1e-8, 1e-8, 1e-8, 1e-12, 1e12, None)
+    prob.lm_auto_solve(1)
+    st = prob.lm_auto_wait(1).copy()
+    d_dev = prob.cam_step()
+    assert d_dev.shape == (6 * C,) and st[31] == 1 and st[15] == 0 and st[14] == 0
+    assert np.abs(d_dev - dc).max() <= 1e-7 * np.abs(dc).max()
+    assert abs(st[13] - x[keep] @ x[keep]) <= 1e-13 * (x[keep] @ x[keep])
+    prob.close()
+
+
+def test_camera_block6_is_refused_late_and_beyond_26_cameras(mc):
+    p = mc.synth.make_problem(3, 10, seed=2)
+    prob = mc.ops.Problem(p["uvs"], p["obj"])
+    prob.set_params(0, orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"]))
+    prob.linearize(0)                                        # the solver buffers exist now
+    with pytest.raises(mc.ops.McbaError):
+        prob.set_camera_block(6)
+    prob.close()
+    p = mc.synth.make_problem(27, 4, seed=2, rows=1, cols=2)
+    prob = mc.ops.Problem(p["uvs"], p["obj"])
+    assert prob.set_camera_block(6) is False and prob.n == 12 * 27
+    prob.close()
+
+
+@pytest.mark.parametrize("shape,kw", [((4, 90), dict()), ((6, 700), dict(loss="cauchy", f_scale=0.7)), ((12, 30), dict()), ((3, 40), dict(reduced_solver="host"))])
+def test_fix_intrinsics_compact_block_equals_flag_path(mc, shape, kw):
+    """bundle_adjust(fix_intrinsics=True) on the 6-wide camera block (the default) and on the 12-wide block with the intrinsics'
+    rows held by flags (MCBA_FIXED_COMPACT=0, round 3's path): the same decisions, the same optimum, intrinsics untouched."""
+    p = mc.synth.make_problem(shape[0], shape[1], seed=91, missing=0.1, scalar_nans=5)
+    args = (p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    opts = dict(n_frames=None, fix_intrinsics=True, ftol=1e-12, xtol=1e-12, gtol=1e-10, verbose=0, return_jac=False, **kw)
+    out = []
+    for flag in ("1", "0"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            out.append(_with_env({"MCBA_FIXED_COMPACT": flag}, lambda: mc.bundle_adjust(*args, **opts)[4]))
+    a, b = out
+    C = shape[0]
+    assert a.status > 0 and b.status > 0
+    ha, hb = np.array(a.lm["history"]), np.array(b.lm["history"])
+    k = min(len(ha), len(hb), 8)
+    np.testing.assert_allclose(ha[:k, 2], hb[:k, 2], rtol=1e-9)
+    assert abs(a.cost - b.cost) <= 1e-10 * b.cost
+    # (the rig's 6-DoF gauge is free: two runs that differ in round-off end at different x on the same orbit -- compare what it predicts)
+    assert np.abs(orc.predict_from_x(a.x, C, p["obj"]) - orc.predict_from_x(b.x, C, p["obj"])).max() < 1e-5
+    x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    np.testing.assert_array_equal(a.x[:12 * C].reshape(C, 12)[:, :6], x0[:12 * C].reshape(C, 12)[:, :6])
+    assert np.all(a.grad[:12 * C].reshape(C, 12)[:, :6] == 0) and a.grad.shape == b.grad.shape
+    assert np.abs(a.grad - b.grad).max() <= 0.05 * np.abs(b.grad).max() + 1e-6   # (both at the round-off floor of a gradient that started at ~1e6)
