@@ -221,6 +221,58 @@ def cpu_baseline(sample_frames=1000, max_nfev=12):
     }
 
 
+def tick_bytes(C, F, N, cw=12):
+    """SURVEY 8(d)'s accounting of one fused LM iteration, for any shape: the trial linearisation reads the observations and poses
+    and writes V_f / g_f per frame and the W block (cw x 6) per (camera, frame); the Schur pass and the back-substitution re-read
+    them; the trial cost needs the observations once more.  218.8 MB at 6 x 10 000 x 54, cw = 12."""
+    obs, poses, vg, w = 16 * C * F * N, 48 * F, 336 * F, 48 * cw * C * F
+    return (obs + poses) + (vg + w) + (vg + w) + (vg + w + poses) + (obs + poses)
+
+
+def other_configs(m, headline_ms_per_step):
+    """LM-iteration time of the BASELINE configs that are not the bench workload, same loop, same counting (every iteration
+    linearises its trial point), untimed with respect to `value`: configs[0] 2 x 50 x 54 (the reference's CPU-runnable case),
+    configs[1] 6 x 1 000 x 54 with the intrinsics held fixed (the library's 6-wide camera block).  configs[2] is the headline."""
+    out = {}
+    for key, (Cc, Fc, fixed) in (("configs[0]", (2, 50, False)), ("configs[1]", (6, 1000, True))):
+        p = m.synth.make_problem(Cc, Fc, rows=ROWS, cols=COLS, seed=0)
+        x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+        prob = m.ops.Problem(p["uvs"], p["obj"])
+        if fixed:
+            assert prob.set_camera_block(6)
+        lm = m.solver.LevenbergMarquardt(prob, ftol=0.0, xtol=0.0, gtol=0.0)
+        lm.start(x0)
+        for _ in range(100):
+            lm.iterate(always_linearize=True)
+        prob.synchronize()
+        best = 1e9
+        for _ in range(3):
+            n0, t0 = lm.nfev, time.perf_counter()
+            for _ in range(200):
+                lm.iterate(always_linearize=True)
+            lm.finalize()
+            prob.synchronize()
+            best = min(best, (time.perf_counter() - t0) / max(lm.nfev - n0, 1))
+        prob.profile_enable(True)
+        for _ in range(40):
+            lm.iterate(always_linearize=True)
+        kern = {k: round(1e3 * ms / n, 2) for k, (ms, n) in prob.profile_read().items() if n}
+        prob.profile_enable(False)
+        tb = tick_bytes(Cc, Fc, ROWS * COLS, 6 if fixed else 12)
+        out[key] = {"shape": f"{Cc} cameras x {Fc} frames x {ROWS * COLS} points" + (", intrinsics held fixed (camera block 6 wide)" if fixed else ", all parameters free"),
+                    "us_per_iteration": round(best * 1e6, 2), "it_per_s": round(1.0 / best, 1), "kernels_us_by_hip_events": kern,
+                    "tick_roofline": {"bound": "hbm", "algorithmic_bytes_per_iteration": tb, "achieved": tb / best / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tb / best / 1e9 / HBM_PEAK_GBS},
+                    "cost_end": lm.cost}
+        prob.close()
+    tb = tick_bytes(C, F_PER_GPU, ROWS * COLS)
+    out["configs[2]"] = {"shape": f"{C} cameras x {F_PER_GPU} frames x {ROWS * COLS} points, all parameters free (the bench workload: `value`)", "us_per_iteration": round(1e3 * headline_ms_per_step, 2),
+                         "it_per_s": round(1e3 / headline_ms_per_step, 1),
+                         "tick_roofline": {"bound": "hbm", "algorithmic_bytes_per_iteration": tb, "achieved": tb / (headline_ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": tb / (headline_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    out["note"] = "wall clock per LM iteration of the device-resident loop (best of 3 x 200 iterations after 100 warm-up iterations); bytes = SURVEY 8(d)'s accounting generalised (bench.py: tick_bytes)"
+    return out
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -254,6 +306,7 @@ def main():
     ap.add_argument("--frames-total", type=int, default=0, help="strong scaling: this many frames of ONE rig sharded over the ranks (100000 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the wall-clock measurement of the user-level bundle_adjust() call")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the per-iteration times of BASELINE configs[0] and configs[1]")
     ap.add_argument("--prewarm", type=int, default=300, help="untimed clock-ramp iterations of a throw-away solve before the W warm-up steps")
     args = ap.parse_args()
 
@@ -392,7 +445,7 @@ def main():
             traffic_source = "profiles/pmc_traffic.json <- " + str(pmc.get("_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier gpurun call")) + " (not measured in this run)"
         ach = dom_bytes / (dom_ms * 1e-3) / 1e9
         hbm = {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": dom_bytes}
-        roofline = {"kernel": dom, "bound": "hbm", **hbm, "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": dom_ms * 1e3}
+        roofline = {"kernel": dom, "bound": "hbm", "n_samples": int(kern[dom][1]), **hbm, "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": dom_ms * 1e3}
         if dom == "k_gram":
             # the binding roof of this kernel is the FP64 vector pipe, not HBM (PMC traffic = 1.02 x algorithmic bytes).  `frac` =
             # REAL flops (2 FMA + MUL + ADD, as the SQ_INSTS_VALU_*_F64 counters count them) / the FP64 vector peak;
@@ -401,7 +454,7 @@ def main():
             # the FP64 vector rate, so the dense-MFMA peak for this dtype is the same 78.6 TFLOP/s.)
             real, slots, mix = gram_work(C, F, N)
             tf, tfs = real / (dom_ms * 1e-3) / 1e12, slots / (dom_ms * 1e-3) / 1e12
-            roofline = {"kernel": dom, "bound": "valu_f64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+            roofline = {"kernel": dom, "bound": "valu_f64", "n_samples": int(kern[dom][1]), "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
                         "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": dom_ms * 1e3, "flops_per_launch": real,
                         "frac_issue_slots": tfs / FP64_VALU_PEAK_TFLOPS, "issue_slot_flops_per_launch": slots,
                         "measured_issue_ceiling": FP64_VALU_MEASURED_TFLOPS, "frac_issue_slots_of_measured_ceiling": tfs / FP64_VALU_MEASURED_TFLOPS,
@@ -457,6 +510,8 @@ def main():
         }
         if share_gpu:
             out["rehearsal"] = f"{world} ranks SHARE GPU 0 (fewer GPUs than ranks on this box): collectives are host-staged gloo all-reduces, not RCCL; `value` is not a scaling measurement"
+        if world == 1 and not args.frames_total and F == F_PER_GPU and not args.no_other_configs:
+            out["configs"] = other_configs(m, 1e3 * dt / args.steps)
         if world == 1 and not args.no_end_to_end and not args.frames_total:
             e2e = end_to_end(m, p)
             out["end_to_end_ms"] = e2e["ms"]
