@@ -113,6 +113,52 @@ class HostStagedGloo(TorchDistributed):
         self._ar(problem.reduce_tensor[: problem.nsys + 8])
 
 
+class InProcessShards:
+    """REHEARSAL of north_star's partition inside ONE process: `world` frame shards, one ops.Problem and one LevenbergMarquardt per
+    shard, each driven by its own Python thread (the C-ABI calls release the GIL); `comm(rank)` is the shard's collective: the
+    slices of the reduce buffers meet in host memory behind a barrier and every shard adds them IN RANK ORDER (so all get the same
+    bits, as after an all-reduce).  For boxes that show one GPU and admit at most six processes on it: eight ranks as eight
+    processes (tests/test_gpu_multirank.py runs up to six) are refused there.  Same kernels, same tick sequence as a frame-sharded
+    run with torch.distributed issuing the collective; no fabric, no RCCL -- the arithmetic and the control flow only."""
+
+    def __init__(self, world):
+        import threading
+
+        self.world = int(world)
+        self.barrier = threading.Barrier(self.world)
+        self.parts = [None] * self.world
+
+    def comm(self, rank, problem, device):
+        problem.enable_collective(device)
+        return _ShardComm(self, rank)
+
+
+class _ShardComm(TorchDistributed):
+    def __init__(self, owner, rank):  # (no process group: TorchDistributed's constructor is not called)
+        self.owner, self.rank, self.world = owner, int(rank), owner.world
+
+    def _ar(self, t):
+        import torch
+
+        o = self.owner
+        o.parts[self.rank] = t.cpu().numpy().copy()   # (.cpu() synchronises the stream the library launches on: the null stream)
+        o.barrier.wait()
+        total = o.parts[0].copy()
+        for r in range(1, self.world):
+            total += o.parts[r]
+        o.barrier.wait()                               # nobody overwrites its part before everybody has read it
+        t.copy_(torch.from_numpy(total))
+
+    def all_reduce_system(self, problem):
+        self._ar(problem.reduce_tensor[: problem.nsys])
+
+    def all_reduce_trial(self, problem):
+        self._ar(problem.reduce_tensor[problem.nsys : problem.nsys + 8])
+
+    def all_reduce_tick(self, problem):
+        self._ar(problem.reduce_tensor[: problem.nsys + 8])
+
+
 # Damping schedule of the Levenberg-Marquardt loop (Nielsen's rule: lambda *= max(DEC_FLOOR, 1 - (2 ratio - 1)^3) on an accepted step,
 # lambda *= nu, nu *= 2 on a rejected one).  Nielsen's floor of 1/3 and a start at 1e-4 cost the bench problem (6 x 10 000 x 54 from a
 # perturbed start) 24 evaluations to the reference's ftol = 1e-4, six of them rejected first steps and twelve just to bring the damping
