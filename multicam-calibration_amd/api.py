@@ -14,6 +14,7 @@ cost, so it converges to the same minimiser (gauge aside); the iterate sequence 
 """
 import os
 import warnings
+import weakref
 
 import numpy as np
 import scipy.sparse as sp
@@ -67,6 +68,68 @@ class _Lazy:
         self.thunk = thunk
 
 
+class _JacobianSource:
+    """What a lazily attached `result.jac` is produced from: the GPU handle of the solve while it lasts, and enough to build a new one
+    (a reference to the caller's observation array, the selected frames, the solution) when it does not.  The handles that pending
+    results hold are counted: beyond MCBA_JAC_HOLD_MB (default 1024 MiB of observations + parameters; 0 = hold nothing) the oldest
+    are closed at once -- a sweep that keeps a list of results does not pin ~0.4 GB of HBM per result -- and a result
+    whose handle is gone re-uploads its frames when (if) the field is finally read."""
+
+    _refs = []   # weak references to the sources that still own a handle, oldest first (a dropped result frees its handle by itself)
+
+    class _Live:
+        def __get__(self, obj, cls):
+            alive = [r() for r in cls._refs]
+            cls._refs = [r for r, a in zip(cls._refs, alive) if a is not None and a.prob is not None]
+            return [a for a in alive if a is not None and a.prob is not None]
+
+    live = _Live()
+
+    def __init__(self, prob, uvs_all, frames, objpoints, x, slot, loss, f_scale, device, robust, nan_bits, shape4):
+        self.prob, self.uvs_all, self.frames, self.obj, self.x, self.slot = prob, uvs_all, frames, objpoints, x, slot
+        self.loss, self.f_scale, self.device, self.robust, self.nan_bits, self.shape4 = loss, f_scale, device, robust, nan_bits, shape4
+        self.bytes = 3 * 8 * int(np.prod(shape4)) + 16 * x.size   # two observation layouts + the residual buffer, the parameter slots
+        _JacobianSource._refs.append(weakref.ref(self))
+        _JacobianSource.trim()
+
+    @classmethod
+    def trim(cls):
+        cap = int(os.environ.get("MCBA_JAC_HOLD_MB", "1024")) << 20
+        live = cls.live
+        while live and sum(s.bytes for s in live) > cap:
+            live.pop(0).release()
+
+    def release(self):
+        if self.prob is not None:
+            self.prob.close()
+            self.prob = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def mask(self):
+        return None if self.nan_bits is None else np.unpackbits(self.nan_bits, count=int(np.prod(self.shape4))).astype(bool).reshape(self.shape4)
+
+    def csr(self):
+        try:
+            prob, slot = self.prob, self.slot
+            if prob is None:   # the handle was released under pressure: upload the selected frames again
+                prob = self.prob = ops.Problem(np.ascontiguousarray(self.uvs_all[:, self.frames]), self.obj, device=self.device, loss=self.loss, f_scale=self.f_scale)
+                prob.set_params(0, self.x)
+                slot = 0
+            m = self.mask()
+            uvs = np.zeros(self.shape4) if m is None else np.where(m, 0.0, np.nan)   # (jacobian_structure only looks at which scalars are NaN)
+            idx, indptr, shape, mask = jacobian_structure(uvs)  # CSR indices: 0.25 s of numpy at 6 x 10k x 54 -- only when asked for
+            prob.jacobian_eval(slot, robust_scaled=self.robust)
+            data, _ = prob.jacobian_download(want_res=False)
+            return sp.csr_matrix((data[mask].ravel(), idx, indptr), shape=shape)
+        finally:
+            self.release()
+
+
 class LazyOptimizeResult(OptimizeResult):
     """scipy's OptimizeResult (a dict with attribute access) whose expensive fields are materialised when first read.
     `result.fun` (the residual vector at the solution, trf.py:557-560) stays on the GPU until then: 52 MB of device-to-host copy at
@@ -82,6 +145,11 @@ class LazyOptimizeResult(OptimizeResult):
     def __getitem__(self, key):
         self._resolve(key)
         return dict.__getitem__(self, key)
+
+    def __iter__(self):
+        # (defined so that dict(result), {**result} and OptimizeResult(result) leave CPython's fast path for dict subclasses -- it
+        #  copies the raw slots, placeholders included -- and go through keys() + __getitem__, which resolves each field)
+        return dict.__iter__(self)
 
     def get(self, key, default=None):
         self._resolve(key)
@@ -357,28 +425,18 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         # read or the result is dropped.  return_jac=False releases the handle at once.
         slot = result.lm["slot"]
         need_mask = not all_seen  # (every selected detection complete -- the pre-filter counted them on the GPU: no NaN mask to apply)
-        src, frames = (all_calib_uvs, use_frames) if need_mask else (None, None)
+        shape4 = (n_cameras, use_frames.size, all_calib_uvs.shape[2], 2)
+        # which scalars are observed is fixed NOW (one bit each), not when a lazy field is first read: the caller may NaN out
+        # detections of its array in place between this call and that read
+        seen_bits = np.packbits(~np.isnan(all_calib_uvs[:, use_frames])) if need_mask else None
         vec = prob.residuals_detach(slot)
 
-        def fun(vec=vec, src=src, frames=frames):
+        def fun(vec=vec, bits=seen_bits, shape4=shape4):
             r = vec.download()
-            return r.ravel() if src is None else r[~np.isnan(src[:, frames])]
+            return r.ravel() if bits is None else r[np.unpackbits(bits, count=r.size).astype(bool).reshape(shape4)]
 
         dict.__setitem__(result, "fun", _Lazy(fun))
-        if return_jac:
-            jprob, robust, shape3 = prob, kw["loss"] != "linear", (n_cameras, use_frames.size, all_calib_uvs.shape[2])
-
-            def jac(jprob=jprob, src=src, frames=frames):
-                try:
-                    uvs = np.zeros(shape3 + (2,)) if src is None else src[:, frames]
-                    idx, indptr, shape, mask = jacobian_structure(uvs)  # CSR indices: 0.25 s of numpy at 6 x 10k x 54 -- only when asked for
-                    jprob.jacobian_eval(slot, robust_scaled=robust)
-                    data, _ = jprob.jacobian_download(want_res=False)
-                    return sp.csr_matrix((data[mask].ravel(), idx, indptr), shape=shape)
-                finally:
-                    jprob.close()
-
-            dict.__setitem__(result, "jac", _Lazy(jac))
+        x_local = result.x.copy() if return_jac else None   # this process's frames (a frame-sharded run assembles the global vector below)
         red = prob.get_reduced()
         gcam = np.zeros(12 * n_cameras)
         gcam[prob.cam_index if hasattr(prob, "cam_index") else slice(None)] = red["gc"]   # (6-wide camera block: the gradient entries of the intrinsics held fixed are 0, as with flags)
@@ -399,7 +457,11 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             result.lm["frame_positions"] = positions
         result.grad = grad
         if return_jac:
-            prob = None   # owned by the lazy `jac` field now (closed when that field is produced, or with the result)
+            # (the caller's array is referenced, not copied: only a result whose handle had to be released re-reads its frames from it)
+            jsrc = _JacobianSource(prob, all_calib_uvs, use_frames, calib_objpoints, x_local, slot, kw["loss"], kw.get("f_scale", 1.0), device, kw["loss"] != "linear",
+                                   seen_bits, shape4)
+            dict.__setitem__(result, "jac", _Lazy(jsrc.csr))
+            prob = None   # owned by the lazy `jac` field now (closed when that field is produced, with the result, or under MCBA_JAC_HOLD_MB pressure)
     finally:
         if prob_all is not None:
             prob_all.close()

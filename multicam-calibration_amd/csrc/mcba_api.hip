@@ -141,28 +141,37 @@ int check_launch() {
 // ---- buffer pool.  hipMalloc / hipFree / hipHostMalloc are synchronising driver calls of 50-400 us each, and a
 // bundle_adjust() call creates and destroys three handles of ~25 buffers: 4 ms of its 16 ms at 6 x 10 000 x 54 was hipFree alone.
 // Freed buffers are parked here (per device, keyed by their exact size -- repeated calls ask for the same sizes) and handed out
-// again; MCBA_POOL_MB caps what is parked (default 8192 MiB of the 288 GB; 0 switches the pool off), mcba_pool_trim() returns
-// everything to the driver.  Re-use is safe without events: every kernel and copy of this library is enqueued on the handle's
+// again; MCBA_POOL_MB caps what is parked (default 2048 MiB of the 288 GB -- other allocators of the process, torch's or RCCL's, cannot
+// see parked memory --; 0 switches the pool off; pinned host memory: 256 MiB), mcba_pool_trim() returns everything to the driver, and
+// so does an allocation of this library that the driver answers with out-of-memory, before it asks once more.  Re-use is safe without events: every kernel and copy of this library is enqueued on the handle's
 // stream and mcba_destroy synchronises that stream before it parks a buffer.
 struct BufferPool {
   std::mutex mu;
   std::multimap<std::pair<int, size_t>, void*> dev;     // (device, bytes) -> pointer
   std::multimap<std::pair<unsigned, size_t>, void*> host;  // (hipHostMalloc flags, bytes) -> pointer
-  size_t parked = 0;
+  size_t parked = 0, parked_host = 0;
+  const size_t host_cap = (size_t)256 << 20;  // pinned host memory parked at most (state rings and staging buffers: a few hundred KB each)
   size_t cap() {
-    static size_t c = [] { const char* e = getenv("MCBA_POOL_MB"); return (size_t)(e ? atoll(e) : 8192) << 20; }();
+    static size_t c = [] { const char* e = getenv("MCBA_POOL_MB"); return (size_t)(e ? atoll(e) : 2048) << 20; }();
     return c;
   }
 };
 BufferPool g_pool;
 
+void pool_release_all();
 hipError_t pool_malloc(void** p, size_t bytes, int device) {
   {
     std::lock_guard<std::mutex> lk(g_pool.mu);
     auto it = g_pool.dev.find({device, bytes});
     if (it != g_pool.dev.end()) { *p = it->second; g_pool.dev.erase(it); g_pool.parked -= bytes; return hipSuccess; }
   }
-  return hipMalloc(p, bytes);
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory) {  // what the pool has parked is memory too: give it back to the driver and ask once more
+    (void)hipGetLastError();
+    pool_release_all();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
 }
 void pool_free(void* p, size_t bytes, int device) {
   if (!p) return;
@@ -176,15 +185,27 @@ hipError_t pool_host_malloc(void** p, size_t bytes, unsigned flags) {
   {
     std::lock_guard<std::mutex> lk(g_pool.mu);
     auto it = g_pool.host.find({flags, bytes});
-    if (it != g_pool.host.end()) { *p = it->second; g_pool.host.erase(it); return hipSuccess; }
+    if (it != g_pool.host.end()) { *p = it->second; g_pool.host.erase(it); g_pool.parked_host -= bytes; return hipSuccess; }
   }
   return hipHostMalloc(p, bytes, flags);
 }
 void pool_host_free(void* p, size_t bytes, unsigned flags) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(g_pool.mu);
-  if (g_pool.cap() == 0) { (void)hipHostFree(p); return; }
+  if (g_pool.cap() == 0 || g_pool.parked_host + bytes > g_pool.host_cap) { (void)hipHostFree(p); return; }
   g_pool.host.insert({{flags, bytes}, p});
+  g_pool.parked_host += bytes;
+}
+void pool_release_all() {
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (auto& kv : g_pool.dev) { (void)hipSetDevice(kv.first.first); (void)hipFree(kv.second); }
+  for (auto& kv : g_pool.host) (void)hipHostFree(kv.second);
+  g_pool.dev.clear();
+  g_pool.host.clear();
+  g_pool.parked = g_pool.parked_host = 0;
+  (void)hipSetDevice(cur);
 }
 
 // zero-filled device buffer from the pool, registered with the handle (mcba_destroy parks it again).  The fill is
@@ -392,7 +413,9 @@ static int ensure_solver(mcba_handle* h) {
   if (h->have_solver) return MCBA_OK;
   const int C = h->C;
   int rc;
-#define DA(p, cnt) if ((rc = dalloc(h, &h->p, (cnt))) != MCBA_OK) return rc;
+  // (re-entered after a failed attempt -- out of memory part-way -- it keeps what it already has: a slot that is set is not allocated
+  //  again, so nothing leaks and mcba_destroy finds every buffer once)
+#define DA(p, cnt) if (!h->p && (rc = dalloc(h, &h->p, (cnt))) != MCBA_OK) return rc;
   DA(rec2[0], (size_t)h->Fpad * C * MCBA_REC);
   DA(rec2[1], (size_t)h->Fpad * C * MCBA_REC);
   DA(gpart2[0], (size_t)C * h->nfb * MCBA_GP);
@@ -409,7 +432,7 @@ static int ensure_solver(mcba_handle* h) {
   DA(swork, h->solve_lds ? 16 : 2 * (size_t)h->npad * h->npad + 64 * (size_t)h->npad);  // two sets of 16 x 16 tiles of the lower triangle (mcba_solve.hip, right-looking variant)
   DA(fixed, (size_t)h->n);
   DA(dscale, h->nx);
-  if (h->gram_split == 3) DA(gchunk, mcba::gram_chunk_doubles(C, h->nfb, h->gram_nchunk));
+  if (h->gram_split == 3) { DA(gchunk, mcba::gram_chunk_doubles(C, h->nfb, h->gram_nchunk)); }
 #undef DA
   if (mcba::solve_set_lds_limit(h->npad, h->solve_lds) != 0) return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_solve_cam");
   h->fuse_backsub = h->solve_lds != 0;
@@ -418,7 +441,7 @@ static int ensure_solver(mcba_handle* h) {
   if (h->fuse_backsub && mcba::solve_backsub_set_lds_limit(h->npad, h->cw) != 0) h->fuse_backsub = false;
   h->fuse_max_polls = 200000;
   if (const char* e = getenv("MCBA_FUSE_MAX_POLLS")) h->fuse_max_polls = std::max(0, atoi(e));  // test knob: 0 forces every poll to time out
-  {
+  if (!h->ring) {
     h->ring_bytes = ((size_t)kRing * MCBA_LMS + 8) * sizeof(double);  // + the poll-timeout counter the GPU bumps
     h->ring_flags = hipHostMallocMapped | hipHostMallocCoherent;
     hipError_t e = pool_host_malloc(reinterpret_cast<void**>(&h->ring), h->ring_bytes, h->ring_flags);
@@ -430,10 +453,13 @@ static int ensure_solver(mcba_handle* h) {
   h->red = h->red_own;
   std::vector<int> ci, cj;
   for (int a = 0; a < h->NT; ++a) for (int b = a; b < h->NT; ++b) { ci.push_back(a); cj.push_back(b); }
-  HIPCHK(hipMemcpyAsync(h->tile_i, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));  // (pageable source: staged before the call returns)
+  HIPCHK(hipMemcpyAsync(h->tile_i, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->tile_j, cj.data(), cj.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  h->pinned_bytes = (h->nsys + 8 + MCBA_LMS + h->n) * sizeof(double);
-  HIPCHK(pool_host_malloc(reinterpret_cast<void**>(&h->pinned), h->pinned_bytes, hipHostMallocDefault));
+  HIPCHK(hipStreamSynchronize(h->stream));  // the sources are locals of this function (once per handle: ~10 us)
+  if (!h->pinned) {
+    h->pinned_bytes = (h->nsys + 8 + MCBA_LMS + h->n) * sizeof(double);
+    HIPCHK(pool_host_malloc(reinterpret_cast<void**>(&h->pinned), h->pinned_bytes, hipHostMallocDefault));
+  }
   size_t lds = mcba::syrk_lds_bytes(C, h->FS, h->cw);
   if (lds > 64 * 1024) {
     if (mcba::syrk_set_lds_limit(lds) != 0) return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_syrk");
@@ -459,15 +485,7 @@ int mcba_destroy(mcba_handle* h) {
 }
 
 int mcba_pool_trim(void) {
-  std::lock_guard<std::mutex> lk(g_pool.mu);
-  int cur = 0;
-  (void)hipGetDevice(&cur);
-  for (auto& kv : g_pool.dev) { (void)hipSetDevice(kv.first.first); (void)hipFree(kv.second); }
-  for (auto& kv : g_pool.host) (void)hipHostFree(kv.second);
-  g_pool.dev.clear();
-  g_pool.host.clear();
-  g_pool.parked = 0;
-  (void)hipSetDevice(cur);
+  pool_release_all();
   return MCBA_OK;
 }
 

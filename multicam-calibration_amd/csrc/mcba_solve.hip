@@ -223,12 +223,20 @@ __device__ __forceinline__ void rl_unflatten(int t, int& Ir, int& Jr) {
 // ONE compute unit pulls it at ~45 GB/s (0.66 MB at 24 cameras: 38 k cycles, 2 MB at 40 cameras: 99 k -- more tiles in flight per
 // wavefront change nothing), so the OFF-DIAGONAL tiles right of column 0 -- no damping in them, nothing that depends on the LM
 // state -- are brought into the tile scratch by NS other workgroups, a tile or two per wavefront, while workgroup 0 reads its
-// state, takes its decision and does the first 16 pivots.  Each stager releases a word carrying the launch's number in the handle's life (SolveArgs.stage_tag; the scratch is zero at allocation);
-// workgroup 0 acquires all of them before it touches the scratch (bounded polls: if a stager does not show up it stages the
-// tiles itself -- the values are the same, so a late stager does no harm).
+// state, takes its decision and does the first 16 pivots.  Protocol (T = the launch's number in the handle's life, SolveArgs.stage_tag;
+// the scratch is zero at allocation, T only grows):
+//   stager b:     CLAIMS its share first -- atomic max of its claim word with 2 T: an old value below 2 T means "mine", 2 T + 1 means
+//                 workgroup 0 has given up on it: it exits WITHOUT a store --, stages its tiles, releases its done word = T.
+//   workgroup 0:  waits (bounded) for the done words; for a stager whose word has not come it raises the claim word to 2 T + 1: an
+//                 old value of 2 T means the stager is running -- its word is then awaited without the bound --, anything lower means
+//                 it never started and now never will: workgroup 0 stages that share itself.
+// (Round 3 let workgroup 0 re-stage everything after the bounded wait with no claim: a stager that was only LATE -- an oversubscribed
+//  GPU -- would then have written the original tiles over ones the factorisation had already updated.  ADVICE r3.)
 constexpr int kRlMaxStagers = 16;  // (8, 16 and 32 measured the same to 1 %: 12C = 288: 129.2 / 129.6 / 131.4 us)
 __host__ __device__ inline int rl_stagers(int npad) { const int nblk = npad >> 4, moff = (nblk - 1) * (nblk - 2) / 2; return min(kRlMaxStagers, max(1, moff / 8)); }
 __device__ __forceinline__ double* rl_stage_flags(const SolveArgs& a, int nblk) { return a.work + 2 * rl_tile(nblk, 0) + 256 * 8; }
+__device__ __forceinline__ unsigned long long* rl_stage_claims(const SolveArgs& a, int nblk) { return reinterpret_cast<unsigned long long*>(rl_stage_flags(a, nblk) + kRlMaxStagers); }
+__device__ __forceinline__ unsigned long long rl_stage_tag(const SolveArgs& a) { return (unsigned long long)fabs(a.stage_tag); }  // (test hooks: a negative tag, a tag + 0.5)
 __device__ __forceinline__ void rl_stage_offdiag(const SolveArgs& a, int part, int nparts, int lane, int wave) {  // tiles (I, J), 1 <= J < I, share `part` of `nparts`
   const int n = a.n, nblk = a.npad >> 4, m = nblk - 2;
   if (m <= 0) return;
@@ -257,6 +265,18 @@ __device__ __forceinline__ void rl_stage_offdiag(const SolveArgs& a, int part, i
 __device__ __forceinline__ void rl_stager(const SolveArgs& a, int b, int ns) {
   if (a.stage_tag < 0.0) return;  // (MCBA_SOLVE_STAGERS=-1, tests: stagers that never show up -- workgroup 0 must time out and do the work itself)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  __shared__ int s_mine;
+  if (threadIdx.x == 0) {
+    if (a.stage_tag != floor(a.stage_tag)) {  // (MCBA_SOLVE_STAGERS=-2, tests: a LATE stager -- it shows up ~0.2 s after workgroup 0 has given up on it)
+      const long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < 20000000LL) __builtin_amdgcn_s_sleep(64);
+    }
+    const unsigned long long tag2 = 2 * rl_stage_tag(a);
+    const unsigned long long old = __hip_atomic_fetch_max(rl_stage_claims(a, a.npad >> 4) + b, tag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_mine = old < tag2 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_mine) return;  // workgroup 0 gave up on this stager and does (or did) its share: not a single store from here
   // (the dummy tile of a wavefront past its run: the stagers share workgroup 0's eight -- harmless, nobody reads them)
   rl_stage_offdiag(a, b * nw + wave, ns * nw, lane, wave & 7);
   __threadfence();
@@ -371,13 +391,25 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
       if (wave == 1) {  // ... and one wavefront waits for the stagers' words (lane b: stager b), bounded
         const int ns = (int)gridDim.x - 1;
         const double* fl = rl_stage_flags(a, nblk);
+        const int lb = min(lane, kRlMaxStagers - 1);
         bool ok = lane >= ns;
         for (int polls = 0; polls < 40000 && !__all(ok); ++polls) {
-          if (!ok) ok = __hip_atomic_load(fl + min(lane, kRlMaxStagers - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fabs(a.stage_tag);
+          if (!ok) ok = __hip_atomic_load(fl + lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fabs(a.stage_tag);
           if (!__all(ok)) __builtin_amdgcn_s_sleep(8);
         }
+        bool abandoned = false;
+        if (!ok) {  // this stager's word has not come: take its share away from it, unless it is already at work
+          const unsigned long long tag2 = 2 * rl_stage_tag(a);
+          const unsigned long long old = __hip_atomic_fetch_max(rl_stage_claims(a, nblk) + lb, tag2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (old == tag2) {  // it has started, so it will finish: its word is awaited without the bound
+            while (__hip_atomic_load(fl + lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fabs(a.stage_tag)) __builtin_amdgcn_s_sleep(8);
+          } else {
+            abandoned = true;
+          }
+        }
+        const unsigned long long gone = __ballot(abandoned);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the stagers wrote is visible to this CU from here on
-        if (lane == 0) *stage_miss = __all(ok) ? 0 : 1;
+        if (lane == 0) *stage_miss = (int)(gone & 0xFFFFu);   // the stagers whose share this workgroup stages itself
       }
     } else if (k + 1 < nblk) {
       const int J0 = k + 1, m = nblk - J0;        // panel k - 1 is in Pop; tiles (I, J), J0 <= J <= I < nblk: m (m + 1) / 2 of them
@@ -425,9 +457,16 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
     }
     }
     __syncthreads();
-    if (k == 0 && ((int)gridDim.x == 1 || *stage_miss)) {  // no stagers in this launch, or one did not show up in time: the same tiles, by this workgroup
-      rl_stage_offdiag(a, wave, NW, lane, wave);
-      __syncthreads();
+    if (k == 0) {
+      if ((int)gridDim.x == 1) {  // no stagers in this launch: the same tiles, by this workgroup
+        rl_stage_offdiag(a, wave, NW, lane, wave);
+        __syncthreads();
+      } else if (*stage_miss) {   // stagers that never started (their claim words now say so: they will not write): their shares, by this workgroup
+        const int gone = *stage_miss, ns = (int)gridDim.x - 1;
+        for (int b = 0; b < ns; ++b)
+          if ((gone >> b) & 1) rl_stage_offdiag(a, b * NW + wave, ns * NW, lane, wave);
+        __syncthreads();
+      }
     }
 #ifdef MCBA_SOLVE_TIMING
     const long long t1 = clock64();
@@ -960,9 +999,11 @@ void launch_solve_cam(hipStream_t st, const SolveArgs& a) {
   }
   int ns = rl_stagers(a.npad);
   SolveArgs b = a;
-  if (const char* e = getenv("MCBA_SOLVE_STAGERS")) {  // 0: workgroup 0 brings the tiles in itself; -1 (tests): stagers are launched but do nothing, so workgroup 0's bounded wait runs out
+  if (const char* e = getenv("MCBA_SOLVE_STAGERS")) {  // 0: workgroup 0 brings the tiles in itself; -1 (tests): stagers are launched but do nothing, so workgroup 0's bounded wait runs out; -2 (tests): late stagers
     const int v = atoi(e);
-    if (v < 0) b.stage_tag = -b.stage_tag; else ns = std::min(kRlMaxStagers, v);
+    if (v == -2) b.stage_tag += 0.5;            // (tests: stagers that show up ~0.2 s late -- after workgroup 0 has taken their shares)
+    else if (v < 0) b.stage_tag = -b.stage_tag;
+    else ns = std::min(kRlMaxStagers, v);
   }
   hipLaunchKernelGGL((k_solve_cam<512, false, 1>), dim3(1 + ns), dim3(512), lds, st, b);  // workgroup 0 solves, the others bring the system's tiles in
 }

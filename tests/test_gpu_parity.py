@@ -410,7 +410,9 @@ def test_right_looking_solve_is_the_same_with_and_without_stagers(mc, monkeypatc
     p = mc.synth.make_problem(C, 40, seed=77, missing=0.1)
     x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
     steps = {}
-    for ns in ("default", "0", "3", "-1"):   # -1: stagers that never release their word -> the bounded wait runs out (tens of ms), then the fallback
+    # -1: stagers that never claim their share -> the bounded wait runs out (tens of ms), workgroup 0 takes every share;
+    # -2: LATE stagers (0.2 s): they find their claim words raised by workgroup 0 and must not write a single tile over the factor in progress
+    for ns in ("default", "0", "3", "-1", "-2"):
         if ns == "default":
             monkeypatch.delenv("MCBA_SOLVE_STAGERS", raising=False)
         else:
@@ -430,7 +432,7 @@ def test_right_looking_solve_is_the_same_with_and_without_stagers(mc, monkeypatc
             out.append(prob.cam_step().copy())
         prob.close()
         steps[ns] = out
-    for ns in ("0", "3", "-1"):
+    for ns in ("0", "3", "-1", "-2"):
         for a, b in zip(steps["default"], steps[ns]):
             np.testing.assert_array_equal(a, b)
 

@@ -192,3 +192,39 @@ def test_fused_backsub_poll_timeout_is_observable_and_harmless(mc, shape):
     assert a.cost == b.cost
     np.testing.assert_array_equal(np.array(a.lm["history"]), np.array(b.lm["history"]))
     np.testing.assert_array_equal(c.x, b.x)
+
+
+# ------------------------------------------------------------------ round 4: the lazy fields fix their mask at call time; pending Jacobians do not pin HBM without bound
+def test_lazy_fields_keep_the_mask_of_call_time_and_release_handles_under_pressure(mc):
+    p = mc.synth.make_problem(3, 70, seed=5, missing=0.2, scalar_nans=4)
+    uvs = p["uvs"].copy()
+    args = lambda: (uvs, p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    kw = dict(n_frames=None, ftol=1e-10, verbose=0)
+    ref = quiet(mc.bundle_adjust, *args(), **kw)[4]
+    Jref, fref = ref.jac.copy(), ref.fun.copy()
+    # (i) the caller edits its array between the call and the first read (NaN-ing detections for a second pass): fun / jac are those of the call
+    res = quiet(mc.bundle_adjust, *args(), **kw)[4]
+    uvs[0, :5] = np.nan
+    np.testing.assert_array_equal(res.fun, fref)
+    J = res.jac
+    assert J.shape == Jref.shape and (J != Jref).nnz == 0
+    uvs[...] = p["uvs"]
+    # (ii) dict(result) / {**result} / OptimizeResult(result) see resolved fields, not placeholders
+    res = quiet(mc.bundle_adjust, *args(), **kw)[4]
+    d = dict(res)
+    assert isinstance(d["fun"], np.ndarray) and d["jac"].shape == Jref.shape
+    # (iii) a sweep that keeps its results: with a hold budget of 0 no pending result owns a handle, and its Jacobian is still produced on demand
+    with env(MCBA_JAC_HOLD_MB="0"):
+        held = [quiet(mc.bundle_adjust, *args(), **kw)[4] for _ in range(3)]
+        assert not mc.api._JacobianSource.live
+        assert all(isinstance(dict.get(r, "jac"), mc.api._Lazy) for r in held)
+        J2 = held[1].jac
+    assert (J2 != Jref).nnz == 0
+    # ... and with the default budget the handle is kept (no second upload) until the field is read or the result dropped
+    keep = quiet(mc.bundle_adjust, *args(), **kw)[4]
+    assert len(mc.api._JacobianSource.live) == 1
+    del keep
+    import gc
+
+    gc.collect()
+    assert not mc.api._JacobianSource.live

@@ -23,8 +23,12 @@ def hc():
     src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
     lib = os.path.join(HERE, "hostcheck", "libhostcheck.so")
     hdrs = [os.path.join(HERE, "..", "multicam-calibration_amd", "csrc", h) for h in ("mcba_math.h", "mcba_lm.h", "mcba_lm_state.h")]
+    flags = ["-O2"]
+    if os.environ.get("MCBA_HOSTCHECK_SANITIZE") == "1":   # the run test_hostcheck_under_sanitizers starts: AddressSanitizer + UBSan build of the same text
+        lib = os.path.join(HERE, "hostcheck", "libhostcheck_san.so")
+        flags = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
-        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", lib, src])
+        subprocess.check_call(["g++"] + flags + ["-shared", "-fPIC", "-o", lib, src])
     return ctypes.CDLL(lib)
 
 
@@ -119,3 +123,19 @@ def test_chol6(hc):
     ok = hc.hc_chol_solve(P(V[np.triu_indices(6)].copy()), P(b), P(x))
     assert ok == 1
     np.testing.assert_allclose(x, np.linalg.solve(V, b), rtol=1e-11)
+
+
+def test_hostcheck_under_sanitizers():
+    """The device math header and the LM decision compiled for the CPU with -fsanitize=address,undefined and driven through every
+    test of this file in a child process (the ASan runtime has to be the first library of the process: LD_PRELOAD).  GPU
+    AddressSanitizer is not available on the GPU boxes -- the CPU build is where out-of-bounds indexing of the packed triangles,
+    the 6 x 6 helpers and the accumulator structs would show."""
+    if os.environ.get("MCBA_HOSTCHECK_SANITIZE") == "1":
+        pytest.skip("this IS the sanitizer run")
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan.so not found next to gcc")
+    env = dict(os.environ, MCBA_HOSTCHECK_SANITIZE="1", LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([os.sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.abspath(__file__)], env=env, cwd=os.path.join(HERE, ".."), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "passed" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
