@@ -237,11 +237,15 @@ __host__ __device__ inline int rl_stagers(int npad) { const int nblk = npad >> 4
 __device__ __forceinline__ double* rl_stage_flags(const SolveArgs& a, int nblk) { return a.work + 2 * rl_tile(nblk, 0) + 256 * 8; }
 __device__ __forceinline__ unsigned long long* rl_stage_claims(const SolveArgs& a, int nblk) { return reinterpret_cast<unsigned long long*>(rl_stage_flags(a, nblk) + kRlMaxStagers); }
 __device__ __forceinline__ unsigned long long rl_stage_tag(const SolveArgs& a) { return (unsigned long long)fabs(a.stage_tag); }  // (test hooks: a negative tag, a tag + 0.5)
-__device__ __forceinline__ void rl_stage_offdiag(const SolveArgs& a, int part, int nparts, int lane, int wave) {  // tiles (I, J), 1 <= J < I, share `part` of `nparts`
+struct RlNoGate { __device__ __forceinline__ bool operator()() const { return true; } };
+// `gate` is called once, after the first batch of loads has been issued and before the first store: false = leave without storing
+template <class Gate = RlNoGate>
+__device__ __forceinline__ void rl_stage_offdiag(const SolveArgs& a, int part, int nparts, int lane, int wave, Gate gate = Gate()) {  // tiles (I, J), 1 <= J < I, share `part` of `nparts`
   const int n = a.n, nblk = a.npad >> 4, m = nblk - 2;
-  if (m <= 0) return;
+  if (m <= 0) { (void)gate(); return; }
   const int M = m * (m + 1) / 2;
   const int t_begin = (int)(((long long)M * part) / nparts), ntile = (int)(((long long)M * (part + 1)) / nparts) - t_begin;
+  if (ntile <= 0) (void)gate();  // (every wavefront of a stager passes the gate's barrier exactly once)
   const double* __restrict__ S0 = a.red;
   double* T1 = a.work;
   int Ir, Jr;
@@ -258,6 +262,7 @@ __device__ __forceinline__ void rl_stage_offdiag(const SolveArgs& a, int part, i
       v[j] = rl_system_load(S0, n, Is[j], Js[j], lane);
       if (++Jr > Ir) { ++Ir; Jr = 0; }
     }
+    if (done == 0 && !gate()) return;
 #pragma unroll
     for (int j = 0; j < 8; ++j) rl_tile_store(dstp[j], lane, rl_system_fixup(v[j], nullptr, a.fixed, n, Is[j], Js[j], lane));  // (no diagonal entry in these tiles: no damping)
   }
@@ -265,20 +270,31 @@ __device__ __forceinline__ void rl_stage_offdiag(const SolveArgs& a, int part, i
 __device__ __forceinline__ void rl_stager(const SolveArgs& a, int b, int ns) {
   if (a.stage_tag < 0.0) return;  // (MCBA_SOLVE_STAGERS=-1, tests: stagers that never show up -- workgroup 0 must time out and do the work itself)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-  __shared__ int s_mine;
-  if (threadIdx.x == 0) {
-    if (a.stage_tag != floor(a.stage_tag)) {  // (MCBA_SOLVE_STAGERS=-2, tests: a LATE stager -- it shows up ~0.2 s after workgroup 0 has given up on it)
-      const long long t0 = wall_clock64();
-      while (wall_clock64() - t0 < 20000000LL) __builtin_amdgcn_s_sleep(64);
+  // (the claim's outcome travels through the first word of the DYNAMIC LDS, which a stager does not use otherwise: a static __shared__
+  //  variable in this kernel moves the dynamic region off its 16-byte alignment and every 32-byte LDS access of workgroup 0's block
+  //  steps with it -- 130 -> 222 us at 12C = 288 when tried)
+  extern __shared__ double smem[];
+  volatile int* s_mine_p = reinterpret_cast<volatile int*>(smem);
+#define s_mine (*s_mine_p)
+  // the claim (an atomic round trip, ~2 us) is taken while the first tiles are already on their way: the gate sits between the loads and the
+  // first store
+  auto gate = [&]() -> bool {
+    if (threadIdx.x == 0) {
+      if (a.stage_tag != floor(a.stage_tag)) {  // (MCBA_SOLVE_STAGERS=-2, tests: a LATE stager -- it shows up ~0.2 s after workgroup 0 has given up on it)
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < 20000000LL) __builtin_amdgcn_s_sleep(64);
+      }
+      const unsigned long long tag2 = 2 * rl_stage_tag(a);
+      const unsigned long long old = __hip_atomic_fetch_max(rl_stage_claims(a, a.npad >> 4) + b, tag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_mine = old < tag2 ? 1 : 0;
     }
-    const unsigned long long tag2 = 2 * rl_stage_tag(a);
-    const unsigned long long old = __hip_atomic_fetch_max(rl_stage_claims(a, a.npad >> 4) + b, tag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_mine = old < tag2 ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_mine) return;  // workgroup 0 gave up on this stager and does (or did) its share: not a single store from here
+    __syncthreads();
+    return s_mine != 0;  // false: workgroup 0 gave up on this stager and does (or did) its share -- not a single store from here
+  };
   // (the dummy tile of a wavefront past its run: the stagers share workgroup 0's eight -- harmless, nobody reads them)
-  rl_stage_offdiag(a, b * nw + wave, ns * nw, lane, wave & 7);
+  rl_stage_offdiag(a, b * nw + wave, ns * nw, lane, wave & 7, gate);
+  if (!s_mine) return;
+#undef s_mine
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(rl_stage_flags(a, a.npad >> 4) + b, a.stage_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -457,16 +473,13 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
     }
     }
     __syncthreads();
-    if (k == 0) {
-      if ((int)gridDim.x == 1) {  // no stagers in this launch: the same tiles, by this workgroup
-        rl_stage_offdiag(a, wave, NW, lane, wave);
-        __syncthreads();
-      } else if (*stage_miss) {   // stagers that never started (their claim words now say so: they will not write): their shares, by this workgroup
-        const int gone = *stage_miss, ns = (int)gridDim.x - 1;
-        for (int b = 0; b < ns; ++b)
-          if ((gone >> b) & 1) rl_stage_offdiag(a, b * NW + wave, ns * NW, lane, wave);
-        __syncthreads();
-      }
+    if (k == 0 && ((int)gridDim.x == 1 || *stage_miss)) {
+      // no stagers in this launch: the same tiles, by this workgroup; or stagers that never started (their claim words now say so: they
+      // will not write): their shares
+      const int ns = (int)gridDim.x - 1, gone = ns == 0 ? 1 : *stage_miss, nsh = ns == 0 ? 1 : ns;
+      for (int b = 0; b < nsh; ++b)
+        if ((gone >> b) & 1) rl_stage_offdiag(a, b * NW + wave, nsh * NW, lane, wave);
+      __syncthreads();
     }
 #ifdef MCBA_SOLVE_TIMING
     const long long t1 = clock64();
