@@ -55,6 +55,37 @@ __device__ __forceinline__ void backsub_stamp_timeout(const BacksubWait* w) {
 
 __device__ __forceinline__ double load_coherent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// ---- the READER SIDE of the release word, in one place.
+// The solve releases the word with an agent-scope release store after a fence (mcba_solve.hip: post_state).  A reader polls it with
+// release_word_poll and then calls release_word_acquired() ONCE before it touches anything the word guards.  What that does:
+//   default            a COMPILER barrier only.  Everything read behind the word -- the camera step, DONE / SKIP of the LM state -- is
+//                      fetched with load_coherent (agent-scope relaxed atomic loads: they bypass the per-XCD L2, which is not coherent
+//                      across XCDs, so no stale line can be served and no invalidation is needed), the hardware issues a wavefront's
+//                      loads in order, and only ONE wavefront per workgroup reads (the others get the values through LDS behind a
+//                      barrier).  Under the HIP memory model this is still a data race (relaxed loads do not synchronise with the
+//                      release): it relies on gfx950 behaviour, and tests/test_gpu_parity_large.py::test_fused_backsub_full_size_bit_identical
+//                      stresses it at more than one waiting workgroup per CU (157 / 469 workgroups x 150 ticks, bit-identical iterates).
+//   -DMCBA_POLL_ACQUIRE  the formally complete form: an agent-scope acquire fence (= an L2 invalidation) in the polling wavefront --
+//                      157 of them per launch at 6 x 10 000: k_solve_backsub 28.3 -> 31.0 us, +2.5 us per iteration (three
+//                      alternations on one box, round 3).  Not the default.
+__device__ __forceinline__ void release_word_acquired() {
+#ifdef MCBA_POLL_ACQUIRE
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
+// polls until the word equals one of `a`, `b` (returns 1), equals `stop` (returns 0) or max_polls ran out (returns -1)
+__device__ __forceinline__ int release_word_poll(const double* word, double a, double b, double stop, int max_polls) {
+  for (int polls = 0;; ) {
+    const double v = load_coherent(word);
+    if (v == a || v == b) return 1;
+    if (v == stop) return 0;
+    if (++polls > max_polls) return -1;
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
 // CW: camera block width -- 12, or 6 = the intrinsics of every camera are held fixed: the camera step has 6 entries per camera
 // (rho, t), only the W rows 6..11 of a record are read (18 of its 36 double2 rows), the intrinsics are copied to the trial slot.
 template <class DcSrc, int CW = 12>
@@ -110,29 +141,12 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
     // seen" and "state read" with 118 of them queueing per XCD).
     double* mail = wait->mail;  // [0]: 1 camera step fetched, 0 no step this tick (or the solve never posted); [8 ..] camera step
     if (wave == 0) {
-      int polls = 0, got = 0;
       const double base = 4.0 * wait->seq;
-      for (;;) {
-        const double v = load_coherent(wait->flag);
-        if (v == base + 1.0 || v == base + 2.0) { got = 1; break; }
-        if (v == base + 3.0) break;                          // the solve ended without a step (terminated, or nothing to solve)
-        if (++polls > wait->max_polls) {                     // the solve never posted: leave the trial slot alone, and say so
-          if (lane == 0) backsub_stamp_timeout(wait);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-      // Reader side of the release word: every datum read after the poll -- the camera step here, DONE / SKIP of the
-      // state below -- is fetched with agent-scope atomic loads (load_coherent: they bypass the per-XCD L2, which is not coherent
-      // across XCDs), so nothing stale can be served from a cache and no invalidation is needed; the compiler barrier keeps the
-      // fetches behind the poll, the hardware issues them in order.  The formally complete alternative -- an agent-scope acquire
-      // fence in this ONE polling wavefront per workgroup, -DMCBA_POLL_ACQUIRE -- invalidates the L2 157 times per launch and was
-      // measured at +2.5 us per iteration (k_solve_backsub 28.3 -> 31.0 us, three alternations on one box): not the default.
-#ifdef MCBA_POLL_ACQUIRE
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#else
-      asm volatile("" ::: "memory");  // (compiler: the fetches below stay behind the poll; the hardware issues in order)
-#endif
+      // (base + 3: the solve ended without a step -- terminated, or nothing to solve; -1: the solve never posted -- leave the trial slot alone, and say so)
+      const int rc = release_word_poll(wait->flag, base + 1.0, base + 2.0, base + 3.0, wait->max_polls);
+      if (rc < 0 && lane == 0) backsub_stamp_timeout(wait);
+      const int got = rc > 0 ? 1 : 0;
+      release_word_acquired();
       if (got) {
         for (int i = lane; i < nc; i += 64) mail[8 + i] = load_coherent(wait->dc + i);
       }
@@ -209,17 +223,9 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
   double a = wave_sum63(pred), b = wave_sum63(dn2), cc = wave_sum63(xn2);
   FSTAMP(4);
   if (wait) {  // the steps are ready; they count only if the solve's FINAL state still wants a trial step (a failed solve does not)
-    int polls = 0;
-    bool posted = true;
-    while (load_coherent(wait->flag) != 4.0 * wait->seq + 2.0) {
-      if (++polls > wait->max_polls) { posted = false; break; }
-      __builtin_amdgcn_s_sleep(4);
-    }
-#ifdef MCBA_POLL_ACQUIRE
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#else
-    asm volatile("" ::: "memory");
-#endif
+    const double fin_word = 4.0 * wait->seq + 2.0;
+    const bool posted = release_word_poll(wait->flag, fin_word, fin_word, -1.0, wait->max_polls) > 0;
+    release_word_acquired();
     if (!posted && lane == 0) backsub_stamp_timeout(wait);
     if (!posted || load_coherent(sl.lms + MCBA_LM_DONE) != 0.0 || load_coherent(sl.lms + MCBA_LM_SKIP) != 0.0) return;
   }

@@ -30,6 +30,9 @@
 #ifndef MCBA_GRAM_PIPE
 #define MCBA_GRAM_PIPE 1
 #endif
+#ifndef MCBA_GRAM_GLDS
+#define MCBA_GRAM_GLDS 0   // experiment: depth of an LDS-resident observation ring filled by LDS-DMA (0 = off)
+#endif
 
 namespace mcba {
 
@@ -240,12 +243,88 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #ifdef MCBA_GRAM_TIMING
   const long long gt1 = clock64();
 #endif
+#if MCBA_GRAM_GLDS
+  if constexpr (MODE == 0 && ROLE == 2) {
+    // EXPERIMENT (round 4): the observation ring lives in LDS, filled by LDS-DMA (global_load_lds_dwordx4: no VGPR destination), GD
+    // points deep; registers hold the current and the next point only
+    constexpr int GD = MCBA_GRAM_GLDS;
+    typedef __attribute__((address_space(3))) double2 lds_d2;
+    typedef __attribute__((address_space(1))) const void gvoid;
+    lds_d2* rl = (lds_d2*)chunk;   // [GD][64] double2 of this wavefront
+    auto issue = [&](int pt, int slot) {
+      const double2* src = op + (size_t)min(pt, N - 1) * Fpad;
+      __builtin_amdgcn_global_load_lds((gvoid*)src, (__attribute__((address_space(3))) void*)(rl + slot * 64), 16, 0, 0);
+    };
+#pragma unroll
+    for (int j = 0; j < GD; ++j) issue(j, j);
+    double xc[3] = {obj[0], obj[1], obj[2]};
+    const int p1 = min(1, N - 1);
+    double xn[3] = {obj[3 * p1], obj[3 * p1 + 1], obj[3 * p1 + 2]};
+    // LDS reads of the ring as opaque instructions: a ds_read the compiler can see is preceded by an s_waitcnt vmcnt(0) (it may alias
+    // an LDS-DMA in flight), which would drain the ring at every point.  The waits are placed by hand: vmcnt(GD - 2) before a slot is
+    // read (the DMAs retire in order), lgkmcnt(0) one iteration later, just before the value is used.
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    auto lds_read = [&](int slot) {
+      v2d r;
+      const unsigned addr = (unsigned)(unsigned long)(rl + slot * 64 + lane);
+      asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+      return r;
+    };
+    auto landed = [&](v2d& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)::"memory"); };
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD - 2) : "memory");
+    v2d o_cur = lds_read(0), o_nxt = lds_read(1);
+    landed(o_cur);
+    ObsLead qc;
+    obs_lead<true, FAST>(pc, xc, qc, is_num(o_cur[0]) || is_num(o_cur[1]));
+    auto accumulate = [&](v2d o2, const double Xo[3], const ObsLead& ql) {
+      ObsCommon q;
+      obs_finish(K, ql, q);
+      const bool vu = is_num(o2[0]), vv = is_num(o2[1]);
+      any = any || vu || vv;
+      double wu2, wv2, gu, gv;
+      obs_weights<LOSS, FAST>(o2[0] - q.up, vu, fs2, ifs2, cost, wu2, gu);
+      obs_weights<LOSS, FAST>(o2[1] - q.vp, vv, fs2, ifs2, cost, wv2, gv);
+      {
+        double E[6];
+        obs_row_cam<0>(q, E);
+        gram_add_row<0>(ga, E, wu2, gu);
+        double l4 = q.fa * q.s;
+        gram_add_row<0>(gb, E, wu2, gu, q.a * q.d, l4, l4 * q.s);
+      }
+      {
+        double E[6];
+        obs_row_cam<1>(q, E);
+        gram_add_row<1>(ga, E, wv2, gv);
+        double l4 = q.fb * q.s;
+        gram_add_row<1>(gb, E, wv2, gv, q.b * q.d, l4, l4 * q.s);
+      }
+    };
+    for (int p = 0; p < N; ++p) {
+      landed(o_nxt);                                                 // (read from LDS an iteration ago)
+      issue(p + GD, p & (GD - 1));                                   // the slot of point p (now in o_cur) takes point p + GD
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD - 2) : "memory");  // point p + 2 has landed
+      v2d o_nn = lds_read((p + 2) & (GD - 1));
+      const int p2 = min(p + 2, N - 1);
+      const double xnn[3] = {obj[3 * p2], obj[3 * p2 + 1], obj[3 * p2 + 2]};
+      ObsLead qn;
+      obs_lead<true, FAST>(pc, xn, qn, is_num(o_nxt[0]) || is_num(o_nxt[1]));
+      accumulate(o_cur, xc, qc);
+      qc = qn; o_cur = o_nxt; o_nxt = o_nn;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { xc[i] = xn[i]; xn[i] = xnn[i]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else
+#endif
   if constexpr ((ROLE == 2 || MODE == 3) && MCBA_GRAM_PIPE) {
     // Software-pipelined, branch-free point loop (fused variant, one wavefront per SIMD): the projection of point p + 1 --
     // a serial chain (rotate, reciprocal, distortion polynomial) -- is issued next to the 180 independent accumulator
     // updates of point p, which is what fills the FP64 pipe when no second wavefront is there to do it.  Lanes without
     // an observation project a harmless point and add exact zeros.
-    constexpr int RD = 4;  // observation ring: points p .. p + 3 resident
+#ifndef MCBA_GRAM_RD
+#define MCBA_GRAM_RD 4
+#endif
+    constexpr int RD = MCBA_GRAM_RD;  // observation ring: points p .. p + RD - 1 resident
     double2 r4[RD];
     double x4[RD][3];
 #pragma unroll
@@ -755,6 +834,11 @@ __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t,
   gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1);
   if (!g.run) return;
   const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));  // wavefronts of this workgroup that have a frame block
+#if MCBA_GRAM_GLDS
+  __shared__ __align__(16) double2 s_ring[4][MCBA_GRAM_GLDS][64];
+  gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun, 0, -1, &s_ring[threadIdx.x >> 6][0][0]);
+  return;
+#endif
   gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun);
 }
 

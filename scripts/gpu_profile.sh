@@ -28,4 +28,18 @@ python3 scripts/e2e_breakdown.py > $OUT/${TAG}_e2e_breakdown.json 2> $OUT/${TAG}
 python3 scripts/other_shapes.py > $OUT/${TAG}_other_shapes.json 2> $OUT/${TAG}_shapes.err
 MCBA_SHAPES="24,6250,10,20" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_shard5_stats -- python3 scripts/other_shapes.py > $OUT/${TAG}_shard5.json 2> $OUT/${TAG}_shard5.err
 find $OUT/${TAG}_shard5_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_shard5_kernel_stats.csv \;
+# round 4: the shapes that are not one round of the wavefront slots -- rocprofv3 kernel stats of the LM loop at BASELINE configs[1]
+# (6 x 1 000 x 54, intrinsics held fixed: the 6-wide camera block), the same size with every parameter free, configs[0] (2 x 50), a
+# configs[3] shard (6 x 12 500: fused round + point-split tail); HBM counter passes at configs[1]; the FULL configs[4] problem on one GPU
+for S in "config1:6,1000,6,9,1" "c1free:6,1000,6,9" "config0:2,50,6,9" "shard4:6,12500,6,9"; do
+  N=${S%%:*}; SH=${S#*:}
+  MCBA_SHAPES="$SH" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${N}_stats -- python3 scripts/other_shapes.py > $OUT/${TAG}_${N}.json 2> $OUT/${TAG}_${N}.err
+  find $OUT/${TAG}_${N}_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_${N}_kernel_stats.csv \;
+done
+MCBA_SHAPE="6,1000,6,9" MCBA_FIXED=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_c1_fetch -- python3 scripts/profile_kernels.py > $OUT/${TAG}_pmc_c1_fetch.log 2>&1
+MCBA_SHAPE="6,1000,6,9" MCBA_FIXED=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_c1_write -- python3 scripts/profile_kernels.py > $OUT/${TAG}_pmc_c1_write.log 2>&1
+MCBA_SHAPE="6,1000,6,9" MCBA_FIXED=1 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_LDS --output-format csv -d $OUT/${TAG}_pmc_c1_sq -- python3 scripts/profile_kernels.py > $OUT/${TAG}_pmc_c1_sq.log 2>&1
+python3 scripts/pmc_summary.py $OUT/${TAG}_pmc_config1_summary.json $OUT/${TAG}_pmc_c1_fetch $OUT/${TAG}_pmc_c1_write $OUT/${TAG}_pmc_c1_sq > $OUT/${TAG}_pmc_config1_summary.log
+echo "round-4 shapes done"
+MCBA_SHAPES="24,50000,10,20" python3 scripts/other_shapes.py > $OUT/${TAG}_config5_full.json 2> $OUT/${TAG}_config5_full.err
 echo "profile set $TAG done"

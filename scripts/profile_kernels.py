@@ -1,5 +1,6 @@
 """Fixed launch sequence for rocprofv3 counter passes: 12 LM steps + 6 Jacobian evaluations at 6x10kx54
-   (MCBA_SHAPE="C,F,rows,cols", e.g. "24,6250,10,20": another shape, reduced system solved on the GPU, no Jacobian evaluations).
+   (MCBA_SHAPE="C,F,rows,cols", e.g. "24,6250,10,20": another shape, reduced system solved on the GPU, no Jacobian evaluations;
+   MCBA_FIXED=1: intrinsics held fixed).
    rocprofv3 --pmc <counters> --output-format csv -d <dir> -- python3 scripts/profile_kernels.py"""
 import os
 import sys
@@ -16,6 +17,8 @@ if shape:
 p = m.synth.make_problem(C, F, rows=rows, cols=cols, seed=0)
 x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
 prob = m.ops.Problem(p["uvs"], p["obj"])
+if os.environ.get("MCBA_FIXED"):   # BASELINE configs[1]: intrinsics held fixed (camera block 6 wide)
+    assert prob.set_camera_block(6)
 lm = m.solver.LevenbergMarquardt(prob, ftol=0.0, xtol=0.0, gtol=0.0, **(dict(reduced_solver="device", depth=2) if shape else {}))
 lm.start(x0)
 for _ in range(12):

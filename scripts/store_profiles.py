@@ -19,7 +19,10 @@ def main(tag, rnd):
     for a, b in ((f"{tag}_bench.json", f"bench_{tag}.json"), (f"{tag}_kernel_stats.csv", f"bench_default_kernel_stats_{tag}.csv"), (f"{tag}_pmc_summary.json", f"pmc_{tag}_summary.json"),
                  (f"{tag}_dist_kernel_stats.csv", f"forced_dist_kernel_stats_{tag}.csv"), (f"{tag}_dist_bench.json", f"forced_dist_bench_{tag}.json"),
                  (f"{tag}_e2e_breakdown.json", f"e2e_breakdown_{tag}.json"), (f"{tag}_other_shapes.json", f"other_shapes_{tag}.json"),
-                 (f"{tag}_shard5_kernel_stats.csv", f"shard5_kernel_stats_{tag}.csv")):
+                 (f"{tag}_shard5_kernel_stats.csv", f"shard5_kernel_stats_{tag}.csv"),
+                 (f"{tag}_config1_kernel_stats.csv", f"config1_kernel_stats_{tag}.csv"), (f"{tag}_c1free_kernel_stats.csv", f"shape_6x1000_free_kernel_stats_{tag}.csv"),
+                 (f"{tag}_config0_kernel_stats.csv", f"config0_kernel_stats_{tag}.csv"), (f"{tag}_shard4_kernel_stats.csv", f"shard4_kernel_stats_{tag}.csv"),
+                 (f"{tag}_pmc_config1_summary.json", f"pmc_config1_{tag}_summary.json"), (f"{tag}_config5_full.json", f"config5_full_one_gpu_{tag}.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, b))
         else:
