@@ -352,3 +352,56 @@ def test_north_star_partition_eight_shards(tag, shape):
     ca, cb = out[0].x[: 12 * C].reshape(C, 12), one.x[: 12 * C].reshape(C, 12)
     assert (np.abs(ca[:, :6] - cb[:, :6]) / np.abs(cb[:, :6])).max() < 1e-6
     print(f"[{tag}] one handle: {t_one:.2f} s for nfev {one.nfev} ({1e3 * t_one / one.nfev:.2f} ms per evaluation); eight shards in one process: {t_eight:.2f} s, nfev {out[0].nfev}, cost {out[0].cost:.9g}")
+
+
+def test_frame_shards_with_the_six_wide_camera_block():
+    """BASELINE configs[1] frame-sharded: three shards in one process (solver.InProcessShards), every handle on the 6-wide camera block
+    (intrinsics fixed): the collective carries the (6C)^2 + 3 * 6C + 16 + 8 doubles of that system.  Same decisions on every shard; the cost
+    and the predictions of the one-handle solve; the intrinsics untouched."""
+    import threading
+
+    import torch
+
+    import multicam_calibration_amd as m
+    from oracle import ba_oracle as orc
+
+    C, F, world = 6, 3 * 700, 3
+    p = m.synth.make_problem(C, F, seed=12, missing=0.1)
+    x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    kw = dict(ftol=1e-13, xtol=1e-12, gtol=1e-9, max_nfev=30)
+    prob = m.ops.Problem(p["uvs"], p["obj"])
+    assert prob.set_camera_block(6)
+    one = m.solver.lm_solve(prob, x0, **kw)
+    prob.close()
+    bounds = np.linspace(0, F, world + 1).astype(int)
+    shards = m.solver.InProcessShards(world)
+    out, err = [None] * world, []
+
+    def run(rank):
+        try:
+            lo, hi = bounds[rank], bounds[rank + 1]
+            pr = m.ops.Problem(np.ascontiguousarray(p["uvs"][:, lo:hi]), p["obj"])
+            assert pr.set_camera_block(6)            # before the collective's buffer is sized
+            comm = shards.comm(rank, pr, torch.device("cuda:0"))
+            assert pr.reduced_size() == (6 * C) ** 2 + 3 * 6 * C + 16 + 8 + 2 * 32
+            xs = np.concatenate([x0[: 12 * C], x0[12 * C:].reshape(F, 6)[lo:hi].ravel()])
+            out[rank] = m.solver.lm_solve(pr, xs, comm=comm, **kw)
+            pr.close()
+        except BaseException as e:  # noqa: BLE001
+            err.append(e)
+            shards.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not err, err
+    h0 = np.array([(h[0], h[1], h[2], h[5]) for h in out[0].lm["history"]])
+    for r in out[1:]:
+        np.testing.assert_array_equal(np.array([(h[0], h[1], h[2], h[5]) for h in r.lm["history"]]), h0)
+        np.testing.assert_array_equal(r.x[: 12 * C], out[0].x[: 12 * C])
+    assert one.status > 0 and out[0].status > 0 and abs(out[0].cost - one.cost) <= 1e-10 * one.cost
+    np.testing.assert_array_equal(out[0].x[: 12 * C].reshape(C, 12)[:, :6], x0[: 12 * C].reshape(C, 12)[:, :6])
+    xa = np.concatenate([out[0].x[: 12 * C]] + [r.x[12 * C:] for r in out])
+    assert np.abs(orc.predict_from_x(xa, C, p["obj"]) - orc.predict_from_x(one.x, C, p["obj"])).max() < 1e-5
