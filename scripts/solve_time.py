@@ -1,5 +1,5 @@
 """k_solve_cam phase stamps (build with MCBA_HIPCC_FLAGS=-DMCBA_SOLVE_TIMING) and launch time.
-usage: python scripts/solve_time.py [cameras ...]      (MCBA_LIB = an alternative build)
+usage: python scripts/solve_time.py [cameras[:6] ...]      (MCBA_LIB = an alternative build; ":6" = the 6-wide camera block)
 Beyond 9 cameras (right-looking variant) the stamps of slots 27 / 29 / 30 are the backward sweep and intervals A / B of block step
 k = launch number - 1: MCBA_SOLVE_LAUNCHES=N prints them for the first N - 1 launches."""
 import sys
@@ -13,10 +13,13 @@ import os
 if os.environ.get("MCBA_LIB"):
     m.ops.LIB_PATH = os.environ["MCBA_LIB"]
 
-for C in [int(a) for a in sys.argv[1:]] or [6, 24]:
+for arg in sys.argv[1:] or ["6", "24"]:   # "C" or "C:6" (the 6-wide camera block: intrinsics fixed)
+    C = int(arg.split(":")[0])
     p = m.synth.make_problem(C, 256, seed=0)
     x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
     prob = m.ops.Problem(p["uvs"], p["obj"])
+    if arg.endswith(":6"):
+        assert prob.set_camera_block(6)
     prob.set_params(0, x0)
     prob.linearize(0)
     prob.build_reduced(1e-3)
@@ -33,5 +36,5 @@ for C in [int(a) for a in sys.argv[1:]] or [6, 24]:
         print("per launch (slots 27, 29, 30):", per_launch)
     prof = prob.profile_read()
     ms, n = prof["k_solve_cam"]
-    print("C=%d n=%d: k_solve_cam %.2f us avg; stamps (cycles): %s" % (C, 12 * C, 1e3 * ms / n, np.array2string(st[25:31], precision=6)))
+    print("C=%d n=%d: k_solve_cam %.2f us avg; stamps (cycles): %s" % (C, prob.n, 1e3 * ms / n, np.array2string(st[25:31], precision=6)))
     prob.close()
