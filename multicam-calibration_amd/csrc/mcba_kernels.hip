@@ -766,12 +766,14 @@ struct GramStart {
   bool run;
 };
 __device__ __forceinline__ void gram_start(GramStart& g, CamConst& s_cam, const double2* __restrict__ obs_t, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1, double* rec0, double* rec1,
-                                           double* gp0, double* gp1, int C, int N, int Fpad, int fb0, int fb1, int p_lo = 0, int p_hi = -1, int npw = 1) {
+                                           double* gp0, double* gp1, int C, int N, int Fpad, int fb0, int fb1, int p_lo = 0, int p_hi = -1, int npw = 1,
+                                           int bxo = -1, int co = -1) {  // bxo, co: workgroup coordinates decoded by the caller (k_gram_mixed) instead of blockIdx.x / .y
   if (p_hi < 0) p_hi = N;
-  const int c = blockIdx.y;
+  const int c = co >= 0 ? co : (int)blockIdx.y;
+  const int bx = bxo >= 0 ? bxo : (int)blockIdx.x;
   const int wave = threadIdx.x >> 6;
   g.lane = threadIdx.x & 63;
-  g.fb = fb0 + blockIdx.x * ((blockDim.x >> 6) / npw) + wave / npw;  // this launch covers the frame blocks [fb0, fb1), one per wavefront (point split: per npw wavefronts)
+  g.fb = fb0 + bx * ((blockDim.x >> 6) / npw) + wave / npw;  // this launch covers the frame blocks [fb0, fb1), one per wavefront (point split: per npw wavefronts)
   const bool have = g.fb < fb1;
   const int fbc = have ? g.fb : fb1 - 1;
   double st3 = 0.0, st14 = 0.0, st15 = 0.0;
@@ -862,6 +864,35 @@ __global__ __launch_bounds__(256) void k_gram_psplit(const double2* __restrict__
   gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1, p_lo, max(p_hi, p_lo + 1), NPW);  // (an empty piece -- fewer points than wavefronts -- still prefetches a valid point)
   if (!g.run) return;
   gram_body<LOSS, ROLE, FAST, 3, NPW>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, 0, p_lo, p_hi, reinterpret_cast<double2*>(s_xch));
+}
+
+// Whole rounds of the wavefront slots fused AND the short last round point-split, in ONE launch (round 4): a 1-D grid whose first
+// nf C workgroups are k_gram's (four frame blocks of one camera each, the frame blocks [0, fba)), the rest k_gram_psplit's over
+// [fba, nfb).  Workgroups are dispatched in id order: every CU starts on a fused workgroup and takes point-split ones as it
+// comes free -- the two-launch form paid a kernel boundary (end-of-kernel write-back, dispatch, a second start-up round trip) in between.
+template <int LOSS, bool FAST, int NPW>
+__global__ __launch_bounds__(256) void k_gram_mixed(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
+                                                       double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, int fba,
+                                                       int nf, int nt, double fs2, double ifs2) {
+  __shared__ CamConst s_cam;
+  __shared__ double s_cost[8];
+  extern __shared__ __align__(16) double s_xch[];
+  const int id = blockIdx.x;
+  GramStart g;
+  if (id < nf * C) {
+    const int c = id / nf, bx = id - c * nf;
+    gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, 0, fba, 0, -1, 1, bx, c);
+    if (!g.run) return;
+    const int nrun = min(4, fba - bx * 4);
+    gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun);
+  } else {
+    const int id2 = id - nf * C, c = id2 / nt, bx = id2 - c * nt;
+    const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) % NPW;
+    const int p_lo = (int)(((long long)N * part) / NPW), p_hi = (int)(((long long)N * (part + 1)) / NPW);
+    gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fba, nfb, p_lo, max(p_hi, p_lo + 1), NPW, bx, c);
+    if (!g.run) return;
+    gram_body<LOSS, 2, FAST, 3, NPW>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, 0, p_lo, p_hi, reinterpret_cast<double2*>(s_xch));
+  }
 }
 
 // Point-chunk tail (gram_body MODE 1 / 2).  k_gram_chunk: grid (frame blocks, C, nchunk) of ONE-wavefront workgroups (with four
@@ -1741,8 +1772,21 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
   if (split == 4) { psplit(0, nfb); return; }
   if (split == 5) {  // whole rounds of the wavefront slots fused, the short last round point-split
     const int fba5 = gram_round_blocks(C, nfb);
-    if (fba5 > 0 && fba5 < nfb) { fused(0, fba5); psplit(fba5, nfb); }
-    else fused(0, nfb);
+    if (fba5 > 0 && fba5 < nfb) {
+      static const bool two_launches = [] { const char* e = getenv("MCBA_GRAM_MIXED"); return e && atoi(e) == 0; }();  // (0: the two-launch form, for A/B)
+      if (two_launches) { fused(0, fba5); psplit(fba5, nfb); return; }
+      const int per = npw == 4 ? 1 : 2, nf = (fba5 + 3) / 4, nt = (nfb - fba5 + per - 1) / per;
+      const size_t lds = gram_psplit_lds_bytes(npw == 4 ? 4 : 2, 12);
+      const bool fast = planar && f_scale == 1.0;
+      dim3 grid((nf + nt) * C);
+#define MX_GO(FASTV, NPWV) DISPATCH_LOSS(loss, (k_gram_mixed<L, FASTV, NPWV><<<grid, block, lds, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fba5, nf, nt, fs2, ifs2)))
+      if (npw == 4) {
+        if (fast) { MX_GO(true, 4); } else { MX_GO(false, 4); }
+      } else {
+        if (fast) { MX_GO(true, 2); } else { MX_GO(false, 2); }
+      }
+#undef MX_GO
+    } else fused(0, nfb);
     return;
   }
   if (split == 1) { roles(0, nfb); return; }
@@ -1872,7 +1916,11 @@ int gram_psplit_set_lds_limit() {
   int rc = 0;
 #define PS_K(L) reinterpret_cast<const void*>(k_gram_psplit<L, true, 4, 2>), reinterpret_cast<const void*>(k_gram_psplit<L, false, 4, 2>), \
                 reinterpret_cast<const void*>(k_gram_psplit<L, true, 2, 2>), reinterpret_cast<const void*>(k_gram_psplit<L, false, 2, 2>)
-  const void* ks[] = {PS_K(LOSS_LINEAR), PS_K(LOSS_SOFT_L1), PS_K(LOSS_HUBER), PS_K(LOSS_CAUCHY), PS_K(LOSS_ARCTAN)};
+#define MX_K(L) reinterpret_cast<const void*>(k_gram_mixed<L, true, 4>), reinterpret_cast<const void*>(k_gram_mixed<L, false, 4>), \
+                reinterpret_cast<const void*>(k_gram_mixed<L, true, 2>), reinterpret_cast<const void*>(k_gram_mixed<L, false, 2>)
+  const void* ks[] = {PS_K(LOSS_LINEAR), PS_K(LOSS_SOFT_L1), PS_K(LOSS_HUBER), PS_K(LOSS_CAUCHY), PS_K(LOSS_ARCTAN),
+                      MX_K(LOSS_LINEAR), MX_K(LOSS_SOFT_L1), MX_K(LOSS_HUBER), MX_K(LOSS_CAUCHY), MX_K(LOSS_ARCTAN)};
+#undef MX_K
 #undef PS_K
   for (const void* k : ks) {
     int r = (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_psplit_lds_bytes(4, 12));
