@@ -785,12 +785,18 @@ def test_camera_block6_is_refused_late_and_beyond_26_cameras(mc):
     prob.close()
 
 
-@pytest.mark.parametrize("shape,kw", [((4, 90), dict()), ((6, 700), dict(loss="cauchy", f_scale=0.7)), ((12, 30), dict()), ((3, 40), dict(reduced_solver="host"))])
+@pytest.mark.parametrize("shape,kw", [((4, 90), dict()), ((6, 700), dict(loss="cauchy", f_scale=0.7)), ((12, 30), dict()), ((3, 40), dict(reduced_solver="host")),
+                                      ((3, 60), dict(x_scale="numeric")), ((3, 60), dict(x_scale="numeric", reduced_solver="host"))])
 def test_fix_intrinsics_compact_block_equals_flag_path(mc, shape, kw):
     """bundle_adjust(fix_intrinsics=True) on the 6-wide camera block (the default) and on the 12-wide block with the intrinsics'
     rows held by flags (MCBA_FIXED_COMPACT=0, round 3's path): the same decisions, the same optimum, intrinsics untouched."""
-    p = mc.synth.make_problem(shape[0], shape[1], seed=91, missing=0.1, scalar_nans=5)
+    numeric = kw.get("x_scale") == "numeric"
+    p = mc.synth.make_problem(shape[0], shape[1], seed=91, missing=0.0 if numeric else 0.1, scalar_nans=0 if numeric else 5)   # (numeric x_scale: every frame is used, so its length is known)
     args = (p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    kw = dict(kw)
+    if kw.get("x_scale") == "numeric":   # least_squares' numeric x_scale in the layout of x: the 6-wide system picks its rows out of it
+        x0s = np.abs(orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"]))
+        kw["x_scale"] = np.where(x0s > 1e-3, x0s, 1.0) * np.random.default_rng(5).uniform(0.5, 2.0, x0s.size)
     opts = dict(n_frames=None, fix_intrinsics=True, ftol=1e-12, xtol=1e-12, gtol=1e-10, verbose=0, return_jac=False, **kw)
     out = []
     for flag in ("1", "0"):
