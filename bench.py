@@ -454,10 +454,16 @@ def main():
             # the FP64 vector rate, so the dense-MFMA peak for this dtype is the same 78.6 TFLOP/s.)
             real, slots, mix = gram_work(C, F, N)
             tf, tfs = real / (dom_ms * 1e-3) / 1e12, slots / (dom_ms * 1e-3) / 1e12
+            try:   # the FP64 vector rate this GPU sustains (independent v_fma_f64, one wavefront per SIMD on every CU), measured now
+                live_ceiling = m.ops.fp64_issue_rate(local_rank)
+            except Exception:  # noqa: BLE001
+                live_ceiling = None
             roofline = {"kernel": dom, "bound": "valu_f64", "n_samples": int(kern[dom][1]), "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
                         "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": dom_ms * 1e3, "flops_per_launch": real,
                         "frac_issue_slots": tfs / FP64_VALU_PEAK_TFLOPS, "issue_slot_flops_per_launch": slots,
                         "measured_issue_ceiling": FP64_VALU_MEASURED_TFLOPS, "frac_issue_slots_of_measured_ceiling": tfs / FP64_VALU_MEASURED_TFLOPS,
+                        "live_issue_ceiling": {"tflops": live_ceiling, "frac_issue_slots": (tfs / live_ceiling) if live_ceiling else None,
+                                               "what": "independent v_fma_f64 with three distinct register pairs each, one wavefront per SIMD on every CU (mcba_fp64_issue_rate), measured in this run"},
                         "instructions_per_point_observation": mix, "hbm": hbm,
                         "note": "frac = real FP64 flops (2 x FMA + MUL + ADD) / 78.6 TFLOP/s; frac_issue_slots counts every FP64 instruction as an FMA"}
         tick_bytes = TICK_ALGORITHMIC_BYTES_10K * F / F_PER_GPU

@@ -293,6 +293,10 @@ int mcba_profile_stride(mcba_handle* h, int stride);
 /* Drains the recorded events.  names: '\n'-separated kernel names in the order of ms[] / calls[]. */
 int mcba_profile_read(mcba_handle* h, double* ms_total, int* calls, int capacity, int* n_kernels);
 const char* mcba_profile_names(void);
+/* Measurement aid (round 4): TFLOP/s of independent v_fma_f64 (2 flop each) that `device` sustains with one wavefront per SIMD on every
+ * compute unit -- the occupancy and the operand pattern of k_gram's accumulate block.  bench.py reports k_gram's FP64 instruction stream
+ * against it next to the datasheet peak (the reference has no counterpart: its arithmetic is numpy / scipy on the host). */
+int mcba_fp64_issue_rate(int device, double* tflops);
 int mcba_synchronize(mcba_handle* h);
 
 #ifdef __cplusplus

@@ -1526,6 +1526,23 @@ int mcba_get_frame_gradient(mcba_handle* h, double* host) {
   return MCBA_OK;
 }
 
+// Measurement aid (bench.py): the FP64 vector rate this device sustains with one wavefront per SIMD on every compute unit issuing
+// independent v_fma_f64 -- what k_gram's instruction stream can be priced against besides the datasheet peak.  ~0.3 ms of GPU time.
+int mcba_fp64_issue_rate(int device, double* tflops) {
+  if (!tflops) return fail(MCBA_ERR_ARG, "mcba_fp64_issue_rate: NULL");
+  *tflops = 0.0;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MCBA_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(MCBA_ERR_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  int ncu = 256;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+  *tflops = mcba::measure_fp64_issue_rate(ncu);
+  if (!(*tflops > 0.0)) return fail(MCBA_ERR_HIP, "mcba_fp64_issue_rate: the measurement kernel failed");
+  return MCBA_OK;
+}
+
 int mcba_profile_enable(mcba_handle* h, int on) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
   h->prof = on != 0;

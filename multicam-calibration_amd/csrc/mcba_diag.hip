@@ -432,6 +432,52 @@ int launch_select_hist(hipStream_t st, const double* v, const unsigned char* fma
   return hipStreamSynchronize(st) == hipSuccess ? 0 : 1;
 }
 
+// ---------------------------------------------------------------- measurement aid: the FP64 vector issue rate this GPU sustains
+// One wavefront per SIMD on every CU (the occupancy of the fused k_gram), each issuing independent v_fma_f64 with three distinct register
+// pairs per instruction -- the operand pattern of the Gram update acc[6 i + j] += u[i] * v[j] (scripts/micro/fma_f64_operands.hip, MODE 1).
+// bench.py prices k_gram's FP64 instruction stream against what this returns, next to the datasheet peak.
+__global__ __launch_bounds__(256) void k_fp64_issue_rate(double* out, int iters, double a, double b) {
+  double acc[36], u[6], v[6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = threadIdx.x + i;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { u[i] = a + 1e-3 * (threadIdx.x + i); v[i] = b + 1e-4 * ((int)threadIdx.x - i); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(acc[6 * i + j]) : "v"(u[i]), "v"(v[j]));
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// -> TFLOP/s (2 flop per FMA) with `ncu` workgroups of four wavefronts; 0 on failure
+double measure_fp64_issue_rate(int ncu) {
+  double* out = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&out), (size_t)ncu * 256 * sizeof(double)) != hipSuccess) return 0.0;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const int iters = 4000;
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {  // (the first repetition also ramps the clocks)
+    (void)hipEventRecord(e0, nullptr);
+    k_fp64_issue_rate<<<dim3(ncu), dim3(256), 0, nullptr>>>(out, iters, 1.0000001, 1e-9);
+    (void)hipEventRecord(e1, nullptr);
+    if (hipEventSynchronize(e1) != hipSuccess) { best = 0.f; break; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(out);
+  if (!(best > 0.f) || best > 1e29f) return 0.0;
+  return (double)ncu * 4 * 64 * (double)iters * 36 * 2 / (best * 1e-3) / 1e12;
+}
+
 void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N) {
   const size_t total = (size_t)C * Fdst * N;
   k_gather_frames<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(src_raw), frames, reinterpret_cast<double2*>(dst_raw), C, Fsrc, Fdst, N);

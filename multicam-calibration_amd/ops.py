@@ -85,6 +85,7 @@ SYMBOLS = [
     ("mcba_profile_read", ctypes.c_int, [_h, _dp, _ip, ctypes.c_int, _ip]),
     ("mcba_profile_names", ctypes.c_char_p, []),
     ("mcba_synchronize", ctypes.c_int, [_h]),
+    ("mcba_fp64_issue_rate", ctypes.c_int, [ctypes.c_int, _dp]),
 ]
 
 LM_STATE = 32  # MCBA_LM_STATE of include/mcba.h
@@ -157,6 +158,16 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+def fp64_issue_rate(device=0):
+    """TFLOP/s of independent v_fma_f64 the device sustains at one wavefront per SIMD (include/mcba.h: mcba_fp64_issue_rate)."""
+    lib = load_library()
+    t = ctypes.c_double()
+    rc = lib.mcba_fp64_issue_rate(int(device), ctypes.byref(t))
+    if rc != OK:
+        raise McbaError(rc, lib.mcba_last_error().decode())
+    return t.value
 
 
 def pool_trim():
