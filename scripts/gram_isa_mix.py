@@ -61,7 +61,7 @@ def main():
     labels = {m.group(1): i for i, l in enumerate(body) if (m := re.match(r"^(\.LBB[0-9_]+):", l))}
     best = None
     for i, l in enumerate(body):
-        m = re.search(r"s_cbranch_\w+\s+(\.LBB[0-9_]+)", l)
+        m = re.search(r"s_c?branch\w*\s+(\.LBB[0-9_]+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < i and "Loop Header" in body[labels[m.group(1)]]:   # (other backward branches are exits)
             if best is None or i - labels[m.group(1)] > best[1] - best[0]:
                 best = (labels[m.group(1)], i)
