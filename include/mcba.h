@@ -110,6 +110,10 @@ int mcba_residuals_detach(mcba_handle* h, int slot, mcba_buffer** out);
 size_t mcba_buffer_count(const mcba_buffer* b);
 int mcba_buffer_download(mcba_buffer* b, double* host);
 int mcba_buffer_free(mcba_buffer* b);
+/* Which scalars of the uploaded observations are present (not NaN), from the GPU's own copy: bits = numpy.packbits(~numpy.isnan(uvs))
+ * over the (C, F, N, 2) array, (2 C F N + 7) / 8 bytes, host.  It is the row selection of the reference's residual vector and
+ * Jacobian (bundle_adjustment.py:68-69 `mask = ~np.isnan(uvs)`, :101) without a pass over the caller's array; synchronises. */
+int mcba_seen_bits(mcba_handle* h, unsigned char* bits);
 /* Materialise residuals + analytic Jacobian blocks on the GPU: per scalar residual 18 doubles
  * [12 camera columns | 6 frame-pose columns] in (C,F,N,2,18) order = the CSR `data` array of the
  * reference's Jacobian when no observation is missing.  robust_scaled != 0 applies scipy's

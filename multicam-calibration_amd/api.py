@@ -427,8 +427,14 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         need_mask = not all_seen  # (every selected detection complete -- the pre-filter counted them on the GPU: no NaN mask to apply)
         shape4 = (n_cameras, use_frames.size, all_calib_uvs.shape[2], 2)
         # which scalars are observed is fixed NOW (one bit each), not when a lazy field is first read: the caller may NaN out
-        # detections of its array in place between this call and that read
-        seen_bits = np.packbits(~np.isnan(all_calib_uvs[:, use_frames])) if need_mask else None
+        # detections of its array in place between this call and that read.  The bits come from the GPU's copy of the
+        # selected frames (k_seen_bits: 0.8 MB of D2H at 6 x 10 000 x 54; the same thing in numpy over the caller's array is 24 ms)
+        if not need_mask:
+            seen_bits = None
+        elif hasattr(prob, "seen_bits"):
+            seen_bits = prob.seen_bits()
+        else:
+            seen_bits = np.packbits(~np.isnan(all_calib_uvs)[:, use_frames])
         vec = prob.residuals_detach(slot)
 
         def fun(vec=vec, bits=seen_bits, shape4=shape4):

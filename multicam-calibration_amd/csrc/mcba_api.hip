@@ -1487,6 +1487,24 @@ int mcba_buffer_free(mcba_buffer* b) {
   return MCBA_OK;
 }
 
+// numpy.packbits(~numpy.isnan(uvs)) of the uploaded observations, taken from the device copy (k_seen_bits): 0.8 MB of D2H at
+// 6 x 10 000 x 54 instead of 24 ms of numpy over the caller's 52 MB.
+int mcba_seen_bits(mcba_handle* h, unsigned char* bits) {
+  if (!h || !bits) return fail(MCBA_ERR_ARG, "mcba_seen_bits: bad argument");
+  if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_seen_bits: upload observations first");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t count = (size_t)2 * h->C * h->F * h->N, words = (count + 63) / 64;
+  unsigned long long* d = nullptr;
+  HIPCHK(pool_malloc(reinterpret_cast<void**>(&d), words * 8, h->device));
+  mcba::launch_seen_bits(h->stream, h->obs_raw, count, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(bits, d, (count + 7) / 8, hipMemcpyDeviceToHost, h->stream);
+  hipError_t e2 = hipStreamSynchronize(h->stream);
+  pool_free(d, words * 8, h->device);
+  if (e != hipSuccess || e2 != hipSuccess) { g_err = std::string("mcba_seen_bits: ") + hipGetErrorString(e != hipSuccess ? e : e2); return MCBA_ERR_HIP; }
+  return MCBA_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // One pass of the radix select behind mcba_error_median, for callers that hold only a SHARD of the frames (frame-sharded
 // bundle_adjust: every rank runs the pre-filter on its own slice): the 256-bin histogram of byte `pass` (0 = most significant)

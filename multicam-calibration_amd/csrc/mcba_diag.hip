@@ -9,6 +9,8 @@
 //                    radix select on the bit patterns of the (non-negative) doubles, 8 passes of one byte; histogram in LDS,
 //                    integer atomics only -> the result is the exact order statistic, bit for bit.
 //   k_gather_frames  observations of a frame subset, device to device, for the handle the solver then runs on.
+//   k_seen_bits      which observation scalars are present, one bit each in numpy.packbits order: the row selection of the
+//                    reference's residual vector and Jacobian (bundle_adjustment.py:68-69, 101) taken from the GPU's own copy.
 //   k_undistort      `undistort_points` (geometry.py:328-358): OpenCV's fixed-point iteration for (k1 k2 p1 p2 k3).
 //   k_reproj_diag    `plot_residuals` (viz.py:166-186) without the plotting: distortion-free reprojection of the board,
 //                    least-squares homography from the undistorted detections to the board plane per (camera, frame),
@@ -159,6 +161,16 @@ __global__ void k_gather_frames(const double2* __restrict__ src, const int* __re
   const size_t cf = i / N;
   const int f = (int)(cf % Fdst), c = (int)(cf / Fdst);
   dst[i] = src[((size_t)c * Fsrc + frames[f]) * N + p];
+}
+
+// ---------------------------------------------------------------- presence bits of the observation scalars
+// bit i (numpy.packbits order: scalar 8 b + j is bit 7 - j of byte b) = scalar i of the (camera, frame, point, u|v) array is not NaN.
+// One wavefront = 64 consecutive scalars = one 8-byte word: the ballot, bit-reversed and byte-swapped.
+__global__ __launch_bounds__(256) void k_seen_bits(const double* __restrict__ obs_raw, size_t count, unsigned long long* __restrict__ words) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const double v = i < count ? __builtin_nontemporal_load(obs_raw + i) : __builtin_nan("");
+  const unsigned long long b = __ballot(v == v);
+  if ((threadIdx.x & 63) == 0) words[i >> 6] = __builtin_bswap64(__brevll(b));
 }
 
 // ---------------------------------------------------------------- undistortion (cv2.undistortPoints(src, K, dist, None, K))
@@ -481,6 +493,10 @@ double measure_fp64_issue_rate(int ncu) {
 void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N) {
   const size_t total = (size_t)C * Fdst * N;
   k_gather_frames<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(src_raw), frames, reinterpret_cast<double2*>(dst_raw), C, Fsrc, Fdst, N);
+}
+
+void launch_seen_bits(hipStream_t st, const double* obs_raw, size_t count, unsigned long long* words) {
+  if (count) k_seen_bits<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st>>>(obs_raw, count, words);
 }
 
 void launch_undistort(hipStream_t st, const double* uv, double* out, size_t n, const double* K4, const double* dist5, int iters) {

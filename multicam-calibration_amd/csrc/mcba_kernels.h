@@ -111,6 +111,7 @@ void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, 
 int launch_select_hist(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int Fpad, void* sel, unsigned long long prefix, int pass, unsigned int* hist256);
 double measure_fp64_issue_rate(int ncu);  // TFLOP/s of independent v_fma_f64 at one wavefront per SIMD on `ncu` compute units (measurement aid)
 void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N);
+void launch_seen_bits(hipStream_t st, const double* obs_raw, size_t count, unsigned long long* words);  // words: ceil(count / 64) of them
 void launch_undistort(hipStream_t st, const double* uv, double* out, size_t n, const double* K4, const double* dist5, int iters);
 void launch_reproj_diag(hipStream_t st, const double* obs_t, const double* obj, const double* x, const double* dist5, const double* bn, double* und, double* repro, double* trans, double* err, int C, int F, int N,
                         int Fpad, int iters, int lm_iters);

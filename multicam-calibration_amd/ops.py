@@ -41,6 +41,7 @@ SYMBOLS = [
     ("mcba_copy_params", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int]),
     ("mcba_cost", ctypes.c_int, [_h, ctypes.c_int, _dp, _dp]),
     ("mcba_residuals", ctypes.c_int, [_h, ctypes.c_int, _dp]),
+    ("mcba_seen_bits", ctypes.c_int, [_h, ctypes.POINTER(ctypes.c_ubyte)]),
     ("mcba_jacobian_eval", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int]),
     ("mcba_jacobian_download", ctypes.c_int, [_h, _dp, _dp]),
     ("mcba_linearize", ctypes.c_int, [_h, ctypes.c_int]),
@@ -327,6 +328,13 @@ class Problem:
         buf = _h()
         self._chk(self.lib.mcba_residuals_detach(self.handle, slot, ctypes.byref(buf)))
         return DeviceArray(self.lib, buf, (self.C, self.F, self.N, 2))
+
+    def seen_bits(self):
+        """numpy.packbits(~numpy.isnan(uvs)) of the uploaded (C,F,N,2) observations, computed on the GPU from its own copy
+        (mcba_seen_bits): the row selection of the reference's residual vector / Jacobian (bundle_adjustment.py:68-69)."""
+        bits = np.empty((2 * self.C * self.F * self.N + 7) // 8, np.uint8)
+        self._chk(self.lib.mcba_seen_bits(self.handle, bits.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))))
+        return bits
 
     def set_x_scale(self, x_scale):
         """least_squares' numeric x_scale for this shard's parameter vector (nx positive numbers), or None for 'jac'."""

@@ -1,6 +1,7 @@
 """Where the wall time of the user-level call goes: bundle_adjust() from host arrays to the 5-tuple at BASELINE configs[2]
 (6 x 10 000 x 54), return_jac=False, warm.  Every ops.Problem method (each one is a C-ABI crossing that synchronises when it
 returns host data) and the host-side stages are wrapped with wall-clock timers; prints one JSON object.
+MCBA_E2E_MISSING=<probability> drops whole detections (then result.fun / result.jac need the row mask: mcba_seen_bits).
 usage: python scripts/e2e_breakdown.py [frames] [reps]"""
 import contextlib
 import functools
@@ -47,7 +48,14 @@ solver.lm_solve = timed("solver.lm_solve", solver.lm_solve)
 api.serialize_params = timed("api.serialize_params", api.serialize_params)
 api.deserialize_params = timed("api.deserialize_params", api.deserialize_params)
 
-p = m.synth.make_problem(6, F, seed=0)
+import os
+
+MISSING = float(os.environ.get("MCBA_E2E_MISSING", "0"))
+p = m.synth.make_problem(6, F, seed=0, missing=MISSING)
+
+
+if os.environ.get("MCBA_E2E_HOSTMASK") == "1":   # round 4 before mcba_seen_bits: the mask from a numpy pass over the caller's array
+    ops.Problem.seen_bits = timed("host mask (numpy)", lambda self: np.packbits(~np.isnan(p["uvs"][:, np.arange(self.F)])))
 
 
 def run():
@@ -66,5 +74,5 @@ for _ in range(REPS):
     times.append(time.perf_counter() - t0)
 res = out[4]
 tab = {k: {"ms_per_call_site": 1e3 * v[0] / REPS, "calls": v[1] / REPS} for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])}
-print(json.dumps({"workload": f"bundle_adjust 6x{F}x54 return_jac=False, warm", "end_to_end_ms": {"min": 1e3 * min(times), "median": 1e3 * float(np.median(times)), "all": [1e3 * t for t in times]},
+print(json.dumps({"workload": f"bundle_adjust 6x{F}x54 return_jac=False, warm, missing detections {MISSING}", "end_to_end_ms": {"min": 1e3 * min(times), "median": 1e3 * float(np.median(times)), "all": [1e3 * t for t in times]},
                   "nfev": int(res.nfev), "status": int(res.status), "cost": float(res.cost), "breakdown_ms (nested: inner calls are included in outer ones)": tab}, indent=1))

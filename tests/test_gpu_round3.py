@@ -228,3 +228,27 @@ def test_lazy_fields_keep_the_mask_of_call_time_and_release_handles_under_pressu
 
     gc.collect()
     assert not mc.api._JacobianSource.live
+
+
+# ------------------------------------------------------------------ round 4: the presence bits of the observations come from the GPU's copy
+@pytest.mark.parametrize("shape", [(2, 1, 1), (3, 7, 5), (2, 50, 54), (6, 333, 35), (5, 64, 16)])
+def test_seen_bits_equal_numpy_packbits(mc, shape):
+    C, F, N = shape   # scalar counts 4, 210, 10 800, 139 860, 10 240: below one wavefront, ragged last word / last byte, whole words
+    rng = np.random.default_rng(C * 1000 + F)
+    uvs = rng.normal(size=(C, F, N, 2))
+    uvs[rng.random((C, F, N)) < 0.3] = np.nan          # whole detections ...
+    uvs[rng.random((C, F, N, 2)) < 0.05] = np.nan      # ... and single scalars
+    uvs[..., -1, :] = np.nan if F % 2 else uvs[..., -1, :]
+    obj = rng.normal(size=(N, 3))
+    prob = mc.ops.Problem(uvs, obj)
+    try:
+        np.testing.assert_array_equal(prob.seen_bits(), np.packbits(~np.isnan(uvs)))
+        if F > 3:
+            keep = np.array([F - 1, 0, 2])
+            sub = prob.subset(keep)                       # (frames gathered on the device)
+            try:
+                np.testing.assert_array_equal(sub.seen_bits(), np.packbits(~np.isnan(uvs[:, keep])))
+            finally:
+                sub.close()
+    finally:
+        prob.close()
