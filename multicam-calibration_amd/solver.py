@@ -132,6 +132,30 @@ class InProcessShards:
         problem.enable_collective(device)
         return _ShardComm(self, rank)
 
+    def run(self, fn):
+        """fn(rank) on one thread per shard; returns the results in rank order.  A shard that raises breaks the barrier, so that
+        the others do not wait for it, and its exception is re-raised here."""
+        import threading
+
+        out, err = [None] * self.world, []
+
+        def body(rank):
+            try:
+                out[rank] = fn(rank)
+            except BaseException as e:  # noqa: BLE001
+                err.append(e)
+                self.barrier.abort()
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if err:
+            first = [e for e in err if not isinstance(e, threading.BrokenBarrierError)] or err
+            raise first[0]
+        return out
+
 
 class _ShardComm(TorchDistributed):
     def __init__(self, owner, rank):  # (no process group: TorchDistributed's constructor is not called)

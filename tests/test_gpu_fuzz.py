@@ -1,0 +1,178 @@
+"""Randomised end-to-end checks of bundle_adjust() on the GPU against the ORACLE's objective (run with `-m gpu` on an MI355X).
+
+scipy's TRF needs hundreds of evaluations to reach a tight optimum (the committed goldens were made that way, offline), so the seeded
+random cases here are judged by properties the reference's minimiser has, each evaluated with the oracle (numpy restatement of
+bundle_adjustment.py) at the point the GPU returns:
+  * the frames used are the oracle's pre-filter selection;
+  * `cost`, `fun` are the oracle's robust cost / residual vector at `x`; the cost did not go up;
+  * `x` is a STATIONARY point of the oracle's objective: its gradient J^T rho'(f) (scipy's, common.py:720-731) is at the round-off floor
+    of the initial gradient, and equals `result.grad`;
+  * variants of the product that must not matter do not: the reduced camera system solved on the device or on the host, the 6-wide camera
+    block or flags on the 12-wide one (fix_intrinsics), frame shards in one process (the north_star's partition) against one handle."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mc():
+    import multicam_calibration_amd as m
+
+    m.ops.load_library()
+    return m
+
+
+def quiet(f, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return f(*a, **k)
+
+
+@contextlib.contextmanager
+def env(**kv):
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update({k: str(v) for k, v in kv.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def draw(it):
+    rng = np.random.default_rng(9000 + it)
+    C = int(rng.choice([1, 2, 3, 4, 6, 9, 10, 14, 20]))
+    F = int(rng.integers(3, 40)) if C > 6 else int(rng.integers(3, 200))
+    rows, cols = int(rng.integers(2, 5)), int(rng.integers(2, 6))
+    loss = str(rng.choice(["soft_l1", "linear", "huber", "cauchy", "arctan"]))
+    opts = dict(loss=loss, f_scale=float(rng.choice([1.0, 0.5, 2.5])) if loss != "linear" else 1.0)
+    mk = dict(n_cameras=C, n_frames=F, rows=rows, cols=cols, pitch=float(rng.choice([12.5, 40.0])), seed=700 + it, perturb_seed=800 + it,
+              missing=float(rng.choice([0.0, 0.1, 0.3])), scalar_nans=int(rng.choice([0, 0, 7])), outlier_frames=int(rng.choice([0, 0, 2])) if F > 10 else 0)
+    fixed = bool(rng.random() < 0.35) and C <= 26
+    return mk, opts, fixed
+
+
+CASES = list(range(64))
+
+
+@pytest.mark.parametrize("it", CASES)
+def test_returned_point_is_a_minimiser_of_the_oracle_objective(mc, it):
+    mk, opts, fixed = draw(it)
+    p = mc.synth.make_problem(**mk)
+    C = mk["n_cameras"]
+    args = (p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    kw = dict(n_frames=None, ftol=1e-13, xtol=1e-13, gtol=1e-11, verbose=0, max_nfev=400, fix_intrinsics=fixed, **opts)
+    tag = f"case {it}: {mk} {opts} fixed={fixed}"
+    e, intr, poses, use, res = quiet(mc.bundle_adjust, *args, **kw)
+    # a redescending loss (cauchy, arctan) far from the optimum is a different matter: scipy's TRF does not terminate within 400
+    # evaluations on cases 12 / 15 either, and which local minimum is reached depends on round-off -- there the consistency checks
+    # below apply, termination and the agreement of the variants are asked of linear / soft_l1 / huber
+    tame = opts["loss"] in ("linear", "soft_l1", "huber")
+    assert res.status > 0 or not tame, tag
+    # the selection: the oracle's pre-filter (bundle_adjustment.py:265-298)
+    use_o = quiet(orc.prefilter_frames, *args, None, None)[0]
+    np.testing.assert_array_equal(use, use_o, err_msg=tag)
+    if use.size == 0:   # (one camera: no frame is complete in two -- the reference hands least_squares an empty problem)
+        assert res.status == 1 and res.nfev == 1 and res.fun.size == 0 and res.cost == 0.0, tag
+        np.testing.assert_array_equal(res.x, orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"][use]))
+        return
+    uvs = p["uvs"][:, use]
+    x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"][use])
+    x = res.x
+    assert x.shape == x0.shape
+    # cost / fun at x are the oracle's
+    f = orc.residuals(x, uvs, p["obj"])
+    cost = orc.robust_cost(f, opts["loss"], opts["f_scale"])
+    assert abs(res.cost - cost) <= 1e-11 * cost + 1e-14, tag
+    np.testing.assert_allclose(res.fun, f, rtol=0, atol=1e-9 * max(1.0, np.abs(f).max()), err_msg=tag)
+    c0 = orc.robust_cost(orc.residuals(x0, uvs, p["obj"]), opts["loss"], opts["f_scale"])
+    assert cost <= c0 * (1 + 1e-12), tag
+    # stationarity in the oracle's gradient (free parameters), against the gradient at the start
+    _, gc0, _, gf0, _, _ = orc.normal_equations(x0, uvs, p["obj"], opts["loss"], opts["f_scale"])
+    _, gc, _, gf, _, _ = orc.normal_equations(x, uvs, p["obj"], opts["loss"], opts["f_scale"])
+    if fixed:
+        gc0, gc = gc0.copy(), gc.copy()
+        gc0[:, :6], gc[:, :6] = 0.0, 0.0
+        np.testing.assert_array_equal(x[:12 * C].reshape(C, 12)[:, :6], x0[:12 * C].reshape(C, 12)[:, :6], err_msg=tag)   # intrinsics untouched
+    g0 = max(np.abs(gc0).max(), np.abs(gf0).max())
+    g = np.concatenate([gc.ravel(), gf.ravel()])
+    if tame:   # (a redescending loss can crawl into its ftol / xtol test well before the gradient vanishes)
+        assert np.abs(g).max() <= 1e-7 * g0 + 1e-8, (tag, np.abs(g).max(), g0)
+    assert np.abs(res.grad - g).max() <= 1e-6 * max(g0, np.abs(g).max()) + 1e-7, tag
+    assert abs(res.optimality - np.abs(res.grad).max()) <= 1e-12 * g0 + 1e-300, tag
+    # returned pieces are x, re-shaped the reference's way
+    e2, i2, p2 = orc.deserialize_params(x, C)
+    np.testing.assert_array_equal(e, e2)
+    np.testing.assert_array_equal(poses, p2)
+    for (K, d), (K2, d2) in zip(intr, i2):
+        np.testing.assert_array_equal(K, K2)
+        np.testing.assert_array_equal(d, d2)
+
+    if not tame:
+        return
+    # ---- variants that must not matter (compared through what they predict: the rig's gauge is free)
+    pred = orc.predict_from_x(x, C, p["obj"])
+    others = {"host-solved camera system": dict(reduced_solver="host")}
+    for name, extra in others.items():
+        r = quiet(mc.bundle_adjust, *args, **kw, **extra)[4]
+        assert r.status > 0 and abs(r.cost - res.cost) <= 1e-9 * res.cost + 1e-13, (tag, name)
+        assert np.abs(orc.predict_from_x(r.x, C, p["obj"]) - pred).max() < 1e-4, (tag, name)
+    if fixed:
+        with env(MCBA_FIXED_COMPACT="0"):
+            r = quiet(mc.bundle_adjust, *args, **kw)[4]
+        assert r.status > 0 and abs(r.cost - res.cost) <= 1e-9 * res.cost + 1e-13, (tag, "flags on the 12-wide block")
+        assert np.abs(orc.predict_from_x(r.x, C, p["obj"]) - pred).max() < 1e-4, (tag, "flags on the 12-wide block")
+
+
+@pytest.mark.parametrize("it", [2, 8, 14, 21, 23, 30, 37, 41, 48, 55, 62])
+def test_frame_shards_in_one_process_reach_the_same_minimiser(mc, it):
+    """The north_star's partition on random problems: the frames dealt out to 3 shards (solver.InProcessShards: one handle and one LM loop
+    per shard, one rank-ordered sum of the reduced camera systems per iteration) against ONE handle -- same decisions, same optimum."""
+    from multicam_calibration_amd import solver
+
+    mk, opts, fixed = draw(it)
+    mk = dict(mk, outlier_frames=0, n_frames=max(mk["n_frames"], 9))
+    p = mc.synth.make_problem(**mk)
+    C, F = mk["n_cameras"], mk["n_frames"]
+    x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+
+    import torch
+
+    def one(frames, rank=None, shards=None):
+        prob = mc.ops.Problem(np.ascontiguousarray(p["uvs"][:, frames]), p["obj"], loss=opts["loss"], f_scale=opts["f_scale"])
+        try:
+            if fixed:
+                assert prob.set_camera_block(6)          # (before the collective's buffer is sized)
+            comm = shards.comm(rank, prob, torch.device("cuda:0")) if shards is not None else None
+            xs = np.concatenate([x0[:12 * C], x0[12 * C:].reshape(F, 6)[frames].ravel()])
+            return solver.lm_solve(prob, xs, comm=comm, ftol=1e-13, xtol=1e-13, gtol=1e-11, max_nfev=300, verbose=0)
+        finally:
+            prob.close()
+
+    whole = one(np.arange(F))
+    world = 3
+    parts = [np.arange(F)[r::world] for r in range(world)]
+    shards = solver.InProcessShards(world)
+    res = shards.run(lambda rank: one(parts[rank], rank, shards))
+    key = lambda r: np.array([(h[0], h[1], h[2], h[5]) for h in r.lm["history"]])
+    for r in res[1:]:
+        np.testing.assert_array_equal(key(r), key(res[0]))                       # every shard takes the same decisions, to the bit
+        np.testing.assert_array_equal(r.x[:12 * C], res[0].x[:12 * C])
+    assert res[0].status > 0 and whole.status > 0
+    assert abs(res[0].cost - whole.cost) <= 1e-9 * whole.cost + 1e-13
+    xg = np.empty_like(x0)
+    xg[:12 * C] = res[0].x[:12 * C]
+    for r, fr in zip(res, parts):
+        xg[12 * C:].reshape(F, 6)[fr] = r.x[12 * C:].reshape(-1, 6)
+    assert np.abs(orc.predict_from_x(xg, C, p["obj"]) - orc.predict_from_x(whole.x, C, p["obj"])).max() < 1e-4
+    if fixed:
+        np.testing.assert_array_equal(xg[:12 * C].reshape(C, 12)[:, :6], x0[:12 * C].reshape(C, 12)[:, :6])

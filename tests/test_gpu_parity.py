@@ -786,6 +786,9 @@ def test_camera_block6_is_refused_late_and_beyond_26_cameras(mc):
 
 
 @pytest.mark.parametrize("shape,kw", [((4, 90), dict()), ((6, 700), dict(loss="cauchy", f_scale=0.7)), ((12, 30), dict()), ((3, 40), dict(reduced_solver="host")),
+                                      ((17, 14), dict()),     # 103 rows: the last size whose factor stays in LDS; separate k_backsub launch (more than 9 cameras)
+                                      ((21, 11), dict()),     # 127 rows: the right-looking solve on the 6-wide system
+                                      ((26, 9), dict(loss="huber")),   # the widest rig the 6-wide block serves
                                       ((3, 60), dict(x_scale="numeric")), ((3, 60), dict(x_scale="numeric", reduced_solver="host"))])
 def test_fix_intrinsics_compact_block_equals_flag_path(mc, shape, kw):
     """bundle_adjust(fix_intrinsics=True) on the 6-wide camera block (the default) and on the 12-wide block with the intrinsics'
