@@ -75,6 +75,7 @@ struct mcba_handle {
   // k_solve_backsub (single-GPU ticks, factor in LDS): the solve's launch also runs the back-substitution of the NEXT trial step;
   // trial_ready = the last tick did so, the next one must not back-substitute again.  The flag word sits behind the camera step.
   bool fuse_backsub = false, trial_ready = false;
+  unsigned long long last_solve_seq = 0;  // sequence number of the last mcba_lm_auto_solve / tick (what a timed-out back-substitution of that launch stamps)
   unsigned long long solve_launches = 0;  // k_solve_cam launches so far (SolveArgs.stage_tag)
   int ncu = 256, lds_optin = 160 * 1024;  // compute units and the LDS a workgroup may ask for (hipGetDeviceProperties at create; MI355X: 256 / 160 KiB)
   bool spec_copy_ready = false;  // the last k_reduce_system was a speculative one: the pre-decision state copy is in place
@@ -885,7 +886,7 @@ static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, boo
   {
     Scope sc(h, K_REDUCE);
     mcba::launch_reduce_system(h->stream, decide_here ? post_sel(h) : sl, h->gpart2[0], h->gpart2[1], h->spart, h->fpart, h->tile_i, h->tile_j, h->red, h->C, h->nfb, h->G, h->NT, h->NP, h->nfblocks, rank_slot,
-                               spec ? h->bpart : nullptr, h->nbblocks, spec ? post_state(h) : nullptr, h->cw);
+                               spec ? h->bpart : nullptr, h->nbblocks, spec ? post_state(h) : nullptr, h->cw, spec ? timeout_word(h) : nullptr, (double)h->last_solve_seq);
   }
   if ((rc = check_launch())) return rc;
   h->have_red = true;
@@ -956,6 +957,7 @@ int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, d
   HIPCHK(hipMemsetAsync(h->dcbuf + h->n, 0, 8 * sizeof(double), h->stream));  // sequence numbers restart: no stale release word
   HIPCHK(hipStreamSynchronize(h->stream));
   h->trial_ready = false;
+  h->last_solve_seq = 0;
   h->auto_ready = true;
   if (const char* e = getenv("MCBA_SPECULATE")) h->speculate = atoi(e) != 0;
   return MCBA_OK;
@@ -976,6 +978,7 @@ static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, b
   a.flag = fuse_next ? h->dcbuf + h->n : nullptr;
   a.timeout_word = timeout_word(h);
   a.seq = (double)seq; a.gtol = h->gtol; a.lam_max = h->lam_max;
+  h->last_solve_seq = seq;
   a.stage_tag = (double)(++h->solve_launches);
   a.n = h->n; a.npad = h->npad; a.use_lds = h->solve_lds; a.cw = h->cw;
   a.decide = decide ? 1 : 0; a.lam_min = h->lam_min; a.ftol = h->ftol; a.xtol = h->xtol; a.dec_floor = h->dec_floor;

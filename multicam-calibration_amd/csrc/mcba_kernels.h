@@ -87,7 +87,8 @@ int syrk_items_per_thread();
 // bpart != nullptr (speculative frame-sharded ticks): the trial scalars are summed here as well (red + nsys .. + 8) and the LM
 // state is copied to state_copy (MCBA_LMS doubles)
 void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot,
-                          const double* bpart = nullptr, int nbp = 0, double* state_copy = nullptr, int cw = 12);
+                          const double* bpart = nullptr, int nbp = 0, double* state_copy = nullptr, int cw = 12,
+                          const double* timeout_word = nullptr, double seq_prev = 0.0);  // (speculative ticks: trial scalar 5 = the previous fused back-substitution of this shard gave up)
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad, int cw = 12);
 void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const double* dc_dev, double* x0, double* x1, double* bpart, int C, int F, int Fpad, int cw = 12);
 size_t solve_lds_bytes(int npad, int use_lds);

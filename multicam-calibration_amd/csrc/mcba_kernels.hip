@@ -1391,7 +1391,8 @@ __device__ __forceinline__ double run_sum(const double* __restrict__ p, int coun
 template <int RR>
 __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __restrict__ gp0, const double* __restrict__ gp1, const double* __restrict__ spart, const double* __restrict__ fpart,
                                                         const int* __restrict__ tile_i, const int* __restrict__ tile_j, double* __restrict__ red, int C, int nfb, int G, int NT, int NP,
-                                                        int nfblocks, int rank_slot, const double* __restrict__ bpart, int nbp, double* __restrict__ state_copy, int cw) {
+                                                        int nfblocks, int rank_slot, const double* __restrict__ bpart, int nbp, double* __restrict__ state_copy, int cw,
+                                                        const double* __restrict__ timeout_word, double seq_prev) {
   const int n = cw * C, coff = 12 - cw;  // cw = 6: intrinsics held fixed -- row i of the system is parameter coff + i % cw of camera i / cw
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ double s_part[RR][16][64];
@@ -1521,11 +1522,15 @@ __global__ __launch_bounds__(1024) void k_reduce_system(Sel sl, const double* __
     }
     if (lane == 63) tail[2 * n + jj] = v;
   } else if (bpart && task < 2 * n + 24) {
-    // speculative (frame-sharded) ticks: the trial point's scalars [cost, pred_f, |d_f|^2, |x_f|^2, #pairs, 0, 0, 0] for the
+    // speculative (frame-sharded) ticks: the trial point's scalars [cost, pred_f, |d_f|^2, |x_f|^2, #pairs, stale, 0, 0] for the
     // all-reduce that follows -- the reduction is built from the trial linearisation, so its cost and pair count are the
-    // trial point's; what used to be a launch of its own (k_sum_trial) is eight more wavefront tasks here
+    // trial point's; what used to be a launch of its own (k_sum_trial) is eight more wavefront tasks here.
+    // stale: 1 if a back-substitution workgroup of THIS shard's previous k_solve_backsub gave up waiting for its solve (the trial
+    // point is then stale here).  Summed over the shards by the collective, so that every shard discards the tick -- a shard that
+    // rebuilt on its own would part from the others' decisions, and from then on from their sequence of collectives.
     const int jj = task - (2 * n + 16);
     double a = 0.0;
+    if (jj == 5 && lane == 0 && timeout_word && seq_prev > 0.0 && *timeout_word == seq_prev) a = 1.0;
     if (jj == 0 || jj == 4) {
       const int total = C * nfb, kk = jj == 0 ? 90 : 91;
       for (int base = 0; base < total; base += 512) {
@@ -1882,12 +1887,12 @@ void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, 
 int syrk_items_per_thread() { return SYRK_IPT; }
 
 void launch_reduce_system(hipStream_t st, Sel s, const double* gp0, const double* gp1, const double* spart, const double* fpart, const int* tile_i, const int* tile_j, double* red, int C, int nfb, int G, int NT, int NP, int nfblocks, int rank_slot,
-                          const double* bpart, int nbp, double* state_copy, int cw) {
+                          const double* bpart, int nbp, double* state_copy, int cw, const double* timeout_word, double seq_prev) {
   int n = cw * C;
   int tail_blocks = (2 * n + 16 + (bpart ? 9 : 0) + 15) / 16;
   // many tile pairs and few partials per pair (the 16-tile k_syrk: one workgroup per CU): one block per (pair, register) instead of four
-  if (NP >= 64 && G <= 128) k_reduce_system<4><<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy, cw);
-  else k_reduce_system<1><<<dim3(16 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy, cw);
+  if (NP >= 64 && G <= 128) k_reduce_system<4><<<dim3(4 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy, cw, timeout_word, seq_prev);
+  else k_reduce_system<1><<<dim3(16 * NP + tail_blocks), dim3(1024), 0, st>>>(s, gp0, gp1, spart, fpart, tile_i, tile_j, red, C, nfb, G, NT, NP, nfblocks, rank_slot, bpart, nbp, state_copy, cw, timeout_word, seq_prev);
 }
 
 void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const CamStep& dc, double* x0, double* x1, double* bpart, int C, int F, int Fpad, int cw) {

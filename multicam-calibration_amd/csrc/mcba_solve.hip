@@ -662,9 +662,10 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
     lms[MCBA_LM_TICK] += 1.0;
     if (a.decide) {  // one-collective ticks: the decision is taken here, on the all-reduced trial scalars
       if (lms[MCBA_LM_SKIP] != 0.0) lm_mark_rebuild(lms);  // this tick only rebuilt the system (no trial)
-      else if (a.timeout_word && *a.timeout_word == a.seq - 1.0 && a.seq > 1.0) {
-        // the previous tick's fused back-substitution gave up waiting: the trial point (and the speculative reduction built on
-        // it) is stale -- nothing is decided, the next tick rebuilds the system of the current point
+      else if (a.red[(size_t)n * n + 3 * n + 16 + 5] != 0.0) {
+        // the previous tick's fused back-substitution gave up waiting ON SOME SHARD (trial scalar 5: k_reduce_system's flag, summed by
+        // the collective -- a shard that found out from its own word alone would part from the others here): the trial point (and
+        // the speculative reduction built on it) is stale -- nothing is decided, the next tick rebuilds the system of the current point
         lm_mark_rebuild(lms);
         lms[MCBA_LM_SKIP] = 1.0;
         lms[MCBA_LM_SOLVE_INFO] = 4.0;

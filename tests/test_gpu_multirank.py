@@ -222,7 +222,9 @@ def _full_worker(rank, world, port, out_dir, shape, n_frames):
     import io
     import time
 
-    faulthandler.dump_traceback_later(int(os.environ.get("MCBA_TEST_WATCHDOG_S", "240")), exit=True)   # a hung rank reports where and ends: the test fails instead of hanging
+    # a hung rank reports where and ends: the test fails instead of hanging -- BEFORE the collectives' own timeout (180 s) fires in a
+    # rank that is only waiting for it, so that the rank that is stuck is the one whose stack is printed
+    faulthandler.dump_traceback_later(int(os.environ.get("MCBA_TEST_WATCHDOG_S", "150")), exit=True)
 
     import torch.distributed as dist
 
@@ -405,3 +407,65 @@ def test_frame_shards_with_the_six_wide_camera_block():
     np.testing.assert_array_equal(out[0].x[: 12 * C].reshape(C, 12)[:, :6], x0[: 12 * C].reshape(C, 12)[:, :6])
     xa = np.concatenate([out[0].x[: 12 * C]] + [r.x[12 * C:] for r in out])
     assert np.abs(orc.predict_from_x(xa, C, p["obj"]) - orc.predict_from_x(one.x, C, p["obj"])).max() < 1e-5
+
+
+def test_a_poll_timeout_on_one_shard_is_seen_by_all():
+    """The fused back-substitution's bounded poll (mcba_backsub.h) running out on ONE shard only: its trial point is stale, so that
+    tick must decide nothing -- on EVERY shard, or the shard that rebuilt alone takes other decisions from then on and, in a run with
+    real collectives, ends with another number of them (a hang).  The flag travels in the all-reduced trial scalars (slot 5).
+    Two shards in one process; shard 1's handle is created with MCBA_FUSE_MAX_POLLS=0 (its first fused poll gives up at once)."""
+    import torch
+
+    import multicam_calibration_amd as m
+    from oracle import ba_oracle as orc
+
+    C, F, world = 4, 2 * 320, 2
+    p = m.synth.make_problem(C, F, seed=31, missing=0.1)
+    x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    kw = dict(ftol=1e-13, xtol=1e-12, gtol=1e-9, max_nfev=40)
+    bounds = np.linspace(0, F, world + 1).astype(int)
+
+    def solve(polls_of_shard_1):
+        shards = m.solver.InProcessShards(world)
+        probs, comms, xs = [], [], []
+        for r in range(world):
+            old = os.environ.get("MCBA_FUSE_MAX_POLLS")
+            if r == 1 and polls_of_shard_1 is not None:
+                os.environ["MCBA_FUSE_MAX_POLLS"] = polls_of_shard_1
+            try:   # (the knob is read when the handle allocates its solver buffers: at the first linearisation)
+                pr = m.ops.Problem(np.ascontiguousarray(p["uvs"][:, bounds[r]:bounds[r + 1]]), p["obj"])
+                comms.append(shards.comm(r, pr, torch.device("cuda:0")))
+                xs.append(np.concatenate([x0[: 12 * C], x0[12 * C:].reshape(F, 6)[bounds[r]:bounds[r + 1]].ravel()]))
+                pr.set_params(0, xs[-1])
+                pr.linearize(0)
+                probs.append(pr)
+            finally:
+                if old is None:
+                    os.environ.pop("MCBA_FUSE_MAX_POLLS", None)
+                else:
+                    os.environ["MCBA_FUSE_MAX_POLLS"] = old
+
+        def run(rank):
+            pr = probs[rank]
+            try:
+                res = m.solver.lm_solve(pr, xs[rank], comm=comms[rank], **kw)
+                return res, pr.fuse_status()
+            finally:
+                pr.close()
+
+        return shards.run(run)
+
+    calm = solve(None)
+    hit = solve("0")
+    key = lambda r: np.array([(h[0], h[1], h[2], h[5]) for h in r.lm["history"]])
+    for out in (calm, hit):
+        np.testing.assert_array_equal(key(out[1][0]), key(out[0][0]))                       # both shards: the same decisions, to the bit
+        np.testing.assert_array_equal(out[1][0].x[: 12 * C], out[0][0].x[: 12 * C])
+        assert out[0][0].status > 0 and out[0][0].status == out[1][0].status and out[0][0].nfev == out[1][0].nfev
+    assert calm[0][1][0] == 0 and calm[1][1][0] == 0 and calm[0][0].lm["rebuilds"] == calm[1][0].lm["rebuilds"]
+    assert hit[1][1][0] > 0 and not hit[1][1][1]                                            # shard 1: the event is on record, its handle left the fused launch
+    assert hit[0][1][0] == 0                                                                # shard 0 never timed out itself ...
+    assert hit[0][0].lm["rebuilds"] == hit[1][0].lm["rebuilds"] > calm[0][0].lm["rebuilds"]  # ... and discarded the same tick
+    assert abs(hit[0][0].cost - calm[0][0].cost) <= 1e-9 * calm[0][0].cost
+    xa = lambda out: np.concatenate([out[0][0].x[: 12 * C]] + [o[0].x[12 * C:] for o in out])
+    assert np.abs(orc.predict_from_x(xa(hit), C, p["obj"]) - orc.predict_from_x(xa(calm), C, p["obj"])).max() < 1e-5
