@@ -176,3 +176,33 @@ def test_frame_shards_in_one_process_reach_the_same_minimiser(mc, it):
     assert np.abs(orc.predict_from_x(xg, C, p["obj"]) - orc.predict_from_x(whole.x, C, p["obj"])).max() < 1e-4
     if fixed:
         np.testing.assert_array_equal(xg[:12 * C].reshape(C, 12)[:, :6], x0[:12 * C].reshape(C, 12)[:, :6])
+
+
+def test_frame_selection_matches_the_oracle_prefilter(mc, capsys):
+    """The wrapper's pre-filter (bundle_adjustment.py:265-298) over random recordings: frames complete in two cameras, the 5 x nan-median
+    threshold (or the caller's), the random subsample drawn from the global numpy RNG when n_frames is smaller than what is left --
+    the same frames in the same order as the oracle, and the reference's printed line (threshold to 1e-12)."""
+    rng = np.random.default_rng(77)
+    for it in range(40):
+        C = int(rng.choice([2, 3, 5, 8]))
+        F = int(rng.choice([1, 5, 63, 64, 65, 200, 333]))
+        p = mc.synth.make_problem(C, F, rows=int(rng.integers(1, 4)), cols=int(rng.integers(2, 5)), seed=300 + it, missing=float(rng.choice([0.0, 0.2, 0.6])),
+                                  scalar_nans=int(rng.choice([0, 5])), outlier_frames=int(rng.choice([0, 1, 3])) if F > 5 else 0)
+        if rng.random() < 0.2:
+            p["uvs"][int(rng.integers(C))] = np.nan                       # a camera that sees nothing
+        thr = None if rng.random() < 0.6 else float(rng.choice([0.5, 5.0, 1e9]))
+        nf = None if rng.random() < 0.4 else int(rng.integers(1, F + 3))
+        args = (p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+        tag = f"case {it}: C={C} F={F} n_frames={nf} threshold={thr}"
+        np.random.seed(it)
+        want, _, _, line = orc.prefilter_frames(*args, nf, thr)
+        np.random.seed(it)
+        got = mc.api.select_frames(*args, nf, thr)
+        out = capsys.readouterr().out
+        np.testing.assert_array_equal(got, want, err_msg=tag)
+        assert got.dtype.kind == "i"
+        # the printed line: the same counts; the threshold is 5 x the exact median of the GPU's own errors, which differ from numpy's in the last bits
+        head, _, t_got = out.strip().splitlines()[-1].rpartition(" ")
+        head_o, _, t_want = line.rpartition(" ")
+        assert head == head_o, (tag, out, line)
+        assert (t_got == t_want == "nan") or abs(float(t_got) - float(t_want)) <= 1e-12 * abs(float(t_want)), (tag, out, line)

@@ -65,3 +65,25 @@ def test_the_config5_rig_triangulates(mc):
     intr_t = [(K, np.array([d[0], d[1], 1e-3, -5e-4, 1e-3])) for K, d in intr]
     want = tri.triangulate(uvs, ext, intr_t)
     assert np.abs(mc.triangulate(uvs, ext, intr_t) - want).max() <= 1e-8 * np.abs(want).max()
+
+
+def test_random_rigs_and_occlusion_patterns_vs_oracle(mc):
+    """Seeded random sweep: 2..64 cameras (both kernels, the 8 | 9 switch, the 64-camera limit), point counts around the 64-lane
+    wavefront, occlusion from none to almost everything (points left with 0, 1, 2 views), single missing coordinates -- NaN pattern
+    identical to the oracle's, values to the DLT's conditioning."""
+    rng = np.random.default_rng(404)
+    for it in range(40):
+        C = int(rng.choice([2, 3, 4, 7, 8, 9, 10, 16, 33, 63, 64]))
+        P = int(rng.choice([1, 2, 63, 64, 65, 130, 257]))
+        uvs, ext, intr, X = scene(C=C, P=P, seed=1000 + it, noise=float(rng.choice([0.0, 0.3])), p_unseen=float(rng.choice([0.0, 0.3, 0.7, 0.95])))
+        uvs = [u.copy() for u in uvs]
+        for _ in range(int(rng.integers(0, 4))):           # a detection with ONE coordinate missing counts as unseen (geometry.py: isnan(...).any)
+            uvs[int(rng.integers(C))][int(rng.integers(P)), int(rng.integers(2))] = np.nan
+        want = tri.triangulate(uvs, ext, intr)
+        got = mc.triangulate(uvs, ext, intr)
+        tag = f"case {it}: C={C} P={P}"
+        assert got.shape == want.shape == (P, 3), tag
+        assert np.array_equal(np.isnan(got), np.isnan(want)), tag
+        ok = ~np.isnan(want).any(1)
+        if ok.any():
+            assert np.abs(got[ok] - want[ok]).max() <= 1e-7 * max(1.0, np.abs(want[ok]).max()), (tag, np.abs(got[ok] - want[ok]).max())
