@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_seen_bits(const double* __restrict__ ob
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const double v = i < count ? __builtin_nontemporal_load(obs_raw + i) : __builtin_nan("");
   const unsigned long long b = __ballot(v == v);
-  if ((threadIdx.x & 63) == 0) words[i >> 6] = __builtin_bswap64(__brevll(b));
+  if ((threadIdx.x & 63) == 0 && i < count) words[i >> 6] = __builtin_bswap64(__brevll(b));  // (the last block's wavefronts past the end own no word)
 }
 
 // ---------------------------------------------------------------- undistortion (cv2.undistortPoints(src, K, dist, None, K))
