@@ -11,7 +11,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py --no-cpu-baseline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --no-cpu-baseline --no-end-to-end > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err
+# (--no-other-configs: the headline tick alone -- configs[0] runs the same k_syrk / k_solve_backsub instances at a tenth of the size and would be averaged in)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --no-cpu-baseline --no-end-to-end --no-other-configs > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err
 echo "kernel stats done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 scripts/profile_kernels.py > $OUT/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 scripts/profile_kernels.py > $OUT/${TAG}_pmc_write.log 2>&1
