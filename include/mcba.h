@@ -200,8 +200,10 @@ int mcba_lm_iterate(mcba_handle* h, const double* delta_cam, double pred_cam, do
  *                       decide = 1: the stand-alone decision kernel first (sharded runs with TWO collectives: trial scalars,
  *                       then the system);  decide = 2: SPECULATIVE reduction (sharded runs with ONE collective): the trial
  *                       linearisation is reduced before the decision is known, on the prediction "accepted, lambda' =
- *                       max(lambda / 3, lambda_min)", and the 8 trial scalars are (re)written behind the system; the caller
- *                       all-reduces [system | trial scalars] in one go
+ *                       max(lambda / 3, lambda_min)", and the 8 trial scalars [cost, pred_f, |d_f|^2, |x_f|^2, #pairs, stale, 0, 0]
+ *                       are (re)written behind the system (stale = 1 if a back-substitution workgroup of this handle's previous fused
+ *                       launch gave up waiting for its solve: the SUM over the shards is what the deciding solve tests, so that every
+ *                       shard discards such a tick); the caller all-reduces [system | trial scalars] in one go
  *                       (offset 0, n*n + 3n + 16 + 8 doubles) and calls mcba_lm_auto_solve(seq, decide = 1), which takes
  *                       the decision and, if the prediction does not hold (rejected step, or another damping), marks the
  *                       next tick as a rebuild-only tick instead of solving;
