@@ -84,6 +84,13 @@ int mcba_set_loss(mcba_handle* h, int loss, double f_scale);
  * (MCBA_ERR_ARG afterwards, and for width 6 with more than 26 cameras: hold those with the `fixed` flags instead). */
 int mcba_set_camera_block(mcba_handle* h, int width);
 int mcba_get_camera_block(const mcba_handle* h);
+/* Curvature weight of the linearisations enqueued from now on: w = max(rho' + 2 rho'' f^2, floor * rho'), 0 < floor <= 1.
+ * 1 (default) = the IRLS weight rho' (monotone: the model for points far from the optimum); 0.1 = Triggs' second-order term with a
+ * safety floor (fast at the optimum).  The reference has no counterpart: scipy's TRF always uses the Triggs weight clamped at EPS
+ * (common.py:720-731); the stationary point does not depend on the choice, the number of evaluations does (16 -> 6 to the reference's
+ * default tolerance at 6 x 10 000 x 54).  solver.py switches between ticks: IRLS, Triggs after an accepted step that gained < 1 %. */
+int mcba_set_curvature_floor(mcba_handle* h, double floor);
+double mcba_get_curvature_floor(const mcba_handle* h);
 
 /* least_squares' numeric `x_scale` (forwarded verbatim by the reference: bundle_adjustment.py:301-313; scipy least_squares.py
  * :243, trf.py:415-420): 12C + 6F positive doubles in the layout of x -> the FIXED damping matrix D = diag(1 / x_scale^2) replaces

@@ -308,6 +308,8 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
       device=0             HIP device ordinal (distributed: defaults to LOCAL_RANK)
       fix_intrinsics=False hold fx fy cx cy k1 k2 of every camera (BASELINE config 2); extrinsics + poses only
       lam0=1e-2, dec_floor=0.1   damping schedule of the LM loop (solver.py); dec_floor=1/3 is Nielsen's classical rule
+      curvature="auto"           curvature model of the linearisations (solver.py: CURV_SWITCH): "auto" = the IRLS weight rho' until an accepted step
+                                 gains less than 1 % of the cost, then Triggs' second-order term; "irls" / "triggs" = one of them throughout
       return_jac=True      attach the robust-rescaled CSR Jacobian as `result.jac` (18 nnz/row; 1.4 GB at 6x10k x54) -- lazily: it is
                            produced when the field is first read; until then the result keeps the GPU handle alive
                            (return_jac=False releases it at once)
@@ -335,7 +337,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     device = opt_kwargs.pop("device", 0)
     fix_intrinsics = opt_kwargs.pop("fix_intrinsics", False)
     return_jac = opt_kwargs.pop("return_jac", True)
-    lm_kwargs = {k: opt_kwargs.pop(k) for k in ("lam0", "dec_floor", "reduced_solver") if k in opt_kwargs}
+    lm_kwargs = {k: opt_kwargs.pop(k) for k in ("lam0", "dec_floor", "reduced_solver", "curvature") if k in opt_kwargs}
 
     kw = dict(verbose=2, x_scale="jac", ftol=1e-4, method="trf", loss="soft_l1")
     kw.update(opt_kwargs)

@@ -57,6 +57,7 @@ struct mcba_handle {
   int gram_split = 0;  // 0: both accumulator sets in one lane (1 wave/SIMD); 1: two roles, two waves/SIMD (few frames); 2 / 3: fused rounds + split-role / point-chunk tail;
                        // 4: point split inside the workgroup (gram_npw wavefronts per (camera, frame block)); 5: fused rounds + point-split tail
   int gram_npw = 4;
+  double curv_floor = 1.0;  // curvature weight of the NEXT linearisations: max(Triggs, curv_floor rho') -- 1 = IRLS (mcba_set_curvature_floor; csrc/mcba_math.h)
   int cw = 12;         // camera block width: 12, or 6 = the intrinsics of every camera are held fixed (mcba_set_camera_block; BASELINE configs[1]): n = cw C
   size_t nx = 0, nsys = 0;
   double* pinned = nullptr;  // nsys + 8 doubles, + 12C for dc
@@ -131,6 +132,8 @@ mcba::Sel spec_sel(const mcba_handle* h) { return mcba::Sel{h->red + h->nsys + 8
 // the state AFTER the decision k_syrk took itself (single-GPU ticks): a second buffer behind the first
 double* post_state(const mcba_handle* h) { return h->red + h->nsys + 8 + MCBA_LMS; }
 mcba::Sel post_sel(const mcba_handle* h) { return mcba::Sel{post_state(h), 0, 0.0, 0, 0.0}; }
+// a linearisation's selector: + the curvature floor this handle linearises with (mcba_set_curvature_floor)
+mcba::Sel gram_sel(const mcba_handle* h, mcba::Sel s) { s.cfl = h->curv_floor; return s; }
 mcba::SyrkFuse no_fuse() { mcba::SyrkFuse z{}; return z; }
 
 int check_launch() {
@@ -361,7 +364,7 @@ static int derive_geometry(mcba_handle* h) {
 
 extern "C" {
 
-int mcba_abi_version(void) { return 5; }  // 5: camera block width (intrinsics held fixed: 6C x 6C camera system), round 4
+int mcba_abi_version(void) { return 5; }  // 5: camera block width (intrinsics held fixed: 6C x 6C camera system), curvature floor per linearisation, round 4
 const char* mcba_last_error(void) { return g_err.c_str(); }
 const char* mcba_profile_names(void) { return kKernelNames; }
 
@@ -560,6 +563,17 @@ int mcba_set_camera_block(mcba_handle* h, int width) {
 }
 int mcba_get_camera_block(const mcba_handle* h) { return h ? h->cw : 0; }
 
+// Curvature weight of the linearisations this handle launches from now on: w = max(rho' + 2 rho'' f^2, floor rho') (csrc/mcba_math.h).
+// 1 (the default) = the IRLS weight rho': monotone, the model to be far from the optimum with; 0.1 = Triggs' second-order term with a
+// safety floor: the model to finish with.  A kernel argument: takes effect with the next linearisation that is ENQUEUED (the caller's
+// LM driver switches between ticks; solver.py), costs nothing, changes no buffer.
+int mcba_set_curvature_floor(mcba_handle* h, double floor) {
+  if (!h || !(floor > 0.0) || floor > 1.0) return fail(MCBA_ERR_ARG, "mcba_set_curvature_floor: 0 < floor <= 1");
+  h->curv_floor = floor;
+  return MCBA_OK;
+}
+double mcba_get_curvature_floor(const mcba_handle* h) { return h ? h->curv_floor : 0.0; }
+
 static int slot_ok(mcba_handle* h, int slot) { return h && (slot == 0 || slot == 1); }
 
 int mcba_set_params(mcba_handle* h, int slot, const double* x) {
@@ -679,7 +693,7 @@ int mcba_linearize(mcba_handle* h, int slot) {
   NEED_SOLVER(h);
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
   }
   int rc = check_launch();
   if (rc) return rc;
@@ -758,7 +772,7 @@ int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, 
   const int alt = 1 - h->lin;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, host_sel(0), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -808,6 +822,7 @@ int mcba_lm_set_state(mcba_handle* h, const double* state) {
   NEED_SOLVER(h);
   double* stage = h->pinned + h->nsys + 8;
   memcpy(stage, state, MCBA_LMS * sizeof(double));
+  if (!(stage[MCBA_LM_CFL] > 0.0)) stage[MCBA_LM_CFL] = h->curv_floor;  // (a caller that fills the first four entries only: the handle's model, fixed)
   HIPCHK(hipMemcpyAsync(h->red + h->nsys + 8, stage, MCBA_LMS * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (sel != h->lin) {
@@ -834,7 +849,7 @@ static int lm_trial_impl(mcba_handle* h, const double* delta_cam, const mcba::De
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);  // trial point = the OTHER slot / buffer
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, dev_sel(h, 1)), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -1016,7 +1031,7 @@ static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, dev_sel(h, 1), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, dev_sel(h, 1)), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
   }
   if ((rc = check_launch())) return rc;
   if (!sum_here) return MCBA_OK;

@@ -24,6 +24,7 @@ struct Sel {
   double lam;   // host value of the damping (lms == nullptr); lambda_min when spec != 0
   int spec;     // speculative Schur reduction of the trial linearisation (see sel_spec in mcba_kernels.hip)
   double dec;   // spec != 0: floor of Nielsen's factor the prediction assumes (mcba_lm.h: lm_spec_lambda)
+  double cfl = 1.0;  // k_gram only: curvature floor of this linearisation (mcba_math.h: lm_weight) -- 1 = the IRLS weight rho', 0.1 = Triggs with a floor
 };
 // k_syrk's fused decision prologue (single-GPU ticks of the device-resident loop; see k_syrk in mcba_kernels.hip)
 struct SyrkFuse {

@@ -111,11 +111,11 @@ __device__ __forceinline__ double uni(double v) {
 }
 __device__ __forceinline__ bool is_num(double v) { return v == v; }
 template <int LOSS, bool UNIT = false>
-__device__ __forceinline__ void obs_weights(double r, bool valid, double fs2, double ifs2, double& cost, double& w2, double& g) {
+__device__ __forceinline__ void obs_weights(double r, bool valid, double fs2, double ifs2, double cfl, double& cost, double& w2, double& g) {
   double rh, gw, ww;
   loss_weights<LOSS, UNIT>(r, fs2, ifs2, rh, gw, ww);
   cost += valid ? rh : 0.0;
-  w2 = valid ? lm_weight(gw, ww) : 0.0;
+  w2 = valid ? lm_weight(gw, ww, cfl) : 0.0;
   g = valid ? gw * r : 0.0;
 }
 
@@ -168,7 +168,7 @@ __host__ __device__ constexpr int gram_xch_doubles(int npw, bool with_b) {
 }
 template <int LOSS, int ROLE, bool FAST = false, int MODE = 0, int NPW = 1>
 __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
-                                          double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2,
+                                          double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2, double cfl,
                                           const double (&pz0)[6], const double2 (&pre)[4], double* s_cost, int nrun, int p_lo = 0, int p_hi = -1, double2* chunk = nullptr, int nchunk = 1,
                                           size_t chunk_stride = 0) {
   if (p_hi < 0) p_hi = N;
@@ -224,8 +224,8 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       ObsCommon q;
       obs_common(K, pc, Xo, q);
       double wu2, wv2, gu, gv;
-      obs_weights<LOSS>(o2.x - q.up, vu, fs2, ifs2, cost, wu2, gu);
-      obs_weights<LOSS>(o2.y - q.vp, vv, fs2, ifs2, cost, wv2, gv);
+      obs_weights<LOSS>(o2.x - q.up, vu, fs2, ifs2, cfl, cost, wu2, gu);
+      obs_weights<LOSS>(o2.y - q.vp, vv, fs2, ifs2, cfl, cost, wv2, gv);
       {  // u row, completely, before the v row exists: one [A|P] row live at a time
         double E[6];
         obs_row_cam<0>(q, E);
@@ -282,8 +282,8 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       const bool vu = is_num(o2[0]), vv = is_num(o2[1]);
       any = any || vu || vv;
       double wu2, wv2, gu, gv;
-      obs_weights<LOSS, FAST>(o2[0] - q.up, vu, fs2, ifs2, cost, wu2, gu);
-      obs_weights<LOSS, FAST>(o2[1] - q.vp, vv, fs2, ifs2, cost, wv2, gv);
+      obs_weights<LOSS, FAST>(o2[0] - q.up, vu, fs2, ifs2, cfl, cost, wu2, gu);
+      obs_weights<LOSS, FAST>(o2[1] - q.vp, vv, fs2, ifs2, cfl, cost, wv2, gv);
       {
         double E[6];
         obs_row_cam<0>(q, E);
@@ -342,8 +342,8 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       const bool vu = is_num(o2.x), vv = is_num(o2.y);
       any = any || vu || vv;
       double wu2, wv2, gu, gv;
-      obs_weights<LOSS, FAST>(o2.x - q.up, vu, fs2, ifs2, cost, wu2, gu);
-      obs_weights<LOSS, FAST>(o2.y - q.vp, vv, fs2, ifs2, cost, wv2, gv);
+      obs_weights<LOSS, FAST>(o2.x - q.up, vu, fs2, ifs2, cfl, cost, wu2, gu);
+      obs_weights<LOSS, FAST>(o2.y - q.vp, vv, fs2, ifs2, cfl, cost, wv2, gv);
       {
         double E[6];
         obs_row_cam<0>(q, E);
@@ -764,6 +764,7 @@ struct GramStart {
   double2 pre[4];
   int fb, lane;
   bool run;
+  double cfl;  // curvature floor of this linearisation: the LM state's (device-resident loops) or the launch's (Sel.cfl)
 };
 __device__ __forceinline__ void gram_start(GramStart& g, CamConst& s_cam, const double2* __restrict__ obs_t, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1, double* rec0, double* rec1,
                                            double* gp0, double* gp1, int C, int N, int Fpad, int fb0, int fb1, int p_lo = 0, int p_hi = -1, int npw = 1,
@@ -776,8 +777,8 @@ __device__ __forceinline__ void gram_start(GramStart& g, CamConst& s_cam, const 
   g.fb = fb0 + bx * ((blockDim.x >> 6) / npw) + wave / npw;  // this launch covers the frame blocks [fb0, fb1), one per wavefront (point split: per npw wavefronts)
   const bool have = g.fb < fb1;
   const int fbc = have ? g.fb : fb1 - 1;
-  double st3 = 0.0, st14 = 0.0, st15 = 0.0;
-  if (sl.lms) { st3 = sl.lms[3]; st14 = sl.lms[MCBA_LM_SKIP]; st15 = sl.lms[MCBA_LM_DONE]; }
+  double st3 = 0.0, st14 = 0.0, st15 = 0.0, st25 = sl.cfl;
+  if (sl.lms) { st3 = sl.lms[3]; st14 = sl.lms[MCBA_LM_SKIP]; st15 = sl.lms[MCBA_LM_DONE]; st25 = sl.lms[MCBA_LM_CFL]; }
   const size_t po = (size_t)12 * C + 6 * ((size_t)fbc * 64 + g.lane);
   double pa[6], pb[6], ca[12], cb[12];
 #pragma unroll
@@ -804,6 +805,7 @@ __device__ __forceinline__ void gram_start(GramStart& g, CamConst& s_cam, const 
     for (int i = 0; i < 12; ++i) cm[i] = sidx ? cb[i] : ca[i];
     make_cam_const(cm, s_cam);
   }
+  g.cfl = st25;
   g.run = active;
   if (active) __syncthreads();  // (uniform: the state is the same for every thread)
   g.run = active && have;
@@ -821,8 +823,8 @@ __global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict
   if (!g.run) return;
   const int c = blockIdx.y;
   const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));  // wavefronts of this workgroup that have a frame block
-  if (blockIdx.z == 0) gram_body<LOSS, 0>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun);
-  else gram_body<LOSS, 1>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun);
+  if (blockIdx.z == 0) gram_body<LOSS, 0>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, nrun);
+  else gram_body<LOSS, 1>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, nrun);
 }
 
 // Both roles in one lane: grid.z = 1, one wave per SIMD (all 87 accumulators + temporaries in the 512-register file).
@@ -838,10 +840,10 @@ __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t,
   const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));  // wavefronts of this workgroup that have a frame block
 #if MCBA_GRAM_GLDS
   __shared__ __align__(16) double2 s_ring[4][MCBA_GRAM_GLDS][64];
-  gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun, 0, -1, &s_ring[threadIdx.x >> 6][0][0]);
+  gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, nrun, 0, -1, &s_ring[threadIdx.x >> 6][0][0]);
   return;
 #endif
-  gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun);
+  gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, nrun);
 }
 
 // Point split inside the workgroup (gram_body MODE 3): the workgroup's four wavefronts are 4 / NPW (camera, frame block) items of
@@ -863,7 +865,7 @@ __global__ __launch_bounds__(256) void k_gram_psplit(const double2* __restrict__
   GramStart g;
   gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1, p_lo, max(p_hi, p_lo + 1), NPW);  // (an empty piece -- fewer points than wavefronts -- still prefetches a valid point)
   if (!g.run) return;
-  gram_body<LOSS, ROLE, FAST, 3, NPW>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, 0, p_lo, p_hi, reinterpret_cast<double2*>(s_xch));
+  gram_body<LOSS, ROLE, FAST, 3, NPW>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, 0, p_lo, p_hi, reinterpret_cast<double2*>(s_xch));
 }
 
 // Whole rounds of the wavefront slots fused AND the short last round point-split, in ONE launch (round 4): a 1-D grid whose first
@@ -884,14 +886,14 @@ __global__ __launch_bounds__(256) void k_gram_mixed(const double2* __restrict__ 
     gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, 0, fba, 0, -1, 1, bx, c);
     if (!g.run) return;
     const int nrun = min(4, fba - bx * 4);
-    gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun);
+    gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, nrun);
   } else {
     const int id2 = id - nf * C, c = id2 / nt, bx = id2 - c * nt;
     const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) % NPW;
     const int p_lo = (int)(((long long)N * part) / NPW), p_hi = (int)(((long long)N * (part + 1)) / NPW);
     gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fba, nfb, p_lo, max(p_hi, p_lo + 1), NPW, bx, c);
     if (!g.run) return;
-    gram_body<LOSS, 2, FAST, 3, NPW>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, 0, p_lo, p_hi, reinterpret_cast<double2*>(s_xch));
+    gram_body<LOSS, 2, FAST, 3, NPW>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, 0, p_lo, p_hi, reinterpret_cast<double2*>(s_xch));
   }
 }
 
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(64) void k_gram_chunk(const double2* __restrict__ o
   if (!g.run) return;
   const int ntb = fb1 - fb0;
   double2* dst = chunk + ((((size_t)blockIdx.y * ntb + (g.fb - fb0)) * nchunk + blockIdx.z) * (kGramRaw / 2)) * 64 + g.lane;
-  gram_body<LOSS, 2, FAST, 1>(s_cam, obs_t, obj, g.x, nullptr, nullptr, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, 0, p_lo, p_hi, dst);
+  gram_body<LOSS, 2, FAST, 1>(s_cam, obs_t, obj, g.x, nullptr, nullptr, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, 0, p_lo, p_hi, dst);
 }
 template <int LOSS, bool FAST>
 __global__ __launch_bounds__(256) void k_gram_combine(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
@@ -925,7 +927,7 @@ __global__ __launch_bounds__(256) void k_gram_combine(const double2* __restrict_
   const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));
   const int ntb = fb1 - fb0;
   const double2* src = chunk + (((size_t)blockIdx.y * ntb + (g.fb - fb0)) * nchunk * (kGramRaw / 2)) * 64 + g.lane;
-  gram_body<LOSS, 2, FAST, 2>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.pz, g.pre, s_cost, nrun, 0, N, const_cast<double2*>(src), nchunk,
+  gram_body<LOSS, 2, FAST, 2>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, nrun, 0, N, const_cast<double2*>(src), nchunk,
                               (size_t)(kGramRaw / 2) * 64);
 }
 

@@ -42,8 +42,8 @@ MCBA_HD void lm_decide(const double* trial8, const DecideArgs& da, const LmPre& 
   double ratio = ok ? (cost - cost_new) / pred : -1.0;
   double dF = cost - cost_new;
   // round-off guard: near the optimum the last Gauss-Newton corrections change the cost by less than FP64 resolves
-  // (|dF| ~ EPS * F * sqrt(m)); such a step is neutral, not bad -- accept it with the damping unchanged
-  bool neutral = isfinite(cost_new) && pred >= 0.0 && fabs(dF) <= 32.0 * MCBA_EPS * fabs(cost);
+  // (|dF| ~ EPS * F * sqrt(m)); such a step is neutral, not bad -- accept it with the damping unchanged (band: MCBA_NEUTRAL_BAND, mcba_math.h)
+  bool neutral = isfinite(cost_new) && pred >= 0.0 && fabs(dF) <= MCBA_NEUTRAL_BAND * fabs(cost);
   bool accepted = (ratio > 0.0 && dF >= 0.0) || neutral;
   if (accepted) {
     if (!(ratio > 0.0 && dF >= 0.0)) ratio = 0.5;  // neutral: factor 1 in Nielsen's rule
@@ -54,13 +54,27 @@ MCBA_HD void lm_decide(const double* trial8, const DecideArgs& da, const LmPre& 
     sel ^= 1;
     cost = cost_new;
   } else {
-    lam = fmin(lam * nu, da.lam_max);
-    nu *= 2.0;
+    // (a grey rejection -- the cost rose by less than MCBA_GREY_LEVEL of itself: round-off decides such tests -- doubles the damping
+    //  without escalating; mcba_math.h)
+    const bool grey = cost_new - cost_before <= MCBA_GREY_LEVEL * cost_before;
+    lam = fmin(lam * (grey ? 2.0 : nu), da.lam_max);
+    nu = grey ? 2.0 : nu * 2.0;
   }
   const double step_norm = sqrt(trial8[2] + dcn2), x_norm = sqrt(trial8[3] + xcn2);
   lms[0] = cost; lms[1] = lam; lms[2] = nu; lms[3] = sel; lms[4] = accepted ? 1.0 : 0.0;
   lms[5] = cost_new; lms[6] = pred; lms[7] = ratio;
   lms[8] = step_norm; lms[9] = x_norm; lms[10] = dF;
+  // curvature model of the next linearisations (mcba_math.h: lm_weight; solver.py: CURV_SWITCH): the majoriser (IRLS) while steps still
+  // gain, Triggs' second-order term once an accepted step gained less than the switch fraction of the cost, back after a rejection.
+  // Taken here, with the decision, so that every driver (device-resident, host solve, host-driven) changes model at the same step.
+  {
+    const double sw = lms[MCBA_LM_CFL_SWITCH];
+    if (sw > 0.0) {
+      // (a rejection at round-off level -- the tail of a converged run -- is no reason to leave Triggs: only a cost that really went up)
+      if (!accepted) { if (!(cost_new - cost_before <= MCBA_GREY_LEVEL * cost_before)) lms[MCBA_LM_CFL] = MCBA_CURV_FLOOR_IRLS; }
+      else if (neutral || dF < sw * cost_before) lms[MCBA_LM_CFL] = MCBA_CURV_FLOOR_TRIGGS;
+    }
+  }
   if (dev) {  // termination tests of solver.LevenbergMarquardt._iterate_device, verdict applied by the next k_solve_cam
     const bool ftol_ok = fmax(dF, 0.0) < da.ftol * cost_before && ratio > 0.25;
     const bool xtol_ok = step_norm < da.xtol * (da.xtol + x_norm);

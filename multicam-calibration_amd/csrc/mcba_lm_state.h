@@ -19,6 +19,8 @@
 #define MCBA_LM_TICK 22        // ticks that did work
 #define MCBA_LM_SOLVE_INFO 23  // 0 ok, 1 reduced system not positive definite / non-finite step, 2 a frame block failed
 #define MCBA_LM_REBUILD 24     // 1: the last tick was a damping-only rebuild (no trial)
+#define MCBA_LM_CFL 25         // curvature floor of the NEXT linearisations (mcba_math.h: lm_weight): 1 = IRLS, 0.1 = Triggs with a floor
+#define MCBA_LM_CFL_SWITCH 26  // > 0: the decision moves MCBA_LM_CFL -- Triggs after an accepted step that gained less than this fraction of the cost, IRLS after a rejected one; 0: fixed
 #define MCBA_LM_SEQ 31         // host ring slots only: sequence number of the tick, written last
 
 namespace mcba {

@@ -29,13 +29,29 @@ namespace mcba {
 enum Loss { LOSS_LINEAR = 0, LOSS_SOFT_L1 = 1, LOSS_HUBER = 2, LOSS_CAUCHY = 3, LOSS_ARCTAN = 4 };
 
 constexpr double MCBA_EPS = 2.220446049250313e-16;
-// Curvature floor of the LM's internal Gauss-Newton weight, as a fraction of the IRLS weight rho'.
-// scipy clamps the Triggs weight rho' + 2 rho'' f^2 at EPS (common.py:724-726); for the concave zone of
-// huber/cauchy/arctan (and far outliers of soft_l1) that leaves J^T J ~ 0 and Marquardt scaling cannot
-// regularise.  rho' J^T J is the majorising (always descending) quadratic, so a fraction of it is a safe floor.
-// The floor only steers the iteration: the stationary point (J^T rho' f = 0) does not depend on it, and the
+// Resolution of the robust cost as the kernels evaluate it (a sum over up to ~1e7 terms, reduced per wavefront, per workgroup, per
+// launch).  A step whose gain is inside MCBA_NEUTRAL_BAND of the cost is NEUTRAL: accepted with the damping unchanged (mcba_lm.h).
+// A step that is rejected with a cost increase below MCBA_GREY_LEVEL is a GREY rejection: the accept / reject test is a coin toss
+// there (the 9-camera golden evaluates its optimum 55-70 EPS lower than its neighbours), so the damping only doubles -- the escalation
+// nu *= 2 is for steps that really went uphill.  Before round 4 five such rejections in a row took the damping from 1e-9 to 0.27 and
+// the step-size test ended the run 7e-6 away from the optimum (profiles/round4/NOTES_round4.md section 13).  The same level decides
+// whether a rejection sends the curvature model back to IRLS (below).
+constexpr double MCBA_NEUTRAL_BAND = 32.0 * MCBA_EPS;
+constexpr double MCBA_GREY_LEVEL = 1e-9;
+// Curvature weight of the LM's normal equations: scipy's Triggs weight with a floor in units of the IRLS weight rho',
+//   w = max(rho' + 2 rho'' f^2, floor * rho'),      floor a RUN-TIME value per linearisation (Sel.cfl, mcba_set_curvature_floor).
+// scipy clamps the Triggs weight at EPS (common.py:724-726); for the concave zone of huber / cauchy / arctan (and far outliers of
+// soft_l1) that leaves J^T J ~ 0 and Marquardt scaling cannot regularise.  rho' J^T J is the majorising (always descending) quadratic:
+//   floor = 1   : w = rho' (rho'' <= 0 for every loss here): plain IRLS -- monotone, robust far from the optimum, linear rate at it;
+//   floor = 0.1 : Triggs' second-order term with a safety floor -- fast AT the optimum, but away from it the model UNDER-estimates the
+//                 cost along the step wherever residuals are large: steps are rejected, the damping climbs (rounds 1-3 ran on this
+//                 alone: 16 evaluations to the reference's default tolerance on the bench problem where IRLS needs 6, and
+//                 redescending losses started far from the optimum did not terminate within 400: round 4's randomised sweep,
+//                 tests/test_gpu_fuzz.py, profiles/round4/NOTES_round4.md section 13).
+// The LM driver (solver.py) starts on IRLS and switches to Triggs when an accepted step gained less than 1 % of the cost, back on a
+// rejected step.  The weight only steers the iteration: the stationary point (J^T rho' f = 0) does not depend on it, and the
 // materialised Jacobian (k_jacobian -> result.jac) keeps scipy's exact scaling.
-constexpr double MCBA_CURV_FLOOR = 0.1;
+constexpr double MCBA_CURV_FLOOR_IRLS = 1.0, MCBA_CURV_FLOOR_TRIGGS = 0.1;
 
 // ---------------------------------------------------------------- fast reciprocal / reciprocal square root
 // On the GPU: the hardware seed (v_rcp_f64 / v_rsq_f64: 4.6e-8 / 5.2e-8 relative error, measured on MI355X by
@@ -208,7 +224,7 @@ MCBA_HD void make_chain_const(const double* Rc, const double* Jrc, const double*
 //      gw = rho'(z)                      (gradient weight:  g = J^T (rho' f))
 //      w2 = max(rho' + 2 rho'' f^2, EPS) (scipy's J_scale^2: J~^T J~ = sum w2 j^T j)
 // lm_weight() turns (gw, w2) into the curvature weight the LM normal equations use.
-MCBA_HD double lm_weight(double gw, double w2) { return fmax(w2, MCBA_CURV_FLOOR * gw); }
+MCBA_HD double lm_weight(double gw, double w2, double floor) { return fmax(w2, floor * gw); }
 // UNIT: f_scale == 1 (the reference's default), known at compile time: the two multiplications by 1.0 disappear (and 1 + r^2
 // becomes one fused multiply-add: results agree with the general code to the last bit or two)
 template <int LOSS, bool UNIT = false>

@@ -42,6 +42,8 @@ SYMBOLS = [
     ("mcba_cost", ctypes.c_int, [_h, ctypes.c_int, _dp, _dp]),
     ("mcba_residuals", ctypes.c_int, [_h, ctypes.c_int, _dp]),
     ("mcba_seen_bits", ctypes.c_int, [_h, ctypes.POINTER(ctypes.c_ubyte)]),
+    ("mcba_set_curvature_floor", ctypes.c_int, [_h, ctypes.c_double]),
+    ("mcba_get_curvature_floor", ctypes.c_double, [_h]),
     ("mcba_jacobian_eval", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int]),
     ("mcba_jacobian_download", ctypes.c_int, [_h, _dp, _dp]),
     ("mcba_linearize", ctypes.c_int, [_h, ctypes.c_int]),
@@ -329,6 +331,13 @@ class Problem:
         self._chk(self.lib.mcba_residuals_detach(self.handle, slot, ctypes.byref(buf)))
         return DeviceArray(self.lib, buf, (self.C, self.F, self.N, 2))
 
+    def set_curvature_floor(self, floor):
+        """Curvature weight of the linearisations enqueued from now on: max(Triggs, floor * rho') -- 1 = IRLS, 0.1 = Triggs with a
+        floor (include/mcba.h: mcba_set_curvature_floor).  Returns the value in force before."""
+        old = self.lib.mcba_get_curvature_floor(self.handle)
+        self._chk(self.lib.mcba_set_curvature_floor(self.handle, float(floor)))
+        return old
+
     def seen_bits(self):
         """numpy.packbits(~numpy.isnan(uvs)) of the uploaded (C,F,N,2) observations, computed on the GPU from its own copy
         (mcba_seen_bits): the row selection of the reference's residual vector / Jacobian (bundle_adjustment.py:68-69)."""
@@ -418,9 +427,12 @@ class Problem:
         return self._trial.copy()
 
     # ---- device-resident LM iteration (one host synchronisation per iteration)
-    def lm_set_state(self, cost, lam, nu, sel):
+    def lm_set_state(self, cost, lam, nu, sel, curv_floor=0.0, curv_switch=0.0):
+        """curv_floor: curvature model of the next linearisations (0 = the handle's, set_curvature_floor); curv_switch > 0: the device decision
+        switches it (csrc/mcba_lm.h: Triggs after an accepted step that gained less than this fraction of the cost, IRLS after a rejection)."""
         st = np.zeros(LM_STATE)
         st[:4] = cost, lam, nu, sel
+        st[25], st[26] = curv_floor, curv_switch
         self._chk(self.lib.mcba_lm_set_state(self.handle, _p(st)))
 
     def lm_iterate(self, delta_cam, pred_cam, dcn2, xcn2, lam_min, lam_max):

@@ -20,6 +20,8 @@ from scipy.linalg import lapack
 from scipy.optimize import OptimizeResult
 
 EPS = np.finfo(float).eps
+NEUTRAL_BAND = 32 * EPS   # csrc/mcba_math.h MCBA_NEUTRAL_BAND: a gain inside this fraction of the cost = a neutral step
+GREY_LEVEL = 1e-9         # csrc/mcba_math.h MCBA_GREY_LEVEL: a rejection whose cost rose by less than this fraction doubles the damping without escalating, and keeps the curvature model
 
 TERMINATION_MESSAGES = {
     -1: "Improper input parameters status returned from `leastsq`",
@@ -195,6 +197,15 @@ LAM0 = 1e-2
 DEC_FLOOR = 0.1
 LAM_MIN = 1e-9
 
+# Curvature model of the linearisations (csrc/mcba_math.h: lm_weight = max(Triggs weight, floor * rho')).  The loop starts on the
+# IRLS weight rho' (floor 1: the majorising quadratic -- monotone, the model to be far from the optimum with) and moves to Triggs'
+# second-order term (floor 0.1: fast AT the optimum) once an accepted step gained less than CURV_SWITCH of the cost; a rejected step
+# whose cost rose by more than GREY_LEVEL (not a round-off rejection in the tail of a converged run) sends it back.  Rounds 1-3 ran on Triggs alone: 16 evaluations to the reference's default tolerance on the bench problem (IRLS /
+# this rule: 6), and redescending losses started far from the optimum ran into max_nfev (profiles/round4/NOTES_round4.md section 13).
+# The minimiser does not depend on it.  `curvature=` "auto" (this rule), "irls", "triggs"; MCBA_CURVATURE overrides the default.
+CURV_IRLS, CURV_TRIGGS = 1.0, 0.1
+CURV_SWITCH = 1e-2
+
 MAX_RANKS = 12  # per-rank max |g_f| slots in the reduce buffer's scalar block (include/mcba.h: scal[4..15])
 
 
@@ -244,8 +255,14 @@ class LevenbergMarquardt:
       host-driven (`iterate` itself): decision here as well -- what the CPU test double (tests/fake_problem.py) runs."""
 
     def __init__(self, problem, comm=None, free_cam_mask=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, lam0=LAM0, lam_min=LAM_MIN, lam_max=1e12, speculative=True,
-                 reduced_solver=None, depth=2, x_scale=None, dec_floor=DEC_FLOOR):
+                 reduced_solver=None, depth=2, x_scale=None, dec_floor=DEC_FLOOR, curvature=None):
         self.p = problem
+        if curvature is None:
+            curvature = os.environ.get("MCBA_CURVATURE", "auto")
+        if curvature not in ("auto", "irls", "triggs"):
+            raise ValueError("curvature must be 'auto', 'irls' or 'triggs'")
+        self.curvature = curvature
+        self.curv_floor = None
         self.comm = comm or SingleProcess()
         n = problem.n   # size of the camera system: 12 C, or 6 C when the problem holds every camera's intrinsics fixed (ops.Problem.set_camera_block)
         # where the camera system's variables sit in the parameter vector
@@ -291,6 +308,7 @@ class LevenbergMarquardt:
         self.cur = 0
         self.p.set_params(0, x0)
         self.x_cam = x0[self.cam_index].copy()
+        self._set_curvature(CURV_TRIGGS if self.curvature == "triggs" else CURV_IRLS)
         self.p.linearize(0)
         self.nfev, self.njev = 1, 1
         self.lam, self.nu = self.lam0, 2.0
@@ -307,7 +325,7 @@ class LevenbergMarquardt:
         if not np.isfinite(self.cost):
             raise ValueError("Residuals are not finite in the initial point.")
         if self.device_decide:
-            self.p.lm_set_state(self.cost, self.lam, self.nu, self.cur)
+            self.p.lm_set_state(self.cost, self.lam, self.nu, self.cur, self.curv_floor, CURV_SWITCH if self.curvature == "auto" else 0.0)
         if self.device_solve:
             p = self.p
             p.synchronize()  # no tick of an earlier run may still be posting into the ring
@@ -317,6 +335,25 @@ class LevenbergMarquardt:
             st = p.lm_auto_wait(1)
             self.g_inf = float(st[16])
             self._status0 = int(st[15]) or None
+
+    def _set_curvature(self, floor):
+        """The model of the linearisations ENQUEUED from here on (a kernel argument of k_gram: nothing is recomputed)."""
+        if floor != self.curv_floor:
+            self.curv_floor = floor
+            if hasattr(self.p, "set_curvature_floor"):
+                self.p.set_curvature_floor(floor)
+
+    def _curvature_after(self, accepted, dF, cost_before):
+        """The switching rule (see CURV_SWITCH above) of the HOST-DRIVEN loop, applied with every decision.  The loops whose decision
+        runs on the GPU have it inside lm_decide (csrc/mcba_lm.h: the same rule on the same numbers; the model travels in the LM
+        state, slots 25 / 26), so that every driver -- and every rank of a frame-sharded run -- changes model at the same step."""
+        if self.curvature != "auto":
+            return
+        if not accepted:
+            if not (-dF <= GREY_LEVEL * cost_before):   # (a rejection at round-off level is no reason to leave Triggs)
+                self._set_curvature(CURV_IRLS)
+        elif 0.0 <= dF < CURV_SWITCH * cost_before or abs(dF) <= NEUTRAL_BAND * abs(cost_before):
+            self._set_curvature(CURV_TRIGGS)
 
     def _issue_tick(self):
         p, comm = self.p, self.comm
@@ -374,6 +411,7 @@ class LevenbergMarquardt:
         if accepted:
             self.actual_reduction, self.step_norm = dF, step_norm
         self.accepted = bool(accepted)
+        self.curv_floor = float(st[25])   # (the model the device decision left for the next linearisations: csrc/mcba_lm.h)
         return done or None
 
     def _refresh_system(self):
@@ -419,7 +457,7 @@ class LevenbergMarquardt:
         if dc is None:  # more damping, rebuild the reduced system on the GPU
             self.lam = min(lam * self.nu, self.lam_max)
             self.nu *= 2
-            p.lm_set_state(self.cost, self.lam, self.nu, self.cur)
+            p.lm_set_state(self.cost, self.lam, self.nu, self.cur, self.curv_floor, CURV_SWITCH if self.curvature == "auto" else 0.0)
             p.lm_rebuild(comm.rank % 12)
             if distributed:
                 comm.all_reduce_system(p)
@@ -458,6 +496,7 @@ class LevenbergMarquardt:
             status = 3
         self._adopt(new_red)
         self.accepted = bool(accepted)
+        self.curv_floor = float(st[25])   # (switched by the device decision: csrc/mcba_lm.h)
         return status
 
     # ------------------------------------------------------------------ one iteration
@@ -512,7 +551,7 @@ class LevenbergMarquardt:
             self.history.append((self.nfev, self.cost, cost_new, pred, ratio, lam, step_norm))
             # round-off guard (same rule, same ORDER as lm_decide in csrc/mcba_lm.h): |dF| below FP64 resolution of the cost
             # = neutral step, accepted with ratio := 0.5 BEFORE the termination tests look at the ratio
-            neutral = bool(np.isfinite(cost_new) and pred >= 0 and abs(dF) <= 32 * EPS * abs(self.cost))
+            neutral = bool(np.isfinite(cost_new) and pred >= 0 and abs(dF) <= NEUTRAL_BAND * abs(self.cost))
             accepted = (ratio > 0 and dF >= 0) or neutral
             if accepted and not (ratio > 0 and dF >= 0):
                 ratio = 0.5
@@ -529,10 +568,12 @@ class LevenbergMarquardt:
             elif status == 2:
                 status = None  # ftol needs an accepted step (ratio > 0.25)
         if not accepted:
-            self.lam = min(lam * self.nu, self.lam_max)
-            self.nu *= 2
+            grey = dc is not None and bool(cost_new - self.cost <= GREY_LEVEL * self.cost)   # (same rule as lm_decide, csrc/mcba_lm.h)
+            self.lam = min(lam * (2.0 if grey else self.nu), self.lam_max)
+            self.nu = 2.0 if grey else self.nu * 2
             if self.lam >= self.lam_max and status is None:
                 status = 3
+        self._curvature_after(accepted, (self.cost - cost_new) if dc is not None else 0.0, self.cost)  # (before the linearisations below: they are the next model's)
         if accepted and self.speculative:
             p.accept_linearization()
         elif accepted or (always_linearize and not self.speculative):
@@ -568,7 +609,7 @@ class LevenbergMarquardt:
         return OptimizeResult(
             x=x, cost=self.cost, optimality=self.g_inf, nfev=self.nfev, njev=self.njev, status=status, message=TERMINATION_MESSAGES[status],
             success=status > 0, active_mask=np.zeros_like(x),
-            lm=dict(iterations=self.iteration, steps=self.steps, lam=self.lam, slot=self.cur, history=self.history, rebuilds=getattr(self, "rebuilds", 0),
+            lm=dict(iterations=self.iteration, steps=self.steps, lam=self.lam, slot=self.cur, history=self.history, rebuilds=getattr(self, "rebuilds", 0), curvature=self.curvature, curvature_floor=self.curv_floor,
                     # which collective backend the frame-sharded loop ran on (DirectRCCL, TorchDistributed [+ why direct RCCL was not
                     # used], HostStagedGloo = rehearsal, SingleProcess) and where the reduced system was solved
                     collectives=type(self.comm).__name__, collectives_fallback_reason=getattr(self.comm, "fallback_reason", None), world=self.comm.world,
@@ -578,10 +619,10 @@ class LevenbergMarquardt:
 
 
 def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=LAM0, max_iterations=None, speculative=True,
-             reduced_solver=None, x_scale=None, dec_floor=DEC_FLOOR):
+             reduced_solver=None, x_scale=None, dec_floor=DEC_FLOOR, curvature=None):
     """Minimise the robust reprojection cost from x0 (this shard's flat vector, a7 layout of SURVEY.md).
     `fun` / `jac` / `grad` of the OptimizeResult are attached by api.bundle_adjust."""
-    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative, reduced_solver=reduced_solver, x_scale=x_scale, dec_floor=dec_floor)
+    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative, reduced_solver=reduced_solver, x_scale=x_scale, dec_floor=dec_floor, curvature=curvature)
     if max_nfev is None:
         max_nfev = 100 * np.size(x0)  # trf.py:437-438
     lm.max_nfev, lm.max_steps = max_nfev, max_iterations

@@ -301,7 +301,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
 
 
 # --------------------------------------------------------------------------- dense normal equations / Schur (checker for the GPU assembly)
-CURV_FLOOR = 0.1  # csrc/mcba_math.h MCBA_CURV_FLOOR: the LM's curvature weight is max(Triggs, 0.1 rho')
+CURV_FLOOR = 1.0  # csrc/mcba_math.h: the LM's curvature weight is max(Triggs, floor * rho'); 1.0 = the IRLS weight rho' = the library's default (mcba_set_curvature_floor), 0.1 = Triggs with a floor
 
 
 def normal_equations(x, all_calib_uvs, calib_objpoints, loss="soft_l1", f_scale=1.0, curv_floor=CURV_FLOOR):

@@ -13,6 +13,8 @@ _l = ctypes.CDLL(sys.argv[1])
 m.ops.SYMBOLS = [s for s in m.ops.SYMBOLS if hasattr(_l, s[0])]   # (an older build of the ABI: bind what it has)
 if not hasattr(_l, "mcba_set_x_scale"):
     m.ops.Problem.set_x_scale = lambda self, x: None
+if not hasattr(_l, "mcba_set_curvature_floor"):   # (a build from before the run-time curvature floor)
+    del m.ops.Problem.set_curvature_floor
 C, F = 6, 10000
 p = m.synth.make_problem(C, F, seed=0)
 x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])

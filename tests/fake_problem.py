@@ -21,12 +21,17 @@ class OracleProblem:
         self.reduce_tensor = None
         self._red = np.zeros(self.nsys + 8)
         self.calls = dict(linearize=0, build_reduced=0, step=0)
+        self.curv_floor = orc.CURV_FLOOR
 
     def enable_collective(self, device="cpu"):
         import torch
 
         self.reduce_tensor = torch.zeros(self.nsys + 8, dtype=torch.float64)
         self._red = self.reduce_tensor.numpy()
+
+    def set_curvature_floor(self, floor):
+        old, self.curv_floor = self.curv_floor, float(floor)
+        return old
 
     def set_params(self, slot, x):
         self.x[slot] = np.array(x, dtype=float)
@@ -36,7 +41,7 @@ class OracleProblem:
 
     def linearize(self, slot):
         self.calls["linearize"] += 1
-        self.lin = orc.normal_equations(self.x[slot], self.uvs, self.obj, self.loss, self.f_scale)
+        self.lin = orc.normal_equations(self.x[slot], self.uvs, self.obj, self.loss, self.f_scale, self.curv_floor)
         self.lin_x = self.x[slot].copy()
 
     def build_reduced(self, lam, rank_slot=0):
@@ -81,7 +86,7 @@ class OracleProblem:
     def step_linearize(self, dc, lam, src, dst):
         self.step(dc, lam, src, dst)
         self.calls["linearize"] += 1
-        self.lin_trial = orc.normal_equations(self.x[dst], self.uvs, self.obj, self.loss, self.f_scale)
+        self.lin_trial = orc.normal_equations(self.x[dst], self.uvs, self.obj, self.loss, self.f_scale, self.curv_floor)
 
     def accept_linearization(self):
         self.lin = self.lin_trial

@@ -10,12 +10,14 @@
 
 using namespace mcba;
 
+static double g_curv_floor = MCBA_CURV_FLOOR_IRLS;  // the product's default (hc_set_curvature_floor: 0.1 = Triggs with a floor)
+
 template <int LOSS>
 static void weights(double r, bool valid, double fs2, double ifs2, double& cost, double& w2, double& gw) {
   if (!valid) { w2 = 0; gw = 0; return; }
   double rh, g1, ww;
   loss_weights<LOSS>(r, fs2, ifs2, rh, g1, ww);
-  cost += rh; w2 = lm_weight(g1, ww); gw = g1 * r;
+  cost += rh; w2 = lm_weight(g1, ww, g_curv_floor); gw = g1 * r;
 }
 
 static void weights_dyn(int loss, double r, bool valid, double fs2, double ifs2, double& cost, double& w2, double& gw) {
@@ -29,6 +31,8 @@ static void weights_dyn(int loss, double r, bool valid, double fs2, double ifs2,
 }
 
 extern "C" {
+
+void hc_set_curvature_floor(double v) { g_curv_floor = v; }
 
 // x: 12C + 6F ; uvs (C,F,N,2) ; outputs U (C,78) gc (C,12) W (C,F,72) V (C,F,21) gf (C,F,6) cost (1)
 void hc_normal_eq(int C, int F, int N, const double* uvs, const double* obj, const double* x, int loss, double f_scale,

@@ -7,6 +7,7 @@ bundle_adjustment.py) at the point the GPU returns:
   * `cost`, `fun` are the oracle's robust cost / residual vector at `x`; the cost did not go up;
   * `x` is a STATIONARY point of the oracle's objective: its gradient J^T rho'(f) (scipy's, common.py:720-731) is at the round-off floor
     of the initial gradient, and equals `result.grad`;
+  * every case terminates (all five losses);
   * variants of the product that must not matter do not: the reduced camera system solved on the device or on the host, the 6-wide camera
     block or flags on the 12-wide one (fix_intrinsics), frame shards in one process (the north_star's partition) against one handle."""
 import contextlib
@@ -73,11 +74,12 @@ def test_returned_point_is_a_minimiser_of_the_oracle_objective(mc, it):
     kw = dict(n_frames=None, ftol=1e-13, xtol=1e-13, gtol=1e-11, verbose=0, max_nfev=400, fix_intrinsics=fixed, **opts)
     tag = f"case {it}: {mk} {opts} fixed={fixed}"
     e, intr, poses, use, res = quiet(mc.bundle_adjust, *args, **kw)
-    # a redescending loss (cauchy, arctan) far from the optimum is a different matter: scipy's TRF does not terminate within 400
-    # evaluations on cases 12 / 15 either, and which local minimum is reached depends on round-off -- there the consistency checks
-    # below apply, termination and the agreement of the variants are asked of linear / soft_l1 / huber
+    # every loss terminates (with Triggs' curvature alone -- rounds 1-3 -- eight of these 64 cases ran into max_nfev: redescending losses
+    # started far from the optimum; the loop now starts on the IRLS weight, solver.py: CURV_SWITCH).  For the redescending losses
+    # (cauchy, arctan) WHICH local minimum is reached may still depend on round-off, so stationarity to 1e-7 and the agreement of the
+    # variants are asked of linear / soft_l1 / huber.
     tame = opts["loss"] in ("linear", "soft_l1", "huber")
-    assert res.status > 0 or not tame, tag
+    assert res.status > 0, tag
     # the selection: the oracle's pre-filter (bundle_adjustment.py:265-298)
     use_o = quiet(orc.prefilter_frames, *args, None, None)[0]
     np.testing.assert_array_equal(use, use_o, err_msg=tag)

@@ -490,22 +490,26 @@ def test_device_loop_equals_host_solve_loop(mc, kw):
     out = {}
     for mode in ("device", "host"):
         with contextlib.redirect_stdout(io.StringIO()):
-            e, i, po, use, res = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=1e-10, xtol=1e-10, gtol=1e-10,
+            e, i, po, use, res = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=1e-10, xtol=1e-14, gtol=1e-10,   # (xtol out of the way: whether the LAST step also passes the step-size test is a coin toss at round-off level)
                                                   verbose=0, reduced_solver=mode, return_jac=False, **kw)
         out[mode] = res
     a, b = out["device"], out["host"]
     assert a.status > 0 and b.status > 0
     assert abs(a.cost - b.cost) <= 1e-10 * b.cost
-    assert a.status == b.status
-    assert a.nfev == b.nfev and a.lm["iterations"] == b.lm["iterations"]
+    # (the loop converges in a handful of steps; whether the step that gains ~ftol * cost is the last one is decided by the last bits of
+    #  two different linear solves -- LAPACK's and the GPU's: one evaluation more or less)
+    assert abs(a.nfev - b.nfev) <= 1 and abs(a.lm["iterations"] - b.lm["iterations"]) <= 1
+    assert a.status == b.status or a.nfev != b.nfev
     assert np.abs(a.x - b.x).max() <= 1e-8 * np.abs(b.x).max()
-    assert abs(a.optimality - b.optimality) <= 0.1 * b.optimality + 1e-9   # round-off level of a gradient that started at ~1e6
+    assert abs(a.optimality - b.optimality) <= 0.1 * b.optimality + 1e-9 or a.nfev != b.nfev   # round-off level of a gradient that started at ~1e6
     ha, hb = np.array(a.lm["history"]), np.array(b.lm["history"])
-    np.testing.assert_allclose(ha[:, 1:3], hb[:, 1:3], rtol=1e-10)   # cost before / after every trial step
+    k = min(len(ha), len(hb))
+    np.testing.assert_allclose(ha[:k, 1:3], hb[:k, 1:3], rtol=1e-10)   # cost before / after every trial step
 
 
+@pytest.mark.parametrize("curvature", ["auto", "triggs"])   # (Triggs alone, the model of rounds 1-3: this start then costs rejected steps -- the fused launch's hard case)
 @pytest.mark.parametrize("shape", [(6, 300, {}), (9, 70, dict(missing=0.3)), (3, 130, dict(missing=0.2, outlier_frames=4))])
-def test_fused_solve_backsub_is_bit_identical(mc, shape):
+def test_fused_solve_backsub_is_bit_identical(mc, shape, curvature):
     """k_solve_backsub (the reduced solve and the NEXT trial step's back-substitution in one launch, the back-substitution
     workgroups waiting for the solve's release word) against the two separate launches (MCBA_FUSE_BACKSUB=0, read in
     mcba_create): same arithmetic in the same order -> the same iterates to the last bit, incl. rejected steps (bad start)."""
@@ -519,7 +523,7 @@ def test_fused_solve_backsub_is_bit_identical(mc, shape):
             os.environ["MCBA_FUSE_BACKSUB"] = mode
             with contextlib.redirect_stdout(io.StringIO()):
                 out[mode] = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=1e-12, xtol=1e-12, gtol=1e-9,
-                                             verbose=0, return_jac=False, max_nfev=120)[4]
+                                             verbose=0, return_jac=False, max_nfev=120, curvature=curvature)[4]
     finally:
         if old is None:
             del os.environ["MCBA_FUSE_BACKSUB"]
@@ -527,7 +531,7 @@ def test_fused_solve_backsub_is_bit_identical(mc, shape):
             os.environ["MCBA_FUSE_BACKSUB"] = old
     a, b = out["1"], out["0"]
     assert a.status == b.status and a.nfev == b.nfev and a.lm["iterations"] == b.lm["iterations"]
-    assert a.lm["iterations"] < a.nfev - 1                       # some steps were rejected
+    assert curvature == "auto" or a.lm["iterations"] < a.nfev - 1   # some steps were rejected
     np.testing.assert_array_equal(a.x, b.x)
     assert a.cost == b.cost
     np.testing.assert_array_equal(np.array(a.lm["history"]), np.array(b.lm["history"]))
@@ -815,6 +819,81 @@ def test_fix_intrinsics_compact_block_equals_flag_path(mc, shape, kw):
     # (the rig's 6-DoF gauge is free: two runs that differ in round-off end at different x on the same orbit -- compare what it predicts)
     assert np.abs(orc.predict_from_x(a.x, C, p["obj"]) - orc.predict_from_x(b.x, C, p["obj"])).max() < 1e-5
     x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    _, gc0, _, gf0, _, _ = orc.normal_equations(x0, p["uvs"], p["obj"], kw.get("loss", "soft_l1"), kw.get("f_scale", 1.0))
+    g0 = max(np.abs(gc0[:, 6:]).max(), np.abs(gf0).max())
     np.testing.assert_array_equal(a.x[:12 * C].reshape(C, 12)[:, :6], x0[:12 * C].reshape(C, 12)[:, :6])
     assert np.all(a.grad[:12 * C].reshape(C, 12)[:, :6] == 0) and a.grad.shape == b.grad.shape
-    assert np.abs(a.grad - b.grad).max() <= 0.05 * np.abs(b.grad).max() + 1e-6   # (both at the round-off floor of a gradient that started at ~1e6)
+    assert max(np.abs(a.grad).max(), np.abs(b.grad).max()) <= 1e-6 * g0 + 1e-6   # (both stationary to what ftol = xtol = 1e-12 resolve of a gradient that started at g0 ~ 1e6)
+
+
+# ------------------------------------------------------------------ round 4: the curvature model of a linearisation is a run-time choice
+@pytest.mark.parametrize("loss,fs", [("soft_l1", 1.0), ("cauchy", 0.6), ("huber", 1.5), ("arctan", 2.0)])
+def test_curvature_floor_irls_and_triggs_vs_oracle(mc, loss, fs):
+    """mcba_set_curvature_floor: the normal equations with the IRLS weight rho' (floor 1, the default) and with Triggs' second-order term
+    floored at 0.1 rho' -- each against the oracle's dense assembly with the same floor; the gradient, the cost and the materialised
+    Jacobian do not depend on it."""
+    p = mc.synth.make_problem(3, 70, seed=77, missing=0.2, noise=1.5, rows=3, cols=4)   # (noise 1.5 px: enough residuals in the concave zone for the two to differ)
+    C, F = p["uvs"].shape[:2]
+    x = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = mc.ops.Problem(p["uvs"], p["obj"], loss=loss, f_scale=fs)
+    out = {}
+    for floor in (1.0, 0.1):
+        assert prob.set_curvature_floor(floor) == 1.0   # (returns the value in force before: the default, then the 1.0 just set)
+        prob.set_params(0, x)
+        prob.linearize(0)
+        prob.build_reduced(1e-3)
+        red = {k: v.copy() for k, v in prob.get_reduced().items()}
+        U, gc, V, gf, W, cost = orc.normal_equations(x, p["uvs"], p["obj"], loss, fs, curv_floor=floor)
+        Df2 = np.stack([np.where(np.diag(V[f]) > 0, np.diag(V[f]), 1.0) for f in range(F)])
+        S, rhs = orc.schur_reduce(U, gc, V, gf, W, 1e-3, np.zeros((C, 12)), Df2)
+        assert np.abs(red["S0"] - S).max() <= 1e-10 * np.abs(S).max(), floor
+        assert np.abs(red["rhs"] - rhs).max() <= 1e-10 * np.abs(rhs).max(), floor
+        assert np.abs(red["gc"] - gc.ravel()).max() <= 1e-10 * np.abs(gc).max() and abs(red["scal"][0] - cost) <= 1e-12 * cost
+        out[floor] = red
+    assert np.abs(out[1.0]["S0"] - out[0.1]["S0"]).max() > 1e-4 * np.abs(out[1.0]["S0"]).max()   # two different models ...
+    np.testing.assert_array_equal(out[1.0]["gc"], out[0.1]["gc"])                                 # ... of the same function
+    assert out[1.0]["scal"][0] == out[0.1]["scal"][0]
+    with pytest.raises(mc.ops.McbaError):
+        prob.set_curvature_floor(0.0)
+    with pytest.raises(mc.ops.McbaError):
+        prob.set_curvature_floor(1.5)
+    prob.close()
+
+
+def test_curvature_policy_of_the_lm_loop(mc):
+    """solver.py's rule (decided on the GPU with every accept / reject: csrc/mcba_lm.h): IRLS from the start, Triggs once an accepted step
+    gains less than 1 % of the cost.  The three settings reach the same minimiser; "auto" needs the fewest evaluations from a perturbed
+    start; the device-resident loop, the host-solve loop and the host-driven loop on the oracle take the same steps."""
+    p = mc.synth.make_problem(4, 120, seed=5, missing=0.1)
+    args = (p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    kw = dict(n_frames=None, ftol=1e-12, xtol=1e-14, gtol=1e-10, verbose=0, return_jac=False, outlier_threshold=1e9)
+    res = {}
+    for curv in ("auto", "irls", "triggs"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            res[curv] = mc.bundle_adjust(*args, curvature=curv, **kw)[4]
+        assert res[curv].status > 0 and res[curv].lm["curvature"] == curv
+    assert res["irls"].lm["curvature_floor"] == 1.0 and res["triggs"].lm["curvature_floor"] == 0.1
+    assert res["auto"].lm["curvature_floor"] == 0.1                              # converged: the last linearisations were Triggs'
+    for curv in ("irls", "triggs"):
+        assert abs(res[curv].cost - res["auto"].cost) <= 1e-9 * res["auto"].cost
+        assert np.abs(orc.predict_from_x(res[curv].x, 4, p["obj"]) - orc.predict_from_x(res["auto"].x, 4, p["obj"])).max() < 1e-4
+    assert res["auto"].nfev <= res["irls"].nfev and res["auto"].nfev < res["triggs"].nfev
+    with contextlib.redirect_stdout(io.StringIO()):
+        host = mc.bundle_adjust(*args, reduced_solver="host", **kw)[4]
+    k = min(len(host.lm["history"]), len(res["auto"].lm["history"]))
+    np.testing.assert_allclose(np.array(host.lm["history"])[:k, 1:3], np.array(res["auto"].lm["history"])[:k, 1:3], rtol=1e-10)
+    from fake_problem import OracleProblem
+
+    x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    ref = mc.solver.lm_solve(OracleProblem(p["uvs"], p["obj"]), x0, ftol=1e-12, xtol=1e-14, gtol=1e-10)
+    prob = mc.ops.Problem(p["uvs"], p["obj"])
+    got = mc.solver.lm_solve(prob, x0, ftol=1e-12, xtol=1e-14, gtol=1e-10)
+    prob.close()
+    ha, hb = np.array(ref.lm["history"]), np.array(got.lm["history"])
+    live = (ha[:, 1] - ha[:, 2]) > 1e-9 * ha[:, 1]
+    k = min(int(np.argmin(live)) if not live.all() else len(ha), len(hb))
+    assert k >= 4
+    np.testing.assert_allclose(hb[:k, 1:3], ha[:k, 1:3], rtol=1e-6)               # the same trial costs while the steps still gain: the same models
+    np.testing.assert_allclose(hb[:k, 5], ha[:k, 5], rtol=1e-4)
+    with pytest.raises(ValueError):
+        mc.bundle_adjust(*args, curvature="newton", **kw)

@@ -145,8 +145,10 @@ def test_numeric_x_scale_matches_the_oracle_driven_lm(mc, reduced_solver, scalar
     jac = mc.solver.lm_solve(prob, x0, reduced_solver=reduced_solver, ftol=0.0, xtol=1e-13, gtol=1e-9, max_nfev=60)   # back to 'jac' on the same handle
     prob.close()
     ha, hb, hj = np.array(ref.lm["history"]), np.array(got.lm["history"]), np.array(jac.lm["history"])
-    n = min(len(ha), len(hb), 12)
-    assert n >= 5
+    # the steps that still change the cost by more than round-off (the loop converges in a handful of steps; with ftol = 0 it then runs on at noise level, where gain ratios -- and with them the dampings -- are not reproducible between two implementations)
+    live = int(np.argmax(~((ha[:, 1] - ha[:, 2]) > 1e-9 * ha[:, 1]))) if (~((ha[:, 1] - ha[:, 2]) > 1e-9 * ha[:, 1])).any() else len(ha)
+    n = min(len(ha), len(hb), 12, live)
+    assert n >= 4
     np.testing.assert_allclose(hb[:n, 1:3], ha[:n, 1:3], rtol=1e-6)    # cost before / after every trial step (far from the optimum round-off differences grow: 1e-8 observed)
     np.testing.assert_allclose(hb[:n, 5], ha[:n, 5], rtol=1e-4)        # the damping schedule (a function of the gain ratios)
     assert not np.allclose(hj[:3, 2], hb[:3, 2], rtol=1e-6)            # ... and it is not the 'jac' path
