@@ -1,8 +1,8 @@
 """Host side of the GPU solver: Levenberg-Marquardt on the Schur-reduced camera system.
 
 Replaces the optimisation loop the reference delegates to scipy (`trf_no_bounds`,
-scipy/optimize/_lsq/trf.py:401-560, + LSMR): same objective (robust cost 0.5*sum rho(f^2), Triggs
-rescaling as scipy/optimize/_lsq/common.py:720-731), same termination tests and status codes
+scipy/optimize/_lsq/trf.py:401-560, + LSMR): same objective (robust cost 0.5*sum rho(f^2); curvature: the IRLS weight rho' far from the
+optimum, scipy's Triggs rescaling -- common.py:720-731 -- at it: CURV_SWITCH below), same termination tests and status codes
 (common.py:705-717), but the step comes from an exact damped Gauss-Newton solve:
 
     linearise (GPU)  ->  Schur complement of the 6x6 frame blocks (GPU)  ->  [all-reduce over frame shards]
