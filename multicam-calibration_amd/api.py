@@ -307,7 +307,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     Extra keyword arguments (defaults preserve reference behaviour):
       device=0             HIP device ordinal (distributed: defaults to LOCAL_RANK)
       fix_intrinsics=False hold fx fy cx cy k1 k2 of every camera (BASELINE config 2); extrinsics + poses only
-      lam0=1e-2, dec_floor=0.1   damping schedule of the LM loop (solver.py); dec_floor=1/3 is Nielsen's classical rule
+      lam0=1e-3, dec_floor=0.1   damping schedule of the LM loop (solver.py); dec_floor=1/3 is Nielsen's classical rule
       curvature="auto"           curvature model of the linearisations (solver.py: CURV_SWITCH): "auto" = the IRLS weight rho' until an accepted step
                                  gains less than 1 % of the cost, then Triggs' second-order term; "irls" / "triggs" = one of them throughout
       return_jac=True      attach the robust-rescaled CSR Jacobian as `result.jac` (18 nnz/row; 1.4 GB at 6x10k x54) -- lazily: it is

@@ -129,7 +129,7 @@ def test_point_split_lm_loop_matches_fused(mc, C, F, board, split, npw):
                     os.environ[k] = v
     a, b = out
     ha, hb = np.array(a.lm["history"]), np.array(b.lm["history"])
-    assert ha.shape == hb.shape and len(ha) >= 8
+    assert ha.shape == hb.shape and len(ha) >= 5
     np.testing.assert_allclose(hb[:, 2], ha[:, 2], rtol=1e-11)      # trial costs
     np.testing.assert_allclose(hb[:, 5], ha[:, 5], rtol=1e-6)       # dampings: the same accept / reject sequence
     assert abs(a.cost - b.cost) <= 1e-11 * a.cost
