@@ -168,11 +168,16 @@ int mcba_step_fetch(mcba_handle* h, const double* delta_cam, double lambda, int 
  * The reduce buffer carries, behind the system (n*n+3n+16) and the 8 trial scalars, MCBA_LM_STATE = 32 doubles:
  *   0 cost  1 lambda  2 nu  3 sel (index of the current parameter slot AND linearisation buffer)  4 accepted
  *   5 cost_new  6 predicted reduction  7 ratio  8 step norm  9 x norm  10 actual reduction;
- *   11..24 belong to the device-resident solve below (0 for the host-solve entry points), 25..31 reserved.
+ *   11..24 belong to the device-resident solve below (0 for the host-solve entry points);
+ *   25 curvature floor of the NEXT linearisations (1 = the IRLS weight rho', 0.1 = Triggs' term with a floor; 0 in the array handed to
+ *      mcba_lm_set_state = the handle's value, mcba_set_curvature_floor)   26 switch fraction (> 0: the decision moves slot 25 -- Triggs
+ *      after an accepted step that gained less than this fraction of the cost, IRLS after a rejection whose cost rose by more than 1e-9 of
+ *      itself; 0: slot 25 stays)   27..31 reserved.
  * mcba_lm_set_state uploads it (after mcba_linearize(slot = sel) + mcba_build_reduced);
  * mcba_lm_trial            : back-substitute delta_cam from the current point, linearise the trial point
  *                            (other slot / buffer), sum its cost  -> trial scalars;  [all-reduce them when sharded]
- * mcba_lm_decide_reduce    : accept/reject (with a round-off guard for |dF| <= 32 EPS F) + Nielsen damping update ON THE
+ * mcba_lm_decide_reduce    : accept/reject (with a round-off guard for |dF| <= 32 EPS F) + Nielsen damping update (a rejection whose
+ *                            cost rose by less than 1e-9 of itself doubles the damping without escalating) ON THE
  *                            GPU (same rule as the host driver, solver.py),
  *                            then Schur-reduce whichever linearisation is now current with the new lambda;
  *                            pred_cam = d_c^T(lambda D_c d_c - g_c), dcn2 = |d_c|^2, xcn2 = |x_c|^2 from the host solve;
