@@ -365,3 +365,25 @@ def test_bundle_adjust_distributed_two_ranks(tmp_path, monkeypatch, variant):
     pb = orc.predict_from_x(res.x, 3, p["obj"])
     assert np.abs(pa - pb).max() < 1e-6
     assert np.abs(r0["grad"]).max() < 1e-5
+
+
+def test_curvature_rule_of_the_host_driven_loop():
+    """solver.py: CURV_SWITCH -- the loop linearises with the IRLS weight rho' until an accepted step gains less than 1 % of the cost, then
+    with Triggs' second-order term (the rule lm_decide applies on the GPU: csrc/mcba_lm.h; here its host-driven mirror on the oracle).
+    One minimiser whatever the setting; the rule needs fewer evaluations than Triggs alone (the model of rounds 1-3)."""
+    p = synth.make_problem(3, 25, seed=11, missing=0.1)
+    x0 = api.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    res = {}
+    for curv in ("auto", "irls", "triggs"):
+        prob = OracleProblem(p["uvs"], p["obj"])
+        res[curv] = solver.lm_solve(prob, x0, ftol=1e-12, xtol=1e-14, gtol=1e-10, curvature=curv)
+        assert res[curv].status > 0 and res[curv].lm["curvature"] == curv
+        assert prob.curv_floor == res[curv].lm["curvature_floor"]
+    assert res["irls"].lm["curvature_floor"] == solver.CURV_IRLS and res["triggs"].lm["curvature_floor"] == solver.CURV_TRIGGS
+    assert res["auto"].lm["curvature_floor"] == solver.CURV_TRIGGS          # converged: the last linearisations were Triggs'
+    for curv in ("irls", "triggs"):
+        assert abs(res[curv].cost - res["auto"].cost) <= 1e-9 * res["auto"].cost
+        assert np.abs(orc.predict_from_x(res[curv].x, 3, p["obj"]) - orc.predict_from_x(res["auto"].x, 3, p["obj"])).max() < 1e-5
+    assert res["auto"].nfev < res["triggs"].nfev
+    with pytest.raises(ValueError):
+        solver.lm_solve(OracleProblem(p["uvs"], p["obj"]), x0, curvature="newton")
