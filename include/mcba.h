@@ -51,7 +51,9 @@ typedef struct mcba_handle mcba_handle;
 typedef struct mcba_buffer mcba_buffer;   /* a device array that outlives its handle (mcba_residuals_detach) */
 
 /* ---- library ------------------------------------------------------------------------------- */
-int mcba_abi_version(void);            /* bumped when this header changes incompatibly */
+int mcba_abi_version(void);            /* 6.  Bumped when this header changes: 6 (round 5) ADDS mcba_prefilter, mcba_lm_run, mcba_lm_history, mcba_lm_result and leaves every
+                                        * ABI-5 entry point as it was.  (ABI 5 gave LM-state slots 25 / 26 -- "reserved" before -- their meaning: curvature floor / switch
+                                        * fraction; a caller that zeroes them gets the handle's floor, fixed.) */
 const char* mcba_last_error(void);
 int mcba_device_count(int* count);
 
@@ -237,6 +239,28 @@ int mcba_lm_auto_trial(mcba_handle* h, int decide);
 int mcba_lm_auto_reduce(mcba_handle* h, int decide, int rank_slot);
 int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot);
 int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state);
+/* ---- whole stages of bundle_adjust() per crossing (round 5, ABI 6) ----------------------------------------------
+ * mcba_lm_run: the device-resident loop from start to finish in ONE call -- what the caller otherwise drives through
+ * mcba_set_params, mcba_linearize, mcba_reduce_fetch, mcba_lm_set_state, mcba_lm_auto_config, mcba_lm_auto_solve and then
+ * mcba_lm_auto_tick / mcba_lm_auto_wait per iteration (the loop scipy's trf_no_bounds runs on the host: trf.py:401-560).  Nothing waits
+ * between the upload of x0 and the first tick: the start state is written on the device from the reduced system of the start point,
+ * the first `depth` ticks are enqueued behind the first solve, then the host polls the state ring.  The ticks, their order and every
+ * decision are those of the per-call sequence (the device decides; the host only keeps `depth` ticks in flight).
+ *   x0      12C + 6F doubles, or NULL to start from what parameter slot 0 holds (mcba_create_subset gathers it on the device)
+ *   opt     13 doubles: 0 ftol 1 xtol 2 gtol (0 = that test off) 3 lambda_0 4 lambda_min 5 lambda_max 6 floor of Nielsen's factor
+ *           (0 = 1/3) 7 curvature floor of the first linearisations (mcba_set_curvature_floor) 8 curvature switch fraction (state slot
+ *           26; 0 = fixed model) 9 max_nfev 10 max iterations (< 0: none) 11 ticks in flight (1..12) 12 rank slot (0 on one GPU)
+ *   fixed   n bytes (1 = camera-system variable held fixed) or NULL
+ *   summary 4 doubles out: 0 status (scipy's 1..4; 0 = a limit was reached) 1 rows recorded 2 rows consumed by the loop proper (the
+ *           rest were retired by the final drain of ticks still in flight) 3 iterations
+ * MCBA_ERR_NONFINITE: "Residuals are not finite in the initial point." (least_squares.py).  With a direct RCCL communicator attached the
+ * start system is all-reduced and every tick carries its collective, as in mcba_lm_auto_tick.
+ * mcba_lm_history: the MCBA_LM_STATE doubles every retired tick posted, row 0 = the solve of the start point (cost, optimality).
+ * mcba_lm_result: [x | gradient] of parameter slot `slot`, 2 (12C + 6F) doubles, in one device-to-host copy: the camera gradient g_c of
+ * the reduce buffer scattered to the parameter layout (0 where a parameter is held fixed), the frame gradients (OptimizeResult.grad). */
+int mcba_lm_run(mcba_handle* h, const double* x0, const double* opt, const unsigned char* fixed, double* summary);
+int mcba_lm_history(mcba_handle* h, double* rows, size_t capacity_rows);
+int mcba_lm_result(mcba_handle* h, int slot, double* out);
 /* k_solve_backsub's back-substitution workgroups wait for the solve of the same launch with a BOUNDED poll (~0.5 s).  If one ever
  * runs out, it stamps the tick's number into a device word and a host-mapped word: the next tick's decision discards its (stale)
  * trial point and only rebuilds the system, and mcba_lm_auto_wait switches the handle to the two-launch path (k_solve_cam, then
@@ -284,9 +308,20 @@ int mcba_error_median(mcba_handle* h, const unsigned char* frame_mask, double* m
  * histograms over the ranks, picks the bin that holds the wanted rank, extends the prefix and calls again: 8 passes give the exact
  * order statistic whatever the sharding.  Synchronises. */
 int mcba_error_histogram(mcba_handle* h, const unsigned char* frame_mask, unsigned long long prefix, int pass, unsigned long long* hist256);
+/* The whole pre-filter (bundle_adjustment.py:265-285) in ONE call and one host synchronisation (round 5, ABI 6): upload of the
+ * observations + board (both NULL: those already uploaded) and of x (12C + 6F: the parameters every frame is scored at, slot 0),
+ * re-layout, the reprojection errors, and -- on the device -- which frames are complete in at least two cameras (:266), the worst
+ * camera's nan-mean error per frame (:279), the threshold (outlier_threshold, or NaN: 5 x np.nanmedian of the used frames' per-point
+ * errors, :281-282, exact by radix select) and the comparison (:285).  status: F bytes out, bit 0 = frame used (:266), bit 1 = excluded
+ * as an outlier, bit 2 = complete in every camera.  info: 8 doubles out, 0 threshold 1 median 2 number of values under the median
+ * 3 (1 = the median's candidate list overflowed and the eight-pass select of mcba_error_median ran instead) 4 frames used 5 excluded
+ * 6 kept frames that are incomplete in some camera.  The per-point errors and per-(camera, frame) statistics stay on the device as
+ * after mcba_frame_errors(h, 0, ...). */
+int mcba_prefilter(mcba_handle* h, const double* uvs, const double* objpoints, const double* x, double outlier_threshold, unsigned char* status, double* info8);
 /* New handle on the same device / stream holding the observations of n_frames frames of `src` (indices into its frames,
  * any order, repeats allowed) -- gathered device to device: what bundle_adjust solves on after the pre-filter, without
- * a second host upload (the reference slices all_calib_uvs[:, use_frames]: bundle_adjustment.py:298,312). */
+ * a second host upload (the reference slices all_calib_uvs[:, use_frames]: bundle_adjustment.py:298,312).  Parameter slot 0 of the
+ * new handle = the camera blocks of src's slot 0 + the poses of the chosen frames (ABI 6).  Does not synchronise. */
 int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, int n_frames);
 
 /* ---- geometry helpers and diagnostics around the solver ---------------------------------------- */

@@ -28,23 +28,27 @@ _PATH_ONLY = ("jac", "tr_solver", "tr_options", "jac_sparsity", "diff_step", "me
 
 def serialize_params(all_extrinsics, all_intrinsics, calib_poses):
     """[C x (fx fy cx cy k1 k2 rx ry rz tx ty tz) | F x pose6]  (bundle_adjustment.py:128-157)."""
-    cams = np.empty((len(all_extrinsics), 12))
+    C = len(all_extrinsics)
+    poses = np.asarray(calib_poses, dtype=np.float64)
+    x = np.empty(12 * C + poses.size)
+    cams = x[: 12 * C].reshape(C, 12)
     for c, (ext, (K, dist)) in enumerate(zip(all_extrinsics, all_intrinsics)):
         K = np.asarray(K, dtype=float)
-        cams[c, :4] = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+        cams[c, 0], cams[c, 1], cams[c, 2], cams[c, 3] = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
         cams[c, 4:6] = np.asarray(dist, dtype=float)[:2]
         cams[c, 6:] = ext
-    return np.concatenate([cams.ravel(), np.asarray(calib_poses, dtype=float).ravel()])
+    x[12 * C:] = poses.ravel()
+    return x
 
 
 def deserialize_params(x, n_cameras):
     """Inverse of serialize_params (bundle_adjustment.py:160-192)."""
     cams = np.asarray(x[: 12 * n_cameras]).reshape(n_cameras, 12)
-    intr = []
-    for c in range(n_cameras):
-        K = np.eye(3)
-        K[0, 0], K[1, 1], K[0, 2], K[1, 2] = cams[c, :4]
-        intr.append((K, np.pad(cams[c, 4:6], (0, 3))))
+    Ks = np.zeros((n_cameras, 3, 3))
+    Ks[:, 0, 0], Ks[:, 1, 1], Ks[:, 0, 2], Ks[:, 1, 2], Ks[:, 2, 2] = cams[:, 0], cams[:, 1], cams[:, 2], cams[:, 3], 1.0
+    dists = np.zeros((n_cameras, 5))
+    dists[:, :2] = cams[:, 4:6]
+    intr = [(Ks[c].copy(), dists[c].copy()) for c in range(n_cameras)]   # (arrays of their own, as the reference returns them)
     return cams[:, 6:].copy(), intr, np.asarray(x[12 * n_cameras :]).reshape(-1, 6).copy()
 
 
@@ -216,6 +220,28 @@ def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     radix-select histograms are all-reduced (8 passes x 256 integer bins per order statistic), and rank 0 alone prints the
     reference's line and draws the subsample from the global numpy RNG (:293-296); the selection is broadcast."""
     C, F_all, N = all_calib_uvs.shape[:3]
+    if group is None and F_all > 0 and hasattr(ops.Problem, "prefilter") and os.environ.get("MCBA_PREFILTER_FUSED", "1") != "0":
+        # one GPU: upload + scoring + the whole selection in ONE C-ABI crossing and one host synchronisation (mcba_prefilter); what is
+        # left for the host is what must happen there -- the printed line and the draw from the GLOBAL numpy RNG (:287-296)
+        prob = ops.Problem(all_calib_uvs, calib_objpoints, device=device, upload=False, **problem_kw)
+        try:
+            # (a NaN threshold compares False with everything -- nothing is excluded --: +inf does the same and leaves NaN free to mean "5 x median" at the ABI)
+            thr_in = None if outlier_threshold is None else (float("inf") if np.isnan(float(outlier_threshold)) else float(outlier_threshold))
+            status, thr, _ = prob.prefilter(serialize_params(all_extrinsics, all_intrinsics, calib_poses), thr_in)
+        except BaseException:
+            prob.close()
+            raise
+        use0 = np.flatnonzero(status & 1)
+        excluded = (status[use0] & 2) != 0
+        use_frames = use0[~excluded]
+        shown = thr if outlier_threshold is None else outlier_threshold
+        print(f"Excluding {int(excluded.sum())} out of {len(use_frames)} frames based on an outlier threshold of {shown}")
+        if not (n_frames is None or n_frames > len(use_frames)):
+            use_frames = np.random.choice(use_frames, n_frames, replace=False)
+        if keep_problem:
+            return use_frames, prob, bool((status[use_frames] & 4).all()), 0
+        prob.close()
+        return use_frames
     dist, rank, world = None, 0, 1
     if group is not None:
         import torch
@@ -353,6 +379,14 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     calib_objpoints = np.asarray(calib_objpoints, dtype=np.float64)
     calib_poses = np.asarray(calib_poses, dtype=np.float64)
     n_cameras = all_calib_uvs.shape[0]
+    # The kernels' camera model is (fx fy cx cy k1 k2) -- all the reference ever optimises (serialize_params drops the rest:
+    # bundle_adjustment.py:149-155) -- but its PRE-FILTER projects with the full matrix (geometry.py:323: K @ p): a skew K[0,1] or a
+    # non-trivial third row would select other frames there than here.  Refused rather than silently ignored.
+    for c, (K, _) in enumerate(all_intrinsics):
+        K = np.asarray(K, dtype=np.float64)
+        if K.shape != (3, 3) or K[0, 1] != 0.0 or K[1, 0] != 0.0 or K[2, 0] != 0.0 or K[2, 1] != 0.0 or K[2, 2] != 1.0:
+            raise ValueError(f"camera {c}: the camera matrix must be [[fx, 0, cx], [0, fy, cy], [0, 0, 1]] (skew / a general third row are not supported by the GPU solver; "
+                             "the reference's pre-filter would honour them, geometry.py:323)")
 
     pkw = {}
     if distributed:
@@ -393,8 +427,15 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
                 print("Function evaluations 1, initial cost 0.0000e+00, final cost 0.0000e+00, first-order optimality 0.00e+00.")
             ext, intr, poses = deserialize_params(x0, n_cameras)
             return ext, intr, poses, use_frames, result
-        if local:          # the frames are already on the GPU (pre-filter): gather the selection there, no second upload
+        x0_on_device = False
+        if local and not distributed and hasattr(prob_all, "lm_run") and use_frames.size == prob_all.F and bool((use_frames == np.arange(prob_all.F)).all()):
+            # every frame, in order: the pre-filter's handle IS the problem (observations and start point are where they belong)
+            prob, prob_all = prob_all, None
+            prob.set_loss(kw["loss"], kw.get("f_scale", 1.0))
+            x0_on_device = True
+        elif local:        # the frames are already on the GPU (pre-filter): gather the selection there, no second upload
             prob = prob_all.subset(use_frames - lo, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0))
+            x0_on_device = hasattr(prob, "lm_run")   # (mcba_create_subset gathers the parameters of the chosen frames as well)
         else:
             prob = ops.Problem(np.ascontiguousarray(all_calib_uvs[:, use_frames]), calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0), **pkw)
         if prob_all is not None:
@@ -417,7 +458,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         if max_nfev is None:
             max_nfev = 100 * (12 * n_cameras + 6 * len(all_use))  # trf.py:437-438 on the GLOBAL vector: identical on every rank
         result = solver.lm_solve(prob, x0, ftol=tol("ftol", 1e-4), xtol=tol("xtol", 1e-8), gtol=tol("gtol", 1e-8),
-                                 max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, x_scale=x_scale, **lm_kwargs)
+                                 max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, x_scale=x_scale, x0_on_device=x0_on_device, **lm_kwargs)
         result = LazyOptimizeResult(result)
 
         # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560).  `fun` and `jac` are LAZY: the residual
@@ -445,12 +486,14 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
 
         dict.__setitem__(result, "fun", _Lazy(fun))
         x_local = result.x.copy() if return_jac else None   # this process's frames (a frame-sharded run assembles the global vector below)
-        red = prob.get_reduced()
-        gcam = np.zeros(12 * n_cameras)
-        gcam[prob.cam_index if hasattr(prob, "cam_index") else slice(None)] = red["gc"]   # (6-wide camera block: the gradient entries of the intrinsics held fixed are 0, as with flags)
-        grad = np.concatenate([gcam, prob.frame_gradient().ravel()])
-        if free is not None:
-            grad[: 12 * n_cameras][~free] = 0.0
+        grad = result.lm.pop("grad", None)   # (device-resident loop: packed next to x on the GPU and fetched with it -- mcba_lm_result)
+        if grad is None:
+            red = prob.get_reduced()
+            gcam = np.zeros(12 * n_cameras)
+            gcam[prob.cam_index if hasattr(prob, "cam_index") else slice(None)] = red["gc"]   # (6-wide camera block: the gradient entries of the intrinsics held fixed are 0, as with flags)
+            grad = np.concatenate([gcam, prob.frame_gradient().ravel()])
+            if free is not None:
+                grad[: 12 * n_cameras][~free] = 0.0
         if distributed:
             # assemble the global vectors in selection order: cameras are identical on every rank, poses / frame gradients are gathered
             parts = [None] * world

@@ -33,12 +33,34 @@ def is_stale():
 
 
 def build(force=False, verbose=False, out=None):
-    """hipcc --offload-arch=gfx950 -> multicam-calibration_amd/libmcba.so (cross-compiles without a GPU).
+    """hipcc --offload-arch=gfx950 -> multicam-calibration_amd/libmcba.so (cross-compiles without a GPU).  One object per source,
+    compiled in parallel and only when stale (an object depends on its source and on every header), then linked.
     out: another output path (development: A/B builds for scripts/gram_ab.py, selected at run time with MCBA_LIB)."""
     if out is None and not force and not is_stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
+
     extra = os.environ.get("MCBA_HIPCC_FLAGS", "").split()  # development only (e.g. -DMCBA_SOLVE_TIMING, -save-temps)
-    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", out or LIB, "-ldl"] + SCHED_FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES]
+    objdir = os.path.join(CSRC, ".obj" if out is None and not extra else ".obj_" + str(abs(hash((out, tuple(extra))))))
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, d) for d in DEPS if d not in SOURCES]
+    hdr_time = max(os.path.getmtime(hh) for hh in headers)
+    common = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"] + SCHED_FLAGS + extra
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        srcp = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), hdr_time):
+            return obj
+        cmd = common + ["-c", "-o", obj, srcp]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out or LIB, "-ldl"] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

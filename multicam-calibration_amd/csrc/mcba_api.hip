@@ -48,6 +48,14 @@ struct mcba_handle {
   double *jac = nullptr, *res = nullptr;
   double *err = nullptr, *dmean = nullptr, *dfull = nullptr, *repro = nullptr, *trans = nullptr, *und = nullptr;  // pre-filter / diagnostics (lazy)
   unsigned char *sel = nullptr, *fmask = nullptr;
+  // mcba_prefilter (the selection on the device): scratch state, per-frame status / worst mean error, the packed result and its pinned landing place
+  unsigned char *pf_state = nullptr, *pf_status = nullptr, *pf_packed = nullptr, *pf_host = nullptr;
+  double* pf_worst = nullptr;
+  size_t pf_host_bytes = 0;
+  double* core_arena = nullptr;            // mcba_create: x[0] | x[1] | obj
+  unsigned char* solver_arena = nullptr;   // ensure_solver: the one allocation the solver buffers below are pieces of
+  int* sub_frames = nullptr;   // mcba_create_subset: the frame indices on the device (kept with the handle: no synchronisation to free them)
+  double* outbuf = nullptr;    // mcba_lm_result: [x | gradient] packed for one device-to-host copy
   double* obj_host = nullptr;  // board points as uploaded (diagnostics normalise them on the host)
   int planar = 0;              // every board point has z = 0 exactly (the fused k_gram then runs its planar instance)
   int *tile_i = nullptr, *tile_j = nullptr;
@@ -78,6 +86,7 @@ struct mcba_handle {
   bool fuse_backsub = false, trial_ready = false;
   unsigned long long last_solve_seq = 0;  // sequence number of the last mcba_lm_auto_solve / tick (what a timed-out back-substitution of that launch stamps)
   unsigned long long solve_launches = 0;  // k_solve_cam launches so far (SolveArgs.stage_tag)
+  int slots = 1024;  // wavefront slots of the device (4 x CUs): where k_gram's launch variants cut this shard into rounds
   int ncu = 256, lds_optin = 160 * 1024;  // compute units and the LDS a workgroup may ask for (hipGetDeviceProperties at create; MI355X: 256 / 160 KiB)
   bool spec_copy_ready = false;  // the last k_reduce_system was a speculative one: the pre-decision state copy is in place
   double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8, lam_min = 1e-12, lam_max = 1e12;
@@ -90,6 +99,7 @@ struct mcba_handle {
   std::vector<EvRec> evs;
   std::vector<hipEvent_t> pool;
   std::vector<DevBuf> bufs;        // every pooled device buffer (mcba_destroy parks them)
+  std::vector<double> hist;        // mcba_lm_run: the state every retired tick posted (MCBA_LMS doubles each; row 0 = the solve of the start point)
   bool have_solver = false;        // solver buffers are allocated on first use (ensure_solver): a pre-filter handle never needs them
   size_t ring_bytes = 0, pinned_bytes = 0;
   unsigned ring_flags = 0;
@@ -221,6 +231,7 @@ int dalloc(mcba_handle* h, T** p, size_t count, bool zero = true) {
   HIPCHK(pool_malloc(reinterpret_cast<void**>(p), bytes, h->device));
   h->bufs.push_back({reinterpret_cast<void**>(p), bytes});
   if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
+  else if (getenv("MCBA_POISON") && atoi(getenv("MCBA_POISON")) != 0) HIPCHK(hipMemsetAsync(*p, 0xFF, bytes, h->stream));  // (tests: whatever relies on a fill that is no longer made shows)
   return MCBA_OK;
 }
 
@@ -260,13 +271,36 @@ static int rccl_fail(const char* what, ncclResult_t r) {
   return MCBA_ERR_HIP;
 }
 
+// The tile-pair tables of k_syrk / k_reduce_system (pair p of the NT x NT tile grid's upper triangle -> (i, j)) depend on NT alone:
+// uploaded once per (device, NT) and process, shared by every handle and never freed (at most a few KB each) -- so the first solver
+// call of a handle neither copies nor synchronises for them.
+static int tile_tables(int device, int NT, int** ti, int** tj) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, std::pair<int*, int*>> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find({device, NT});
+  if (it == cache.end()) {
+    std::vector<int> ci, cj;
+    for (int a = 0; a < NT; ++a) for (int b = a; b < NT; ++b) { ci.push_back(a); cj.push_back(b); }
+    int *di = nullptr, *dj = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&di), ci.size() * sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dj), cj.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(di, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dj, cj.data(), cj.size() * sizeof(int), hipMemcpyHostToDevice));
+    it = cache.insert({{device, NT}, {di, dj}}).first;
+  }
+  *ti = it->second.first;
+  *tj = it->second.second;
+  return MCBA_OK;
+}
+
 // Launch geometry of the solver kernels, derived from the problem's shape, the device and the camera block width (h->cw): called by
 // mcba_create and again by mcba_set_camera_block.
 static int derive_geometry(mcba_handle* h) {
   const int C = h->C, F = h->F, N = h->N, device = h->device;
   (void)N;
   const int ncu = h->ncu, slots = 4 * h->ncu;  // wavefront slots at one wavefront per SIMD
-  mcba::gram_set_slots(slots);
+  h->slots = slots;
   h->n = h->cw * C;
   h->nsys = (size_t)h->n * h->n + 3 * h->n + 16;
   // k_syrk geometry: (12C + 1) rows of [Y ; z^T] padded to NT tiles of 16, NP tile pairs (ti <= tj);
@@ -332,15 +366,19 @@ static int derive_geometry(mcba_handle* h) {
   // points each and meet in LDS) -- for shards with at most half a round of items, and for a short last round behind whole fused rounds.
   {
     static bool ps_ready[64] = {};  // the dynamic-LDS limit of its instances is raised once per device
+    static std::mutex ps_mu;        // (handles may be created from several threads: solver.InProcessShards)
     bool ps_ok = (size_t)h->lds_optin >= mcba::gram_psplit_lds_bytes(4) + 2048;
-    if (ps_ok && !ps_ready[device & 63]) { ps_ok = mcba::gram_psplit_set_lds_limit() == 0; ps_ready[device & 63] = ps_ok; (void)hipGetLastError(); }
+    {
+      std::lock_guard<std::mutex> lk(ps_mu);
+      if (ps_ok && !ps_ready[device & 63]) { ps_ok = mcba::gram_psplit_set_lds_limit() == 0; ps_ready[device & 63] = ps_ok; (void)hipGetLastError(); }
+    }
     const int items = C * h->nfb;
     if (ps_ok) {
       if (items <= slots / 4) { h->gram_split = 4; h->gram_npw = 4; }
       else if (items <= slots / 2) { h->gram_split = 4; h->gram_npw = 2; }
       else if (items <= slots) h->gram_split = 0;  // (measured in round 4 at 6 x 7 000 x 54, 660 items: fused 47.4 us, split roles 53.2 us)
       else if (items > slots) {
-        const int fba = mcba::gram_round_blocks(C, h->nfb), tail = C * (h->nfb - fba);
+        const int fba = mcba::gram_round_blocks(C, h->nfb, slots), tail = C * (h->nfb - fba);
         if (fba > 0 && tail > 0 && tail <= slots / 4) { h->gram_split = 5; h->gram_npw = 4; }
         else if (fba > 0 && tail > 0 && tail <= slots / 2 && h->gram_split != 3) { h->gram_split = 5; h->gram_npw = 2; }
       }
@@ -364,7 +402,7 @@ static int derive_geometry(mcba_handle* h) {
 
 extern "C" {
 
-int mcba_abi_version(void) { return 5; }  // 5: camera block width (intrinsics held fixed: 6C x 6C camera system), curvature floor per linearisation, round 4
+int mcba_abi_version(void) { return 6; }  // 6 (round 5): mcba_prefilter, mcba_lm_run / _history / _result -- whole stages of bundle_adjust() per crossing; additions only: every ABI-5 entry point is unchanged
 const char* mcba_last_error(void) { return g_err.c_str(); }
 const char* mcba_profile_names(void) { return kKernelNames; }
 
@@ -402,11 +440,13 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
   // what every handle needs (a pre-filter handle needs nothing else): the two observation layouts, the board, the parameter slots
   DA(obs_t, (size_t)2 * C * N * h->Fpad, false);
   DA(obs_raw, (size_t)2 * C * F * N, false);
-  DA(obj, (size_t)3 * N, true);
-  DA(x[0], h->nx, true);   // (zero: the poses of the padding frames must be finite)
-  DA(x[1], h->nx, true);
+  {  // the two parameter slots and the board: one allocation, one fill (zero: the poses of the padding frames must be finite)
+    const size_t nxp = (h->nx + 31) / 32 * 32;
+    DA(core_arena, 2 * nxp + (size_t)3 * N, true);
+    h->x[0] = h->core_arena; h->x[1] = h->core_arena + nxp; h->obj = h->core_arena + 2 * nxp;
+  }
 #undef DA
-  HIPCHK(hipStreamSynchronize(h->stream));  // the zero fills above ran on the creation stream; the caller may switch streams next
+  // (no synchronisation: the zero fills above are ordered before everything else on this stream, and mcba_set_stream waits for the old stream when it changes it)
   *out = h;
   return MCBA_OK;
 }
@@ -414,31 +454,42 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
 // Solver buffers, allocated on first use (linearise / reduce / LM entry points): records, partial sums, reduce buffer, the host-
 // mapped state ring.  A handle that only runs the pre-filter (api.select_frames over ALL frames of a long recording) never gets
 // here, so its footprint is the observations alone.
+static bool poison_enabled() {   // MCBA_POISON=1 (tests): buffers that are handed out WITHOUT a zero fill are filled with 0xFF bytes (NaN) instead -- whatever relies on a fill shows
+  static const bool on = [] { const char* e = getenv("MCBA_POISON"); return e && atoi(e) != 0; }();
+  return on;
+}
 static int ensure_solver(mcba_handle* h) {
   if (h->have_solver) return MCBA_OK;
   const int C = h->C;
   int rc;
-  // (re-entered after a failed attempt -- out of memory part-way -- it keeps what it already has: a slot that is set is not allocated
-  //  again, so nothing leaks and mcba_destroy finds every buffer once)
-#define DA(p, cnt) if (!h->p && (rc = dalloc(h, &h->p, (cnt))) != MCBA_OK) return rc;
-  DA(rec2[0], (size_t)h->Fpad * C * MCBA_REC);
-  DA(rec2[1], (size_t)h->Fpad * C * MCBA_REC);
-  DA(gpart2[0], (size_t)C * h->nfb * MCBA_GP);
-  DA(gpart2[1], (size_t)C * h->nfb * MCBA_GP);
-  DA(fbuf, (size_t)h->Fpad * MCBA_FB);
-  DA(fpart, (size_t)2 * h->nfblocks);
-  DA(spart, (size_t)h->G * h->NP * 256 + 64 + 12 * (size_t)h->G);  // + per-workgroup stamps of MCBA_SYRK_TIMING builds
-  DA(cpart, (size_t)2 * C * h->nfb * h->nch);
-  DA(bpart, (size_t)3 * h->nbblocks);
-  DA(red_own, h->nsys + 8 + 2 * MCBA_LMS);
-  DA(tile_i, (size_t)h->NP);
-  DA(tile_j, (size_t)h->NP);
-  DA(dcbuf, (size_t)h->n + 8);  // + the word k_solve_backsub's solve releases, + the poll-timeout stamp
-  DA(swork, h->solve_lds ? 16 : 2 * (size_t)h->npad * h->npad + 64 * (size_t)h->npad);  // two sets of 16 x 16 tiles of the lower triangle (mcba_solve.hip, right-looking variant)
-  DA(fixed, (size_t)h->n);
-  DA(dscale, h->nx);
-  if (h->gram_split == 3) { DA(gchunk, mcba::gram_chunk_doubles(C, h->nfb, h->gram_nchunk)); }
-#undef DA
+  // ONE device allocation for the whole set (round 5: sixteen pool look-ups and sixteen fill launches -- ~50 us of host time and as
+  // much of the stream in front of the first linearisation -- became one of each), cut into 256-byte aligned pieces.  The pieces a
+  // kernel overwrites completely before anything reads them (linearisation records, k_syrk's partial tiles, the point-chunk scratch:
+  // 110 of the 116 MB at 6 x 10 000 x 54) sit behind the ones that start from zero and are not filled.
+  if (!h->solver_arena) {
+    struct Piece { double** p; size_t count; };
+    double** none = nullptr;
+    (void)none;
+    const size_t n_swork = h->solve_lds ? 16 : 2 * (size_t)h->npad * h->npad + 64 * (size_t)h->npad;  // two sets of 16 x 16 tiles of the lower triangle (mcba_solve.hip, right-looking variant)
+    Piece zeroed[] = {{&h->gpart2[0], (size_t)C * h->nfb * MCBA_GP}, {&h->gpart2[1], (size_t)C * h->nfb * MCBA_GP}, {&h->fbuf, (size_t)h->Fpad * MCBA_FB}, {&h->fpart, (size_t)2 * h->nfblocks},
+                      {&h->cpart, (size_t)2 * C * h->nfb * h->nch}, {&h->bpart, (size_t)3 * h->nbblocks}, {&h->red_own, h->nsys + 8 + 2 * MCBA_LMS},
+                      {&h->dcbuf, (size_t)h->n + 8},  // + the word k_solve_backsub's solve releases, + the poll-timeout stamp
+                      {&h->swork, n_swork}, {&h->dscale, h->nx}, {reinterpret_cast<double**>(&h->fixed), ((size_t)h->n + 7) / 8}};
+    Piece plain[] = {{&h->rec2[0], (size_t)h->Fpad * C * MCBA_REC}, {&h->rec2[1], (size_t)h->Fpad * C * MCBA_REC},
+                     {&h->spart, (size_t)h->G * h->NP * 256 + 64 + 12 * (size_t)h->G},  // + per-workgroup stamps of MCBA_SYRK_TIMING builds
+                     {&h->gchunk, h->gram_split == 3 ? mcba::gram_chunk_doubles(C, h->nfb, h->gram_nchunk, h->slots) : 0}};
+    auto padded = [](size_t count) { return (std::max<size_t>(count, 1) * sizeof(double) + 255) / 256 * 256; };
+    size_t zero_bytes = 0, total = 0;
+    for (auto& pc : zeroed) zero_bytes += padded(pc.count);
+    total = zero_bytes;
+    for (auto& pc : plain) if (pc.count) total += padded(pc.count);
+    if ((rc = dalloc(h, &h->solver_arena, total, false)) != MCBA_OK) return rc;
+    HIPCHK(hipMemsetAsync(h->solver_arena, 0, zero_bytes, h->stream));
+    if (poison_enabled()) HIPCHK(hipMemsetAsync(h->solver_arena + zero_bytes, 0xFF, total - zero_bytes, h->stream));
+    size_t off = 0;
+    for (auto& pc : zeroed) { *pc.p = reinterpret_cast<double*>(h->solver_arena + off); off += padded(pc.count); }
+    for (auto& pc : plain) if (pc.count) { *pc.p = reinterpret_cast<double*>(h->solver_arena + off); off += padded(pc.count); }
+  }
   if (mcba::solve_set_lds_limit(h->npad, h->solve_lds) != 0) return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_solve_cam");
   h->fuse_backsub = h->solve_lds != 0;
   if (const char* e = getenv("MCBA_FUSE_BACKSUB")) h->fuse_backsub = h->fuse_backsub && atoi(e) != 0;  // tuning knob
@@ -456,11 +507,7 @@ static int ensure_solver(mcba_handle* h) {
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&h->ring_dev), h->ring, 0) != hipSuccess) return fail(MCBA_ERR_HIP, "hipHostGetDevicePointer failed for the LM state ring");
   }
   h->red = h->red_own;
-  std::vector<int> ci, cj;
-  for (int a = 0; a < h->NT; ++a) for (int b = a; b < h->NT; ++b) { ci.push_back(a); cj.push_back(b); }
-  HIPCHK(hipMemcpyAsync(h->tile_i, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->tile_j, cj.data(), cj.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));  // the sources are locals of this function (once per handle: ~10 us)
+  if ((rc = tile_tables(h->device, h->NT, &h->tile_i, &h->tile_j)) != MCBA_OK) return rc;
   if (!h->pinned) {
     h->pinned_bytes = (h->nsys + 8 + MCBA_LMS + h->n) * sizeof(double);
     HIPCHK(pool_host_malloc(reinterpret_cast<void**>(&h->pinned), h->pinned_bytes, hipHostMallocDefault));
@@ -483,6 +530,7 @@ int mcba_destroy(mcba_handle* h) {
   free(h->obj_host);
   pool_host_free(h->pinned, h->pinned_bytes, hipHostMallocDefault);
   pool_host_free(h->ring, h->ring_bytes, h->ring_flags);
+  pool_host_free(h->pf_host, h->pf_host_bytes, hipHostMallocDefault);
   for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->pool) (void)hipEventDestroy(e);
   delete h;
@@ -507,19 +555,19 @@ int mcba_synchronize(mcba_handle* h) {
   return MCBA_OK;
 }
 
-int mcba_upload_observations(mcba_handle* h, const double* uvs, const double* objpoints) {
-  if (!h || !uvs || !objpoints) return fail(MCBA_ERR_ARG, "mcba_upload_observations: NULL argument");
-  HIPCHK(hipSetDevice(h->device));
+static int upload_impl(mcba_handle* h, const double* uvs, const double* objpoints, bool sync) {
   size_t raw_count = (size_t)2 * h->C * h->F * h->N;
   // both layouts live in HBM: raw (C,F,N) for k_jacobian (lane = point), [C][N][Fpad] for k_gram / k_cost (lane = frame)
   hipError_t e = hipMemcpyAsync(h->obs_raw, uvs, raw_count * sizeof(double), hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(h->obj, objpoints, (size_t)3 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess && !mcba::launch_store_small(h->stream, h->obj, objpoints, (size_t)3 * h->N))   // (boards of up to 160 points: through the kernel arguments)
+    e = hipMemcpyAsync(h->obj, objpoints, (size_t)3 * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) {
     Scope sc(h, K_TRANSPOSE);
     mcba::launch_transpose_obs(h->stream, h->obs_raw, h->obs_t, h->C, h->F, h->N, h->Fpad);
   }
   if (e == hipSuccess) e = hipGetLastError();
-  hipError_t e2 = hipStreamSynchronize(h->stream);
+  // (the sources are pageable host memory: the copies are staged / done when the calls return; callers that go on enqueueing need no wait)
+  hipError_t e2 = sync ? hipStreamSynchronize(h->stream) : hipSuccess;
   if (e != hipSuccess || e2 != hipSuccess) { g_err = std::string("upload: ") + hipGetErrorString(e != hipSuccess ? e : e2); return MCBA_ERR_HIP; }
   if (!h->obj_host) h->obj_host = static_cast<double*>(malloc((size_t)3 * h->N * sizeof(double)));
   if (h->obj_host) memcpy(h->obj_host, objpoints, (size_t)3 * h->N * sizeof(double));
@@ -529,6 +577,12 @@ int mcba_upload_observations(mcba_handle* h, const double* uvs, const double* ob
   h->have_obs = true;
   h->have_lin = h->have_red = h->have_jac = false;
   return MCBA_OK;
+}
+
+int mcba_upload_observations(mcba_handle* h, const double* uvs, const double* objpoints) {
+  if (!h || !uvs || !objpoints) return fail(MCBA_ERR_ARG, "mcba_upload_observations: NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  return upload_impl(h, uvs, objpoints, true);
 }
 
 int mcba_set_loss(mcba_handle* h, int loss, double f_scale) {
@@ -547,7 +601,8 @@ int mcba_set_loss(mcba_handle* h, int loss, double f_scale) {
 int mcba_set_camera_block(mcba_handle* h, int width) {
   if (!h || (width != 6 && width != 12)) return fail(MCBA_ERR_ARG, "mcba_set_camera_block: width 6 or 12");
   if (width == h->cw) return MCBA_OK;
-  if (h->have_solver) return fail(MCBA_ERR_ARG, "mcba_set_camera_block: call it before the first solver entry point of the handle");
+  // (any solver buffer, not just a complete set: a first attempt that ran out of memory part-way leaves buffers sized for the old width behind)
+  if (h->have_solver || h->solver_arena) return fail(MCBA_ERR_ARG, "mcba_set_camera_block: call it before the first solver entry point of the handle");
   if (width == 6) {
     const int nt = (6 * h->C + 1 + 15) / 16;
     if (nt * (nt + 1) / 2 > 64) return fail(MCBA_ERR_ARG, "mcba_set_camera_block: more than 26 cameras -- hold the intrinsics with the flags of mcba_lm_auto_config instead");
@@ -693,7 +748,7 @@ int mcba_linearize(mcba_handle* h, int slot) {
   NEED_SOLVER(h);
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots);
   }
   int rc = check_launch();
   if (rc) return rc;
@@ -772,7 +827,7 @@ int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, 
   const int alt = 1 - h->lin;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -849,7 +904,7 @@ static int lm_trial_impl(mcba_handle* h, const double* delta_cam, const mcba::De
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);  // trial point = the OTHER slot / buffer
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, dev_sel(h, 1)), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, dev_sel(h, 1)), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -880,7 +935,7 @@ static int lm_reduce_chain(mcba_handle* h, int rank_slot, bool spec = false, boo
     // ... except where its point-split variant ran (one frame block per wavefront group: every slot holds its own cost)
     if (h->gram_split == 4) { fz.cdense = 0; fz.cinner = h->nfb; }
     else if (h->gram_split == 5) {
-      const int fba = mcba::gram_round_blocks(h->C, h->nfb);
+      const int fba = mcba::gram_round_blocks(h->C, h->nfb, h->slots);
       if (fba > 0 && fba < h->nfb) { fz.cdense = fba / 4; fz.cinner = fba / 4 + (h->nfb - fba); }
     }
     fz.couter = (size_t)MCBA_GP * h->nfb;
@@ -1031,7 +1086,7 @@ static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, dev_sel(h, 1)), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, dev_sel(h, 1)), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots);
   }
   if ((rc = check_launch())) return rc;
   if (!sum_here) return MCBA_OK;
@@ -1152,14 +1207,199 @@ int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The whole device-resident LM loop in ONE call (round 5): what solver.LevenbergMarquardt.start() + its iterate() loop + finalize() do
+// through a dozen crossings and six host synchronisations before the first tick -- upload x0, linearise, reduce, read the cost back,
+// write the state, configure, solve -- is enqueued here without a single wait: the start state is written ON THE DEVICE from the reduced
+// system (k_lm_init), the first ticks are enqueued behind the first solve at once, and the host then only polls the ring.  Same ticks,
+// same decisions, same order as the Python loop (the device decides; this loop only chooses how many ticks are in flight, by the same
+// rule).  opt: 0 ftol 1 xtol 2 gtol 3 lam0 4 lam_min 5 lam_max 6 dec_floor 7 curvature floor 8 curvature switch (0 = fixed model)
+// 9 max_nfev 10 max ticks (< 0: no limit) 11 ticks in flight (depth) 12 rank slot.  x0 NULL = start from what slot 0 holds.
+// summary: 0 status (scipy's; 0 = a limit was reached) 1 rows recorded 2 rows the main loop consumed (the rest were retired by the
+// final drain) -- fetch the rows with mcba_lm_history.
+int mcba_lm_run(mcba_handle* h, const double* x0, const double* opt, const unsigned char* fixed, double* summary) {
+  if (!h || !opt || !summary) return fail(MCBA_ERR_ARG, "mcba_lm_run: bad argument");
+  if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_lm_run: upload observations first");
+  const double lam0 = opt[3], lam_min = opt[4], lam_max = opt[5], cfl = opt[7], cfl_switch = opt[8];
+  const int depth = std::max(1, std::min((int)opt[11], 12)), rank_slot = (int)opt[12];
+  const double max_nfev = opt[9], max_ticks = opt[10];
+  if (!(lam0 > 0.0) || !(lam_min > 0.0) || !(lam_max > lam_min) || !(cfl > 0.0) || cfl > 1.0 || rank_slot < 0 || rank_slot > 11 || !(opt[6] >= 0.0) || opt[6] >= 1.0)
+    return fail(MCBA_ERR_ARG, "mcba_lm_run: bad option");
+  HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
+  int rc;
+  if (h->auto_ready) HIPCHK(hipStreamSynchronize(h->stream));  // no tick of an earlier run may still be posting into the ring
+  if (x0) HIPCHK(hipMemcpyAsync(h->x[0], x0, ((size_t)12 * h->C + (size_t)6 * h->F) * sizeof(double), hipMemcpyHostToDevice, h->stream));  // (pageable: staged when the call returns)
+  h->curv_floor = cfl;
+  h->dec_floor = opt[6];
+  h->lin = 0;   // parameter slot 0 and linearisation buffer 0 belong together (mcba_lm_set_state's convention)
+  {
+    Scope sc(h, K_GRAM);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[0], h->x[0], h->rec2[0], h->rec2[0], h->gpart2[0], h->gpart2[0], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots);
+  }
+  if ((rc = check_launch())) return rc;
+  h->have_lin = true; h->have_spec = false;
+  if ((rc = mcba_build_reduced(h, lam0, rank_slot))) return rc;
+  if (h->comm && (rc = mcba_comm_allreduce(h, 0, h->nsys))) return rc;
+  mcba::launch_lm_init(h->stream, h->red + (size_t)h->n * h->n + 3 * (size_t)h->n, h->red + h->nsys + 8, lam0, 0, cfl, cfl_switch);
+  if ((rc = check_launch())) return rc;
+  // mcba_lm_auto_config, without its two waits
+  h->ftol = opt[0]; h->xtol = opt[1]; h->gtol = opt[2]; h->lam_min = lam_min; h->lam_max = lam_max;
+  h->have_fixed = fixed != nullptr;
+  if (fixed) HIPCHK(hipMemcpyAsync(h->fixed, fixed, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  memset(h->ring, 0, (size_t)kRing * MCBA_LMS * sizeof(double));
+  HIPCHK(hipMemsetAsync(h->dcbuf + h->n, 0, 8 * sizeof(double), h->stream));
+  h->trial_ready = false;
+  h->last_solve_seq = 0;
+  h->auto_ready = true;
+  if (const char* e = getenv("MCBA_SPECULATE")) h->speculate = atoi(e) != 0;
+  if ((rc = auto_solve_impl(h, 1, 0, false))) return rc;
+
+  h->hist.clear();
+  unsigned long long issued = 1, retired = 1;
+  double nfev = 1.0, st[MCBA_LMS];
+  auto top_up = [&]() -> int {
+    while (issued - retired < (unsigned long long)depth) {
+      const double inflight = (double)(issued - retired);
+      if (nfev + inflight >= max_nfev) break;
+      if (max_ticks >= 0.0 && (double)(issued - 1) >= max_ticks) break;
+      ++issued;
+      int r = mcba_lm_auto_tick(h, issued, rank_slot);
+      if (r) return r;
+    }
+    return MCBA_OK;
+  };
+  if ((rc = top_up())) return rc;            // the first ticks go in behind the first solve: nobody waits for it on the way
+  if ((rc = mcba_lm_auto_wait(h, 1, st))) return rc;
+  h->hist.insert(h->hist.end(), st, st + MCBA_LMS);
+  if (!std::isfinite(st[0])) return fail(MCBA_ERR_NONFINITE, "Residuals are not finite in the initial point.");
+  const int status0 = (int)st[MCBA_LM_DONE];
+  int status = -1;
+  double steps = 0.0;
+  for (;;) {
+    if (nfev >= max_nfev || (max_ticks >= 0.0 && steps >= max_ticks)) { status = 0; break; }
+    steps += 1.0;
+    if (status0) { status = status0; break; }
+    if ((rc = top_up())) return rc;
+    if (issued == retired) { status = 0; break; }
+    ++retired;
+    if ((rc = mcba_lm_auto_wait(h, retired, st))) return rc;
+    h->hist.insert(h->hist.end(), st, st + MCBA_LMS);
+    if (st[MCBA_LM_REBUILD] == 0.0) nfev = 1.0 + st[MCBA_LM_NFEV];
+    if (st[MCBA_LM_DONE] != 0.0) { status = (int)st[MCBA_LM_DONE]; break; }
+  }
+  const size_t n_main = h->hist.size() / MCBA_LMS;
+  while (retired < issued) {   // stopped with ticks in flight: retire them (their accepted steps count unless the loop had terminated)
+    ++retired;
+    if ((rc = mcba_lm_auto_wait(h, retired, st))) return rc;
+    h->hist.insert(h->hist.end(), st, st + MCBA_LMS);
+  }
+  summary[0] = (double)status;
+  summary[1] = (double)(h->hist.size() / MCBA_LMS);
+  summary[2] = (double)n_main;
+  summary[3] = steps;
+  return MCBA_OK;
+}
+
+int mcba_lm_history(mcba_handle* h, double* rows, size_t capacity_rows) {
+  if (!h || !rows) return fail(MCBA_ERR_ARG, "mcba_lm_history: bad argument");
+  const size_t n = h->hist.size() / MCBA_LMS;
+  if (capacity_rows < n) return fail(MCBA_ERR_ARG, "mcba_lm_history: buffer too small (summary[1] of mcba_lm_run rows)");
+  if (n) memcpy(rows, h->hist.data(), h->hist.size() * sizeof(double));
+  return MCBA_OK;
+}
+
+// Solution and gradient of the current point in ONE device-to-host copy: out = [x (12C + 6F) | gradient (12C + 6F)] -- x of `slot`, the
+// camera gradient of the reduced system in the reduce buffer (scattered to the parameter layout, zero where a parameter is held fixed by
+// the camera block width or by mcba_lm_auto_config's / mcba_lm_run's flags), the frame gradients.  The reduced system must be that of
+// the current point (after a terminated loop it is; solver.LevenbergMarquardt.finalize rebuilds it otherwise).
+int mcba_lm_result(mcba_handle* h, int slot, double* out) {
+  if (!slot_ok(h, slot) || !out) return fail(MCBA_ERR_ARG, "mcba_lm_result: bad argument");
+  if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_lm_result: no reduced system");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t nx = (size_t)12 * h->C + (size_t)6 * h->F;
+  int rc;
+  if (!h->outbuf && (rc = dalloc(h, &h->outbuf, 2 * nx, false))) return rc;
+  mcba::launch_pack_result(h->stream, h->x[slot], h->red + (size_t)h->n * h->n + 2 * (size_t)h->n, h->fbuf, h->have_fixed ? h->fixed : nullptr, h->outbuf, h->C, h->F, h->cw);
+  if ((rc = check_launch())) return rc;
+  HIPCHK(hipMemcpyAsync(out, h->outbuf, 2 * nx * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // bundle_adjust()'s frame pre-filter on the GPU (reference bundle_adjustment.py:265-285) and frame subsets without a second upload
 static int ensure_diag(mcba_handle* h) {
   int rc;
-  if (!h->err && (rc = dalloc(h, &h->err, (size_t)h->C * h->N * h->Fpad))) return rc;
-  if (!h->dmean && (rc = dalloc(h, &h->dmean, std::max<size_t>((size_t)h->C * h->F, 8)))) return rc;
-  if (!h->dfull && (rc = dalloc(h, &h->dfull, (size_t)h->C * h->F))) return rc;
-  if (!h->sel && (rc = dalloc(h, &h->sel, mcba::select_state_bytes(2 * h->C)))) return rc;
-  if (!h->fmask && (rc = dalloc(h, &h->fmask, (size_t)h->Fpad))) return rc;
+  // (none of them is filled: k_frame_err / k_reproj_diag write every error and statistic, launch_select clears its states, the mask is
+  //  written whole by whoever uses it)
+  if (!h->err && (rc = dalloc(h, &h->err, (size_t)h->C * h->N * h->Fpad, false))) return rc;
+  if (!h->dmean && (rc = dalloc(h, &h->dmean, std::max<size_t>((size_t)h->C * h->F, 8), false))) return rc;
+  if (!h->dfull && (rc = dalloc(h, &h->dfull, (size_t)h->C * h->F, false))) return rc;
+  if (!h->sel && (rc = dalloc(h, &h->sel, mcba::select_state_bytes(2 * h->C), false))) return rc;
+  if (!h->fmask && (rc = dalloc(h, &h->fmask, (size_t)h->Fpad, false))) return rc;
+  return MCBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bundle_adjust()'s pre-filter in ONE call and ONE host synchronisation (round 5): upload (observations, board, parameters of every
+// frame), re-layout, k_frame_err, and the whole selection on the device (mcba_diag.hip: frames complete in two cameras, worst camera's
+// mean error, 5 x nanmedian by a three-pass radix select, the comparison) -- the host reads 80 + F bytes.  The transfer is NOT cut
+// into chunks with kernels in between: measured on the MI355X box (scripts/micro/h2d_pipeline.hip, profiles/round5/h2d_pipeline.txt)
+// one hipMemcpyAsync of the 51.8 MB takes 0.92 ms (56 GB/s, the call blocks: pageable source), six chunks 1.10 ms, twelve 1.23 ms
+// (~30 us per extra call), a pinned staging ring 1.93 ms -- while everything the GPU does behind the copy is ~60 us.
+static int median_of_err(mcba_handle* h, size_t per_group, int groups, bool use_mask, double* median, double* count);
+static int ensure_prefilter(mcba_handle* h) {
+  int rc = ensure_diag(h);
+  if (rc) return rc;
+  if (!h->pf_state && (rc = dalloc(h, &h->pf_state, mcba::prefilter_state_bytes(), false))) return rc;
+  if (!h->pf_status && (rc = dalloc(h, &h->pf_status, (size_t)h->Fpad, false))) return rc;
+  if (!h->pf_worst && (rc = dalloc(h, &h->pf_worst, (size_t)h->Fpad, false))) return rc;
+  if (!h->pf_packed && (rc = dalloc(h, &h->pf_packed, (size_t)h->Fpad + 128, false))) return rc;
+  if (!h->pf_host) {
+    h->pf_host_bytes = (size_t)h->Fpad + 128;
+    HIPCHK(pool_host_malloc(reinterpret_cast<void**>(&h->pf_host), h->pf_host_bytes, hipHostMallocDefault));
+  }
+  return MCBA_OK;
+}
+
+int mcba_prefilter(mcba_handle* h, const double* uvs, const double* objpoints, const double* x, double outlier_threshold, unsigned char* status, double* info8) {
+  if (!h || !x || !status || !info8 || (uvs == nullptr) != (objpoints == nullptr)) return fail(MCBA_ERR_ARG, "mcba_prefilter: bad argument");
+  if (!uvs && !h->have_obs) return fail(MCBA_ERR_ARG, "mcba_prefilter: no observations (pass them, or upload them first)");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_prefilter(h);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h->x[0], x, ((size_t)12 * h->C + (size_t)6 * h->F) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (uvs && (rc = upload_impl(h, uvs, objpoints, false))) return rc;
+  mcba::launch_frame_err(h->stream, h->obs_t, h->obj, h->x[0], h->err, h->dmean, h->dfull, h->C, h->F, h->N, h->Fpad);
+  mcba::launch_prefilter_select(h->stream, h->err, h->dmean, h->dfull, h->fmask, h->pf_status, h->pf_worst, h->pf_state, h->pf_packed, h->C, h->F, h->N, h->Fpad, outlier_threshold);
+  if ((rc = check_launch())) return rc;
+  const size_t nb = 64 + (size_t)h->F;
+  auto fetch = [&]() -> int {
+    HIPCHK(hipMemcpyAsync(h->pf_host, h->pf_packed, nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MCBA_OK;
+  };
+  if ((rc = fetch())) return rc;
+  double info[8];
+  memcpy(info, h->pf_host, sizeof(info));
+  const char* force = getenv("MCBA_PREFILTER_FALLBACK");   // test knob: take the eight-pass select whatever the candidate count
+  if (outlier_threshold != outlier_threshold && (info[3] != 0.0 || (force && atoi(force) != 0))) {
+    // more values share the median's 24 leading bits than the candidate list holds: the eight-pass radix select on the same mask
+    double med = 0.0, cnt = 0.0;
+    if ((rc = median_of_err(h, (size_t)h->C * h->N * h->Fpad, 1, true, &med, &cnt))) return rc;
+    mcba::launch_prefilter_status(h->stream, h->pf_status, h->pf_worst, h->pf_state, h->pf_packed, h->F, 5.0 * med, 0);
+    if ((rc = check_launch())) return rc;
+    if ((rc = fetch())) return rc;
+    memcpy(info, h->pf_host, sizeof(info));
+    info[1] = med; info[2] = cnt; info[3] = 1.0;
+  }
+  memcpy(status, h->pf_host + 64, (size_t)h->F);
+  {  // frames used / excluded / kept but incomplete in some camera (the counts of the printed line)
+    double used = 0, excl = 0, inc = 0;
+    for (int f = 0; f < h->F; ++f) { const unsigned char sf = status[f]; used += sf & 1; excl += (sf >> 1) & 1; inc += ((sf & 7) == 1) ? 1 : 0; }
+    info[4] = used; info[5] = excl; info[6] = inc;
+  }
+  memcpy(info8, info, sizeof(info));
   return MCBA_OK;
 }
 
@@ -1216,14 +1456,18 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
   int rc = mcba_create(out, src->C, n_frames, src->N, src->device);
   if (rc) return rc;
   mcba_handle* h = *out;
+  if (src->stream != h->stream) HIPCHK(hipStreamSynchronize(h->stream));  // mcba_create's zero fills ran on the creation stream
   h->stream = src->stream;
   h->loss = src->loss;
   h->f_scale = src->f_scale;
-  int* d_frames = nullptr;
-  hipError_t e = pool_malloc(reinterpret_cast<void**>(&d_frames), (size_t)n_frames * sizeof(int), h->device);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_frames, frames, (size_t)n_frames * sizeof(int), hipMemcpyHostToDevice, h->stream);
+  // (the index list lives and dies with the new handle: nothing to free here, so nothing to wait for)
+  if ((rc = dalloc(h, &h->sub_frames, (size_t)n_frames, false)) != MCBA_OK) { mcba_destroy(h); *out = nullptr; return rc; }
+  int* d_frames = h->sub_frames;
+  hipError_t e = hipMemcpyAsync(d_frames, frames, (size_t)n_frames * sizeof(int), hipMemcpyHostToDevice, h->stream);  // (pageable source: staged before the call returns)
   if (e == hipSuccess) {
     mcba::launch_gather_frames(h->stream, src->obs_raw, d_frames, h->obs_raw, h->C, src->F, h->F, h->N);
+    // ... and the parameters of the source's slot 0: the camera blocks + the poses of the chosen frames (what bundle_adjust starts from)
+    mcba::launch_gather_params(h->stream, src->x[0], d_frames, h->x[0], h->C, h->F);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(h->obj, src->obj, (size_t)3 * h->N * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
@@ -1232,10 +1476,8 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
     mcba::launch_transpose_obs(h->stream, h->obs_raw, h->obs_t, h->C, h->F, h->N, h->Fpad);
     e = hipGetLastError();
   }
-  hipError_t e2 = hipStreamSynchronize(h->stream);
-  pool_free(d_frames, (size_t)n_frames * sizeof(int), h->device);  // (after the synchronisation above)
-  if (e != hipSuccess || e2 != hipSuccess) {
-    g_err = std::string("mcba_create_subset: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+  if (e != hipSuccess) {
+    g_err = std::string("mcba_create_subset: ") + hipGetErrorString(e);
     mcba_destroy(h);
     *out = nullptr;
     return MCBA_ERR_HIP;
@@ -1479,7 +1721,11 @@ int mcba_residuals_detach(mcba_handle* h, int slot, mcba_buffer** out) {
   NEED_SOLVER(h);
   int rc = ensure_res(h);
   if (rc) return rc;
-  if ((rc = run_cost(h, slot, h->res, nullptr, 0))) return rc;
+  {  // (the residual vector alone: the cost sums of run_cost are not wanted here)
+    Scope sc(h, K_COST);
+    mcba::launch_cost(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->cpart, h->res, h->C, h->F, h->N, h->Fpad, h->nch);
+  }
+  if ((rc = check_launch())) return rc;
   mcba_buffer* b = new mcba_buffer{h->res, (size_t)2 * h->C * h->F * h->N, h->device, h->stream};
   for (size_t i = 0; i < h->bufs.size(); ++i)
     if (h->bufs[i].slot == reinterpret_cast<void**>(&h->res)) { h->bufs.erase(h->bufs.begin() + i); break; }

@@ -152,6 +152,370 @@ __global__ void k_sel_pick(SelState* __restrict__ sts, int pass, int upper, int 
   for (int b = 0; b < 256; ++b) st->hist[b] = 0;
 }
 
+// ---------------------------------------------------------------- the pre-filter's frame selection, all of it on the device
+// (mcba_prefilter: bundle_adjustment.py:266-285 in ONE host synchronisation).  What the host did between k_frame_err and the
+// gather -- which frames are complete in two cameras (:266), the worst camera's mean error per frame (:279), 5 x nanmedian of the
+// per-point errors of those frames (:281-282), the comparison (:285) -- runs here; the host gets one status byte per frame.
+// The median is the exact order statistic by radix select on the bit patterns, as above, but in THREE passes over the 26 MB
+// error array instead of eight, and without the host in between:
+//   pass 0  histogram of the leading 12 bits (sign + exponent; the lanes of a wavefront that share a digit -- nearly all of them --
+//           post ONE LDS atomic) + the per-frame masks (which the later passes and the status kernel read);
+//   pass 1  every workgroup picks the exponent bin of the two middle ranks from pass 0's histogram, then histograms the next 8 bits
+//           of the values in it -- its OWN histogram, stored, not added, to a slot of its own;
+//   pass 2  every workgroup sums those slots and picks the 20-bit prefix, then COMPACTS the values that carry it (LDS staging, one
+//           reservation per workgroup in one of 8 candidate lists: ~10 k of 3.2 M values at 6 x 10 000 x 54);
+//   final   one workgroup selects among the candidates (radix passes over the remaining 44 bits, the candidates in LDS) -> median;
+//   status  exclusion per frame, packed behind the 8 info doubles for ONE device-to-host copy.
+// What shaped it (rocprofv3, profiles/round5/NOTES_round5.md): (i) a first version with 2 198 small workgroups, a ticket per pass for
+// "the last one picks" and one shared candidate counter ran 150-190 us PER PASS: device-scope atomics on ONE address retire at ~70 ns
+// each on this part, whoever issues them; (ii) 128 workgroups adding 1 024-bin histograms into global replicas: 127 us -- ~1 ns per
+// global atomic in aggregate; (iii) what a pass costs beyond that is memory round trips per wavefront (~2 us each), not bytes.  Hence:
+// no tickets (the NEXT pass's workgroups redo the pick: kernel boundary = visibility), no global histogram atomics beyond the handful
+// of exponent bins of pass 0 (8 replicas), candidates reserved once per workgroup in 8 lists, eight 512-byte loads in flight per
+// wavefront.  A candidate list that overflows (all errors equal ...) sets `overflow`; the host then falls back to the eight-pass
+// select above on the same mask.
+constexpr int PF_G = 256;            // workgroups of the passes at most
+constexpr int PF_REP = 8;            // replicas of pass 0's histogram / candidate lists
+constexpr int PF_SEG = 1024;         // candidates a workgroup stages per order statistic
+constexpr int PF_LIST = 32768;       // capacity of one candidate list
+constexpr int PF_BITS_B = 8;         // digit of pass 1
+constexpr int PF_NB = 1 << PF_BITS_B;
+constexpr int PF_ROWS = 8;           // rows a wavefront takes of a work item (loads in flight)
+struct PrefState {
+  unsigned long long histA[PF_REP][4096];
+  unsigned int list_count[2][PF_REP];
+  unsigned int overflow, pad[3];
+  unsigned long long total, rankA[2], prefixA[2];   // written by workgroup 0 of pass 1: the 12-bit bins of the two middle ranks, the ranks inside them
+  unsigned long long rankB[2], prefixB[2];          // written by workgroup 0 of pass 2: the 20-bit prefixes, the ranks inside them
+  double info[8];                                   // 0 threshold  1 median  2 number of values  3 overflow
+  // (not cleared: every slot that is read has been written by the same call)
+  unsigned int partB[PF_G][2][PF_NB];
+  unsigned long long cand[2][PF_REP][PF_LIST];
+};
+size_t prefilter_state_bytes() { return sizeof(PrefState); }
+size_t prefilter_state_clear_bytes() { return offsetof(PrefState, partB); }
+
+// one wavefront: the bin that holds rank r of a histogram of NB bins (a multiple of 64; LDS or global), and the number of values below it
+template <int NB, class T>
+__device__ __forceinline__ void wave_pick_bin(const T* hist, unsigned long long r, int lane, unsigned& digit, unsigned long long& below) {
+  constexpr int PER = NB / 64;
+  unsigned long long cnt[PER];
+  unsigned long long mine = 0;
+#pragma unroll
+  for (int b = 0; b < PER; ++b) { cnt[b] = (unsigned long long)hist[lane * PER + b]; mine += cnt[b]; }
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  const unsigned long long excl = incl - mine;
+  const unsigned long long who = __ballot(r >= excl && r < incl);
+  const int src = who ? __ffsll((long long)who) - 1 : 63;  // (empty histogram: the last lane -- never used: the callers check the total)
+  unsigned d = lane * PER + PER - 1;
+  unsigned long long bl = excl;
+  bool found = false;
+#pragma unroll
+  for (int b = 0; b < PER; ++b) {
+    if (!found) {
+      if (r < bl + cnt[b] || b == PER - 1) { d = (unsigned)(lane * PER + b); found = true; }
+      else bl += cnt[b];
+    }
+  }
+  digit = __shfl(d, src, 64);
+  below = __shfl(bl, src, 64);
+}
+
+// per frame: used (complete in >= 2 cameras, :266), complete in every camera, the worst camera's nan-mean error (np.nanmax, :279)
+__device__ __forceinline__ unsigned char pf_frame_mask(const double* __restrict__ mean_cf, const double* __restrict__ full_cf, int f, int C, int F, int N, double& worst) {
+  int ncomp = 0;
+  double w = __builtin_nan("");
+  for (int c = 0; c < C; ++c) {
+    ncomp += full_cf[(size_t)c * F + f] == (double)N ? 1 : 0;
+    w = fmax(w, mean_cf[(size_t)c * F + f]);  // fmax ignores a NaN operand: NaN only where every camera is NaN (np.fmax.reduce)
+  }
+  worst = w;
+  return (unsigned char)((ncomp > 1 ? 1 : 0) | (ncomp == C ? 4 : 0));
+}
+__global__ __launch_bounds__(256) void k_pf_mask(const double* __restrict__ mean_cf, const double* __restrict__ full_cf, unsigned char* __restrict__ fmask, unsigned char* __restrict__ status,
+                                                 double* __restrict__ worst, int C, int F, int N, int Fpad) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= Fpad) return;
+  if (f >= F) { fmask[f] = 0; return; }
+  double w;
+  const unsigned char s = pf_frame_mask(mean_cf, full_cf, f, C, F, N, w);
+  fmask[f] = s & 1;
+  status[f] = s;
+  worst[f] = w;
+}
+
+// err: [R rows][Fpad].  Work items = (64-frame block, chunk of 16 x PF_ROWS rows); the 16 wavefronts of a workgroup take PF_ROWS rows of
+// an item each; workgroup g takes the items g, g + G, ...
+template <int PASS>
+__global__ __launch_bounds__(1024) void k_pf_pass(const unsigned long long* __restrict__ keys, const double* __restrict__ mean_cf, const double* __restrict__ full_cf, unsigned char* __restrict__ fmask,
+                                                  unsigned char* __restrict__ status, double* __restrict__ worst, int C, int F, int N, int Fpad, PrefState* __restrict__ st) {
+  constexpr int NH = PASS == 0 ? 4096 : (PASS == 1 ? 2 * PF_NB : 4 * PF_SEG);   // LDS words: histogram(s), or the two staged candidate lists (u64 = two words each)
+  __shared__ unsigned int s_h[NH];
+  __shared__ unsigned long long s_sum[PASS == 1 ? 4096 : 2 * PF_NB];   // the previous pass's histogram, summed over its replicas / slots
+  __shared__ unsigned long long s_pre[2], s_rank[2];
+  __shared__ unsigned int s_n[2], s_base[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int CH = 16 * PF_ROWS;
+  const int R = C * N, nfb = Fpad / 64, nrc = (R + CH - 1) / CH, items = nfb * nrc;
+  if (PASS <= 1) for (int b = threadIdx.x; b < NH; b += 1024) s_h[b] = 0;
+  if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+  // ---- the previous pass's pick, by every workgroup (its histogram is complete: kernel boundary)
+  if (PASS == 1) {
+    for (int b = threadIdx.x; b < 4096; b += 1024) {
+      unsigned long long c = 0;
+#pragma unroll
+      for (int k = 0; k < PF_REP; ++k) c += st->histA[k][b];
+      s_sum[b] = c;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      unsigned long long total = 0;
+      for (int b = lane; b < 4096; b += 64) total += s_sum[b];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off, 64);
+      for (int s = 0; s < 2; ++s) {
+        const unsigned long long r = total ? (s ? total / 2 : (total - 1) / 2) : 0;
+        unsigned dg; unsigned long long below;
+        wave_pick_bin<4096>(s_sum, r, lane, dg, below);
+        if (lane == 0) {
+          s_pre[s] = dg; s_rank[s] = r - below;
+          if (blockIdx.x == 0) { st->prefixA[s] = dg; st->rankA[s] = r - below; st->total = total; }
+        }
+      }
+    }
+  }
+  if (PASS == 2) {
+    const bool same = st->prefixA[1] == st->prefixA[0];
+    for (int b = threadIdx.x; b < 2 * PF_NB; b += 1024) s_sum[b] = 0;
+    __syncthreads();
+    {  // sum the slots: thread = (bin, slice of the slots); eight loads in flight
+      const int nbin = same ? PF_NB : 2 * PF_NB, SL = 1024 / nbin;
+      const int b = threadIdx.x % nbin, sl = threadIdx.x / nbin, G = (int)gridDim.x;
+      unsigned long long c = 0;
+      int g = sl;
+      for (; g + 7 * SL < G; g += 8 * SL) {
+        unsigned v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (&st->partB[g + j * SL][0][0])[b];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c += v[j];
+      }
+      for (; g < G; g += SL) c += (&st->partB[g][0][0])[b];
+      atomicAdd(&s_sum[b], c);
+    }
+    __syncthreads();
+    if (wave < 2) {
+      const int s = wave;
+      unsigned dg; unsigned long long below;
+      const unsigned long long r = st->rankA[s];
+      wave_pick_bin<PF_NB>(s_sum + (same ? 0 : s * PF_NB), r, lane, dg, below);
+      if (lane == 0) {
+        const unsigned long long pre = (st->prefixA[s] << PF_BITS_B) | dg;
+        s_pre[s] = pre; s_rank[s] = r - below;
+        if (blockIdx.x == 0) { st->prefixB[s] = pre; st->rankB[s] = r - below; }
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned long long pre0 = PASS ? s_pre[0] : 0, pre1 = PASS ? s_pre[1] : 0;
+  unsigned long long* s_c = reinterpret_cast<unsigned long long*>(s_h);   // PASS 2: [2][PF_SEG] staged candidates
+  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+    const int fb = it % nfb, rc = it / nfb;
+    const int f = fb * 64 + lane;
+    const int r0 = rc * CH + wave * PF_ROWS;
+    unsigned long long k8[PF_ROWS];
+#pragma unroll
+    for (int j = 0; j < PF_ROWS; ++j) k8[j] = r0 + j < R ? keys[(size_t)(r0 + j) * Fpad + f] : 0x7FF8000000000000ull;  // (past the end: NaN = not a value)
+    bool m;
+    if (PASS == 0) {
+      double w = 0.0;
+      const unsigned char sf = f < F ? pf_frame_mask(mean_cf, full_cf, f, C, F, N, w) : (unsigned char)0;
+      m = (sf & 1) != 0;
+      if (rc == 0 && wave == 0) {   // one wavefront per frame block publishes the masks for the later passes / the status kernel
+        fmask[f] = sf & 1;
+        if (f < F) { status[f] = sf; worst[f] = w; }
+      }
+    } else m = fmask[f] != 0;
+#pragma unroll
+    for (int j = 0; j < PF_ROWS; ++j) {
+      const unsigned long long k = k8[j];
+      const double d = __longlong_as_double((long long)k);
+      const bool ok = m && d == d;
+      if (PASS == 0) {
+        const unsigned dig = (unsigned)(k >> 52);
+        unsigned long long rem = __ballot(ok);
+        while (rem) {   // (errors of one order of magnitude share the exponent: without this every instruction is a 64-way conflict on one LDS word)
+          const int lead = __ffsll((long long)rem) - 1;
+          const unsigned dl = __shfl(dig, lead, 64);
+          const unsigned long long same = __ballot(ok && dig == dl) & rem;
+          if (lane == lead) atomicAdd(&s_h[dl], (unsigned)__popcll(same));
+          rem &= ~same;
+        }
+      } else if (PASS == 1) {
+        const unsigned hi = (unsigned)(k >> 52), dig = (unsigned)(k >> (52 - PF_BITS_B)) & (PF_NB - 1);
+        if (ok && hi == (unsigned)pre0) atomicAdd(&s_h[dig], 1u);
+        if (ok && hi == (unsigned)pre1 && pre1 != pre0) atomicAdd(&s_h[PF_NB + dig], 1u);   // (both ranks in one bin, the usual case: state 1 picks from state 0's histogram)
+      } else {
+        const unsigned long long p20 = k >> (52 - PF_BITS_B);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s == 1 && pre1 == pre0) break;   // (the usual case: both middle ranks in one bin -- one list serves both)
+          const bool hit = ok && p20 == (s ? pre1 : pre0);
+          const unsigned long long hm = __ballot(hit);
+          if (hm) {
+            unsigned base = 0;
+            const int lead = __ffsll((long long)hm) - 1;
+            if (lane == lead) base = atomicAdd(&s_n[s], (unsigned)__popcll(hm));
+            base = __shfl(base, lead, 64);
+            const unsigned idx = base + (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
+            if (hit && idx < (unsigned)PF_SEG) s_c[s * PF_SEG + idx] = k;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (PASS == 0) {
+    unsigned long long* dst = st->histA[blockIdx.x % PF_REP];
+    for (int b = threadIdx.x; b < 4096; b += 1024) if (s_h[b]) atomicAdd(&dst[b], (unsigned long long)s_h[b]);   // (a handful of exponent bins per workgroup)
+  } else if (PASS == 1) {
+    for (int b = threadIdx.x; b < 2 * PF_NB; b += 1024) (&st->partB[blockIdx.x][0][0])[b] = s_h[b];
+  } else {
+    const int rep = blockIdx.x % PF_REP;
+    if (threadIdx.x < 2) {
+      const int s = threadIdx.x;
+      const unsigned n = min(s_n[s], (unsigned)PF_SEG);
+      unsigned base = n ? atomicAdd(&st->list_count[s][rep], n) : 0u;
+      if (s_n[s] > (unsigned)PF_SEG || base + n > (unsigned)PF_LIST) { st->overflow = 1u; if (base + n > (unsigned)PF_LIST) base = PF_LIST; }   // (nothing is written past a full list)
+      s_base[s] = base;
+    }
+    __syncthreads();
+    for (int s = 0; s < 2; ++s) {
+      const unsigned n = min(s_n[s], (unsigned)PF_SEG), base = s_base[s];
+      for (unsigned i = threadIdx.x; i < n && base + i < (unsigned)PF_LIST; i += 1024) st->cand[s][rep][base + i] = s_c[s * PF_SEG + i];
+    }
+  }
+}
+
+// final selection among the candidates of each order statistic (one workgroup): radix passes of 11 bits over the bits below the
+// prefix, both order statistics in the same sweep; the candidates of the 8 lists are gathered into LDS when they fit (dynamic LDS)
+constexpr int PF_LDS_LIST = 16384;
+size_t prefilter_final_lds_bytes() { return (size_t)PF_LDS_LIST * sizeof(unsigned long long); }
+__global__ __launch_bounds__(1024) void k_pf_final(PrefState* __restrict__ st, double thr_scale) {
+  extern __shared__ __align__(16) unsigned long long s_list[];
+  __shared__ unsigned int s_h[2][2048];
+  __shared__ unsigned int s_off[2][PF_REP + 1];
+  __shared__ unsigned long long s_low[2], s_r[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int LOWBITS = 52 - PF_BITS_B;
+  const bool one_list = st->prefixB[0] == st->prefixB[1];
+  if (threadIdx.x < 2) {   // offsets of the lists in the gathered one
+    const int s = threadIdx.x;
+    unsigned cnt[PF_REP];
+#pragma unroll
+    for (int k = 0; k < PF_REP; ++k) cnt[k] = min(st->list_count[s][k], (unsigned)PF_LIST);
+    unsigned acc = 0;
+#pragma unroll
+    for (int k = 0; k < PF_REP; ++k) { s_off[s][k] = acc; acc += cnt[k]; }
+    s_off[s][PF_REP] = acc;
+    s_low[s] = 0;
+    s_r[s] = st->rankB[s];
+  }
+  __syncthreads();
+  const unsigned n0 = s_off[0][PF_REP], n1 = one_list ? 0u : s_off[1][PF_REP];
+  const bool in_lds = n0 + n1 <= (unsigned)PF_LDS_LIST;
+  if (in_lds) {
+    for (int k = 0; k < PF_REP; ++k) {
+      const unsigned c0 = s_off[0][k + 1] - s_off[0][k];
+      for (unsigned j = threadIdx.x; j < c0; j += 1024) s_list[s_off[0][k] + j] = st->cand[0][k][j];
+      if (!one_list) {
+        const unsigned c1 = s_off[1][k + 1] - s_off[1][k];
+        for (unsigned j = threadIdx.x; j < c1; j += 1024) s_list[n0 + s_off[1][k] + j] = st->cand[1][k][j];
+      }
+    }
+  }
+  for (int remaining = LOWBITS; remaining > 0;) {
+    const int nb = min(11, remaining), shift = remaining - nb;
+    __syncthreads();
+    for (int b = threadIdx.x; b < 4096; b += 1024) (&s_h[0][0])[b] = 0;
+    __syncthreads();
+    const unsigned long long low0 = s_low[0], low1 = s_low[1];
+    auto count = [&](unsigned long long k, int list) {   // a candidate of `list` (0: of order statistic 0 -- and of 1 when one_list; 1: of order statistic 1)
+      const unsigned long long lw = k & ((1ull << LOWBITS) - 1ull);
+      const unsigned dg = (unsigned)(lw >> shift) & ((1u << nb) - 1u);
+      const unsigned long long up = remaining == LOWBITS ? 0 : lw >> remaining;
+      if (list == 0 && (remaining == LOWBITS || up == low0)) atomicAdd(&s_h[0][dg], 1u);
+      if ((list == 1 || one_list) && (remaining == LOWBITS || up == low1)) atomicAdd(&s_h[1][dg], 1u);
+    };
+    if (in_lds) {
+      for (unsigned i = threadIdx.x; i < n0 + n1; i += 1024) count(s_list[i], i < n0 ? 0 : 1);
+    } else {
+      for (int k = 0; k < PF_REP; ++k) {
+        const unsigned c0 = s_off[0][k + 1] - s_off[0][k];
+        for (unsigned j = threadIdx.x; j < c0; j += 1024) count(st->cand[0][k][j], 0);
+        if (!one_list) {
+          const unsigned c1 = s_off[1][k + 1] - s_off[1][k];
+          for (unsigned j = threadIdx.x; j < c1; j += 1024) count(st->cand[1][k][j], 1);
+        }
+      }
+    }
+    __syncthreads();
+    if (wave < 2) {
+      unsigned dg; unsigned long long below;
+      wave_pick_bin<2048>(&s_h[wave][0], s_r[wave], lane, dg, below);
+      if (lane == 0) { s_r[wave] -= below; s_low[wave] = (s_low[wave] << nb) | dg; }
+    }
+    remaining = shift;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long total = st->total;
+    const double a = __longlong_as_double((long long)((st->prefixB[0] << LOWBITS) | s_low[0])), b = __longlong_as_double((long long)((st->prefixB[1] << LOWBITS) | s_low[1]));
+    const double med = total ? 0.5 * (a + b) : __builtin_nan("");   // np.nanmedian: mean of the two middle values
+    st->info[0] = thr_scale * med;
+    st->info[1] = med;
+    st->info[2] = (double)total;
+    st->info[3] = st->overflow ? 1.0 : 0.0;
+  }
+}
+
+// exclusion (:285): np.nan_to_num(worst mean error) > threshold, for the used frames -- written straight into the packed result
+// [info 8 doubles | status F bytes] that goes to the host in one copy
+__global__ __launch_bounds__(256) void k_pf_status(const double* __restrict__ worst, unsigned char* __restrict__ status, unsigned char* __restrict__ packed, int F, PrefState* __restrict__ st, double thr_arg,
+                                                   int thr_from_state) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  const double thr = thr_from_state ? st->info[0] : thr_arg;
+  if (f < F) {
+    unsigned char s = status[f] & 5;
+    double w = worst[f];
+    w = w != w ? 0.0 : (isinf(w) ? (w > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308) : w);   // np.nan_to_num
+    if ((s & 1) && w > thr) s |= 2;
+    status[f] = s;
+    packed[64 + f] = s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 8) {
+    double v = st->info[threadIdx.x];
+    if (threadIdx.x == 0 && !thr_from_state) v = thr_arg;
+    reinterpret_cast<double*>(packed)[threadIdx.x] = v;
+  }
+}
+
+// parameter vector of a frame subset: the camera blocks, then the poses of the chosen frames
+__global__ __launch_bounds__(256) void k_gather_params(const double* __restrict__ xs, const int* __restrict__ frames, double* __restrict__ xd, int C, int Fdst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int ncam = 12 * C;
+  if (i < ncam) xd[i] = xs[i];
+  else if (i < ncam + 6 * Fdst) {
+    const int j = i - ncam, f = j / 6, k = j - 6 * f;
+    xd[i] = xs[ncam + 6 * (size_t)frames[f] + k];
+  }
+}
+
 // ---------------------------------------------------------------- frame subsets, device to device
 __global__ void k_gather_frames(const double2* __restrict__ src, const int* __restrict__ frames, double2* __restrict__ dst, int C, int Fsrc, int Fdst, int N) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -488,6 +852,55 @@ double measure_fp64_issue_rate(int ncu) {
   (void)hipFree(out);
   if (!(best > 0.f) || best > 1e29f) return 0.0;
   return (double)ncu * 4 * 64 * (double)iters * 36 * 2 / (best * 1e-3) / 1e12;
+}
+
+// The pre-filter's selection behind k_frame_err (mean_cf / full_cf / err as it left them): fmask [Fpad], status [F] (bit 0 used, bit 1
+// excluded as an outlier, bit 2 complete in every camera), worst [F]; `state` = prefilter_state_bytes() of scratch.  threshold NaN:
+// 5 x nanmedian of the used frames' per-point errors (three passes over err), else the caller's.  The result [info 8 doubles | status]
+// lands in `packed` (64 + F bytes) for one device-to-host copy.  No synchronisation.
+void launch_prefilter_select(hipStream_t st, const double* err, const double* mean_cf, const double* full_cf, unsigned char* fmask, unsigned char* status, double* worst, void* state,
+                             unsigned char* packed, int C, int F, int N, int Fpad, double threshold) {
+  PrefState* ps = static_cast<PrefState*>(state);
+  (void)hipMemsetAsync(ps, 0, prefilter_state_clear_bytes(), st);
+  const bool median = threshold != threshold;
+  if (median) {
+    const int R = C * N, nfb = Fpad / 64, items = nfb * ((R + 16 * PF_ROWS - 1) / (16 * PF_ROWS));
+    const int g = std::min(PF_G, items);
+    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prefilter_final_lds_bytes()) == hipSuccess;
+    (void)lds_ok;
+    const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(err);
+    k_pf_pass<0><<<dim3(g), dim3(1024), 0, st>>>(keys, mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad, ps);
+    k_pf_pass<1><<<dim3(g), dim3(1024), 0, st>>>(keys, mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad, ps);
+    k_pf_pass<2><<<dim3(g), dim3(1024), 0, st>>>(keys, mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad, ps);
+    k_pf_final<<<dim3(1), dim3(1024), prefilter_final_lds_bytes(), st>>>(ps, 5.0);
+  } else {
+    k_pf_mask<<<dim3((Fpad + 255) / 256), dim3(256), 0, st>>>(mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad);
+  }
+  launch_prefilter_status(st, status, worst, state, packed, F, threshold, median ? 1 : 0);
+}
+// (also the second half of the fallback: the eight-pass select found the median, the host passes 5 x that)
+void launch_prefilter_status(hipStream_t st, unsigned char* status, const double* worst, void* state, unsigned char* packed, int F, double threshold, int from_state) {
+  k_pf_status<<<dim3((F + 255) / 256), dim3(256), 0, st>>>(worst, status, packed, F, static_cast<PrefState*>(state), threshold, from_state);
+}
+
+// a small host array written to device memory THROUGH THE KERNEL-ARGUMENT SEGMENT (<= 480 doubles): no staging copy, no wait -- a
+// hipMemcpyAsync from pageable memory blocks the caller for ~15-25 us whatever its size (scripts/micro/h2d_pipeline.hip)
+struct SmallVec { double v[480]; };
+__global__ void k_store_small(double* __restrict__ dst, SmallVec sv, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = sv.v[i];
+}
+bool launch_store_small(hipStream_t st, double* dst, const double* src_host, size_t n) {
+  if (n > 480) return false;
+  SmallVec sv;
+  memcpy(sv.v, src_host, n * sizeof(double));
+  k_store_small<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(dst, sv, (int)n);
+  return true;
+}
+
+void launch_gather_params(hipStream_t st, const double* x_src, const int* frames, double* x_dst, int C, int Fdst) {
+  const int n = 12 * C + 6 * Fdst;
+  k_gather_params<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(x_src, frames, x_dst, C, Fdst);
 }
 
 void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N) {

@@ -74,11 +74,12 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
                  int planar = 0,   // planar: every board point has z = 0 exactly (with f_scale = 1 the fused kernel's FAST instance runs)
                  double* chunk = nullptr, int nchunk = 0,   // split == 3: scratch for the point-chunk tail (gram_chunk_doubles) and the number of chunks
                  int npw = 4,                               // split == 4 / 5 (point split inside the workgroup): wavefronts per (camera, frame block), 4 or 2
-                 int cw = 12);                              // camera block width: 12, or 6 = intrinsics held fixed (role A alone: split 4 = point split, anything else = the role-A half of the split roles)
-int gram_round_blocks(int C, int nfb);       // frame blocks (a multiple of 4) that whole rounds of the wavefront slots cover; split 2 / 3 / 5 handle the rest as a tail
+                 int cw = 12,                               // camera block width: 12, or 6 = intrinsics held fixed (role A alone: split 4 = point split, anything else = the role-A half of the split roles)
+                 int slots = 1024);                         // wavefront slots of the device (4 x CUs): where the launch variants cut a shard into rounds
+int gram_round_blocks(int C, int nfb, int slots);   // frame blocks (a multiple of 4) that whole rounds of the wavefront slots cover; split 2 / 3 / 5 handle the rest as a tail
 size_t gram_psplit_lds_bytes(int npw, int cw = 12);  // dynamic LDS of k_gram_psplit
 int gram_psplit_set_lds_limit();             // raises the dynamic-LDS limit of its instances (0 = ok)
-size_t gram_chunk_doubles(int C, int nfb, int nchunk);   // doubles of that scratch for C cameras x nfb frame blocks
+size_t gram_chunk_doubles(int C, int nfb, int nchunk, int slots);   // doubles of that scratch for C cameras x nfb frame blocks
 void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch);
 size_t syrk_lds_bytes(int C, int FS, int cw = 12);
 void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int sq, int sr, int FS, int ppw,
@@ -94,7 +95,6 @@ void launch_backsub(hipStream_t st, Sel s, const double* rec0, const double* rec
 void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double* rec1, const double* fbuf, const double* dc_dev, double* x0, double* x1, double* bpart, int C, int F, int Fpad, int cw = 12);
 size_t solve_lds_bytes(int npad, int use_lds);
 int solve_fits_lds(int npad, int lds_limit);
-void gram_set_slots(int slots);  // wavefront slots of the device (4 x CUs): where k_gram's launch variants cut a shard into rounds
 int solve_set_lds_limit(int npad, int use_lds);
 void launch_solve_cam(hipStream_t st, const SolveArgs& a);
 // solve + the back-substitution of the next trial step in one launch (a.use_lds variants, a.flag set); early_state = the LM state
@@ -104,6 +104,8 @@ void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const doub
                           const double* early_state, int max_polls, int spec, double* timeout_dev, double* timeout_host);  // (a.cw selects the camera block width)
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da);
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
+void launch_lm_init(hipStream_t st, const double* red_scal, double* lms, double lam0, int sel, double cfl, double cfl_switch);  // mcba_lm_run: the start state, on the device
+void launch_pack_result(hipStream_t st, const double* x, const double* gc, const double* fbuf, const unsigned char* fixed, double* out, int C, int F, int cw);  // mcba_lm_result
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);
 int syrk_set_lds_limit(size_t bytes);
 // pre-filter, frame subsets, undistortion, reprojection diagnostics (mcba_diag.hip)
@@ -111,6 +113,13 @@ void launch_frame_err(hipStream_t st, const double* obs_t, const double* obj, co
 size_t select_state_bytes(int groups);  // per group: u64 prefix, rank, count, value (bit pattern of the selected double) + a 256-bin histogram
 void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int groups, int Fpad, void* sel, int upper);
 int launch_select_hist(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int Fpad, void* sel, unsigned long long prefix, int pass, unsigned int* hist256);
+// the pre-filter's selection on the device (mcba_prefilter): see mcba_diag.hip
+size_t prefilter_state_bytes();
+void launch_prefilter_select(hipStream_t st, const double* err, const double* mean_cf, const double* full_cf, unsigned char* fmask, unsigned char* status, double* worst, void* state,
+                             unsigned char* packed, int C, int F, int N, int Fpad, double threshold);
+void launch_prefilter_status(hipStream_t st, unsigned char* status, const double* worst, void* state, unsigned char* packed, int F, double threshold, int from_state);
+void launch_gather_params(hipStream_t st, const double* x_src, const int* frames, double* x_dst, int C, int Fdst);
+bool launch_store_small(hipStream_t st, double* dst, const double* src_host, size_t n);  // <= 480 doubles through the kernel-argument segment (no blocking copy); false: too many
 double measure_fp64_issue_rate(int ncu);  // TFLOP/s of independent v_fma_f64 at one wavefront per SIMD on `ncu` compute units (measurement aid)
 void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N);
 void launch_seen_bits(hipStream_t st, const double* obs_raw, size_t count, unsigned long long* words);  // words: ceil(count / 64) of them

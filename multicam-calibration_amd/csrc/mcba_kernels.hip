@@ -1717,11 +1717,9 @@ void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int 
   k_transpose_obs<<<dim3(Fpad / 64, C, (N + 15) / 16), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(raw), reinterpret_cast<double2*>(obs_t), C, F, N, Fpad);
 }
 
-// wavefront slots of the device at one wavefront per SIMD (4 x compute units; mcba_create sets it from the device properties)
-static int g_gram_slots = 1024;
-void gram_set_slots(int slots) { if (slots >= 64) g_gram_slots = slots; }
-
-int gram_round_blocks(int C, int nfb) { return std::min(nfb, (((C * nfb) / g_gram_slots) * g_gram_slots / C) & ~3); }
+// slots: wavefront slots of the handle's device at one wavefront per SIMD (4 x compute units; derive_geometry keeps it in the handle --
+// not a process-wide value: handles on devices of different sizes may be driven from different threads)
+int gram_round_blocks(int C, int nfb, int slots) { return std::min(nfb, (((C * nfb) / slots) * slots / C) & ~3); }
 size_t gram_psplit_lds_bytes(int npw, int cw) {
   size_t b = (size_t)gram_xch_doubles(npw == 4 ? 4 : 2, cw != 6) * sizeof(double);
 #ifdef MCBA_GRAM_TIMING
@@ -1731,7 +1729,7 @@ size_t gram_psplit_lds_bytes(int npw, int cw) {
 }
 
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,
-                 int planar, double* chunk, int nchunk, int npw, int cw) {
+                 int planar, double* chunk, int nchunk, int npw, int cw, int slots) {
   const int nfb = Fpad / 64;
   dim3 block(256);
   const double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
@@ -1778,7 +1776,7 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
   }
   if (split == 4) { psplit(0, nfb); return; }
   if (split == 5) {  // whole rounds of the wavefront slots fused, the short last round point-split
-    const int fba5 = gram_round_blocks(C, nfb);
+    const int fba5 = gram_round_blocks(C, nfb, slots);
     if (fba5 > 0 && fba5 < nfb) {
       static const bool two_launches = [] { const char* e = getenv("MCBA_GRAM_MIXED"); return e && atoi(e) == 0; }();  // (0: the two-launch form, for A/B)
       if (two_launches) { fused(0, fba5); psplit(fba5, nfb); return; }
@@ -1801,7 +1799,7 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
     // whole rounds of the 1 024 wavefront slots fused; the last, short round as POINT CHUNKS: nchunk wavefronts per (camera, frame
     // block), each over 1 / nchunk of the board's points (ppc a multiple of the loop's four), + one combine launch
     const int items3 = C * nfb;
-    const int fba3 = ((items3 / g_gram_slots) * g_gram_slots / C) & ~3;
+    const int fba3 = ((items3 / slots) * slots / C) & ~3;
     if (fba3 > 0 && fba3 < nfb && chunk && nchunk >= 2) {
       fused(0, fba3);
       const int ppc = ((N + nchunk - 1) / nchunk + 3) & ~3;
@@ -1824,7 +1822,7 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
   // split == 2: whole rounds of the 1024 wavefront slots with the fused variant, the (short) last round with the split
   // roles -- their wavefronts are lighter, so a tail of r items costs ~0.55 of a fused pass instead of a whole one
   const int items = C * nfb;
-  const int fba = split == 2 ? (((items / g_gram_slots) * g_gram_slots / C) & ~3) : nfb;
+  const int fba = split == 2 ? (((items / slots) * slots / C) & ~3) : nfb;
   if (split == 2 && fba > 0 && fba < nfb) {
     fused(0, fba);
     roles(fba, nfb);
@@ -1833,8 +1831,8 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
   }
 }
 
-size_t gram_chunk_doubles(int C, int nfb, int nchunk) {
-  const int items = C * nfb, fba = ((items / g_gram_slots) * g_gram_slots / C) & ~3;
+size_t gram_chunk_doubles(int C, int nfb, int nchunk, int slots) {
+  const int items = C * nfb, fba = ((items / slots) * slots / C) & ~3;
   return (size_t)C * (nfb - fba) * nchunk * kGramRaw * 64;
 }
 
@@ -1908,6 +1906,47 @@ void launch_backsub_dev(hipStream_t st, Sel s, const double* rec0, const double*
 
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da) {
   k_sum_trial<<<dim3(1), dim3(512), 0, st>>>(s, cp0, cp1, cstride, cinner, couter, ncp, bpart, nbp, out, da);
+}
+
+// mcba_lm_run: the LM state a fresh solve starts from, written on the device -- its cost is scalar 0 of the reduced system that was
+// just built (and all-reduced) at the start point, so no host round trip separates that build from the first solve
+__global__ void k_lm_init(const double* __restrict__ red_scal, double* __restrict__ lms, double lam0, double sel, double cfl, double cfl_switch) {
+  const int i = threadIdx.x;
+  if (i >= MCBA_LMS) return;
+  double v = 0.0;
+  if (i == 0) v = red_scal[0];
+  else if (i == 1) v = lam0;
+  else if (i == 2) v = 2.0;
+  else if (i == 3) v = sel;
+  else if (i == MCBA_LM_CFL) v = cfl;
+  else if (i == MCBA_LM_CFL_SWITCH) v = cfl_switch;
+  lms[i] = v;
+}
+void launch_lm_init(hipStream_t st, const double* red_scal, double* lms, double lam0, int sel, double cfl, double cfl_switch) {
+  k_lm_init<<<dim3(1), dim3(64), 0, st>>>(red_scal, lms, lam0, (double)sel, cfl, cfl_switch);
+}
+
+// mcba_lm_result: [x (12C + 6F) | gradient (12C + 6F)] of the current point in one buffer -- the camera gradient g_c of the reduced system
+// scattered to the parameter layout (zero where a parameter is held fixed), the frame gradients from the frame records
+__global__ __launch_bounds__(256) void k_pack_result(const double* __restrict__ x, const double* __restrict__ gc, const double* __restrict__ fbuf, const unsigned char* __restrict__ fixed, double* __restrict__ out, int C, int F,
+                                                     int cw) {
+  const size_t nx = (size_t)12 * C + (size_t)6 * F, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nx) return;
+  out[i] = x[i];
+  double g;
+  if (i < (size_t)12 * C) {
+    const int c = (int)i / 12, k = (int)i % 12;
+    const int row = cw == 12 ? (int)i : (k >= 6 ? 6 * c + (k - 6) : -1);
+    g = row >= 0 && !(fixed && fixed[row]) ? gc[row] : 0.0;
+  } else {
+    const size_t j = i - (size_t)12 * C, f = j / 6, k = j - 6 * f;
+    g = fbuf[f * MCBA_FB + 27 + k];
+  }
+  out[nx + i] = g;
+}
+void launch_pack_result(hipStream_t st, const double* x, const double* gc, const double* fbuf, const unsigned char* fixed, double* out, int C, int F, int cw) {
+  const size_t nx = (size_t)12 * C + (size_t)6 * F;
+  k_pack_result<<<dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st>>>(x, gc, fbuf, fixed, out, C, F, cw);
 }
 
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da) {

@@ -80,6 +80,10 @@ SYMBOLS = [
     ("mcba_frame_errors", ctypes.c_int, [_h, ctypes.c_int, _dp, _dp]),
     ("mcba_error_median", ctypes.c_int, [_h, ctypes.c_char_p, _dp, _dp]),
     ("mcba_create_subset", ctypes.c_int, [ctypes.POINTER(_h), _h, _ip, ctypes.c_int]),
+    ("mcba_prefilter", ctypes.c_int, [_h, _dp, _dp, _dp, ctypes.c_double, ctypes.POINTER(ctypes.c_ubyte), _dp]),
+    ("mcba_lm_run", ctypes.c_int, [_h, _dp, _dp, ctypes.c_char_p, _dp]),
+    ("mcba_lm_history", ctypes.c_int, [_h, _dp, ctypes.c_size_t]),
+    ("mcba_lm_result", ctypes.c_int, [_h, ctypes.c_int, _dp]),
     ("mcba_undistort_points", ctypes.c_int, [ctypes.c_size_t, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp]),
     ("mcba_reprojection_diagnostics", ctypes.c_int, [_h, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp, _dp]),
     ("mcba_triangulate", ctypes.c_int, [ctypes.c_int, ctypes.c_size_t, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
@@ -181,7 +185,8 @@ def pool_trim():
 class Problem:
     """One handle = one GPU = this process's shard of frames."""
 
-    def __init__(self, uvs, objpoints, device=0, loss="soft_l1", f_scale=1.0, stream=None):
+    def __init__(self, uvs, objpoints, device=0, loss="soft_l1", f_scale=1.0, stream=None, upload=True):
+        """upload=False: the handle is created, the observations are NOT sent yet -- `prefilter` uploads and scores them in one call."""
         self.lib = load_library()
         uvs = _f64(uvs)
         objpoints = _f64(objpoints)
@@ -195,9 +200,29 @@ class Problem:
         self._chk(self.lib.mcba_create(ctypes.byref(self.handle), self.C, self.F, self.N, int(device)))
         if stream is not None:
             self._chk(self.lib.mcba_set_stream(self.handle, ctypes.c_void_p(int(stream))))
-        self._chk(self.lib.mcba_upload_observations(self.handle, _p(uvs), _p(objpoints)))
+        if upload:
+            self._chk(self.lib.mcba_upload_observations(self.handle, _p(uvs), _p(objpoints)))
+        else:
+            self._pending = (uvs, objpoints)
         self.set_loss(loss, f_scale)
         self._init_host_views()
+
+    def prefilter(self, x, outlier_threshold=None):
+        """The reference's pre-filter (bundle_adjustment.py:265-285) in one C-ABI crossing and one host synchronisation
+        (include/mcba.h: mcba_prefilter): the observations (if the handle was created with upload=False) and the parameters x of every
+        frame go up, the selection comes back.  Returns (status (F,) uint8 -- bit 0 used, bit 1 excluded as an outlier, bit 2 complete in
+        every camera --, threshold, info (8,))."""
+        x = _f64(x)
+        if x.shape != (self.nx,):
+            raise ValueError(f"x must have {self.nx} entries")
+        status = np.empty(self.F, np.uint8)
+        info = np.empty(8)
+        uvs, obj = getattr(self, "_pending", None) or (None, None)
+        thr = float("nan") if outlier_threshold is None else float(outlier_threshold)
+        self._chk(self.lib.mcba_prefilter(self.handle, None if uvs is None else _p(uvs), None if obj is None else _p(obj), _p(x), thr,
+                                          status.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), _p(info)))
+        self._pending = None
+        return status, float(info[0]), info
 
     def _init_host_views(self):
         self.nsys = self.n * self.n + 3 * self.n + 16
@@ -490,6 +515,33 @@ class Problem:
         rc = self.lib.mcba_lm_auto_tick(self.handle, seq, int(rank_slot))
         if rc:
             self._chk(rc)
+
+    def lm_run(self, x0, ftol, xtol, gtol, lam0, lam_min, lam_max, dec_floor, curv_floor, curv_switch, max_nfev, max_steps, depth, rank_slot=0, fixed_mask=None):
+        """The device-resident LM loop from x0 (None: what slot 0 holds) to termination in ONE C-ABI crossing (include/mcba.h: mcba_lm_run).
+        Returns (status, rows (k, LM_STATE) -- the state every retired tick posted, row 0 = the solve of the start point --, rows the
+        loop proper consumed, iterations)."""
+        opt = np.array([ftol, xtol, gtol, lam0, lam_min, lam_max, dec_floor, curv_floor, curv_switch, float(min(max_nfev, 2 ** 62)), -1.0 if max_steps is None else float(max_steps), depth, rank_slot], dtype=np.float64)
+        summary = np.zeros(4)
+        m = None if fixed_mask is None else np.ascontiguousarray(fixed_mask, dtype=np.uint8).tobytes()
+        if x0 is not None:
+            x0 = _f64(x0)
+            if x0.shape != (self.nx,):
+                raise ValueError(f"x must have {self.nx} entries")
+        rc = self.lib.mcba_lm_run(self.handle, None if x0 is None else _p(x0), _p(opt), m, _p(summary))
+        if rc == ERR_NONFINITE:
+            raise ValueError("Residuals are not finite in the initial point.")
+        self._chk(rc)
+        rows = np.empty((int(summary[1]), LM_STATE))
+        self._chk(self.lib.mcba_lm_history(self.handle, _p(rows), rows.shape[0]))
+        self._auto_state = np.zeros(LM_STATE)
+        self._auto_state_p = _p(self._auto_state)
+        return int(summary[0]), rows, int(summary[2]), int(summary[3])
+
+    def lm_result(self, slot):
+        """(x, gradient) of parameter slot `slot`, each 12C + 6F, in one device-to-host copy (include/mcba.h: mcba_lm_result)."""
+        out = np.empty((2, self.nx))
+        self._chk(self.lib.mcba_lm_result(self.handle, int(slot), _p(out)))
+        return out[0], out[1]
 
     def lm_auto_wait(self, seq):
         """State (LM_STATE doubles, a buffer the next call overwrites) that tick `seq` posted."""

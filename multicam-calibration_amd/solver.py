@@ -308,6 +308,7 @@ class LevenbergMarquardt:
     def start(self, x0):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         self.cur = 0
+        self._last_state = None
         self.p.set_params(0, x0)
         self.x_cam = x0[self.cam_index].copy()
         self._set_curvature(CURV_TRIGGS if self.curvature == "triggs" else CURV_IRLS)
@@ -337,6 +338,47 @@ class LevenbergMarquardt:
             st = p.lm_auto_wait(1)
             self.g_inf = float(st[16])
             self._status0 = int(st[15]) or None
+
+    # ------------------------------------------------------------------ the whole loop in one C-ABI crossing
+    def can_run_on_device(self):
+        """The device-resident loop can be handed to the library as a whole (ops.Problem.lm_run): single GPU, or direct RCCL (the library
+        issues the collectives itself).  MCBA_HOST_LOOP=1 keeps the per-tick Python loop (same ticks, same decisions: the A/B tests)."""
+        return self.device_solve and hasattr(self.p, "lm_run") and isinstance(self.comm, (SingleProcess, DirectRCCL)) and os.environ.get("MCBA_HOST_LOOP", "0") == "0"
+
+    def run_device(self, x0, verbose=0):
+        """start() + the iterate() loop + finalize()'s drain, enqueued and polled by libmcba (mcba_lm_run): one crossing, no host
+        synchronisation before the first tick.  x0 None: parameter slot 0 already holds the start point (ops.Problem.subset gathers it on
+        the device).  The book-keeping below replays the states the ticks posted through the same _retire as the Python loop."""
+        p = self.p
+        self.cur = 0
+        self.curv_floor = CURV_TRIGGS if self.curvature == "triggs" else CURV_IRLS
+        self.nfev, self.njev = 1, 1
+        self.lam, self.nu = self.lam0, 2.0
+        self.iteration, self.steps, self.rebuilds = 0, 0, 0
+        self._terminated = False
+        self.step_norm = self.actual_reduction = None
+        self.history = []
+        status, rows, n_main, steps = p.lm_run(x0, self.ftol, self.xtol, self.gtol, self.lam0, self.lam_min, self.lam_max, self.dec_floor, self.curv_floor,
+                                               CURV_SWITCH if self.curvature == "auto" else 0.0, self.max_nfev if self.max_nfev is not None else 2 ** 62, self.max_steps, self.depth,
+                                               self.comm.rank % 12, None if self.all_free else ~self.free)
+        st0 = rows[0]
+        self.cost = self.cost0 = float(st0[0])
+        self.g_inf = float(st0[16])
+        self._status0 = int(st0[15]) or None
+        if verbose == 2:
+            _print_header()
+            _print_iteration(0, self.nfev, self.cost, None, None, self.g_inf)
+        for st in rows[1:n_main]:
+            self._retire(st)
+            if verbose == 2 and self.accepted:
+                _print_iteration(self.iteration, self.nfev, self.cost, self.actual_reduction, self.step_norm, self.g_inf)
+        for st in rows[n_main:]:   # retired by the final drain (finalize): their accepted steps count unless the loop had terminated
+            if not self._terminated:
+                self._retire(st)
+        self.steps = steps
+        self.issued = self.retired = len(rows)
+        self._last_state = rows[-1]
+        return status
 
     def _set_curvature(self, floor):
         """The model of the linearisations ENQUEUED from here on (a kernel argument of k_gram: nothing is recomputed)."""
@@ -598,7 +640,7 @@ class LevenbergMarquardt:
             if not self._terminated:
                 self._retire(st)
         if st is None:
-            st = self.p.lm_auto_wait(self.retired)
+            st = self._last_state if getattr(self, "_last_state", None) is not None else self.p.lm_auto_wait(self.retired)
         if st[15] == 0 and (st[14] != 0 or st[23] != 0):  # not terminated on the device, and the next tick would have rebuilt
             self.p.lm_rebuild(self.comm.rank % 12)
             self.comm.all_reduce_system(self.p)
@@ -607,7 +649,17 @@ class LevenbergMarquardt:
 
     def result(self, status):
         self.finalize()
-        x = self.p.get_params(self.cur)
+        grad = None
+        if self.device_solve and hasattr(self.p, "lm_result"):
+            x, grad = self.p.lm_result(self.cur)   # solution + gradient in one device-to-host copy (api.bundle_adjust uses the gradient)
+        else:
+            x = self.p.get_params(self.cur)
+        res = self._result(status, x)
+        if grad is not None:
+            res.lm["grad"] = grad
+        return res
+
+    def _result(self, status, x):
         return OptimizeResult(
             x=x, cost=self.cost, optimality=self.g_inf, nfev=self.nfev, njev=self.njev, status=status, message=TERMINATION_MESSAGES[status],
             success=status > 0, active_mask=np.zeros_like(x),
@@ -621,26 +673,31 @@ class LevenbergMarquardt:
 
 
 def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=LAM0, max_iterations=None, speculative=True,
-             reduced_solver=None, x_scale=None, dec_floor=DEC_FLOOR, curvature=None):
+             reduced_solver=None, x_scale=None, dec_floor=DEC_FLOOR, curvature=None, x0_on_device=False):
     """Minimise the robust reprojection cost from x0 (this shard's flat vector, a7 layout of SURVEY.md).
-    `fun` / `jac` / `grad` of the OptimizeResult are attached by api.bundle_adjust."""
+    `fun` / `jac` / `grad` of the OptimizeResult are attached by api.bundle_adjust.
+    x0_on_device: parameter slot 0 of the problem already holds x0 (ops.Problem.subset gathered it on the GPU): nothing is uploaded."""
     lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative, reduced_solver=reduced_solver, x_scale=x_scale, dec_floor=dec_floor, curvature=curvature)
     if max_nfev is None:
         max_nfev = 100 * np.size(x0)  # trf.py:437-438
     lm.max_nfev, lm.max_steps = max_nfev, max_iterations
-    lm.start(x0)
-    cost0 = lm.cost
-    if verbose == 2:
-        _print_header()
-        _print_iteration(0, lm.nfev, lm.cost, None, None, lm.g_inf)
-    status = None
-    while status is None:
-        if lm.nfev >= max_nfev or (max_iterations is not None and lm.steps >= max_iterations):
-            status = 0
-            break
-        status = lm.iterate()
-        if verbose == 2 and getattr(lm, "accepted", False):
-            _print_iteration(lm.iteration, lm.nfev, lm.cost, lm.actual_reduction, lm.step_norm, lm.g_inf)
+    if lm.can_run_on_device():   # the loop as a whole inside libmcba (the verbose table is printed from the states the ticks posted)
+        status = lm.run_device(None if x0_on_device else x0, verbose)
+        cost0 = lm.cost0
+    else:
+        lm.start(x0)
+        cost0 = lm.cost
+        if verbose == 2:
+            _print_header()
+            _print_iteration(0, lm.nfev, lm.cost, None, None, lm.g_inf)
+        status = None
+        while status is None:
+            if lm.nfev >= max_nfev or (max_iterations is not None and lm.steps >= max_iterations):
+                status = 0
+                break
+            status = lm.iterate()
+            if verbose == 2 and getattr(lm, "accepted", False):
+                _print_iteration(lm.iteration, lm.nfev, lm.cost, lm.actual_reduction, lm.step_norm, lm.g_inf)
     res = lm.result(status)
     if verbose >= 1:
         print(TERMINATION_MESSAGES[status])

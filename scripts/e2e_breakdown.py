@@ -51,7 +51,10 @@ api.deserialize_params = timed("api.deserialize_params", api.deserialize_params)
 import os
 
 MISSING = float(os.environ.get("MCBA_E2E_MISSING", "0"))
-p = m.synth.make_problem(6, F, seed=0, missing=MISSING)
+CAMS, ROWS, COLS = 6, 6, 9
+if os.environ.get("MCBA_E2E_SHAPE"):   # "cameras,frames,rows,cols" -- e.g. the reference tutorial's recording 6,2130,5,7
+    CAMS, F, ROWS, COLS = (int(v) for v in os.environ["MCBA_E2E_SHAPE"].split(","))
+p = m.synth.make_problem(CAMS, F, rows=ROWS, cols=COLS, seed=0, missing=MISSING)
 
 
 if os.environ.get("MCBA_E2E_HOSTMASK") == "1":   # round 4 before mcba_seen_bits: the mask from a numpy pass over the caller's array
@@ -74,5 +77,5 @@ for _ in range(REPS):
     times.append(time.perf_counter() - t0)
 res = out[4]
 tab = {k: {"ms_per_call_site": 1e3 * v[0] / REPS, "calls": v[1] / REPS} for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])}
-print(json.dumps({"workload": f"bundle_adjust 6x{F}x54 return_jac=False, warm, missing detections {MISSING}", "end_to_end_ms": {"min": 1e3 * min(times), "median": 1e3 * float(np.median(times)), "all": [1e3 * t for t in times]},
+print(json.dumps({"workload": f"bundle_adjust {CAMS}x{F}x{ROWS * COLS} return_jac=False, warm, missing detections {MISSING}", "end_to_end_ms": {"min": 1e3 * min(times), "median": 1e3 * float(np.median(times)), "all": [1e3 * t for t in times]},
                   "nfev": int(res.nfev), "status": int(res.status), "cost": float(res.cost), "breakdown_ms (nested: inner calls are included in outer ones)": tab}, indent=1))

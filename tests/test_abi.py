@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in include/mcba.h but not exported by libmcba.so"
     bound = {s[0] for s in ops.SYMBOLS}
     assert bound == set(names), (sorted(bound - set(names)), sorted(set(names) - bound))
-    assert ops.load_library().mcba_abi_version() == 5
+    assert ops.load_library().mcba_abi_version() == 6
 
 
 def test_no_gpu_is_a_loud_error_not_a_fallback():

@@ -1,0 +1,217 @@
+"""GPU tests of the round-5 additions to the C ABI (ABI 6): the pre-filter in one crossing with the selection on the device
+(mcba_prefilter: three-pass radix-select median, masks, exclusion), the device-resident LM loop in one crossing (mcba_lm_run) and the
+packed solution + gradient (mcba_lm_result) -- each against the per-call sequence it replaces (which the earlier tests pin to the
+oracle and to the reference's outputs), bit for bit, and against the oracle's pre-filter directly.  Run with `-m gpu` on an MI355X."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mc():
+    import multicam_calibration_amd as m
+
+    m.ops.load_library()
+    return m
+
+
+@contextlib.contextmanager
+def env(**kv):
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update({k: str(v) for k, v in kv.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def captured(f, *a, **k):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = f(*a, **k)
+    return out, buf.getvalue()
+
+
+def _select(mc, p, n_frames, thr, seed, **envkw):
+    with env(**envkw):
+        np.random.seed(seed)
+        use, line = captured(mc.api.select_frames, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames, thr)
+        return use, line, np.random.randint(0, 2**31 - 1)
+
+
+CASES = [
+    dict(C=3, F=70, kw=dict(seed=5, missing=0.2, scalar_nans=4, outlier_frames=3)),
+    dict(C=6, F=333, kw=dict(seed=1, missing=0.3, outlier_frames=7)),
+    dict(C=2, F=50, kw=dict(seed=0)),
+    dict(C=4, F=64, kw=dict(seed=2, missing=0.6)),            # many frames seen by fewer than two cameras
+    dict(C=9, F=129, kw=dict(seed=3, rows=2, cols=2, missing=0.1, outlier_frames=2)),
+    dict(C=1, F=40, kw=dict(seed=4)),                         # one camera: no frame is complete in two
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_fused_prefilter_equals_the_stepwise_one_and_the_oracle(mc, case):
+    """mcba_prefilter against the per-call pre-filter (k_frame_err, host masks, eight-pass median: MCBA_PREFILTER_FUSED=0), against the same
+    call with the eight-pass select forced behind the device masks (MCBA_PREFILTER_FALLBACK=1), and against the ORACLE's restatement of
+    bundle_adjustment.py:265-296: same frames in the same order, same printed line to the last digit, same global-RNG state."""
+    c = CASES[case]
+    p = mc.synth.make_problem(c["C"], c["F"], **c["kw"])
+    for n_frames, thr, seed in ((None, None, 0), (10, None, 1), (c["F"], None, 2), (7, 1.5, 3), (None, 0.25, 4), (None, float("nan"), 5), (None, 3, 6)):
+        a = _select(mc, p, n_frames, thr, seed)
+        b = _select(mc, p, n_frames, thr, seed, MCBA_PREFILTER_FUSED=0)
+        f = _select(mc, p, n_frames, thr, seed, MCBA_PREFILTER_FALLBACK=1)
+        np.testing.assert_array_equal(a[0], b[0])
+        assert a[1] == b[1] and a[2] == b[2], (a[1], b[1])
+        np.testing.assert_array_equal(a[0], f[0])
+        assert a[1] == f[1] and a[2] == f[2], (a[1], f[1])
+        np.random.seed(seed)
+        import warnings
+        with np.errstate(all="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            use_o, thr_o, _, line_o = orc.prefilter_frames(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames, thr)
+        np.testing.assert_array_equal(a[0], use_o)
+        assert np.random.randint(0, 2**31 - 1) == a[2]
+        ta, to = a[1].strip().rsplit(" ", 1), line_o.rsplit(" ", 1)
+        assert ta[0] == to[0]
+        if not np.isnan(float(to[1])):
+            assert abs(float(ta[1]) - float(to[1])) <= 1e-12 * abs(float(to[1]))   # (the oracle's errors differ from the kernel's in the last bits)
+
+
+def test_prefilter_status_bits_and_info(mc):
+    p = mc.synth.make_problem(5, 200, seed=9, missing=0.25, outlier_frames=5, scalar_nans=6)
+    x = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = mc.ops.Problem(p["uvs"], p["obj"], upload=False)
+    status, thr, info = prob.prefilter(x)
+    mean_cf, full_cf = prob.frame_errors(0)          # the per-call kernels on the same handle
+    complete = full_cf == p["uvs"].shape[2]
+    used = complete.sum(0) > 1
+    np.testing.assert_array_equal((status & 1).astype(bool), used)
+    np.testing.assert_array_equal((status & 4).astype(bool), complete.all(0))
+    mask = used.astype(np.uint8)
+    med, cnt = prob.error_median(mask)
+    assert thr == 5 * med and info[1] == med and info[2] == cnt and info[3] == 0
+    worst = np.fmax.reduce(mean_cf, axis=0)
+    excl = used & (np.nan_to_num(worst) > thr)
+    np.testing.assert_array_equal((status & 2).astype(bool), excl)
+    assert (info[4], info[5]) == (used.sum(), excl.sum())
+    # a second call on the same handle (observations already there) with a caller's threshold
+    status2, thr2, info2 = prob.prefilter(x, 0.4)
+    assert thr2 == 0.4
+    np.testing.assert_array_equal((status2 & 2).astype(bool), used & (np.nan_to_num(worst) > 0.4))
+    prob.close()
+
+
+def test_prefilter_median_at_scale_and_degenerate(mc):
+    """The three-pass select at a size with millions of values (against numpy on the downloaded scores) and on data where every error is
+    the SAME number (the candidate list overflows -> the eight-pass fallback must give the same answer)."""
+    p = mc.synth.make_problem(6, 3000, seed=11, missing=0.1)
+    x = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = mc.ops.Problem(p["uvs"], p["obj"], upload=False)
+    status, thr, info = prob.prefilter(x)
+    pred = orc.predict_from_x(x, 6, p["obj"])
+    used = (status & 1).astype(bool)
+    err = np.sqrt(((p["uvs"] - pred) ** 2).sum(-1))[:, used]
+    v = np.sort(err[~np.isnan(err)])
+    assert info[2] == v.size and info[3] == 0
+    # the order statistics are exact: the device median lies between the oracle-side neighbours of the middle (its errors differ in the last bits)
+    assert abs(info[1] - np.median(v)) <= 1e-10 * np.median(v)
+    prob.close()
+    # every observation exactly where the model predicts + a constant offset of (3, 4) px -> every error == 5 (to the bit or nearly): overflow path
+    q = mc.synth.make_problem(2, 20000, seed=12, noise=0.0)
+    xq = mc.serialize_params(q["extrinsics"], q["intrinsics"], q["poses"])
+    uv = orc.predict_from_x(xq, 2, q["obj"]) + np.array([3.0, 4.0])
+    prob = mc.ops.Problem(uv, q["obj"], upload=False)
+    status, thr, info = prob.prefilter(xq)
+    mean_cf, full_cf = prob.frame_errors(0)
+    med, cnt = prob.error_median(np.ones(20000, np.uint8))
+    assert info[1] == med and info[2] == cnt == 2 * 20000 * uv.shape[2] and abs(med - 5.0) < 1e-9
+    assert info[3] == 1.0   # ~2 M values share the median's 24 leading bits: more than the candidate list holds
+    prob.close()
+
+
+def _ba(mc, p, **kw):
+    np.random.seed(0)
+    return captured(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], **kw)
+
+
+@pytest.mark.parametrize("shape", [(2, 50, {}), (3, 70, dict(missing=0.2, scalar_nans=3)), (6, 400, dict(missing=0.1)), (12, 90, dict(rows=3, cols=4))])
+def test_lm_run_equals_the_python_loop(mc, shape):
+    """mcba_lm_run against the per-tick Python loop (MCBA_HOST_LOOP=1): the same ticks -- every trial cost, damping, ratio and step norm
+    to the bit --, the same solution, counters, status, printed table; with limits (max_nfev) and both reduced-solver regimes."""
+    C, F, kw = shape
+    p = mc.synth.make_problem(C, F, seed=3, **kw)
+    for opts in (dict(n_frames=None, verbose=2), dict(n_frames=None, verbose=0, ftol=1e-12, xtol=1e-12, gtol=1e-12), dict(n_frames=F // 2, verbose=1, max_nfev=4),
+                 dict(n_frames=None, verbose=0, loss="cauchy", f_scale=2.0, max_nfev=30), dict(n_frames=None, verbose=0, fix_intrinsics=True), dict(n_frames=None, verbose=0, max_nfev=1)):
+        (ea, ia, pa, ua, ra), outa = _ba(mc, p, **opts)
+        with env(MCBA_HOST_LOOP=1):
+            (eb, ib, pb, ub, rb), outb = _ba(mc, p, **opts)
+        assert outa == outb
+        np.testing.assert_array_equal(ua, ub)
+        np.testing.assert_array_equal(ra.x, rb.x)
+        np.testing.assert_array_equal(ra.grad, rb.grad)
+        assert (ra.cost, ra.nfev, ra.njev, ra.status, ra.optimality) == (rb.cost, rb.nfev, rb.njev, rb.status, rb.optimality)
+        assert ra.lm["history"] == rb.lm["history"] and ra.lm["iterations"] == rb.lm["iterations"] and ra.lm["lam"] == rb.lm["lam"]
+        assert ra.lm["steps"] == rb.lm["steps"] and ra.lm["rebuilds"] == rb.lm["rebuilds"]
+        np.testing.assert_array_equal(ra.fun, rb.fun)
+
+
+def test_identity_selection_solves_on_the_prefilter_handle(mc):
+    """n_frames=None with nothing excluded: no gather, the pre-filter's handle is the problem.  Same solution as the gathered path
+    (forced through a random permutation of all frames: the minimiser does not depend on the frame order)."""
+    p = mc.synth.make_problem(4, 150, seed=6)
+    (e1, i1, p1, u1, r1), _ = _ba(mc, p, n_frames=None, verbose=0, ftol=1e-12, xtol=1e-12, gtol=1e-12)
+    np.testing.assert_array_equal(u1, np.arange(150))
+    (e2, i2, p2, u2, r2), _ = _ba(mc, p, n_frames=150, verbose=0, ftol=1e-12, xtol=1e-12, gtol=1e-12)   # np.random.choice permutes
+    assert sorted(u2) == list(range(150)) and not np.array_equal(u2, u1)
+    assert abs(r1.cost - r2.cost) <= 1e-9 * r1.cost
+    np.testing.assert_allclose(p1[u2], p2, rtol=0, atol=1e-6)
+    f = orc.residuals(r1.x, p["uvs"][:, u1], p["obj"])
+    assert abs(orc.robust_cost(f) - r1.cost) <= 1e-10 * r1.cost
+
+
+def test_lm_result_equals_the_separate_fetches(mc):
+    for C, fixed in ((3, False), (3, True), (11, False)):
+        p = mc.synth.make_problem(C, 80, seed=8, missing=0.15)
+        x0 = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+        prob = mc.ops.Problem(p["uvs"], p["obj"])
+        if fixed:
+            assert prob.set_camera_block(6)
+        lm = mc.solver.LevenbergMarquardt(prob, ftol=1e-10)
+        lm.max_nfev, lm.max_steps = 50, None
+        status = lm.run_device(x0)
+        res = lm.result(status)
+        x, grad = prob.lm_result(lm.cur)
+        np.testing.assert_array_equal(x, prob.get_params(lm.cur))
+        red = prob.get_reduced()
+        gcam = np.zeros(12 * C)
+        gcam[prob.cam_index] = red["gc"]
+        np.testing.assert_array_equal(grad, np.concatenate([gcam, prob.frame_gradient().ravel()]))
+        np.testing.assert_array_equal(res.lm["grad"], grad)
+        prob.close()
+
+
+def test_nonfinite_start_is_scipys_error(mc):
+    p = mc.synth.make_problem(2, 30, seed=1)
+    bad = p["poses"].copy()
+    bad[3, 5] = np.inf
+    with pytest.raises(ValueError, match="Residuals are not finite in the initial point"):
+        captured(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], bad, n_frames=None, outlier_threshold=1e300, verbose=0)
+
+
+def test_skew_in_the_input_intrinsics_is_refused(mc):
+    p = mc.synth.make_problem(2, 30, seed=1)
+    intr = [(K.copy(), d) for K, d in p["intrinsics"]]
+    intr[1][0][0, 1] = 0.3
+    with pytest.raises(ValueError, match="skew"):
+        mc.bundle_adjust(p["uvs"], p["extrinsics"], intr, p["obj"], p["poses"], n_frames=None, verbose=0)
