@@ -88,7 +88,7 @@ def gram_work(C, F, N):
                          "other_valu": pp["valu_other"], "valu": pp["valu"], "fp64_outside_loop_per_pair": out["fp64"], "source": "profiles/gram_flops.json (" + g["source"] + ")"}
 
 
-def end_to_end(m, p, reps=5):
+def end_to_end(m, p, reps=5, full=True):
     """The call users make (reference bundle_adjustment.py:195 -> 5-tuple): host arrays in, 5-tuple out, return_jac=False, default
     tolerances, warm.  Wall-clock per stage: every ops.Problem method is a C-ABI crossing (those that return host data
     synchronise), the host-side stages are timed around them."""
@@ -111,13 +111,12 @@ def end_to_end(m, p, reps=5):
         return w
 
     saved = []
-    for owner, names in ((ops.Problem, ["__init__", "set_params", "frame_errors", "error_median", "subset", "close", "get_params", "get_reduced", "frame_gradient", "residuals_detach",
-                                        "lm_auto_wait", "lm_auto_tick"]),
+    for owner, names in ((ops.Problem, ["__init__", "prefilter", "subset", "close", "lm_run", "lm_result", "residuals_detach", "set_x_scale"]),
                          (api, ["select_frames", "deserialize_params", "serialize_params"]), (solver, ["lm_solve"])):
         for n in names:
             saved.append((owner, n, getattr(owner, n)))
             setattr(owner, n, timed(("ops." if owner is ops.Problem else owner.__name__.split(".")[-1] + ".") + n, getattr(owner, n)))
-    F = p["uvs"].shape[1]
+    Cc, F, Nn = p["uvs"].shape[:3]
 
     def run():
         np.random.seed(0)
@@ -141,7 +140,7 @@ def end_to_end(m, p, reps=5):
         # the reference's own call, no extra keyword at all (return_jac defaults to True): `result.jac` is lazy too, the result
         # keeps the GPU handle until it is dropped
         dflt = []
-        for _ in range(3):
+        for _ in range(3 if full else 0):
             np.random.seed(0)
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
@@ -153,7 +152,7 @@ def end_to_end(m, p, reps=5):
         uvs_m = p["uvs"].copy()
         uvs_m[np.random.default_rng(7).random(uvs_m.shape[:2]) < 0.05] = np.nan
         miss = []
-        for _ in range(4):
+        for _ in range(4 if full else 3):
             np.random.seed(0)
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
@@ -165,18 +164,23 @@ def end_to_end(m, p, reps=5):
             setattr(owner, n, f)
     ms = {k: 1e3 * v / reps for k, v in acc_main.items()}
     total = float(np.median(times))
-    upload = ms.get("ops.__init__", 0.0)
-    prefilter = ms.get("api.select_frames", 0.0) - upload
+    pre = ms.get("ops.prefilter", 0.0) + ms.get("ops.__init__", 0.0)
+    sel = ms.get("api.select_frames", 0.0) - pre
     lm = ms.get("solver.lm_solve", 0.0)
-    d2h = ms.get("ops.get_params", 0.0) + ms.get("ops.get_reduced", 0.0) + ms.get("ops.frame_gradient", 0.0) + ms.get("ops.residuals_detach", 0.0)
     gather = ms.get("ops.subset", 0.0)
     close = ms.get("ops.close", 0.0)
-    return {"ms": total, "ms_min": float(min(times)), "reps": reps, "nfev": int(res.nfev), "status": int(res.status),
-            "what": f"bundle_adjust(host arrays (6,{F},54,2) -> 5-tuple), n_frames={F}, return_jac=False, default tolerances (ftol=1e-4), warm (third call onwards), median of {reps}",
-            "breakdown_ms": {"h2d_upload_and_relayout": upload, "prefilter_kernels_median_host_logic": prefilter, "device_gather_of_selection": gather, "lm_loop": lm,
-                             "d2h_params_gradient": d2h, "handle_teardown": close, "python_rest": total - (upload + prefilter + gather + lm + d2h + close)},
-            "result_fun_first_read_ms": t_fun, "result_fun_size": nres, "default_call_ms": float(np.median(dflt)), "missing_detections_call_ms": float(np.median(miss[1:])),
-            "note": "result.fun stays on the GPU until first read (LazyOptimizeResult); its download is timed separately above and is not part of `ms`; default_call_ms = the same call without return_jac=False (result.jac lazy, the result holds the handle); missing_detections_call_ms = the return_jac=False call with 5 % of the (camera, frame) detections NaN"}
+    detach = ms.get("ops.residuals_detach", 0.0)
+    out = {"ms": total, "ms_min": float(min(times)), "reps": reps, "nfev": int(res.nfev), "status": int(res.status),
+           "what": f"bundle_adjust(host arrays ({Cc},{F},{Nn},2) -> 5-tuple), n_frames={F}, return_jac=False, default tolerances (ftol=1e-4), warm (third call onwards), median of {reps}",
+           "breakdown_ms": {"prefilter_one_crossing_h2d_relayout_scores_selection": pre, "host_selection_print_rng": sel, "device_gather_of_selection": gather,
+                            "lm_solve_total": lm, "of_which_lm_run_one_crossing": ms.get("ops.lm_run", 0.0), "of_which_lm_result_d2h": ms.get("ops.lm_result", 0.0),
+                            "residual_vector_left_on_device": detach, "handle_teardown": close, "python_rest": total - (pre + sel + gather + lm + detach + close)},
+           "result_fun_first_read_ms": t_fun, "result_fun_size": nres, "missing_detections_call_ms": float(np.median(miss[1:])),
+           "note": "three C-ABI crossings carry the call (mcba_prefilter, mcba_lm_run, mcba_lm_result); result.fun / result.grad stay on the GPU until first read (LazyOptimizeResult) -- the download of fun is timed separately above and is not part of `ms`; missing_detections_call_ms = the same call with 5 % of the (camera, frame) detections NaN"}
+    if full:
+        out["default_call_ms"] = float(np.median(dflt))
+        out["note"] += "; default_call_ms = the same call without return_jac=False (result.jac lazy, the result holds the handle)"
+    return out
 
 
 def cpu_baseline(sample_frames=1000, max_nfev=12):
@@ -246,21 +250,23 @@ def other_configs(m, headline_ms_per_step):
     linearises its trial point), untimed with respect to `value`: configs[0] 2 x 50 x 54 (the reference's CPU-runnable case),
     configs[1] 6 x 1 000 x 54 with the intrinsics held fixed (the library's 6-wide camera block).  configs[2] is the headline."""
     out = {}
-    for key, (Cc, Fc, fixed) in (("configs[0]", (2, 50, False)), ("configs[1]", (6, 1000, True))):
-        p = m.synth.make_problem(Cc, Fc, rows=ROWS, cols=COLS, seed=0)
+    for key, (Cc, Fc, fixed, rows, cols) in (("configs[0]", (2, 50, False, ROWS, COLS)), ("configs[1]", (6, 1000, True, ROWS, COLS)),
+                                             ("configs[3] (one of 8 frame shards)", (6, 12500, False, ROWS, COLS)), ("configs[4] (one of 8 frame shards)", (24, 6250, False, 10, 20))):
+        p = m.synth.make_problem(Cc, Fc, rows=rows, cols=cols, seed=0)
         x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
         prob = m.ops.Problem(p["uvs"], p["obj"])
         if fixed:
             assert prob.set_camera_block(6)
         lm = m.solver.LevenbergMarquardt(prob, ftol=0.0, xtol=0.0, gtol=0.0)
         lm.start(x0)
-        for _ in range(100):
+        big = Cc * Fc * rows * cols > 5_000_000
+        for _ in range(40 if big else 100):
             lm.iterate(always_linearize=True)
         prob.synchronize()
         best = 1e9
         for _ in range(3):
             n0, t0 = lm.nfev, time.perf_counter()
-            for _ in range(200):
+            for _ in range(100 if big else 200):
                 lm.iterate(always_linearize=True)
             lm.finalize()
             prob.synchronize()
@@ -270,18 +276,20 @@ def other_configs(m, headline_ms_per_step):
             lm.iterate(always_linearize=True)
         kern = {k: round(1e3 * ms / n, 2) for k, (ms, n) in prob.profile_read().items() if n}
         prob.profile_enable(False)
-        tb = tick_bytes(Cc, Fc, ROWS * COLS, 6 if fixed else 12)
-        out[key] = {"shape": f"{Cc} cameras x {Fc} frames x {ROWS * COLS} points" + (", intrinsics held fixed (camera block 6 wide)" if fixed else ", all parameters free"),
+        tb = tick_bytes(Cc, Fc, rows * cols, 6 if fixed else 12)
+        out[key] = {"shape": f"{Cc} cameras x {Fc} frames x {rows * cols} points" + (", intrinsics held fixed (camera block 6 wide)" if fixed else ", all parameters free"),
                     "us_per_iteration": round(best * 1e6, 2), "it_per_s": round(1.0 / best, 1), "kernels_us_by_hip_events": kern,
                     "tick_roofline": {"bound": "hbm", "algorithmic_bytes_per_iteration": tb, "achieved": tb / best / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tb / best / 1e9 / HBM_PEAK_GBS},
                     "cost_end": lm.cost}
         prob.close()
+        del p, prob, lm
     tb = tick_bytes(C, F_PER_GPU, ROWS * COLS)
     out["configs[2]"] = {"shape": f"{C} cameras x {F_PER_GPU} frames x {ROWS * COLS} points, all parameters free (the bench workload: `value`)", "us_per_iteration": round(1e3 * headline_ms_per_step, 2),
                          "it_per_s": round(1e3 / headline_ms_per_step, 1),
                          "tick_roofline": {"bound": "hbm", "algorithmic_bytes_per_iteration": tb, "achieved": tb / (headline_ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": tb / (headline_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-    out["note"] = "wall clock per LM iteration of the device-resident loop (best of 3 x 200 iterations after 100 warm-up iterations); bytes = SURVEY 8(d)'s accounting generalised (bench.py: tick_bytes)"
+    out["note"] = ("wall clock per LM iteration of the device-resident loop (best of 3 x 200 iterations after 100 warm-up iterations; 3 x 100 after 40 for the shards of configs[3] / [4]); "
+                   "bytes = SURVEY 8(d)'s accounting generalised (bench.py: tick_bytes); configs[3] / [4] are ONE of the eight frame shards north_star partitions them into, on one GPU, without the collective")
     return out
 
 
@@ -420,9 +428,25 @@ def main():
     for _ in range(min(args.steps, 50)):
         lm.iterate(always_linearize=True)
     prof = prob.profile_read()
-    if prof_timed[DOMINANT][1]:
-        prof[DOMINANT] = prof_timed[DOMINANT]
+    # the dominant kernel alone, every launch bracketed, 50 iterations (>= 25 samples whatever --steps is), and what an EMPTY bracket reads
+    # on the same stream: the event pair's own share of each sample
+    prob.profile_enable(True, only=[DOMINANT])
+    for _ in range(50):
+        lm.iterate(always_linearize=True)
+    prof_dom = prob.profile_read()[DOMINANT]
+    dom_events_us = 1e3 * prof_dom[0] / max(prof_dom[1], 1)
+    # ... and once more with the events attached to the kernel's DISPATCH (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps,
+    # the figure rocprofv3 reports -- an event pair recorded around a launch also reads the packet latencies on either side of it)
+    prob.profile_enable(True, only=[DOMINANT], exact=True)
+    for _ in range(50):
+        lm.iterate(always_linearize=True)
+    prof_exact = prob.profile_read()[DOMINANT]
     prob.profile_enable(False)
+    bracket_us = prob.profile_bracket_overhead(200)
+    if prof_exact[1]:
+        prof[DOMINANT] = prof_exact
+    else:   # (a launch variant without dispatch events: the bracketed figure)
+        prof[DOMINANT] = prof_dom
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -471,13 +495,17 @@ def main():
             except Exception:  # noqa: BLE001
                 live_ceiling = None
             roofline = {"kernel": dom, "bound": "valu_f64", "n_samples": int(kern[dom][1]), "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
-                        "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": dom_ms * 1e3, "flops_per_launch": real,
+                        "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": dom_ms * 1e3, "avg_launch_us_by_events_raw": dom_events_us, "event_bracket_overhead_us": bracket_us,
+                        "timed_region_samples": {"n": int(prof_timed[DOMINANT][1]), "avg_us_by_events_raw": (1e3 * prof_timed[DOMINANT][0] / prof_timed[DOMINANT][1]) if prof_timed[DOMINANT][1] else None,
+                                                 "what": "every 8th launch inside the timed region (the brackets must not pace the stream)"},
+                        "flops_per_launch": real,
                         "frac_issue_slots": tfs / FP64_VALU_PEAK_TFLOPS, "issue_slot_flops_per_launch": slots,
                         "measured_issue_ceiling": FP64_VALU_MEASURED_TFLOPS, "frac_issue_slots_of_measured_ceiling": tfs / FP64_VALU_MEASURED_TFLOPS,
                         "live_issue_ceiling": {"tflops": live_ceiling, "frac_issue_slots": (tfs / live_ceiling) if live_ceiling else None,
                                                "what": "independent v_fma_f64 with three distinct register pairs each, one wavefront per SIMD on every CU (mcba_fp64_issue_rate), measured in this run"},
                         "instructions_per_point_observation": mix, "hbm": hbm,
-                        "note": "frac = real FP64 flops (2 x FMA + MUL + ADD) / 78.6 TFLOP/s; frac_issue_slots counts every FP64 instruction as an FMA"}
+                        "note": "frac = real FP64 flops (2 x FMA + MUL + ADD) / 78.6 TFLOP/s; frac_issue_slots counts every FP64 instruction as an FMA; avg_launch_us = mean of 50 launches right after the timed region, "
+                                "timed by events attached to the kernel's dispatch (its own begin / end: the figure rocprofv3 reports); avg_launch_us_by_events_raw = the same launches with event records AROUND them"}
         tick_bytes = TICK_ALGORITHMIC_BYTES_10K * F / F_PER_GPU
         tick_ach = tick_bytes / (dt / args.steps) / 1e9
         tick_roofline = {"bound": "hbm", "achieved": tick_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tick_ach / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": tick_bytes,
@@ -534,6 +562,11 @@ def main():
             e2e = end_to_end(m, p)
             out["end_to_end_ms"] = e2e["ms"]
             out["end_to_end"] = e2e
+            # ... and where users are: the one recording the reference documents (docs/source/calibration_tutorial.ipynb: 6 cameras x 2 130
+            # frames x 35 points) and BASELINE configs[0]
+            out["end_to_end_other_shapes"] = {
+                "reference tutorial 6 x 2130 x 35": end_to_end(m, m.synth.make_problem(6, 2130, rows=5, cols=7, seed=0), reps=7, full=False),
+                "configs[0] 2 x 50 x 54": end_to_end(m, m.synth.make_problem(2, 50, rows=ROWS, cols=COLS, seed=0), reps=7, full=False)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"]["reference_measured_in_survey_container"] = {"value": 0.0098, "unit": "it/s", "ms_per_jacobian_eval": 68679, "source": "BASELINE.md section 2 (the reference itself, 6x10kx54)"}

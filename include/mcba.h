@@ -256,11 +256,14 @@ int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state);
  * MCBA_ERR_NONFINITE: "Residuals are not finite in the initial point." (least_squares.py).  With a direct RCCL communicator attached the
  * start system is all-reduced and every tick carries its collective, as in mcba_lm_auto_tick.
  * mcba_lm_history: the MCBA_LM_STATE doubles every retired tick posted, row 0 = the solve of the start point (cost, optimality).
- * mcba_lm_result: [x | gradient] of parameter slot `slot`, 2 (12C + 6F) doubles, in one device-to-host copy: the camera gradient g_c of
- * the reduce buffer scattered to the parameter layout (0 where a parameter is held fixed), the frame gradients (OptimizeResult.grad). */
+ * mcba_lm_result: x of parameter slot `slot` (12C + 6F doubles -> x_out) and the gradient J^T f there (OptimizeResult.grad: the camera
+ * gradient g_c of the reduce buffer scattered to the parameter layout, 0 where a parameter is held fixed, then the frame gradients),
+ * packed on the device.  grad_out != NULL: x_out must have room for 2 (12C + 6F) doubles and grad_out == x_out + 12C + 6F -- one copy
+ * brings both; grad_dev != NULL (and grad_out NULL): the gradient stays on the device as a mcba_buffer of its own (mcba_buffer_download /
+ * mcba_buffer_free), for callers that attach it lazily; both NULL: x alone. */
 int mcba_lm_run(mcba_handle* h, const double* x0, const double* opt, const unsigned char* fixed, double* summary);
 int mcba_lm_history(mcba_handle* h, double* rows, size_t capacity_rows);
-int mcba_lm_result(mcba_handle* h, int slot, double* out);
+int mcba_lm_result(mcba_handle* h, int slot, double* x_out, double* grad_out, mcba_buffer** grad_dev);
 /* k_solve_backsub's back-substitution workgroups wait for the solve of the same launch with a BOUNDED poll (~0.5 s).  If one ever
  * runs out, it stamps the tick's number into a device word and a host-mapped word: the next tick's decision discards its (stale)
  * trial point and only rebuilds the system, and mcba_lm_auto_wait switches the handle to the two-launch path (k_solve_cam, then
@@ -343,6 +346,13 @@ int mcba_profile_enable(mcba_handle* h, int on);
 /* Bracket only every `stride`-th launch of each selected kernel (event records put barrier packets on the stream:
  * sampling keeps a measured region undisturbed).  Reset to 1 by mcba_profile_enable. */
 int mcba_profile_stride(mcba_handle* h, int stride);
+/* on != 0: the fused k_gram kernel is timed by events attached to its dispatch (the kernel's own begin / end timestamps -- the
+ * figure rocprofv3 reports) instead of event records around the launch; other kernels and k_gram's other launch variants are
+ * bracketed as before.  Reset by mcba_profile_enable. */
+int mcba_profile_exact(mcba_handle* h, int on);
+/* Microseconds an event bracket reads with nothing between its two records, mean of `pairs` (<= 4096) brackets on the handle's stream:
+ * the bracket's own share of an event-timed kernel (bench.py subtracts it: `roofline.avg_launch_us`).  Synchronises. */
+int mcba_profile_bracket_overhead(mcba_handle* h, int pairs, double* us);
 /* Drains the recorded events.  names: '\n'-separated kernel names in the order of ms[] / calls[]. */
 int mcba_profile_read(mcba_handle* h, double* ms_total, int* calls, int capacity, int* n_kernels);
 const char* mcba_profile_names(void);

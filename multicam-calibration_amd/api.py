@@ -458,7 +458,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         if max_nfev is None:
             max_nfev = 100 * (12 * n_cameras + 6 * len(all_use))  # trf.py:437-438 on the GLOBAL vector: identical on every rank
         result = solver.lm_solve(prob, x0, ftol=tol("ftol", 1e-4), xtol=tol("xtol", 1e-8), gtol=tol("gtol", 1e-8),
-                                 max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, x_scale=x_scale, x0_on_device=x0_on_device, **lm_kwargs)
+                                 max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, x_scale=x_scale, x0_on_device=x0_on_device, lazy_grad=not distributed, **lm_kwargs)
         result = LazyOptimizeResult(result)
 
         # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560).  `fun` and `jac` are LAZY: the residual
@@ -506,7 +506,10 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             result.active_mask = np.zeros_like(result.x)
             result.optimality = float(np.abs(grad).max())
             result.lm["frame_positions"] = positions
-        result.grad = grad
+        if isinstance(grad, ops.DeviceArray):   # left on the GPU (mcba_lm_result): downloaded when `result.grad` is first read
+            dict.__setitem__(result, "grad", _Lazy(grad.download))
+        else:
+            result.grad = grad
         if return_jac:
             # (the caller's array is referenced, not copied: only a result whose handle had to be released re-reads its frames from it)
             jsrc = _JacobianSource(prob, all_calib_uvs, use_frames, calib_objpoints, x_local, slot, kw["loss"], kw.get("f_scale", 1.0), device, kw["loss"] != "linear",

@@ -95,6 +95,7 @@ struct mcba_handle {
   bool prof = false;
   unsigned prof_mask = ~0u;
   int prof_stride = 1;             // bracket every prof_stride-th launch of a selected kernel
+  bool prof_exact = false;         // k_gram: events on the dispatch itself (mcba_profile_exact)
   unsigned prof_count[32] = {};
   std::vector<EvRec> evs;
   std::vector<hipEvent_t> pool;
@@ -104,6 +105,9 @@ struct mcba_handle {
   size_t ring_bytes = 0, pinned_bytes = 0;
   unsigned ring_flags = 0;
 };
+
+// a device array that outlives its handle (mcba_residuals_detach, mcba_lm_result)
+struct mcba_buffer { double* dev; size_t count; int device; hipStream_t stream; double* base; size_t base_count; };  // dev / count: what a download delivers; base / base_count: the pooled allocation it lies in
 
 namespace {
 
@@ -127,12 +131,25 @@ hipEvent_t get_event(mcba_handle* h) {
 
 struct Scope {  // brackets one launch with events when profiling
   mcba_handle* h; int kid; hipEvent_t a{}, b{};
-  bool on;
-  Scope(mcba_handle* h_, int k) : h(h_), kid(k), on(h_->prof && ((h_->prof_mask >> k) & 1u) && (h_->prof_count[k]++ % (unsigned)h_->prof_stride) == 0) {
-    if (on) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, h->stream); }
+  bool on, exact;
+  Scope(mcba_handle* h_, int k) : h(h_), kid(k), on(h_->prof && ((h_->prof_mask >> k) & 1u) && (h_->prof_count[k]++ % (unsigned)h_->prof_stride) == 0), exact(false) {
+    if (!on) return;
+    a = get_event(h); b = get_event(h);
+    // k_gram with exact timing asked for (mcba_profile_exact): the events ride on the kernel's dispatch (its own begin / end timestamps,
+    // what rocprofv3 reports); everything else: event records around the launch (which read ~2.5 us more than the kernel takes)
+    exact = h->prof_exact && k == K_GRAM;
+    if (exact) mcba::gram_time_next_launch(a, b);
+    else (void)hipEventRecord(a, h->stream);
   }
   ~Scope() {
-    if (on) { (void)hipEventRecord(b, h->stream); h->evs.push_back({kid, a, b}); }
+    if (!on) return;
+    if (exact && mcba::gram_time_pending()) {   // another launch variant than the fused kernel ran: no exact timing for it
+      mcba::gram_time_next_launch(nullptr, nullptr);
+      h->pool.push_back(a); h->pool.push_back(b);
+      return;
+    }
+    if (!exact) (void)hipEventRecord(b, h->stream);
+    h->evs.push_back({kid, a, b});
   }
 };
 
@@ -1252,7 +1269,8 @@ int mcba_lm_run(mcba_handle* h, const double* x0, const double* opt, const unsig
   h->last_solve_seq = 0;
   h->auto_ready = true;
   if (const char* e = getenv("MCBA_SPECULATE")) h->speculate = atoi(e) != 0;
-  if ((rc = auto_solve_impl(h, 1, 0, false))) return rc;
+  // (with <= 9 cameras the first solve's launch already carries the back-substitution of the first trial step, like every later one)
+  if ((rc = auto_solve_impl(h, 1, 0, false, h->fuse_backsub))) return rc;
 
   h->hist.clear();
   unsigned long long issued = 1, retired = 1;
@@ -1312,8 +1330,8 @@ int mcba_lm_history(mcba_handle* h, double* rows, size_t capacity_rows) {
 // camera gradient of the reduced system in the reduce buffer (scattered to the parameter layout, zero where a parameter is held fixed by
 // the camera block width or by mcba_lm_auto_config's / mcba_lm_run's flags), the frame gradients.  The reduced system must be that of
 // the current point (after a terminated loop it is; solver.LevenbergMarquardt.finalize rebuilds it otherwise).
-int mcba_lm_result(mcba_handle* h, int slot, double* out) {
-  if (!slot_ok(h, slot) || !out) return fail(MCBA_ERR_ARG, "mcba_lm_result: bad argument");
+int mcba_lm_result(mcba_handle* h, int slot, double* x_out, double* grad_out, mcba_buffer** grad_dev) {
+  if (!slot_ok(h, slot) || !x_out || (grad_out && grad_dev)) return fail(MCBA_ERR_ARG, "mcba_lm_result: bad argument");
   if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_lm_result: no reduced system");
   HIPCHK(hipSetDevice(h->device));
   const size_t nx = (size_t)12 * h->C + (size_t)6 * h->F;
@@ -1321,8 +1339,14 @@ int mcba_lm_result(mcba_handle* h, int slot, double* out) {
   if (!h->outbuf && (rc = dalloc(h, &h->outbuf, 2 * nx, false))) return rc;
   mcba::launch_pack_result(h->stream, h->x[slot], h->red + (size_t)h->n * h->n + 2 * (size_t)h->n, h->fbuf, h->have_fixed ? h->fixed : nullptr, h->outbuf, h->C, h->F, h->cw);
   if ((rc = check_launch())) return rc;
-  HIPCHK(hipMemcpyAsync(out, h->outbuf, 2 * nx * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(x_out, h->outbuf, (grad_out ? 2 : 1) * nx * sizeof(double), hipMemcpyDeviceToHost, h->stream));  // (grad_out, if given, must directly follow x_out: one copy)
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (grad_dev) {   // the gradient stays on the device as an object of its own (OptimizeResult.grad is rarely read: 0.48 MB of D2H at 6 x 10 000 x 54)
+    *grad_dev = new mcba_buffer{h->outbuf + nx, nx, h->device, h->stream, h->outbuf, 2 * nx};
+    for (size_t i = 0; i < h->bufs.size(); ++i)
+      if (h->bufs[i].slot == reinterpret_cast<void**>(&h->outbuf)) { h->bufs.erase(h->bufs.begin() + i); break; }
+    h->outbuf = nullptr;
+  }
   return MCBA_OK;
 }
 
@@ -1712,7 +1736,6 @@ int mcba_set_x_scale(mcba_handle* h, const double* x_scale) {
 // Residual vector left ON THE DEVICE and handed to the caller as an object of its own: api.bundle_adjust attaches it to the
 // OptimizeResult and downloads it when (if) `result.fun` is first read -- 52 MB of D2H at 6 x 10 000 x 54 that most callers
 // never look at (the reference materialises it: scipy trf.py:557-560).  The buffer outlives the handle.
-struct mcba_buffer { double* dev; size_t count; int device; hipStream_t stream; };
 
 int mcba_residuals_detach(mcba_handle* h, int slot, mcba_buffer** out) {
   if (!slot_ok(h, slot) || !out) return fail(MCBA_ERR_ARG, "mcba_residuals_detach: bad argument");
@@ -1726,7 +1749,7 @@ int mcba_residuals_detach(mcba_handle* h, int slot, mcba_buffer** out) {
     mcba::launch_cost(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->cpart, h->res, h->C, h->F, h->N, h->Fpad, h->nch);
   }
   if ((rc = check_launch())) return rc;
-  mcba_buffer* b = new mcba_buffer{h->res, (size_t)2 * h->C * h->F * h->N, h->device, h->stream};
+  mcba_buffer* b = new mcba_buffer{h->res, (size_t)2 * h->C * h->F * h->N, h->device, h->stream, h->res, (size_t)2 * h->C * h->F * h->N};
   for (size_t i = 0; i < h->bufs.size(); ++i)
     if (h->bufs[i].slot == reinterpret_cast<void**>(&h->res)) { h->bufs.erase(h->bufs.begin() + i); break; }
   h->res = nullptr;
@@ -1746,7 +1769,7 @@ int mcba_buffer_free(mcba_buffer* b) {
   if (!b) return MCBA_OK;
   (void)hipSetDevice(b->device);
   (void)hipStreamSynchronize(b->stream);
-  pool_free(b->dev, b->count * sizeof(double), b->device);
+  pool_free(b->base, b->base_count * sizeof(double), b->device);
   delete b;
   return MCBA_OK;
 }
@@ -1830,12 +1853,39 @@ int mcba_profile_enable(mcba_handle* h, int on) {
   h->prof = on != 0;
   h->prof_mask = (on == 0 || on == 1) ? ~0u : ((unsigned)on >> 1);
   h->prof_stride = 1;
+  h->prof_exact = false;
+  return MCBA_OK;
+}
+
+// k_gram's launches (the fused kernel) are timed by events attached to the dispatch itself (hipExtLaunchKernelGGL): the kernel's own
+// begin and end, what rocprofv3 reports -- an event pair recorded around a launch reads ~2.5 us more.  Reset by mcba_profile_enable.
+int mcba_profile_exact(mcba_handle* h, int on) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  h->prof_exact = on != 0;
   return MCBA_OK;
 }
 
 int mcba_profile_stride(mcba_handle* h, int stride) {
   if (!h || stride < 1) return fail(MCBA_ERR_ARG, "mcba_profile_stride: stride >= 1 required");
   h->prof_stride = stride;
+  return MCBA_OK;
+}
+
+// What a HIP-event bracket reads with NOTHING between its two records, on the handle's stream (mean of `pairs` back-to-back brackets, in
+// microseconds): the part of a bracketed kernel's time that is the bracket's, not the kernel's.  bench.py subtracts it from the
+// event-timed duration of the dominant kernel so that the figure agrees with rocprofv3's (50.4 us by events, 47.8 by rocprof).
+int mcba_profile_bracket_overhead(mcba_handle* h, int pairs, double* us) {
+  if (!h || !us || pairs < 1 || pairs > 4096) return fail(MCBA_ERR_ARG, "mcba_profile_bracket_overhead: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<hipEvent_t> ev(2 * (size_t)pairs);
+  for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < pairs; ++i) { HIPCHK(hipEventRecord(ev[2 * i], h->stream)); HIPCHK(hipEventRecord(ev[2 * i + 1], h->stream)); }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double tot = 0.0;
+  for (int i = 0; i < pairs; ++i) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); tot += ms; }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *us = 1e3 * tot / pairs;
   return MCBA_OK;
 }
 

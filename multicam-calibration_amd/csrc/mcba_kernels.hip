@@ -18,6 +18,7 @@
 //   k_jacobian          one wavefront per (camera, frame), one lane per board point; rows transposed through
 //                       LDS so the 288 B/observation Jacobian blocks leave as coalesced 16 B/lane stores.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <type_traits>
 #include "mcba_math.h"
@@ -1728,6 +1729,12 @@ size_t gram_psplit_lds_bytes(int npw, int cw) {
   return b;
 }
 
+// Measurement aid: the next fused k_gram launch of this thread carries these two events ON ITS DISPATCH (hipExtLaunchKernelGGL): the
+// kernel's own begin / end timestamps.  Launch variants other than the fused kernel ignore them (the caller then brackets as usual).
+static thread_local hipEvent_t t_ext_start = nullptr, t_ext_stop = nullptr;
+void gram_time_next_launch(hipEvent_t start, hipEvent_t stop) { t_ext_start = start; t_ext_stop = stop; }
+bool gram_time_pending() { return t_ext_start != nullptr; }
+
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,
                  int planar, double* chunk, int nchunk, int npw, int cw, int slots) {
   const int nfb = Fpad / 64;
@@ -1736,6 +1743,18 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
   const double2* o2 = reinterpret_cast<const double2*>(obs_t);
   auto fused = [&](int fb0, int fb1) {
     dim3 grid((fb1 - fb0 + 3) / 4, C, 1);
+    if (t_ext_start && t_ext_stop) {
+      // measurement (gram_time_next_launch): the events ride on the dispatch itself -- they get the kernel's own begin / end
+      // timestamps, what rocprofv3 reports, not the arrival times of barrier packets around it
+      hipEvent_t ea = t_ext_start, eb = t_ext_stop;
+      t_ext_start = t_ext_stop = nullptr;
+      if (planar && f_scale == 1.0) {
+        DISPATCH_LOSS(loss, (hipExtLaunchKernelGGL((k_gram<L, true>), grid, block, 0, st, ea, eb, 0, o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)));
+      } else {
+        DISPATCH_LOSS(loss, (hipExtLaunchKernelGGL((k_gram<L, false>), grid, block, 0, st, ea, eb, 0, o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)));
+      }
+      return;
+    }
     if (planar && f_scale == 1.0) {
       DISPATCH_LOSS(loss, (k_gram<L, true><<<grid, block, 0, st>>>(o2, obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, fb0, fb1, fs2, ifs2)));
     } else {

@@ -83,13 +83,15 @@ SYMBOLS = [
     ("mcba_prefilter", ctypes.c_int, [_h, _dp, _dp, _dp, ctypes.c_double, ctypes.POINTER(ctypes.c_ubyte), _dp]),
     ("mcba_lm_run", ctypes.c_int, [_h, _dp, _dp, ctypes.c_char_p, _dp]),
     ("mcba_lm_history", ctypes.c_int, [_h, _dp, ctypes.c_size_t]),
-    ("mcba_lm_result", ctypes.c_int, [_h, ctypes.c_int, _dp]),
+    ("mcba_lm_result", ctypes.c_int, [_h, ctypes.c_int, _dp, _dp, ctypes.POINTER(_h)]),
     ("mcba_undistort_points", ctypes.c_int, [ctypes.c_size_t, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp]),
     ("mcba_reprojection_diagnostics", ctypes.c_int, [_h, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp, _dp]),
     ("mcba_triangulate", ctypes.c_int, [ctypes.c_int, ctypes.c_size_t, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
     ("mcba_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_profile_stride", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_profile_read", ctypes.c_int, [_h, _dp, _ip, ctypes.c_int, _ip]),
+    ("mcba_profile_bracket_overhead", ctypes.c_int, [_h, ctypes.c_int, _dp]),
+    ("mcba_profile_exact", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_profile_names", ctypes.c_char_p, []),
     ("mcba_synchronize", ctypes.c_int, [_h]),
     ("mcba_fp64_issue_rate", ctypes.c_int, [ctypes.c_int, _dp]),
@@ -537,10 +539,16 @@ class Problem:
         self._auto_state_p = _p(self._auto_state)
         return int(summary[0]), rows, int(summary[2]), int(summary[3])
 
-    def lm_result(self, slot):
-        """(x, gradient) of parameter slot `slot`, each 12C + 6F, in one device-to-host copy (include/mcba.h: mcba_lm_result)."""
+    def lm_result(self, slot, lazy_grad=False):
+        """(x, gradient) of parameter slot `slot`, each 12C + 6F (include/mcba.h: mcba_lm_result).  lazy_grad: the gradient is returned as a
+        DeviceArray that is downloaded when (if) it is read; otherwise one device-to-host copy brings both."""
+        if lazy_grad:
+            x = np.empty(self.nx)
+            buf = _h()
+            self._chk(self.lib.mcba_lm_result(self.handle, int(slot), _p(x), None, ctypes.byref(buf)))
+            return x, DeviceArray(self.lib, buf, (self.nx,))
         out = np.empty((2, self.nx))
-        self._chk(self.lib.mcba_lm_result(self.handle, int(slot), _p(out)))
+        self._chk(self.lib.mcba_lm_result(self.handle, int(slot), _p(out), _p(out[1]), None))
         return out[0], out[1]
 
     def lm_auto_wait(self, seq):
@@ -616,9 +624,10 @@ class Problem:
     def synchronize(self):
         self._chk(self.lib.mcba_synchronize(self.handle))
 
-    def profile_enable(self, on=True, only=None, stride=1):
+    def profile_enable(self, on=True, only=None, stride=1, exact=False):
         """on=True: time every kernel; only=[names]: time just those; stride=k: bracket every k-th launch only
-        (event records cost barrier packets on the stream: sample inside a measured region)."""
+        (event records cost barrier packets on the stream: sample inside a measured region); exact: the fused k_gram kernel is timed by
+        events on its dispatch -- its own begin / end, rocprofv3's figure (mcba_profile_exact)."""
         flag = int(bool(on))
         if on and only:
             names = self.lib.mcba_profile_names().decode().split("\n")
@@ -628,6 +637,14 @@ class Problem:
         self._chk(self.lib.mcba_profile_enable(self.handle, flag))
         if on and stride > 1:
             self._chk(self.lib.mcba_profile_stride(self.handle, int(stride)))
+        if on and exact:
+            self._chk(self.lib.mcba_profile_exact(self.handle, 1))
+
+    def profile_bracket_overhead(self, pairs=200):
+        """Microseconds an empty HIP-event bracket reads on this handle's stream (include/mcba.h: mcba_profile_bracket_overhead)."""
+        us = ctypes.c_double()
+        self._chk(self.lib.mcba_profile_bracket_overhead(self.handle, int(pairs), ctypes.byref(us)))
+        return us.value
 
     def profile_read(self):
         """{kernel name: (total ms, calls)} since the last read."""

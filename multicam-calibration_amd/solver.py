@@ -647,11 +647,11 @@ class LevenbergMarquardt:
             red = self.p.get_reduced()
             self.g_inf = max(float(np.abs(red["gc"][self.free]).max()) if self.free.any() else 0.0, float(red["scal"][4:16].max()))
 
-    def result(self, status):
+    def result(self, status, lazy_grad=False):
         self.finalize()
         grad = None
         if self.device_solve and hasattr(self.p, "lm_result"):
-            x, grad = self.p.lm_result(self.cur)   # solution + gradient in one device-to-host copy (api.bundle_adjust uses the gradient)
+            x, grad = self.p.lm_result(self.cur, lazy_grad)   # solution + gradient packed on the GPU (api.bundle_adjust attaches the gradient; lazy: a DeviceArray)
         else:
             x = self.p.get_params(self.cur)
         res = self._result(status, x)
@@ -673,7 +673,7 @@ class LevenbergMarquardt:
 
 
 def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=LAM0, max_iterations=None, speculative=True,
-             reduced_solver=None, x_scale=None, dec_floor=DEC_FLOOR, curvature=None, x0_on_device=False):
+             reduced_solver=None, x_scale=None, dec_floor=DEC_FLOOR, curvature=None, x0_on_device=False, lazy_grad=False):
     """Minimise the robust reprojection cost from x0 (this shard's flat vector, a7 layout of SURVEY.md).
     `fun` / `jac` / `grad` of the OptimizeResult are attached by api.bundle_adjust.
     x0_on_device: parameter slot 0 of the problem already holds x0 (ops.Problem.subset gathered it on the GPU): nothing is uploaded."""
@@ -698,7 +698,7 @@ def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbos
             status = lm.iterate()
             if verbose == 2 and getattr(lm, "accepted", False):
                 _print_iteration(lm.iteration, lm.nfev, lm.cost, lm.actual_reduction, lm.step_norm, lm.g_inf)
-    res = lm.result(status)
+    res = lm.result(status, lazy_grad)
     if verbose >= 1:
         print(TERMINATION_MESSAGES[status])
         print("Function evaluations {}, initial cost {:.4e}, final cost {:.4e}, first-order optimality {:.2e}.".format(res.nfev, cost0, res.cost, res.optimality))

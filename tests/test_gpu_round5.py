@@ -198,7 +198,10 @@ def test_lm_result_equals_the_separate_fetches(mc):
         gcam[prob.cam_index] = red["gc"]
         np.testing.assert_array_equal(grad, np.concatenate([gcam, prob.frame_gradient().ravel()]))
         np.testing.assert_array_equal(res.lm["grad"], grad)
-        prob.close()
+        x2, g2 = prob.lm_result(lm.cur, lazy_grad=True)      # the gradient left on the device as an object of its own
+        np.testing.assert_array_equal(x2, x)
+        prob.close()                                          # ... which outlives the handle
+        np.testing.assert_array_equal(g2.download(), grad)
 
 
 def test_nonfinite_start_is_scipys_error(mc):
