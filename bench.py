@@ -443,6 +443,27 @@ def main():
     prof_exact = prob.profile_read()[DOMINANT]
     prob.profile_enable(False)
     bracket_us = prob.profile_bracket_overhead(200)
+    # what the formally complete reader of the solve's release word costs (MCBA_STRICT_SYNC=1 / mcba_set_strict_sync: an agent-scope acquire
+    # fence in every waiting workgroup of k_solve_backsub instead of relying on gfx950's ordering): alternating blocks of 200 iterations
+    strict = None
+    if hasattr(prob, "set_strict_sync") and dist is None:
+        per = {False: [], True: []}
+        for rep in range(3):
+            for mode in (False, True):
+                prob.set_strict_sync(mode)
+                for _ in range(10):
+                    lm.iterate(always_linearize=True)
+                lm.finalize()
+                prob.synchronize()
+                n0, t0s = lm.nfev, time.perf_counter()
+                for _ in range(200):
+                    lm.iterate(always_linearize=True)
+                lm.finalize()
+                prob.synchronize()
+                per[mode].append(1e6 * (time.perf_counter() - t0s) / max(lm.nfev - n0, 1))
+        prob.set_strict_sync(False)
+        strict = {"default_us_per_iteration": min(per[False]), "strict_us_per_iteration": min(per[True]), "delta_us": min(per[True]) - min(per[False]),
+                  "what": "LM iteration with the back-substitution workgroups ACQUIRING the solve's release word (agent-scope fence; the HIP memory model's form) against the default (relaxed agent-scope loads + in-order issue); best of 3 alternating blocks of 200 iterations each"}
     if prof_exact[1]:
         prof[DOMINANT] = prof_exact
     else:   # (a launch variant without dispatch events: the bracketed figure)
@@ -550,6 +571,7 @@ def main():
                               "frac_of_measured_write_ceiling": jach / HBM_MEASURED_WRITE_GBS}},
             "kernels_us": {k: round(1e3 * ms / n, 3) for k, (ms, n) in kern.items()},
             "kernel_calls": {k: n for k, (ms, n) in kern.items()},
+            "strict_sync": strict,
             "prewarm": f"{args.prewarm} untimed iterations of a throw-away solve (clock ramp) before the {args.warmup} warm-up steps; the measured solve restarts from x0",
             "lm": {"cost_start": cost0, "cost_end": lm.cost, "accepted": lm.iteration, "steps_total": lm.steps, "lambda": lm.lam,
                    "passes_in_timed_region": ticks, "rebuild_only_passes_total": getattr(lm, "rebuilds", 0)},

@@ -75,6 +75,7 @@ struct mcba_handle {
   double* dscale = nullptr;   // numeric x_scale (least_squares): D = 1 / x_scale^2 in the layout of x; have_xscale says whether it is in use
   bool have_xscale = false;
   int fuse_max_polls = 200000;
+  bool strict_sync = false;   // the fused back-substitution's readers acquire the release word with an agent-scope fence (MCBA_STRICT_SYNC=1 / mcba_set_strict_sync)
   unsigned char* fixed = nullptr;
   bool have_fixed = false, auto_ready = false;
   bool speculate = true;       // frame-sharded ticks: one collective (speculative Schur reduction) instead of two
@@ -445,6 +446,7 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
       if (prop.sharedMemPerBlockOptin > 0) h->lds_optin = (int)std::min<size_t>(prop.sharedMemPerBlockOptin, 160 * 1024);
     }
   }
+  if (const char* e = getenv("MCBA_STRICT_SYNC")) h->strict_sync = atoi(e) != 0;
   h->Fpad = (F + 63) / 64 * 64;
   h->nfb = h->Fpad / 64;
   h->nx = (size_t)12 * C + (size_t)6 * h->Fpad;
@@ -1073,7 +1075,7 @@ static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, b
     Scope sc(h, K_SOLVE);
     if (fuse_next)  // + the back-substitution of the next tick's trial step, overlapped with the solve (polls bounded: ~0.5 s)
       mcba::launch_solve_backsub(h->stream, a, dev_sel(h, 0), h->rec2[0], h->rec2[1], h->fbuf, h->x[0], h->x[1], h->bpart, h->C, h->F, h->Fpad, decide ? post_state(h) : a.lms_in, h->fuse_max_polls, decide ? 1 : 0,
-                                 timeout_word(h), h->ring_dev + (size_t)kRing * MCBA_LMS);
+                                 timeout_word(h), h->ring_dev + (size_t)kRing * MCBA_LMS, h->strict_sync ? 1 : 0);
     else
       mcba::launch_solve_cam(h->stream, a);
   }
@@ -1082,6 +1084,17 @@ static int auto_solve_impl(mcba_handle* h, unsigned long long seq, int decide, b
 }
 
 int mcba_lm_auto_solve(mcba_handle* h, unsigned long long seq, int decide) { return auto_solve_impl(h, seq, decide, false); }
+
+// The release-word protocol between the solve and the back-substitution workgroups of k_solve_backsub (csrc/mcba_backsub.h): by default the
+// readers rely on gfx950 behaviour (agent-scope relaxed loads bypass the per-XCD L2; in-order issue) -- fast, stress-tested, but a data
+// race under the HIP memory model.  on != 0 selects the formally complete reader (an agent-scope acquire fence behind the poll) for this
+// handle, at run time; a new handle starts from MCBA_STRICT_SYNC in the environment (default 0).  Same results to the bit either way.
+int mcba_set_strict_sync(mcba_handle* h, int on) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  h->strict_sync = on != 0;
+  return MCBA_OK;
+}
+int mcba_get_strict_sync(const mcba_handle* h) { return h && h->strict_sync ? 1 : 0; }
 
 int mcba_lm_set_decrease_floor(mcba_handle* h, double dec_floor) {
   if (!h || !(dec_floor >= 0.0) || dec_floor >= 1.0) return fail(MCBA_ERR_ARG, "mcba_lm_set_decrease_floor: 0 <= floor < 1 required (0 = 1/3)");
@@ -1484,6 +1497,7 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
   h->stream = src->stream;
   h->loss = src->loss;
   h->f_scale = src->f_scale;
+  h->strict_sync = src->strict_sync;
   // (the index list lives and dies with the new handle: nothing to free here, so nothing to wait for)
   if ((rc = dalloc(h, &h->sub_frames, (size_t)n_frames, false)) != MCBA_OK) { mcba_destroy(h); *out = nullptr; return rc; }
   int* d_frames = h->sub_frames;

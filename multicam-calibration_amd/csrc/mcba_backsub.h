@@ -46,6 +46,7 @@ struct BacksubWait {
   double* timeout_dev;
   double* timeout_host;
   double dec_floor;     // spec != 0: floor of Nielsen's factor the prediction assumes
+  int strict;           // != 0: the reader acquires the release word with an agent-scope fence (release_word_acquired; MCBA_STRICT_SYNC=1 / mcba_set_strict_sync)
 };
 
 __device__ __forceinline__ void backsub_stamp_timeout(const BacksubWait* w) {
@@ -65,15 +66,14 @@ __device__ __forceinline__ double load_coherent(const double* p) { return __hip_
 //                      barrier).  Under the HIP memory model this is still a data race (relaxed loads do not synchronise with the
 //                      release): it relies on gfx950 behaviour, and tests/test_gpu_parity_large.py::test_fused_backsub_full_size_bit_identical
 //                      stresses it at more than one waiting workgroup per CU (157 / 469 workgroups x 150 ticks, bit-identical iterates).
-//   -DMCBA_POLL_ACQUIRE  the formally complete form: an agent-scope acquire fence (= an L2 invalidation) in the polling wavefront --
-//                      157 of them per launch at 6 x 10 000: k_solve_backsub 28.3 -> 31.0 us, +2.5 us per iteration (three
-//                      alternations on one box, round 3).  Not the default.
-__device__ __forceinline__ void release_word_acquired() {
-#ifdef MCBA_POLL_ACQUIRE
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#else
-  asm volatile("" ::: "memory");
-#endif
+//   strict             the formally complete form, selected AT RUN TIME per handle (MCBA_STRICT_SYNC=1 in the environment when the handle is
+//                      created, or mcba_set_strict_sync): an agent-scope acquire fence (= an L2 invalidation) in the polling wavefront --
+//                      157 of them per launch at 6 x 10 000: k_solve_backsub 28.3 -> 31.0 us, +2.5 us per iteration (three alternations
+//                      on one box, round 3; this round's figure: profiles/round5).  Not the default; both forms run the same tests
+//                      (tests/test_gpu_parity_large.py, tests/test_gpu_round5.py: bit-identical iterates).
+__device__ __forceinline__ void release_word_acquired(int strict) {
+  if (strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  else asm volatile("" ::: "memory");
 }
 // polls until the word equals one of `a`, `b` (returns 1), equals `stop` (returns 0) or max_polls ran out (returns -1)
 __device__ __forceinline__ int release_word_poll(const double* word, double a, double b, double stop, int max_polls) {
@@ -146,7 +146,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
       const int rc = release_word_poll(wait->flag, base + 1.0, base + 2.0, base + 3.0, wait->max_polls);
       if (rc < 0 && lane == 0) backsub_stamp_timeout(wait);
       const int got = rc > 0 ? 1 : 0;
-      release_word_acquired();
+      release_word_acquired(wait->strict);
       if (got) {
         for (int i = lane; i < nc; i += 64) mail[8 + i] = load_coherent(wait->dc + i);
       }
@@ -225,7 +225,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
   if (wait) {  // the steps are ready; they count only if the solve's FINAL state still wants a trial step (a failed solve does not)
     const double fin_word = 4.0 * wait->seq + 2.0;
     const bool posted = release_word_poll(wait->flag, fin_word, fin_word, -1.0, wait->max_polls) > 0;
-    release_word_acquired();
+    release_word_acquired(wait->strict);
     if (!posted && lane == 0) backsub_stamp_timeout(wait);
     if (!posted || load_coherent(sl.lms + MCBA_LM_DONE) != 0.0 || load_coherent(sl.lms + MCBA_LM_SKIP) != 0.0) return;
   }

@@ -103,7 +103,8 @@ void launch_solve_cam(hipStream_t st, const SolveArgs& a);
 // the tick's decision left (final as far as the slot bit goes), or -- spec != 0, the solve decides -- a copy of the state before it
 int solve_backsub_set_lds_limit(int npad, int cw = 12);
 void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const double* rec0, const double* rec1, const double* fbuf, double* x0, double* x1, double* bpart, int C, int F, int Fpad,
-                          const double* early_state, int max_polls, int spec, double* timeout_dev, double* timeout_host);  // (a.cw selects the camera block width)
+                          const double* early_state, int max_polls, int spec, double* timeout_dev, double* timeout_host,   // (a.cw selects the camera block width)
+                          int strict = 0);  // != 0: the waiting workgroups acquire the release word with an agent-scope fence (mcba_backsub.h: release_word_acquired)
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da);
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
 void launch_lm_init(hipStream_t st, const double* red_scal, double* lms, double lam0, int sel, double cfl, double cfl_switch);  // mcba_lm_run: the start state, on the device

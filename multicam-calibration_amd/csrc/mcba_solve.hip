@@ -993,8 +993,8 @@ int solve_backsub_set_lds_limit(int npad, int cw) {
 }
 
 void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const double* rec0, const double* rec1, const double* fbuf, double* x0, double* x1, double* bpart, int C, int F, int Fpad,
-                          const double* early_state, int max_polls, int spec, double* timeout_dev, double* timeout_host) {
-  BacksubArgs b{sl, rec0, rec1, fbuf, x0, x1, bpart, C, F, Fpad, BacksubWait{early_state, a.flag, a.dc, nullptr, a.seq, max_polls, spec, a.lam_min, timeout_dev, timeout_host, a.dec_floor}};
+                          const double* early_state, int max_polls, int spec, double* timeout_dev, double* timeout_host, int strict) {
+  BacksubArgs b{sl, rec0, rec1, fbuf, x0, x1, bpart, C, F, Fpad, BacksubWait{early_state, a.flag, a.dc, nullptr, a.seq, max_polls, spec, a.lam_min, timeout_dev, timeout_host, a.dec_floor, strict}};
   const size_t lds = solve_lds_bytes(a.npad, 1);
   const dim3 grid(1 + Fpad / 64), block(64 * kBacksubWaves);
   if (a.cw == 6) {

@@ -31,6 +31,8 @@ SYMBOLS = [
     ("mcba_buffer_free", ctypes.c_int, [_h]),
     ("mcba_error_histogram", ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_ulonglong, ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong)]),
     ("mcba_lm_fuse_status", ctypes.c_int, [_h, _dp, _ip]),
+    ("mcba_set_strict_sync", ctypes.c_int, [_h, ctypes.c_int]),
+    ("mcba_get_strict_sync", ctypes.c_int, [_h]),
     ("mcba_set_stream", ctypes.c_int, [_h, ctypes.c_void_p]),
     ("mcba_upload_observations", ctypes.c_int, [_h, _dp, _dp]),
     ("mcba_set_loss", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_double]),
@@ -384,6 +386,13 @@ class Problem:
         if rc == ERR_ARG:
             raise ValueError(self.lib.mcba_last_error().decode())
         self._chk(rc)
+
+    def set_strict_sync(self, on=True):
+        """The fused back-substitution's readers acquire the solve's release word with an agent-scope fence (the form the HIP memory model
+        asks for) instead of relying on gfx950's ordering (include/mcba.h: mcba_set_strict_sync).  Returns the setting in force before."""
+        old = bool(self.lib.mcba_get_strict_sync(self.handle))
+        self._chk(self.lib.mcba_set_strict_sync(self.handle, int(bool(on))))
+        return old
 
     def fuse_status(self):
         """(number of the last tick whose fused back-substitution gave up waiting for the solve -- 0: never --, fused launch still in use)."""

@@ -519,17 +519,22 @@ def test_fused_solve_backsub_is_bit_identical(mc, shape, curvature):
     out = {}
     old = os.environ.get("MCBA_FUSE_BACKSUB")
     try:
-        for mode in ("1", "0"):
-            os.environ["MCBA_FUSE_BACKSUB"] = mode
+        for mode in ("1", "0", "strict"):   # strict: the fused launch with the readers acquiring the release word (MCBA_STRICT_SYNC=1)
+            os.environ["MCBA_FUSE_BACKSUB"] = "1" if mode == "strict" else mode
+            os.environ["MCBA_STRICT_SYNC"] = "1" if mode == "strict" else "0"
             with contextlib.redirect_stdout(io.StringIO()):
                 out[mode] = mc.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, ftol=1e-12, xtol=1e-12, gtol=1e-9,
                                              verbose=0, return_jac=False, max_nfev=120, curvature=curvature)[4]
     finally:
+        os.environ.pop("MCBA_STRICT_SYNC", None)
         if old is None:
             del os.environ["MCBA_FUSE_BACKSUB"]
         else:
             os.environ["MCBA_FUSE_BACKSUB"] = old
     a, b = out["1"], out["0"]
+    np.testing.assert_array_equal(a.x, out["strict"].x)
+    assert a.cost == out["strict"].cost and a.nfev == out["strict"].nfev
+    np.testing.assert_array_equal(np.array(a.lm["history"]), np.array(out["strict"].lm["history"]))
     assert a.status == b.status and a.nfev == b.nfev and a.lm["iterations"] == b.lm["iterations"]
     assert curvature == "auto" or a.lm["iterations"] < a.nfev - 1   # some steps were rejected
     np.testing.assert_array_equal(a.x, b.x)

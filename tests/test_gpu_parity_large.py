@@ -266,9 +266,11 @@ def test_fused_backsub_full_size_bit_identical(mc, C, F):
     out = {}
     old = os.environ.get("MCBA_FUSE_BACKSUB")
     try:
-        for mode in ("1", "0"):
-            os.environ["MCBA_FUSE_BACKSUB"] = mode
+        for mode in ("1", "0", "strict"):   # strict: the fused launch with the readers ACQUIRING the release word (MCBA_STRICT_SYNC=1: the HIP memory model's form)
+            os.environ["MCBA_FUSE_BACKSUB"] = "1" if mode == "strict" else mode
+            os.environ["MCBA_STRICT_SYNC"] = "1" if mode == "strict" else "0"
             prob = mc.ops.Problem(p["uvs"], p["obj"])
+            assert bool(prob.lib.mcba_get_strict_sync(prob.handle)) == (mode == "strict")
             lm = mc.solver.LevenbergMarquardt(prob, ftol=0.0, xtol=0.0, gtol=0.0, reduced_solver="device", depth=2)
             lm.start(x0)
             for _ in range(150):
@@ -277,10 +279,12 @@ def test_fused_backsub_full_size_bit_identical(mc, C, F):
             out[mode] = (res.x.copy(), res.cost, res.nfev)
             prob.close()
     finally:
+        os.environ.pop("MCBA_STRICT_SYNC", None)
         if old is None:
             del os.environ["MCBA_FUSE_BACKSUB"]
         else:
             os.environ["MCBA_FUSE_BACKSUB"] = old
-    assert out["1"][2] == out["0"][2]
-    assert out["1"][1] == out["0"][1] and out["1"][1] < 1e-2 * 0.5 * 4.0 * 2 * C * F * 54   # and it went somewhere
+    assert out["1"][2] == out["0"][2] == out["strict"][2]
+    assert out["1"][1] == out["0"][1] == out["strict"][1] and out["1"][1] < 1e-2 * 0.5 * 4.0 * 2 * C * F * 54   # and it went somewhere
     np.testing.assert_array_equal(out["1"][0], out["0"][0])
+    np.testing.assert_array_equal(out["1"][0], out["strict"][0])
