@@ -73,11 +73,12 @@ class _Lazy:
 
 
 class _JacobianSource:
-    """What a lazily attached `result.jac` is produced from: the GPU handle of the solve while it lasts, and enough to build a new one
-    (a reference to the caller's observation array, the selected frames, the solution) when it does not.  The handles that pending
-    results hold are counted: beyond MCBA_JAC_HOLD_MB (default 1024 MiB of observations + parameters; 0 = hold nothing) the oldest
-    are closed at once -- a sweep that keeps a list of results does not pin ~0.4 GB of HBM per result -- and a result
-    whose handle is gone re-uploads its frames when (if) the field is finally read."""
+    """What a lazily attached `result.jac` is produced from: the GPU handle of the solve, trimmed to what a Jacobian needs (observations,
+    board, parameters: ops.Problem.trim -- 0.11 GB at 6 x 10 000 x 54) while it lasts.  The handles that pending results hold are
+    counted by what they REALLY hold (ops.Problem.device_bytes): beyond MCBA_JAC_HOLD_MB (default 1024 MiB; 0 = hold nothing) the oldest
+    are closed at once -- a sweep that keeps a list of results does not pin HBM per result -- and a source that has to let
+    its handle go first copies the observations back FROM THE GPU: the values the solve saw.  A later read re-creates the handle from
+    that copy, never from the caller's array, which may have been changed in place since the call."""
 
     _refs = []   # weak references to the sources that still own a handle, oldest first (a dropped result frees its handle by itself)
 
@@ -89,10 +90,13 @@ class _JacobianSource:
 
     live = _Live()
 
-    def __init__(self, prob, uvs_all, frames, objpoints, x, slot, loss, f_scale, device, robust, nan_bits, shape4):
-        self.prob, self.uvs_all, self.frames, self.obj, self.x, self.slot = prob, uvs_all, frames, objpoints, x, slot
+    def __init__(self, prob, objpoints, x, slot, loss, f_scale, device, robust, nan_bits, shape4):
+        self.prob, self.obj, self.x, self.slot = prob, objpoints, x, slot
         self.loss, self.f_scale, self.device, self.robust, self.nan_bits, self.shape4 = loss, f_scale, device, robust, nan_bits, shape4
-        self.bytes = 3 * 8 * int(np.prod(shape4)) + 16 * x.size   # two observation layouts + the residual buffer, the parameter slots
+        self.host_uvs = None
+        if hasattr(prob, "trim"):
+            prob.trim()
+        self.bytes = prob.device_bytes() if hasattr(prob, "device_bytes") else 3 * 8 * int(np.prod(shape4)) + 16 * x.size
         _JacobianSource._refs.append(weakref.ref(self))
         _JacobianSource.trim()
 
@@ -101,10 +105,12 @@ class _JacobianSource:
         cap = int(os.environ.get("MCBA_JAC_HOLD_MB", "1024")) << 20
         live = cls.live
         while live and sum(s.bytes for s in live) > cap:
-            live.pop(0).release()
+            live.pop(0).release(keep_values=True)
 
-    def release(self):
+    def release(self, keep_values=False):
         if self.prob is not None:
+            if keep_values and self.host_uvs is None and hasattr(self.prob, "download_observations"):
+                self.host_uvs = self.prob.download_observations()   # (from the device copy: what the solve saw)
             self.prob.close()
             self.prob = None
 
@@ -120,8 +126,10 @@ class _JacobianSource:
     def csr(self):
         try:
             prob, slot = self.prob, self.slot
-            if prob is None:   # the handle was released under pressure: upload the selected frames again
-                prob = self.prob = ops.Problem(np.ascontiguousarray(self.uvs_all[:, self.frames]), self.obj, device=self.device, loss=self.loss, f_scale=self.f_scale)
+            if prob is None:   # the handle was released under pressure: a new one from the values it held
+                if self.host_uvs is None:
+                    raise RuntimeError("result.jac: the GPU handle of this result was released and no copy of its observations was kept")
+                prob = self.prob = ops.Problem(self.host_uvs, self.obj, device=self.device, loss=self.loss, f_scale=self.f_scale)
                 prob.set_params(0, self.x)
                 slot = 0
             m = self.mask()
@@ -132,6 +140,7 @@ class _JacobianSource:
             return sp.csr_matrix((data[mask].ravel(), idx, indptr), shape=shape)
         finally:
             self.release()
+            self.host_uvs = None
 
 
 class LazyOptimizeResult(OptimizeResult):
@@ -511,9 +520,8 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         else:
             result.grad = grad
         if return_jac:
-            # (the caller's array is referenced, not copied: only a result whose handle had to be released re-reads its frames from it)
-            jsrc = _JacobianSource(prob, all_calib_uvs, use_frames, calib_objpoints, x_local, slot, kw["loss"], kw.get("f_scale", 1.0), device, kw["loss"] != "linear",
-                                   seen_bits, shape4)
+            # (no reference to the caller's array is kept: a result whose handle has to be released first copies its observations back from the GPU)
+            jsrc = _JacobianSource(prob, calib_objpoints, x_local, slot, kw["loss"], kw.get("f_scale", 1.0), device, kw["loss"] != "linear", seen_bits, shape4)
             dict.__setitem__(result, "jac", _Lazy(jsrc.csr))
             prob = None   # owned by the lazy `jac` field now (closed when that field is produced, with the result, or under MCBA_JAC_HOLD_MB pressure)
     finally:

@@ -556,6 +556,51 @@ int mcba_destroy(mcba_handle* h) {
   return MCBA_OK;
 }
 
+// Device memory a handle holds right now (bytes of its pooled buffers): what a caller that parks handles (api.py: the lazily attached
+// result.jac) accounts for.
+size_t mcba_device_bytes(const mcba_handle* h) {
+  size_t tot = 0;
+  if (h) for (auto& b : h->bufs) tot += b.bytes;
+  return tot;
+}
+
+// Gives back (to the pool) every device buffer except what defines the problem: the observations in both layouts, the board, the two
+// parameter slots (and a subset's index list).  Solver buffers (116 MB at 6 x 10 000 x 54), pre-filter scores, Jacobian / residual blocks
+// go; the next call that needs them allocates them again.  For a handle that is kept only so that a Jacobian can be produced from it
+// later: 0.26 GB -> 0.11 GB at that size.  Synchronises.
+int mcba_trim(mcba_handle* h) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  void** keep[] = {reinterpret_cast<void**>(&h->obs_t), reinterpret_cast<void**>(&h->obs_raw), reinterpret_cast<void**>(&h->core_arena), reinterpret_cast<void**>(&h->sub_frames)};
+  std::vector<DevBuf> kept;
+  for (auto& b : h->bufs) {
+    bool k = false;
+    for (void** s : keep) k = k || b.slot == s;
+    if (k) { kept.push_back(b); continue; }
+    pool_free(*b.slot, b.bytes, h->device);
+    *b.slot = nullptr;
+  }
+  h->bufs.swap(kept);
+  // the pieces of the solver arena
+  h->rec2[0] = h->rec2[1] = h->gpart2[0] = h->gpart2[1] = h->fbuf = h->fpart = h->spart = h->cpart = h->bpart = h->red_own = h->red = h->dcbuf = h->swork = h->dscale = h->gchunk = nullptr;
+  h->fixed = nullptr;
+  h->have_solver = h->have_lin = h->have_red = h->have_spec = h->have_jac = h->auto_ready = h->have_xscale = h->have_fixed = h->trial_ready = false;
+  return MCBA_OK;
+}
+
+// The observations as the handle holds them ((C,F,N,2), what was uploaded or gathered), back to the host: a caller that must let go of a
+// parked handle keeps the VALUES the solve saw (api.py: a released result.jac re-creates its handle from them, not from the caller's
+// array, which may have changed since).
+int mcba_download_observations(mcba_handle* h, double* uvs) {
+  if (!h || !uvs) return fail(MCBA_ERR_ARG, "mcba_download_observations: bad argument");
+  if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_download_observations: no observations");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(uvs, h->obs_raw, (size_t)2 * h->C * h->F * h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
 int mcba_pool_trim(void) {
   pool_release_all();
   return MCBA_OK;

@@ -24,6 +24,9 @@ SYMBOLS = [
     ("mcba_create", ctypes.c_int, [ctypes.POINTER(_h), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("mcba_destroy", ctypes.c_int, [_h]),
     ("mcba_pool_trim", ctypes.c_int, []),
+    ("mcba_device_bytes", ctypes.c_size_t, [_h]),
+    ("mcba_trim", ctypes.c_int, [_h]),
+    ("mcba_download_observations", ctypes.c_int, [_h, _dp]),
     ("mcba_set_x_scale", ctypes.c_int, [_h, _dp]),
     ("mcba_residuals_detach", ctypes.c_int, [_h, ctypes.c_int, ctypes.POINTER(_h)]),
     ("mcba_buffer_count", ctypes.c_size_t, [_h]),
@@ -302,6 +305,20 @@ class Problem:
             self.close()
         except Exception:
             pass
+
+    def device_bytes(self):
+        """Bytes of device memory this handle holds right now (include/mcba.h: mcba_device_bytes)."""
+        return int(self.lib.mcba_device_bytes(self.handle))
+
+    def trim(self):
+        """Give back every device buffer except the observations, the board and the parameter slots (include/mcba.h: mcba_trim)."""
+        self._chk(self.lib.mcba_trim(self.handle))
+
+    def download_observations(self):
+        """(C,F,N,2): the observations as this handle holds them (include/mcba.h: mcba_download_observations)."""
+        out = np.empty((self.C, self.F, self.N, 2))
+        self._chk(self.lib.mcba_download_observations(self.handle, _p(out)))
+        return out
 
     def set_camera_block(self, width):
         """Camera block width (include/mcba.h: mcba_set_camera_block): 12 = every camera parameter is a variable (the reference);

@@ -617,12 +617,15 @@ class LevenbergMarquardt:
             self.nu = 2.0 if grey else self.nu * 2
             if self.lam >= self.lam_max and status is None:
                 status = 3
-        self._curvature_after(accepted, (self.cost - cost_new) if dc is not None else 0.0, self.cost)  # (before the linearisations below: they are the next model's)
         if accepted and self.speculative:
             p.accept_linearization()
         elif accepted or (always_linearize and not self.speculative):
+            # (non-speculative mode: the accepted point is linearised HERE, still under the model its step was decided with -- the speculative
+            #  host path and the device loops keep the trial linearisation, which was built under that model too: every driver changes model
+            #  at the same step and produces the same iterates.  ADVICE r4)
             p.linearize(self.cur)
             self.njev += 1
+        self._curvature_after(accepted, (self.cost - cost_new) if dc is not None else 0.0, self.cost)  # the model of the linearisations enqueued from here on
         self._refresh_system()
         self.accepted = accepted
         return status

@@ -222,10 +222,21 @@ def test_lazy_fields_keep_the_mask_of_call_time_and_release_handles_under_pressu
         assert all(isinstance(dict.get(r, "jac"), mc.api._Lazy) for r in held)
         J2 = held[1].jac
     assert (J2 != Jref).nnz == 0
+    # (iv) ADVICE r4: a result whose handle was released keeps the VALUES the solve saw (copied back from the GPU at release time), not a
+    # reference to the caller's array -- which is edited in place here before the field is read
+    with env(MCBA_JAC_HOLD_MB="0"):
+        r4 = quiet(mc.bundle_adjust, *args(), **kw)[4]
+        uvs[1, 3:9] += 25.0
+        J4 = r4.jac
+    uvs[...] = p["uvs"]
+    assert (J4 != Jref).nnz == 0
     # ... and with the default budget the handle is kept (no second upload) until the field is read or the result dropped
     keep = quiet(mc.bundle_adjust, *args(), **kw)[4]
     assert len(mc.api._JacobianSource.live) == 1
-    del keep
+    src = mc.api._JacobianSource.live[0]
+    obs_bytes = 8 * int(np.prod(src.shape4))   # (the frames the solve ran on: the pre-filter dropped some)
+    assert src.bytes == src.prob.device_bytes() and 2 * obs_bytes <= src.bytes < 3.5 * obs_bytes   # what is parked is what is counted: both observation layouts + parameters, the solver buffers are gone (trim)
+    del keep, src
     import gc
 
     gc.collect()

@@ -247,6 +247,66 @@ def test_host_driven_decision_equals_device_lm_decide():
     assert statuses[3] == 2   # the neutral step is accepted with ratio := 0.5 BEFORE the ftol test, as on the device
 
 
+def test_host_and_device_decision_agree_on_grey_rejections_and_the_curvature_switch():
+    """the grey rejection (the cost rose by less than GREY_LEVEL of itself: the damping doubles without escalating, the model
+    stays) and the curvature switch (Triggs after an accepted step that gained < CURV_SWITCH of the cost, IRLS after a real rejection)
+    exist twice -- lm_decide in csrc/mcba_lm.h (state slots 25 / 26) and solver.py's host-driven loop -- and must agree bit for bit:
+    the host-driven, device and sharded drivers would part ways otherwise."""
+    import ctypes
+    import subprocess
+
+    from test_hostcheck_math import P
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "hostcheck", "libhostcheck.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", lib, os.path.join(here, "hostcheck", "hostcheck.cpp")])
+    hc = ctypes.CDLL(lib)
+    hc.hc_lm_decide.argtypes = [ctypes.POINTER(ctypes.c_double)] * 2 + [ctypes.c_double] * 5
+    hc.hc_lm_decide.restype = None
+    cost0 = 100.0
+    script = [(90.0, 18.0, 1e-2, 4.0),               # accepted, gains 10 %: stays on IRLS
+              (90.0 * (1 + 1e-10), 2.0, 1e-3, 4.0),   # GREY rejection: up by 1e-10 of itself -> damping x 2, nu stays 2, model stays
+              (94.5, 2.0, 1e-3, 4.0),                 # real rejection: damping x nu, nu doubles, model -> IRLS (it is already)
+              (89.7, 0.5, 1e-4, 4.0),                 # accepted, gains 0.33 % < 1 %: -> Triggs
+              (89.7 * (1 + 3e-10), 0.4, 1e-4, 4.0),   # grey rejection while on Triggs: the model stays Triggs
+              (93.0, 0.4, 1e-4, 4.0),                 # real rejection: back to IRLS
+              (89.6, 0.2, 1e-5, 4.0),                 # accepted, small gain: Triggs again
+              (89.6 * (1 - 2e-16), 1e-9, 1e-9, 4.0)]  # neutral step: accepted, Triggs
+    expect_floor = [solver.CURV_IRLS, solver.CURV_IRLS, solver.CURV_IRLS, solver.CURV_TRIGGS, solver.CURV_TRIGGS, solver.CURV_IRLS, solver.CURV_TRIGGS, solver.CURV_TRIGGS]
+    ftol, xtol, lam_min, lam_max = 1e-12, 1e-30, 1e-12, 1e12
+    prob = ScriptedProblem(cost0, script)
+    lm = solver.LevenbergMarquardt(prob, ftol=ftol, xtol=xtol, gtol=0.0, reduced_solver="host", curvature="auto")
+    assert not lm.device_decide and not lm.device_solve
+    lm.start(prob.x[0])
+    assert lm.curv_floor == solver.CURV_IRLS
+    lms = np.zeros(32)
+    lms[:4] = cost0, lm.lam, lm.nu, 0
+    lms[25], lms[26] = solver.CURV_IRLS, solver.CURV_SWITCH
+    seen_grey = seen_real = False
+    for k, t in enumerate(script):
+        lam_b, nu_b, x_cam = lm.lam, lm.nu, lm.x_cam.copy()
+        st = lm.iterate()
+        dc = prob.dcs[k]
+        lms[11] = dc @ (lam_b * prob.diag * dc - prob.gc)
+        lms[12] = dc @ dc
+        lms[13] = x_cam @ x_cam
+        trial8 = np.zeros(8)
+        trial8[:4] = t
+        hc.hc_lm_decide(P(lms), P(trial8), lam_min, lam_max, ftol, xtol, lm.dec_floor)
+        assert bool(lms[4]) == lm.accepted, k
+        assert lms[1] == lm.lam and lms[2] == lm.nu and lms[0] == lm.cost, (k, lms[1], lm.lam, lms[2], lm.nu)
+        assert int(lms[3]) == lm.cur, k
+        assert lms[25] == lm.curv_floor == expect_floor[k], (k, lms[25], lm.curv_floor)
+        assert (st or 0) == int(lms[19]), (k, st, lms[19])
+        if not lm.accepted:
+            grey = lm.lam == 2.0 * lam_b and lm.nu == 2.0
+            seen_grey |= grey and k in (1, 4)
+            seen_real |= (not grey) or k in (2, 5)
+            if k in (2, 5):
+                assert lm.lam == lam_b * nu_b and lm.nu == 2.0 * nu_b, k   # escalating
+    assert seen_grey and seen_real
+
+
 # ------------------------------------------------------------------ world_size 2 over gloo
 def _free_port():
     with socket.socket() as s:
