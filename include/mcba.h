@@ -107,6 +107,17 @@ double mcba_get_curvature_floor(const mcba_handle* h);
  * Marquardt's D = diag(J^T J) (which is x_scale = 'jac', the reference's default) in the frame blocks, the camera block and the
  * predicted reduction.  NULL returns to 'jac'.  MCBA_ERR_ARG with scipy's message if an entry is not positive and finite. */
 int mcba_set_x_scale(mcba_handle* h, const double* x_scale);
+/* Box constraints and the working set of an active-set method (round 5; the reference forwards `bounds` to scipy's least_squares:
+ * bundle_adjustment.py:301-313, scipy trf_bounds).
+ * mcba_set_bounds: lo <= x <= hi, 12C + 6F doubles each in the layout of x (-inf / +inf = none; both NULL = no constraints).  From then
+ *   on the trial point of every mcba_step / mcba_step_linearize / mcba_step_fetch is projected onto the box before its cost is taken;
+ *   the device-resident loops (mcba_lm_iterate, mcba_lm_auto_*, mcba_lm_run) refuse to run while bounds are set.
+ * mcba_set_frozen: mask of 12C + 6F bytes (non-zero = frozen; NULL = none) -- a frozen FRAME coordinate gets a step of exactly 0 and
+ *   nothing couples to it in the Schur reduction and the back-substitution (the reported frame gradient stays the true one); camera
+ *   entries are ignored here (freeze camera parameters with the flags of mcba_lm_auto_config, or leave their rows out of a host solve).
+ *   Takes effect with the next mcba_build_reduced. */
+int mcba_set_bounds(mcba_handle* h, const double* lo, const double* hi);
+int mcba_set_frozen(mcba_handle* h, const unsigned char* mask);
 
 /* ---- parameter slots (two flat vectors live on the GPU: 0 and 1) ----------------------------- */
 int mcba_set_params(mcba_handle* h, int slot, const double* x);   /* 12C+6F doubles, host */

@@ -376,8 +376,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
 
     kw = dict(verbose=2, x_scale="jac", ftol=1e-4, method="trf", loss="soft_l1")
     kw.update(opt_kwargs)
-    if "bounds" in kw:
-        raise NotImplementedError("bounds are not supported by the GPU solver")
+    box = kw.pop("bounds", None)
     if callable(kw.get("loss")):
         raise NotImplementedError("callable losses are not supported by the GPU solver")
     unknown = set(kw) - set(_PATH_ONLY) - {"verbose", "ftol", "xtol", "gtol", "max_nfev", "loss", "f_scale", "x_scale"}
@@ -426,6 +425,30 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         x_scale = _check_x_scale(kw["x_scale"], 12 * n_cameras + 6 * all_use.size)
         if x_scale is not None:  # this shard's part: the camera block and its own frames' blocks
             x_scale = np.concatenate([x_scale[: 12 * n_cameras], x_scale[12 * n_cameras:].reshape(-1, 6)[positions].ravel()])
+        # `bounds` (forwarded by the reference to least_squares: bundle_adjustment.py:301-313): scipy's checks and messages (least_squares.py);
+        # infinite bounds everywhere = scipy's default = the unconstrained solver
+        lohi = None
+        if box is not None:
+            from scipy.optimize import Bounds
+
+            if isinstance(box, Bounds):
+                lb, ub = np.asarray(box.lb, dtype=np.float64), np.asarray(box.ub, dtype=np.float64)
+                lb, ub = (np.resize(lb, x0.size) if lb.ndim == 0 else lb), (np.resize(ub, x0.size) if ub.ndim == 0 else ub)
+            elif len(box) == 2:
+                lb, ub = (np.asarray(b, dtype=np.float64) for b in box)
+                lb, ub = (np.resize(lb, x0.size) if lb.ndim == 0 else lb), (np.resize(ub, x0.size) if ub.ndim == 0 else ub)
+            else:
+                raise ValueError("`bounds` must contain 2 elements.")
+            if lb.shape != x0.shape or ub.shape != x0.shape:
+                raise ValueError("Inconsistent shapes between bounds and `x0`.")
+            if np.any(lb >= ub):
+                raise ValueError("Each lower bound must be strictly less than each upper bound.")
+            if np.any(x0 < lb) or np.any(x0 > ub):
+                raise ValueError("Initial guess is outside of provided bounds")
+            if np.isfinite(lb).any() or np.isfinite(ub).any():
+                if distributed:
+                    raise NotImplementedError("bounds are not supported with distributed=True")
+                lohi = (lb, ub)
         if use_frames.size == 0:
             # nothing to fit: scipy's least_squares on an empty residual vector returns x0 with status 1 (gtol) after one
             # evaluation (what the reference then returns: bundle_adjustment.py:307-327)
@@ -453,7 +476,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         # fix_intrinsics (BASELINE configs[1]): the library's 6-wide camera block -- role A of the linearisation alone, a 6C x 6C
         # camera system -- where it serves the rig (before anything allocates the solver buffers); otherwise flags on the 12-wide one
         free = None
-        if fix_intrinsics and not (os.environ.get("MCBA_FIXED_COMPACT", "1") != "0" and hasattr(prob, "set_camera_block") and prob.set_camera_block(6)):
+        if fix_intrinsics and not (lohi is None and os.environ.get("MCBA_FIXED_COMPACT", "1") != "0" and hasattr(prob, "set_camera_block") and prob.set_camera_block(6)):
             free = np.tile(np.r_[np.zeros(6, bool), np.ones(6, bool)], n_cameras)
         comm = None
         if distributed:
@@ -467,7 +490,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         if max_nfev is None:
             max_nfev = 100 * (12 * n_cameras + 6 * len(all_use))  # trf.py:437-438 on the GLOBAL vector: identical on every rank
         result = solver.lm_solve(prob, x0, ftol=tol("ftol", 1e-4), xtol=tol("xtol", 1e-8), gtol=tol("gtol", 1e-8),
-                                 max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, x_scale=x_scale, x0_on_device=x0_on_device, lazy_grad=not distributed, **lm_kwargs)
+                                 max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, x_scale=x_scale, x0_on_device=x0_on_device and lohi is None, lazy_grad=not distributed, bounds=lohi, **lm_kwargs)
         result = LazyOptimizeResult(result)
 
         # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560).  `fun` and `jac` are LAZY: the residual

@@ -73,7 +73,11 @@ struct mcba_handle {
   // device-resident LM loop (mcba_lm_auto_*)
   double *dcbuf = nullptr, *swork = nullptr;
   double* dscale = nullptr;   // numeric x_scale (least_squares): D = 1 / x_scale^2 in the layout of x; have_xscale says whether it is in use
-  bool have_xscale = false;
+  bool have_xscale = false;   // the XS kernel instances run: a numeric x_scale and / or frozen coordinates are in `dscale`
+  std::vector<double> xs_host;             // numeric x_scale as D = 1 / x_scale^2 (nx entries; empty = 'jac')
+  std::vector<unsigned char> frozen_host;  // coordinates taken out of the system (mcba_set_frozen; empty = none)
+  double *blo = nullptr, *bhi = nullptr;   // box constraints (mcba_set_bounds), in the layout of x
+  bool have_bounds = false;
   int fuse_max_polls = 200000;
   bool strict_sync = false;   // the fused back-substitution's readers acquire the release word with an agent-scope fence (MCBA_STRICT_SYNC=1 / mcba_set_strict_sync)
   unsigned char* fixed = nullptr;
@@ -869,6 +873,7 @@ static int step_common(mcba_handle* h, const double* delta_cam, double lambda, i
     // host-selected: 'current' operands are passed in position 0, the destination slot in position 1
     mcba::launch_backsub(h->stream, host_sel(0, lambda), h->rec2[h->lin], h->rec2[h->lin], h->fbuf, cs, h->x[src], h->x[dst], h->bpart, h->C, h->F, h->Fpad, h->cw);
   }
+  if (h->have_bounds) mcba::launch_clip(h->stream, h->x[dst], h->blo, h->bhi, (size_t)12 * h->C + (size_t)6 * h->F);   // the trial point, projected onto the box
   return check_launch();
 }
 
@@ -956,6 +961,7 @@ int mcba_lm_set_state(mcba_handle* h, const double* state) {
 
 static int lm_trial_impl(mcba_handle* h, const double* delta_cam, const mcba::DecideArgs& da) {
   if (!h || !delta_cam) return fail(MCBA_ERR_ARG, "mcba_lm_trial: bad argument");
+  if (h->have_bounds) return fail(MCBA_ERR_ARG, "box constraints are set (mcba_set_bounds): drive the steps with mcba_step / mcba_step_linearize (the host-driven loop)");
   if (!h->have_lin) return fail(MCBA_ERR_ARG, "mcba_lm_trial: no linearisation");
   HIPCHK(hipSetDevice(h->device));
   mcba::CamStep cs;
@@ -1150,6 +1156,7 @@ int mcba_lm_set_decrease_floor(mcba_handle* h, double dec_floor) {
 // sum_here: k_sum_trial follows (frame-sharded ticks: the trial scalars are all-reduced); otherwise k_syrk sums and decides
 static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   if (!h || !h->auto_ready) return fail(MCBA_ERR_ARG, "mcba_lm_auto_trial: call mcba_lm_auto_config first");
+  if (h->have_bounds) return fail(MCBA_ERR_ARG, "box constraints are set (mcba_set_bounds): the device-resident loop does not project its trial points -- use the host-driven loop");
   if (!h->have_lin) return fail(MCBA_ERR_ARG, "mcba_lm_auto_trial: no linearisation");
   HIPCHK(hipSetDevice(h->device));
   int rc;
@@ -1294,6 +1301,7 @@ int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state) {
 int mcba_lm_run(mcba_handle* h, const double* x0, const double* opt, const unsigned char* fixed, double* summary) {
   if (!h || !opt || !summary) return fail(MCBA_ERR_ARG, "mcba_lm_run: bad argument");
   if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_lm_run: upload observations first");
+  if (h->have_bounds) return fail(MCBA_ERR_ARG, "mcba_lm_run: box constraints are set (mcba_set_bounds) -- use the host-driven loop");
   const double lam0 = opt[3], lam_min = opt[4], lam_max = opt[5], cfl = opt[7], cfl_switch = opt[8];
   const int depth = std::max(1, std::min((int)opt[11], 12)), rank_slot = (int)opt[12];
   const double max_nfev = opt[9], max_ticks = opt[10];
@@ -1773,21 +1781,87 @@ int mcba_comm_destroy(mcba_handle* h) {
 // region lives in the variables x / x_scale; for Levenberg-Marquardt that is a FIXED damping matrix D = diag(1 / x_scale^2)
 // in place of Marquardt's D = diag(J^T J) (= x_scale 'jac').  x_scale: 12C + 6F positive doubles in the layout of x, or NULL
 // to return to 'jac'.
-int mcba_set_x_scale(mcba_handle* h, const double* x_scale) {
-  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
-  HIPCHK(hipSetDevice(h->device));
-  NEED_SOLVER(h);
+static int compose_dscale(mcba_handle* h) {
+  // what the XS kernel instances read per parameter (csrc/mcba_kernels.hip: k_syrk's frame factor): > 0 the caller's fixed D = 1 / x_scale^2,
+  // 0 Marquardt's diag(J^T J), < 0 frozen (frame coordinates only: frozen CAMERA parameters are flags of the camera system -- mcba_lm_auto_config,
+  // or rows the host solve leaves out)
+  const bool any_frozen = !h->frozen_host.empty();
   h->have_red = false;
-  if (!x_scale) { h->have_xscale = false; return MCBA_OK; }
-  const size_t cnt = (size_t)12 * h->C + (size_t)6 * h->F;
-  std::vector<double> d(h->nx, 1.0);
+  if (h->xs_host.empty() && !any_frozen) { h->have_xscale = false; return MCBA_OK; }
+  std::vector<double> d(h->nx, 0.0);
+  const size_t cnt = (size_t)12 * h->C + (size_t)6 * h->F, ncam = (size_t)12 * h->C;
   for (size_t i = 0; i < cnt; ++i) {
-    if (!(x_scale[i] > 0.0) || !std::isfinite(x_scale[i])) return fail(MCBA_ERR_ARG, "`x_scale` must be 'jac' or array_like with positive numbers.");
-    d[i] = 1.0 / (x_scale[i] * x_scale[i]);
+    d[i] = h->xs_host.empty() ? 0.0 : h->xs_host[i];
+    if (any_frozen && i >= ncam && h->frozen_host[i]) d[i] = -1.0;
   }
   HIPCHK(hipMemcpyAsync(h->dscale, d.data(), h->nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->have_xscale = true;
+  return MCBA_OK;
+}
+
+int mcba_set_x_scale(mcba_handle* h, const double* x_scale) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
+  if (!x_scale) {
+    if (h->xs_host.empty() && h->frozen_host.empty()) { h->have_red = false; h->have_xscale = false; return MCBA_OK; }   // (the usual call of every solve: nothing to upload)
+    h->xs_host.clear();
+    return compose_dscale(h);
+  }
+  const size_t cnt = (size_t)12 * h->C + (size_t)6 * h->F;
+  std::vector<double> d(cnt);
+  for (size_t i = 0; i < cnt; ++i) {
+    if (!(x_scale[i] > 0.0) || !std::isfinite(x_scale[i])) return fail(MCBA_ERR_ARG, "`x_scale` must be 'jac' or array_like with positive numbers.");
+    d[i] = 1.0 / (x_scale[i] * x_scale[i]);
+  }
+  h->xs_host.swap(d);
+  return compose_dscale(h);
+}
+
+// Coordinates taken OUT of the system for the linear solves that follow (an active-set method's working set: solver.py, box constraints):
+// mask = 12C + 6F bytes in the layout of x, non-zero = frozen, or NULL for none.  A frozen FRAME coordinate gets a step of exactly 0 and
+// nothing couples to it (its row / column of V_f, its gradient entry, its column of every W block count as zero in k_syrk and k_backsub;
+// the gradient mcba_get_frame_gradient reports stays the true one).  Camera entries of the mask are ignored here: freeze camera parameters
+// with the flags of mcba_lm_auto_config, or leave their rows out of a host solve.  Takes effect with the next mcba_build_reduced.
+int mcba_set_frozen(mcba_handle* h, const unsigned char* mask) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  HIPCHK(hipSetDevice(h->device));
+  NEED_SOLVER(h);
+  const size_t cnt = (size_t)12 * h->C + (size_t)6 * h->F, ncam = (size_t)12 * h->C;
+  bool any = false;
+  if (mask) for (size_t i = ncam; i < cnt; ++i) any = any || mask[i] != 0;
+  if (!any) {
+    if (h->frozen_host.empty()) return MCBA_OK;
+    h->frozen_host.clear();
+    return compose_dscale(h);
+  }
+  h->frozen_host.assign(mask, mask + cnt);
+  return compose_dscale(h);
+}
+
+// Box constraints lo <= x <= hi (12C + 6F doubles each in the layout of x, -inf / +inf = none; both NULL: none at all): from now on the
+// trial point of every mcba_step / mcba_step_linearize / mcba_step_fetch is PROJECTED onto the box before its cost is evaluated (k_clip).
+// The working set is the caller's business (mcba_set_frozen + the camera rows it leaves out of the reduced solve): solver.py's bounded
+// loop.  The device-resident loops (mcba_lm_iterate, mcba_lm_auto_*, mcba_lm_run) refuse to run while bounds are set.  Reference:
+// bundle_adjustment.py:301-313 forwards `bounds` to scipy's least_squares (trf_bounds).
+int mcba_set_bounds(mcba_handle* h, const double* lo, const double* hi) {
+  if (!h || (lo == nullptr) != (hi == nullptr)) return fail(MCBA_ERR_ARG, "mcba_set_bounds: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  if (!lo) { h->have_bounds = false; return MCBA_OK; }
+  const size_t cnt = (size_t)12 * h->C + (size_t)6 * h->F;
+  for (size_t i = 0; i < cnt; ++i)
+    if (!(lo[i] < hi[i])) return fail(MCBA_ERR_ARG, "Each lower bound must be strictly less than each upper bound.");
+  int rc;
+  if (!h->blo && (rc = dalloc(h, &h->blo, h->nx, false))) return rc;
+  if (!h->bhi && (rc = dalloc(h, &h->bhi, h->nx, false))) return rc;
+  std::vector<double> a(h->nx, -INFINITY), b(h->nx, INFINITY);
+  memcpy(a.data(), lo, cnt * sizeof(double));
+  memcpy(b.data(), hi, cnt * sizeof(double));
+  HIPCHK(hipMemcpyAsync(h->blo, a.data(), h->nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->bhi, b.data(), h->nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_bounds = true;
   return MCBA_OK;
 }
 

@@ -108,6 +108,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
 #endif
   double2 v[NR];
   double xv[6], Lp[21], gf[6], D[6];
+  unsigned frozen = 0;
   int sidx_early = 0;
   if (wait) {
     const bool flip = wait->spec && wait->early[MCBA_LM_SKIP] == 0.0;  // (a rebuild-only tick decides nothing)
@@ -130,6 +131,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
     for (int k = 0; k < 21; ++k) Lp[k] = fbp[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { gf[k] = fbp[27 + k]; D[k] = fbp[33 + k]; }
+    frozen = (unsigned)fbp[39];   // coordinates a bound is active on (k_syrk's frame factor: mcba_set_frozen; 0 otherwise): their step is exactly 0
   }
   bool active;
   int sidx;
@@ -209,6 +211,10 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
     double id[6], y[6], dl[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { id[k] = Lp[k * (k + 1) / 2 + k]; t[k] += gf[k]; }  // diagonal slots hold 1 / L_kk
+    if (frozen) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t[k] = ((frozen >> k) & 1u) ? 0.0 : t[k];
+    }
     fwd6(Lp, id, t, y);
     bwd6(Lp, id, y, dl);
 #pragma unroll

@@ -898,6 +898,15 @@ bool launch_store_small(hipStream_t st, double* dst, const double* src_host, siz
   return true;
 }
 
+// box constraints (mcba_set_bounds): the trial point of a step, projected onto the box
+__global__ __launch_bounds__(256) void k_clip(double* __restrict__ x, const double* __restrict__ lo, const double* __restrict__ hi, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] = fmin(fmax(x[i], lo[i]), hi[i]);
+}
+void launch_clip(hipStream_t st, double* x, const double* lo, const double* hi, size_t n) {
+  k_clip<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(x, lo, hi, n);
+}
+
 void launch_gather_params(hipStream_t st, const double* x_src, const int* frames, double* x_dst, int C, int Fdst) {
   const int n = 12 * C + 6 * Fdst;
   k_gather_params<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(x_src, frames, x_dst, C, Fdst);

@@ -122,6 +122,7 @@ void launch_prefilter_select(hipStream_t st, const double* err, const double* me
                              unsigned char* packed, int C, int F, int N, int Fpad, double threshold);
 void launch_prefilter_status(hipStream_t st, unsigned char* status, const double* worst, void* state, unsigned char* packed, int F, double threshold, int from_state);
 void launch_gather_params(hipStream_t st, const double* x_src, const int* frames, double* x_dst, int C, int Fdst);
+void launch_clip(hipStream_t st, double* x, const double* lo, const double* hi, size_t n);  // x <- min(max(x, lo), hi): the trial point of a bounded step
 bool launch_store_small(hipStream_t st, double* dst, const double* src_host, size_t n);  // <= 480 doubles through the kernel-argument segment (no blocking copy); false: too many
 double measure_fp64_issue_rate(int ncu);  // TFLOP/s of independent v_fma_f64 at one wavefront per SIMD on `ncu` compute units (measurement aid)
 void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N);

@@ -1233,40 +1233,61 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
 #pragma unroll
       for (int k = 0; k < 28; ++k) V[k] = s_V[lane * 28 + k];
       double* gf = V + 21;
-      double D[6];
+      double D[6], dsv[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         double d = V[tri6(k, k)];
         // Marquardt scaling D = diag(J^T J) (x_scale = 'jac'), or the caller's fixed D = 1 / x_scale^2 (numeric x_scale)
         // (XS is a template parameter because even a never-taken vector load here costs the default kernel 1.5 us: the wait
         // for it is also a wait for the next stage's prefetched W rows -- vmcnt retires in order)
-        D[k] = XS ? dscale[(size_t)12 * C + 6 * (size_t)(s0 + lane) + k] : (d > 0.0 ? d : 1.0);
+        // XS: the per-parameter entry of `dscale` says what this coordinate is -- > 0: the caller's fixed D = 1 / x_scale^2; 0: Marquardt's
+        // diag(J^T J) as without it; < 0: FROZEN (a bound is active on it, mcba_set_frozen): it leaves the system -- its row and column
+        // of V_f become the identity's, its gradient entry and (below, in the Y build and in k_backsub) its column of every W block
+        // count as zero, so its step is exactly 0 and nothing couples to it
+        const double ds = XS ? dscale[(size_t)12 * C + 6 * (size_t)(s0 + lane) + k] : 0.0;
+        D[k] = ds > 0.0 ? ds : (d > 0.0 ? d : 1.0);
+        dsv[k] = ds;
         V[tri6(k, k)] = d + lambda * D[k];
+      }
+      double gfm[6];
+      unsigned fm = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { gfm[k] = gf[k]; if (XS && dsv[k] < 0.0) fm |= 1u << k; }
+      if (XS && fm) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          if ((fm >> k) & 1u) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) V[j <= k ? tri6(j, k) : tri6(k, j)] = j == k ? 1.0 : 0.0;
+            gfm[k] = 0.0;
+          }
+        }
       }
       double Lp[21], id[6], z[6];
       const bool ok = chol6i(V, Lp);  // diagonal slots: 1 / L_ii
 #pragma unroll
       for (int k = 0; k < 6; ++k) id[k] = Lp[k * (k + 1) / 2 + k];
-      fwd6(Lp, id, gf, z);
+      fwd6(Lp, id, gfm, z);
 #pragma unroll
       for (int k = 0; k < 21; ++k) row[k] = Lp[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { row[21 + k] = id[k]; row[27 + k] = z[k]; gmax = fmax(gmax, fabs(gf[k])); }
+      for (int k = 0; k < 6; ++k) { row[21 + k] = id[k]; row[27 + k] = z[k]; gmax = fmax(gmax, fabs(gfm[k])); }
+      if (XS) row[33] = (double)fm;
       nfail += ok ? 0.0 : 1.0;
       if (by == 0) {
         double o[40];
 #pragma unroll
         for (int k = 0; k < 21; ++k) o[k] = Lp[k];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { o[21 + k] = z[k]; o[27 + k] = gf[k]; o[33 + k] = D[k]; }
-        o[39] = 0.0;
+        for (int k = 0; k < 6; ++k) { o[21 + k] = z[k]; o[27 + k] = gf[k]; o[33 + k] = D[k]; }   // (the TRUE gradient: a frozen coordinate's entry decides when it is released)
+        o[39] = XS ? (double)fm : 0.0;   // which coordinates are frozen: k_backsub drops their column of W^T d_c
         double* fbp = fbuf + (size_t)(s0 + lane) * MCBA_FB;
 #pragma unroll
         for (int k = 0; k < 40; k += 2) *reinterpret_cast<double2*>(fbp + k) = make_double2(o[k], o[k + 1]);
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < 33; ++k) row[k] = 0.0;  // frames past the end: Y = 0, z = 0
+      for (int k = 0; k < 34; ++k) row[k] = 0.0;  // frames past the end: Y = 0, z = 0
     }
   };
 
@@ -1293,6 +1314,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
 #pragma unroll
         for (int k = 0; k < 27; ++k) Lr[k] = Lp[k];
         const bool live = fb + tb < F;
+        const unsigned fm = XS ? (unsigned)Lp[33] : 0u;   // frozen coordinates of this frame: their column of W counts as zero
 #pragma unroll
         for (int it = 0; it < IPT; ++it) {
           const int row = tr0 + rstep * it;
@@ -1300,6 +1322,10 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
             double* dst = s_y + (size_t)row * RS + tb * 6;
             if (row < n) {
               double yr[6];
+              if (XS && fm) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) wreg[it][k] = ((fm >> k) & 1u) ? 0.0 : wreg[it][k];
+              }
               fwd6(Lr, Lr + 21, wreg[it], yr);
 #pragma unroll
               for (int k = 0; k < 6; ++k) dst[k] = live ? yr[k] : 0.0;

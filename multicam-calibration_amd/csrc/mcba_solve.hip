@@ -643,7 +643,8 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
   double gm = 0.0;
   for (int i = tid; i < npad; i += NTHREADS) {
     const bool in = i < n, fx = in && fixed && fixed[i];
-    const double du = in ? (a.dscale ? a.dscale[a.cw == 12 ? i : 12 * (i / 6) + 6 + i % 6] : diagU[i]) : 1.0;  // numeric x_scale: the caller's fixed D = 1 / x_scale^2 (in the layout of x)
+    const double dsc = (in && a.dscale) ? a.dscale[a.cw == 12 ? i : 12 * (i / 6) + 6 + i % 6] : 0.0;  // numeric x_scale: the caller's fixed D = 1 / x_scale^2 (in the layout of x); 0 = Marquardt's diag(U) for this parameter
+    const double du = in ? (dsc > 0.0 ? dsc : diagU[i]) : 1.0;
     damp[i] = du > 0.0 ? du : 1.0;  // scaled by lambda below (the state is not in LDS yet)
     if (in && !fx) gm = fmax(gm, fabs(gc[i]));
   }

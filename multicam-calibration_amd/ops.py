@@ -28,6 +28,8 @@ SYMBOLS = [
     ("mcba_trim", ctypes.c_int, [_h]),
     ("mcba_download_observations", ctypes.c_int, [_h, _dp]),
     ("mcba_set_x_scale", ctypes.c_int, [_h, _dp]),
+    ("mcba_set_bounds", ctypes.c_int, [_h, _dp, _dp]),
+    ("mcba_set_frozen", ctypes.c_int, [_h, ctypes.c_char_p]),
     ("mcba_residuals_detach", ctypes.c_int, [_h, ctypes.c_int, ctypes.POINTER(_h)]),
     ("mcba_buffer_count", ctypes.c_size_t, [_h]),
     ("mcba_buffer_download", ctypes.c_int, [_h, _dp]),
@@ -410,6 +412,27 @@ class Problem:
         old = bool(self.lib.mcba_get_strict_sync(self.handle))
         self._chk(self.lib.mcba_set_strict_sync(self.handle, int(bool(on))))
         return old
+
+    def set_bounds(self, lo, hi):
+        """Box constraints lo <= x <= hi in the layout of x (None, None: none): trial points of step / step_linearize / step_fetch are projected
+        onto the box (include/mcba.h: mcba_set_bounds)."""
+        if lo is None:
+            self._chk(self.lib.mcba_set_bounds(self.handle, None, None))
+            return
+        lo, hi = _f64(lo), _f64(hi)
+        if lo.shape != (self.nx,) or hi.shape != (self.nx,):
+            raise ValueError("Inconsistent shapes between bounds and `x0`.")
+        rc = self.lib.mcba_set_bounds(self.handle, _p(lo), _p(hi))
+        if rc == ERR_ARG:
+            raise ValueError(self.lib.mcba_last_error().decode())
+        self._chk(rc)
+
+    def set_frozen(self, mask):
+        """Frame coordinates taken out of the next linear solves (the working set of the bounded loop; include/mcba.h: mcba_set_frozen)."""
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).tobytes()
+        if m is not None and len(m) != self.nx:
+            raise ValueError(f"mask must have {self.nx} entries")
+        self._chk(self.lib.mcba_set_frozen(self.handle, m))
 
     def fuse_status(self):
         """(number of the last tick whose fused back-substitution gave up waiting for the solve -- 0: never --, fused launch still in use)."""

@@ -239,6 +239,8 @@ def make_comm(problem, device, group=None, direct=None):
 def _solve_spd(S, rhs):
     """S symmetric positive definite -> step, or None if the Cholesky factorisation fails.
     LAPACK dposv straight on the buffer (S is symmetric, so its C-order memory is a valid Fortran matrix)."""
+    if S.size == 0:   # (every camera parameter is held: fixed by the caller, or in the working set of the bounded loop)
+        return np.zeros(0)
     _, d, info = lapack.dposv(S.T, rhs, lower=0, overwrite_a=1, overwrite_b=0)
     if info != 0 or not np.isfinite(d).all():
         return None
@@ -675,16 +677,108 @@ class LevenbergMarquardt:
         )
 
 
+def find_active_constraints(x, lb, ub, rtol=1e-10):
+    """scipy's rule for `OptimizeResult.active_mask` (scipy/optimize/_lsq/common.py: find_active_constraints; trf_bounds calls it with
+    rtol = xtol): -1 a lower bound is active, +1 an upper bound, 0 neither."""
+    active = np.zeros(x.shape, dtype=int)
+    if rtol == 0:
+        active[x <= lb] = -1
+        active[x >= ub] = 1
+        return active
+    lower_dist, upper_dist = x - lb, ub - x
+    lower_threshold, upper_threshold = rtol * np.maximum(1, np.abs(lb)), rtol * np.maximum(1, np.abs(ub))
+    active[np.isfinite(lb) & (lower_dist <= np.minimum(upper_dist, lower_threshold))] = -1
+    active[np.isfinite(ub) & (upper_dist <= np.minimum(lower_dist, upper_threshold))] = 1
+    return active
+
+
+class BoundedLevenbergMarquardt(LevenbergMarquardt):
+    """Box constraints lo <= x <= hi (the reference forwards `bounds` to scipy's least_squares, whose TRF is a bounded solver:
+    bundle_adjustment.py:301-313, scipy trf.py: trf_bounds).  Here: an ACTIVE-SET Levenberg-Marquardt on the same Schur-reduced system.
+      * working set = the coordinates that sit on a bound with the gradient pushing them outward (x_i = lo_i and g_i > 0, or x_i = hi_i and
+        g_i < 0): they leave the linear solve -- camera parameters as rows / columns the reduced solve leaves out, frame coordinates frozen
+        inside the Schur reduction and the back-substitution (ops.Problem.set_frozen: their step is exactly 0) -- and are released as soon
+        as their gradient points inward;
+      * the trial point of every step is PROJECTED onto the box on the GPU (ops.Problem.set_bounds) before its cost is taken, so every
+        iterate is feasible; accept / reject, damping and curvature rules are those of the unbounded host-driven loop;
+      * optimality = the largest gradient entry outside the working set (the KKT residual), the termination tests scipy's.
+    It minimises the same cost over the same box, so it ends at the same constrained minimiser as scipy's trust-region-reflective
+    iteration (the iterates differ, as in the unbounded case).  The decision runs on the host (one synchronisation per iteration): this is
+    an off-default path, built for exactness, not for the bench."""
+
+    def __init__(self, problem, lo, hi, **kw):
+        kw["reduced_solver"] = "host"
+        super().__init__(problem, **kw)
+        self.device_decide = self.device_solve = False
+        self.lo, self.hi = np.ascontiguousarray(lo, dtype=np.float64), np.ascontiguousarray(hi, dtype=np.float64)
+        self.user_free = self.free.copy()
+        self.frozen = np.zeros(problem.nx, dtype=bool)
+        self.ncam = 12 * problem.C
+
+    def start(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        if np.any(x0 < self.lo) or np.any(x0 > self.hi):
+            raise ValueError("Initial guess is outside of provided bounds")
+        self.p.set_bounds(self.lo, self.hi)
+        self.p.set_frozen(None)
+        self.x_host = x0.copy()
+        super().start(x0)
+        self._update_working_set()
+
+    def _update_working_set(self):
+        """After the reduced system of the current point has been built: who is in the working set now?  (Only coordinates that sit ON a
+        bound can be: when none does, nothing is fetched.)"""
+        x, ncam = self.x_host, self.ncam
+        on_lo, on_hi = x <= self.lo, x >= self.hi
+        frozen = np.zeros(x.size, dtype=bool)
+        if on_lo.any() or on_hi.any():
+            gcam = np.zeros(ncam)
+            gcam[self.cam_index] = self.red["gc"]
+            g = np.concatenate([gcam, self.p.frame_gradient().ravel()])
+            frozen = (on_lo & (g > 0)) | (on_hi & (g < 0))
+        frames_changed = bool((frozen[ncam:] != self.frozen[ncam:]).any())
+        self.frozen = frozen
+        self.free = self.user_free & ~frozen[:ncam][self.cam_index]
+        self.all_free = bool(self.free.all())
+        if frames_changed:   # the frame blocks of the reduced system change with the set: build it again (the linearisation stays)
+            self.p.set_frozen(frozen if frozen[ncam:].any() else None)
+            self._refresh_system()
+        else:
+            self.g_inf = max(float(np.abs(self.red["gc"][self.free]).max()) if self.free.any() else 0.0, float(self.red["scal"][4:16].max()))
+
+    def iterate(self, always_linearize=False):
+        status = super().iterate(always_linearize)
+        if getattr(self, "accepted", False):
+            self.x_host = self.p.get_params(self.cur)   # (the projected point: what the GPU holds)
+            self.x_cam = self.x_host[self.cam_index].copy()
+        self._update_working_set()
+        if status is None and self.g_inf < self.gtol:
+            status = 1
+        return status
+
+    def result(self, status, lazy_grad=False):
+        res = super().result(status, False)
+        res.active_mask = find_active_constraints(res.x, self.lo, self.hi, rtol=self.xtol)
+        res.lm["working_set"] = int(self.frozen.sum())
+        return res
+
+
 def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0, comm=None, free_cam_mask=None, lam0=LAM0, max_iterations=None, speculative=True,
-             reduced_solver=None, x_scale=None, dec_floor=DEC_FLOOR, curvature=None, x0_on_device=False, lazy_grad=False):
+             reduced_solver=None, x_scale=None, dec_floor=DEC_FLOOR, curvature=None, x0_on_device=False, lazy_grad=False, bounds=None):
     """Minimise the robust reprojection cost from x0 (this shard's flat vector, a7 layout of SURVEY.md).
     `fun` / `jac` / `grad` of the OptimizeResult are attached by api.bundle_adjust.
     x0_on_device: parameter slot 0 of the problem already holds x0 (ops.Problem.subset gathered it on the GPU): nothing is uploaded."""
-    lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative, reduced_solver=reduced_solver, x_scale=x_scale, dec_floor=dec_floor, curvature=curvature)
+    if bounds is not None:   # (lo, hi) in the layout of x: the active-set loop
+        if comm is not None and not isinstance(comm, SingleProcess):
+            raise NotImplementedError("bounds are not supported in frame-sharded runs")
+        lm = BoundedLevenbergMarquardt(problem, bounds[0], bounds[1], comm=comm, free_cam_mask=free_cam_mask, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, speculative=speculative, x_scale=x_scale,
+                                       dec_floor=dec_floor, curvature=curvature)
+    else:
+        lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative, reduced_solver=reduced_solver, x_scale=x_scale, dec_floor=dec_floor, curvature=curvature)
     if max_nfev is None:
         max_nfev = 100 * np.size(x0)  # trf.py:437-438
     lm.max_nfev, lm.max_steps = max_nfev, max_iterations
-    if lm.can_run_on_device():   # the loop as a whole inside libmcba (the verbose table is printed from the states the ticks posted)
+    if bounds is None and lm.can_run_on_device():   # the loop as a whole inside libmcba (the verbose table is printed from the states the ticks posted)
         status = lm.run_device(None if x0_on_device else x0, verbose)
         cost0 = lm.cost0
     else:

@@ -15,6 +15,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
+def golden():
+    from conftest import GOLDEN
+
+    return lambda name: np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
 def mc():
     import multicam_calibration_amd as m
 
@@ -218,3 +225,86 @@ def test_skew_in_the_input_intrinsics_is_refused(mc):
     intr[1][0][0, 1] = 0.3
     with pytest.raises(ValueError, match="skew"):
         mc.bundle_adjust(p["uvs"], p["extrinsics"], intr, p["obj"], p["poses"], n_frames=None, verbose=0)
+
+
+# ------------------------------------------------------------------ bounds= (the reference forwards it to scipy's bounded TRF)
+def test_bounds_reach_the_reference_bounded_optimum(mc, golden):
+    """Golden = the unmodified reference's bundle_adjust(..., bounds=(lo, hi)) polished to the constrained optimum and certified by
+    finite differences (tests/golden/make_golden_bounds.py): ten bounds active there, five on camera parameters (k1, k2, fx) and five on
+    board-pose coordinates.  The GPU's active-set loop must end at the same point: cost to 1e-9, the same active set, every bounded
+    coordinate ON its bound, parameters to 1e-6 relative; every iterate feasible; unbounded calls untouched (bit-identical)."""
+    from conftest import problem_from_npz
+
+    z = golden("tight_bounds_config1.npz")
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    lo, hi = z["lo"], z["hi"]
+    (e, i, p_, use, res), out = captured(mc.bundle_adjust, uvs, ext, intr, obj, poses, n_frames=None, bounds=(lo, hi), ftol=1e-15, xtol=1e-15, gtol=1e-9, verbose=1, max_nfev=400)
+    np.testing.assert_array_equal(use, z["use"])
+    assert res.status in (1, 2, 3, 4), out
+    assert np.all(res.x >= lo) and np.all(res.x <= hi)
+    assert abs(res.cost - float(z["cost"])) <= 1e-9 * res.cost, (res.cost, float(z["cost"]))
+    np.testing.assert_array_equal(res.active_mask, z["active_mask"])
+    act = z["active_mask"] != 0
+    np.testing.assert_array_equal(res.x[z["active_mask"] == -1], lo[z["active_mask"] == -1])
+    np.testing.assert_array_equal(res.x[z["active_mask"] == 1], hi[z["active_mask"] == 1])
+    # parameters to 1e-6 relative: the intrinsics directly; extrinsics and poses through their gauge-invariant combinations (camera-from-camera
+    # and camera-from-board transforms) -- five active pose bounds take five of the six gauge freedoms, one is left
+    xg, C = z["x"], uvs.shape[0]
+    cam, cam_g = res.x[:12 * C].reshape(C, 12), xg[:12 * C].reshape(C, 12)
+    assert (np.abs(cam[:, :6] - cam_g[:, :6]) / np.abs(cam_g[:, :6])).max() < 1e-6
+    ext_a, _, poses_a = orc.deserialize_params(res.x, C)
+    ext_g, _, poses_g = orc.deserialize_params(xg, C)
+    (cc, cb), (cc_g, cb_g) = orc.invariants(ext_a, poses_a), orc.invariants(ext_g, poses_g)
+    for a, b in ((cc, cc_g), (cb, cb_g)):
+        assert np.abs(a - b)[..., :3, :3].max() < 1e-6
+        assert (np.abs(a - b)[..., :3, 3] / np.abs(b[..., :3, 3]).max()).max() < 1e-6
+    # the oracle's view of the returned point: its robust cost is the reported one, its gradient vanishes off the active set and points outward on it
+    f = orc.residuals(res.x, uvs[:, use], obj)
+    assert abs(orc.robust_cost(f) - res.cost) <= 1e-10 * res.cost
+    js, fs = orc.robust_scales(f)
+    g = orc.jacobian_csr(res.x, uvs[:, use], obj).T @ (js * fs)
+    assert np.abs(g[~act]).max() < 1e-6 * np.abs(g[act]).max()
+    assert np.all(g[z["active_mask"] == -1] > 0) and np.all(g[z["active_mask"] == 1] < 0)
+    np.testing.assert_allclose(res.grad, g, rtol=0, atol=1e-6 * np.abs(g).max())
+    # infinite bounds = scipy's default = the unconstrained solver, bit for bit; a Bounds object and scalars are accepted
+    from scipy.optimize import Bounds
+
+    (_, _, _, _, r0), _ = captured(mc.bundle_adjust, uvs, ext, intr, obj, poses, n_frames=None, verbose=0)
+    (_, _, _, _, r1), _ = captured(mc.bundle_adjust, uvs, ext, intr, obj, poses, n_frames=None, verbose=0, bounds=(-np.inf, np.inf))
+    (_, _, _, _, r2), _ = captured(mc.bundle_adjust, uvs, ext, intr, obj, poses, n_frames=None, verbose=0, bounds=Bounds(np.full(xg.size, -np.inf), np.full(xg.size, np.inf)))
+    np.testing.assert_array_equal(r0.x, r1.x)
+    np.testing.assert_array_equal(r0.x, r2.x)
+    assert not r0.active_mask.any()
+
+
+def test_bounds_with_fixed_intrinsics_and_validation(mc):
+    """Bounds together with fix_intrinsics (flags on the 12-wide camera block): a tight box around the START values of every camera's
+    extrinsics (single bounded coordinates would be evaded through the gauge freedom) -- the cameras cannot reach their unconstrained
+    places, several bounds end active, the poses adapt.  Judged by the oracle: feasible, KKT point, intrinsics untouched."""
+    p = mc.synth.make_problem(3, 40, seed=21)
+    x0 = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    args = (p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    (_, _, _, use, ru), _ = captured(mc.bundle_adjust, *args, n_frames=None, verbose=0, fix_intrinsics=True, ftol=1e-14, xtol=1e-14, gtol=1e-10)
+    lo, hi = np.full(x0.size, -np.inf), np.full(x0.size, np.inf)
+    ext_idx = np.array([12 * c + k for c in range(3) for k in range(6, 12)])
+    delta = np.tile(np.r_[np.full(3, 1e-4), np.full(3, 0.05)], 3)
+    lo[ext_idx], hi[ext_idx] = x0[ext_idx] - delta, x0[ext_idx] + delta
+    (_, intr_b, _, _, rb), _ = captured(mc.bundle_adjust, *args, n_frames=None, verbose=0, fix_intrinsics=True, bounds=(lo, hi), ftol=1e-14, xtol=1e-14, gtol=1e-10, max_nfev=400)
+    assert rb.status > 0 and rb.cost > ru.cost * (1 + 1e-9) and np.all(rb.x >= lo) and np.all(rb.x <= hi)
+    cams0 = x0[:36].reshape(3, 12)
+    np.testing.assert_array_equal(rb.x[:36].reshape(3, 12)[:, :6], cams0[:, :6])   # intrinsics untouched
+    act = rb.active_mask != 0
+    assert set(np.nonzero(act)[0]) <= set(ext_idx) and act.sum() >= 2
+    f = orc.residuals(rb.x, p["uvs"][:, use], p["obj"])
+    assert abs(orc.robust_cost(f) - rb.cost) <= 1e-10 * rb.cost
+    js, fs = orc.robust_scales(f)
+    g = orc.jacobian_csr(rb.x, p["uvs"][:, use], p["obj"]).T @ (js * fs)
+    free = np.ones(x0.size, bool)
+    free[:36] = np.tile(np.r_[np.zeros(6, bool), np.ones(6, bool)], 3)
+    free[act] = False
+    assert np.abs(g[free]).max() < 1e-6 * np.abs(g[act]).max()
+    assert np.all(g[rb.active_mask == -1] > 0) and np.all(g[rb.active_mask == 1] < 0)
+    # scipy's checks, scipy's messages
+    for bad, msg in (((lo, hi, hi), "must contain 2 elements"), ((lo[:5], hi), "Inconsistent shapes"), ((hi, lo), "strictly less"), ((x0 + 1.0, x0 + 2.0), "outside of provided bounds")):
+        with pytest.raises(ValueError, match=msg):
+            captured(mc.bundle_adjust, *args, n_frames=None, verbose=0, bounds=bad)

@@ -447,3 +447,17 @@ def test_curvature_rule_of_the_host_driven_loop():
     assert res["auto"].nfev < res["triggs"].nfev
     with pytest.raises(ValueError):
         solver.lm_solve(OracleProblem(p["uvs"], p["obj"]), x0, curvature="newton")
+
+
+def test_find_active_constraints_is_scipys():
+    """OptimizeResult.active_mask of a bounded run follows scipy's rule (scipy/optimize/_lsq/common.py; trf_bounds passes rtol = xtol)."""
+    from scipy.optimize._lsq.common import find_active_constraints as ref
+
+    rng = np.random.default_rng(3)
+    lb = np.where(rng.random(200) < 0.3, -np.inf, rng.normal(size=200))
+    ub = np.where(rng.random(200) < 0.3, np.inf, lb + np.abs(rng.normal(size=200)) + 1e-3)
+    ub = np.where(np.isfinite(lb), ub, np.where(np.isfinite(ub), rng.normal(size=200), np.inf))
+    x = np.where(np.isfinite(lb), lb, 0.0) + rng.choice([0.0, 1e-12, 1e-9, 1e-7, 0.3], size=200)
+    x = np.where(rng.random(200) < 0.3, np.where(np.isfinite(ub), ub - rng.choice([0.0, 1e-11, 1e-8], size=200), x), x)
+    for rtol in (0.0, 1e-10, 1e-8, 1e-6):
+        np.testing.assert_array_equal(solver.find_active_constraints(x, lb, ub, rtol), ref(x, lb, ub, rtol))
