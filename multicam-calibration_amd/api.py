@@ -421,7 +421,17 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             local = bool(np.bincount(owner, minlength=world).min() > 0)
             positions = np.nonzero(owner == rank)[0] if local else np.array_split(np.arange(all_use.size), world)[rank]
         use_frames = all_use[positions]
-        x0 = serialize_params(all_extrinsics, all_intrinsics, calib_poses[use_frames])
+        nx_local = 12 * n_cameras + 6 * use_frames.size
+
+        class _X0:   # the start vector of this process's frames, built when (if) somebody needs its VALUES: gathering 10 000 poses costs 0.15 ms on the
+            v = None   # host, and the default path never looks at them (mcba_create_subset gathers the start point on the GPU)
+
+            @classmethod
+            def get(cls):
+                if cls.v is None:
+                    cls.v = serialize_params(all_extrinsics, all_intrinsics, calib_poses[use_frames])
+                return cls.v
+
         x_scale = _check_x_scale(kw["x_scale"], 12 * n_cameras + 6 * all_use.size)
         if x_scale is not None:  # this shard's part: the camera block and its own frames' blocks
             x_scale = np.concatenate([x_scale[: 12 * n_cameras], x_scale[12 * n_cameras:].reshape(-1, 6)[positions].ravel()])
@@ -433,17 +443,17 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
 
             if isinstance(box, Bounds):
                 lb, ub = np.asarray(box.lb, dtype=np.float64), np.asarray(box.ub, dtype=np.float64)
-                lb, ub = (np.resize(lb, x0.size) if lb.ndim == 0 else lb), (np.resize(ub, x0.size) if ub.ndim == 0 else ub)
+                lb, ub = (np.resize(lb, nx_local) if lb.ndim == 0 else lb), (np.resize(ub, nx_local) if ub.ndim == 0 else ub)
             elif len(box) == 2:
                 lb, ub = (np.asarray(b, dtype=np.float64) for b in box)
-                lb, ub = (np.resize(lb, x0.size) if lb.ndim == 0 else lb), (np.resize(ub, x0.size) if ub.ndim == 0 else ub)
+                lb, ub = (np.resize(lb, nx_local) if lb.ndim == 0 else lb), (np.resize(ub, nx_local) if ub.ndim == 0 else ub)
             else:
                 raise ValueError("`bounds` must contain 2 elements.")
-            if lb.shape != x0.shape or ub.shape != x0.shape:
+            if lb.shape != (nx_local,) or ub.shape != (nx_local,):
                 raise ValueError("Inconsistent shapes between bounds and `x0`.")
             if np.any(lb >= ub):
                 raise ValueError("Each lower bound must be strictly less than each upper bound.")
-            if np.any(x0 < lb) or np.any(x0 > ub):
+            if np.any(_X0.get() < lb) or np.any(_X0.get() > ub):
                 raise ValueError("Initial guess is outside of provided bounds")
             if np.isfinite(lb).any() or np.isfinite(ub).any():
                 if distributed:
@@ -452,6 +462,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         if use_frames.size == 0:
             # nothing to fit: scipy's least_squares on an empty residual vector returns x0 with status 1 (gtol) after one
             # evaluation (what the reference then returns: bundle_adjustment.py:307-327)
+            x0 = _X0.get()
             result = OptimizeResult(x=x0, cost=0.0, fun=np.empty(0), jac=sp.csr_matrix((0, x0.size)), grad=np.zeros(x0.size), optimality=0.0,
                                     active_mask=np.zeros(x0.size), nfev=1, njev=1, status=1, message=solver.TERMINATION_MESSAGES[1], success=True)
             if kw["verbose"] >= 1:
@@ -489,8 +500,9 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         max_nfev = kw.get("max_nfev")
         if max_nfev is None:
             max_nfev = 100 * (12 * n_cameras + 6 * len(all_use))  # trf.py:437-438 on the GLOBAL vector: identical on every rank
-        result = solver.lm_solve(prob, x0, ftol=tol("ftol", 1e-4), xtol=tol("xtol", 1e-8), gtol=tol("gtol", 1e-8),
-                                 max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, x_scale=x_scale, x0_on_device=x0_on_device and lohi is None, lazy_grad=not distributed, bounds=lohi, **lm_kwargs)
+        on_dev = x0_on_device and lohi is None
+        result = solver.lm_solve(prob, None if on_dev else _X0.get(), ftol=tol("ftol", 1e-4), xtol=tol("xtol", 1e-8), gtol=tol("gtol", 1e-8),
+                                 max_nfev=max_nfev, verbose=kw["verbose"] if rank == 0 else 0, free_cam_mask=free, comm=comm, x_scale=x_scale, x0_on_device=on_dev, lazy_grad=not distributed, bounds=lohi, **lm_kwargs)
         result = LazyOptimizeResult(result)
 
         # ---- OptimizeResult fields the reference's callers can rely on (trf.py:557-560).  `fun` and `jac` are LAZY: the residual

@@ -776,10 +776,12 @@ def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbos
     else:
         lm = LevenbergMarquardt(problem, comm, free_cam_mask, ftol, xtol, gtol, lam0, speculative=speculative, reduced_solver=reduced_solver, x_scale=x_scale, dec_floor=dec_floor, curvature=curvature)
     if max_nfev is None:
-        max_nfev = 100 * np.size(x0)  # trf.py:437-438
+        max_nfev = 100 * (np.size(x0) if x0 is not None else problem.nx)  # trf.py:437-438
     lm.max_nfev, lm.max_steps = max_nfev, max_iterations
+    if x0 is None and not (bounds is None and lm.can_run_on_device()):
+        x0 = problem.get_params(0)   # (the caller left the start point on the device, and this driver wants it on the host)
     if bounds is None and lm.can_run_on_device():   # the loop as a whole inside libmcba (the verbose table is printed from the states the ticks posted)
-        status = lm.run_device(None if x0_on_device else x0, verbose)
+        status = lm.run_device(None if (x0_on_device or x0 is None) else x0, verbose)
         cost0 = lm.cost0
     else:
         lm.start(x0)
