@@ -160,11 +160,11 @@ __global__ void k_sel_pick(SelState* __restrict__ sts, int pass, int upper, int 
 // error array instead of eight, and without the host in between:
 //   pass 0  histogram of the leading 12 bits (sign + exponent; the lanes of a wavefront that share a digit -- nearly all of them --
 //           post ONE LDS atomic) + the per-frame masks (which the later passes and the status kernel read);
-//   pass 1  every workgroup picks the exponent bin of the two middle ranks from pass 0's histogram, then histograms the next 8 bits
-//           of the values in it -- its OWN histogram, stored, not added, to a slot of its own;
-//   pass 2  every workgroup sums those slots and picks the 20-bit prefix, then COMPACTS the values that carry it (LDS staging, one
-//           reservation per workgroup in one of 8 candidate lists: ~10 k of 3.2 M values at 6 x 10 000 x 54);
-//   final   one workgroup selects among the candidates (radix passes over the remaining 44 bits, the candidates in LDS) -> median;
+//   pass 1  every workgroup picks the exponent bin of the two middle ranks from pass 0's histogram, then histograms the next 10 bits
+//           of the values in it -- its OWN histogram, stored, not added, to a slot of its own; k_pf_sum adds the slots up;
+//   pass 2  every workgroup picks the 22-bit prefix, then COMPACTS the values that carry it (LDS staging, one reservation per
+//           workgroup in one of 8 candidate lists: ~2.5 k of 3.2 M values at 6 x 10 000 x 54);
+//   final   one workgroup selects among the candidates (radix passes over the remaining 42 bits, the candidates in LDS) -> median;
 //   status  exclusion per frame, packed behind the 8 info doubles for ONE device-to-host copy.
 // What shaped it (rocprofv3, profiles/round5/NOTES_round5.md): (i) a first version with 2 198 small workgroups, a ticket per pass for
 // "the last one picks" and one shared candidate counter ran 150-190 us PER PASS: device-scope atomics on ONE address retire at ~70 ns
@@ -178,11 +178,13 @@ constexpr int PF_G = 256;            // workgroups of the passes at most
 constexpr int PF_REP = 8;            // replicas of pass 0's histogram / candidate lists
 constexpr int PF_SEG = 1024;         // candidates a workgroup stages per order statistic
 constexpr int PF_LIST = 32768;       // capacity of one candidate list
-constexpr int PF_BITS_B = 8;         // digit of pass 1
+constexpr int PF_BITS_B = 10;        // digit of pass 1
 constexpr int PF_NB = 1 << PF_BITS_B;
 constexpr int PF_ROWS = 8;           // rows a wavefront takes of a work item (loads in flight)
+constexpr int PF_NA = 2048;          // bins of pass 0: the 11 exponent bits (the errors are >= +0: the sign bit is clear)
 struct PrefState {
-  unsigned long long histA[PF_REP][4096];
+  unsigned long long histA[PF_REP][PF_NA];
+  unsigned long long histB[2][PF_NB];               // pass 1's histograms, summed over the workgroups' slots by k_pf_sum
   unsigned int list_count[2][PF_REP];
   unsigned int overflow, pad[3];
   unsigned long long total, rankA[2], prefixA[2];   // written by workgroup 0 of pass 1: the 12-bit bins of the two middle ranks, the ranks inside them
@@ -254,9 +256,9 @@ __global__ __launch_bounds__(256) void k_pf_mask(const double* __restrict__ mean
 template <int PASS>
 __global__ __launch_bounds__(1024) void k_pf_pass(const unsigned long long* __restrict__ keys, const double* __restrict__ mean_cf, const double* __restrict__ full_cf, unsigned char* __restrict__ fmask,
                                                   unsigned char* __restrict__ status, double* __restrict__ worst, int C, int F, int N, int Fpad, PrefState* __restrict__ st) {
-  constexpr int NH = PASS == 0 ? 4096 : (PASS == 1 ? 2 * PF_NB : 4 * PF_SEG);   // LDS words: histogram(s), or the two staged candidate lists (u64 = two words each)
+  constexpr int NH = PASS == 0 ? PF_NA : (PASS == 1 ? 2 * PF_NB : 4 * PF_SEG);   // LDS words: histogram(s), or the two staged candidate lists (u64 = two words each)
   __shared__ unsigned int s_h[NH];
-  __shared__ unsigned long long s_sum[PASS == 1 ? 4096 : 2 * PF_NB];   // the previous pass's histogram, summed over its replicas / slots
+  __shared__ unsigned long long s_sum[PASS == 1 ? PF_NA : 64];   // pass 1: pass 0's histogram, summed over its replicas
   __shared__ unsigned long long s_pre[2], s_rank[2];
   __shared__ unsigned int s_n[2], s_base[2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(1024) void k_pf_pass(const unsigned long long* __re
   if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
   // ---- the previous pass's pick, by every workgroup (its histogram is complete: kernel boundary)
   if (PASS == 1) {
-    for (int b = threadIdx.x; b < 4096; b += 1024) {
+    for (int b = threadIdx.x; b < PF_NA; b += 1024) {
       unsigned long long c = 0;
 #pragma unroll
       for (int k = 0; k < PF_REP; ++k) c += st->histA[k][b];
@@ -275,13 +277,13 @@ __global__ __launch_bounds__(1024) void k_pf_pass(const unsigned long long* __re
     __syncthreads();
     if (wave == 0) {
       unsigned long long total = 0;
-      for (int b = lane; b < 4096; b += 64) total += s_sum[b];
+      for (int b = lane; b < PF_NA; b += 64) total += s_sum[b];
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off, 64);
       for (int s = 0; s < 2; ++s) {
         const unsigned long long r = total ? (s ? total / 2 : (total - 1) / 2) : 0;
         unsigned dg; unsigned long long below;
-        wave_pick_bin<4096>(s_sum, r, lane, dg, below);
+        wave_pick_bin<PF_NA>(s_sum, r, lane, dg, below);
         if (lane == 0) {
           s_pre[s] = dg; s_rank[s] = r - below;
           if (blockIdx.x == 0) { st->prefixA[s] = dg; st->rankA[s] = r - below; st->total = total; }
@@ -289,31 +291,13 @@ __global__ __launch_bounds__(1024) void k_pf_pass(const unsigned long long* __re
       }
     }
   }
-  if (PASS == 2) {
+  if (PASS == 2) {   // pass 1's histograms were summed by k_pf_sum: pick the 22-bit prefixes
     const bool same = st->prefixA[1] == st->prefixA[0];
-    for (int b = threadIdx.x; b < 2 * PF_NB; b += 1024) s_sum[b] = 0;
-    __syncthreads();
-    {  // sum the slots: thread = (bin, slice of the slots); eight loads in flight
-      const int nbin = same ? PF_NB : 2 * PF_NB, SL = 1024 / nbin;
-      const int b = threadIdx.x % nbin, sl = threadIdx.x / nbin, G = (int)gridDim.x;
-      unsigned long long c = 0;
-      int g = sl;
-      for (; g + 7 * SL < G; g += 8 * SL) {
-        unsigned v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (&st->partB[g + j * SL][0][0])[b];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) c += v[j];
-      }
-      for (; g < G; g += SL) c += (&st->partB[g][0][0])[b];
-      atomicAdd(&s_sum[b], c);
-    }
-    __syncthreads();
     if (wave < 2) {
       const int s = wave;
       unsigned dg; unsigned long long below;
       const unsigned long long r = st->rankA[s];
-      wave_pick_bin<PF_NB>(s_sum + (same ? 0 : s * PF_NB), r, lane, dg, below);
+      wave_pick_bin<PF_NB>(&st->histB[same ? 0 : s][0], r, lane, dg, below);
       if (lane == 0) {
         const unsigned long long pre = (st->prefixA[s] << PF_BITS_B) | dg;
         s_pre[s] = pre; s_rank[s] = r - below;
@@ -347,7 +331,7 @@ __global__ __launch_bounds__(1024) void k_pf_pass(const unsigned long long* __re
       const double d = __longlong_as_double((long long)k);
       const bool ok = m && d == d;
       if (PASS == 0) {
-        const unsigned dig = (unsigned)(k >> 52);
+        const unsigned dig = (unsigned)(k >> 52) & (PF_NA - 1);
         unsigned long long rem = __ballot(ok);
         while (rem) {   // (errors of one order of magnitude share the exponent: without this every instruction is a 64-way conflict on one LDS word)
           const int lead = __ffsll((long long)rem) - 1;
@@ -382,7 +366,7 @@ __global__ __launch_bounds__(1024) void k_pf_pass(const unsigned long long* __re
   __syncthreads();
   if (PASS == 0) {
     unsigned long long* dst = st->histA[blockIdx.x % PF_REP];
-    for (int b = threadIdx.x; b < 4096; b += 1024) if (s_h[b]) atomicAdd(&dst[b], (unsigned long long)s_h[b]);   // (a handful of exponent bins per workgroup)
+    for (int b = threadIdx.x; b < PF_NA; b += 1024) if (s_h[b]) atomicAdd(&dst[b], (unsigned long long)s_h[b]);   // (a handful of exponent bins per workgroup)
   } else if (PASS == 1) {
     for (int b = threadIdx.x; b < 2 * PF_NB; b += 1024) (&st->partB[blockIdx.x][0][0])[b] = s_h[b];
   } else {
@@ -400,6 +384,27 @@ __global__ __launch_bounds__(1024) void k_pf_pass(const unsigned long long* __re
       for (unsigned i = threadIdx.x; i < n && base + i < (unsigned)PF_LIST; i += 1024) st->cand[s][rep][base + i] = s_c[s * PF_SEG + i];
     }
   }
+}
+
+// pass 1's per-workgroup histograms (slots) -> histB: 2 PF_NB / 256 workgroups, thread = (bin, quarter of the slots), all loads of a
+// thread independent.  (Summing the slots in pass 2's prologue instead -- every workgroup for itself -- made that prologue 20 us.)
+__global__ __launch_bounds__(1024) void k_pf_sum(PrefState* __restrict__ st, int nslots) {
+  __shared__ unsigned long long s_p[4][256];
+  const int bin = blockIdx.x * 256 + (threadIdx.x & 255), q = threadIdx.x >> 8;
+  const unsigned int* src = &st->partB[0][0][0] + bin;
+  unsigned long long c = 0;
+  int g = q;
+  for (; g + 28 < nslots; g += 32) {
+    unsigned v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(g + 4 * j) * (2 * PF_NB)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c += v[j];
+  }
+  for (; g < nslots; g += 4) c += src[(size_t)g * (2 * PF_NB)];
+  s_p[q][threadIdx.x & 255] = c;
+  __syncthreads();
+  if (q == 0) (&st->histB[0][0])[bin] = s_p[0][threadIdx.x] + s_p[1][threadIdx.x] + s_p[2][threadIdx.x] + s_p[3][threadIdx.x];
 }
 
 // final selection among the candidates of each order statistic (one workgroup): radix passes of 11 bits over the bits below the
@@ -871,6 +876,7 @@ void launch_prefilter_select(hipStream_t st, const double* err, const double* me
     const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(err);
     k_pf_pass<0><<<dim3(g), dim3(1024), 0, st>>>(keys, mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad, ps);
     k_pf_pass<1><<<dim3(g), dim3(1024), 0, st>>>(keys, mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad, ps);
+    k_pf_sum<<<dim3(2 * PF_NB / 256), dim3(1024), 0, st>>>(ps, g);
     k_pf_pass<2><<<dim3(g), dim3(1024), 0, st>>>(keys, mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad, ps);
     k_pf_final<<<dim3(1), dim3(1024), prefilter_final_lds_bytes(), st>>>(ps, 5.0);
   } else {
