@@ -308,3 +308,69 @@ def test_bounds_with_fixed_intrinsics_and_validation(mc):
     for bad, msg in (((lo, hi, hi), "must contain 2 elements"), ((lo[:5], hi), "Inconsistent shapes"), ((hi, lo), "strictly less"), ((x0 + 1.0, x0 + 2.0), "outside of provided bounds")):
         with pytest.raises(ValueError, match=msg):
             captured(mc.bundle_adjust, *args, n_frames=None, verbose=0, bounds=bad)
+
+
+# ------------------------------------------------------------------ more shapes and corner cases of the one-crossing paths
+@pytest.mark.parametrize("shape", [(24, 3000, 10, 20, dict(missing=0.3, outlier_frames=20)), (6, 100000, 6, 9, dict(missing=0.05, outlier_frames=50)), (2, 1, 6, 9, {}),
+                                   (3, 65, 1, 1, dict(missing=0.4)), (5, 127, 2, 3, dict(missing=0.9))])
+def test_fused_prefilter_shapes(mc, shape):
+    """The selection kernels where their work items, slots and candidate lists are cut differently: 4 800 rows of errors (24 cameras x 200
+    points), 1 563 frame blocks (100 000 frames: ~26 k candidates, past the final pass's LDS list), one frame, a one-point board, nearly
+    everything missing -- against the per-call pre-filter (same frames, same line, same RNG state)."""
+    C, F, rows, cols, kw = shape
+    p = mc.synth.make_problem(C, F, rows=rows, cols=cols, seed=7, **kw)
+    for n_frames, thr in ((None, None), (max(1, F // 3), None), (None, 2.0)):
+        a = _select(mc, p, n_frames, thr, 3)
+        b = _select(mc, p, n_frames, thr, 3, MCBA_PREFILTER_FUSED=0)
+        np.testing.assert_array_equal(a[0], b[0])
+        assert a[1] == b[1] and a[2] == b[2], (a[1], b[1])
+
+
+def test_prefilter_without_a_single_valid_error(mc):
+    """Every detection missing: np.nanmedian of nothing is NaN, nothing is complete in two cameras, no frame is used (the reference
+    then hands an empty problem to scipy: status 1 after one evaluation)."""
+    p = mc.synth.make_problem(3, 20, seed=1)
+    uvs = np.full_like(p["uvs"], np.nan)
+    a = _select(mc, dict(p, uvs=uvs), None, None, 0)
+    b = _select(mc, dict(p, uvs=uvs), None, None, 0, MCBA_PREFILTER_FUSED=0)
+    assert a[0].size == 0 and b[0].size == 0 and a[1] == b[1] and "nan" in a[1]
+    (e, i, ps, use, res), _ = captured(mc.bundle_adjust, uvs, p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, verbose=0)
+    assert use.size == 0 and res.status == 1 and res.nfev == 1 and ps.shape == (0, 6)
+
+
+def test_lm_run_with_iteration_limits_and_bounded_with_x_scale(mc):
+    p = mc.synth.make_problem(4, 90, seed=12, missing=0.1)
+    x0 = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    out = {}
+    for mode in ("0", "1"):
+        with env(MCBA_HOST_LOOP=mode):
+            for k in (0, 1, 3):
+                prob = mc.ops.Problem(p["uvs"], p["obj"])
+                res = mc.solver.lm_solve(prob, x0, ftol=0.0, xtol=0.0, gtol=0.0, max_iterations=k)
+                out[mode, k] = (res.x.copy(), res.cost, res.nfev, res.status, res.lm["steps"], res.lm["history"])
+                prob.close()
+    for k in (0, 1, 3):
+        a, b = out["0", k], out["1", k]
+        np.testing.assert_array_equal(a[0], b[0])
+        assert a[1:] == b[1:], (k, a[1:5], b[1:5])
+        assert a[3] == 0 and a[4] == k
+    # bounds together with a numeric x_scale (fixed damping matrix): still a KKT point of the same problem
+    (_, _, _, use, ru), _ = captured(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, verbose=0, ftol=1e-14, xtol=1e-14, gtol=1e-10)
+    xs0 = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"][use])
+    lo, hi = np.full(xs0.size, -np.inf), np.full(xs0.size, np.inf)
+    for i in (4, 5, 12 + 4, 24 + 5, 36 + 0, 36 + 1):
+        b = xs0[i] + 0.5 * (ru.x[i] - xs0[i])
+        if ru.x[i] > xs0[i]:
+            hi[i] = b
+        else:
+            lo[i] = b
+    scale = np.where(np.arange(xs0.size) % 6 < 3, 1.0, 50.0)
+    scale[:48] = np.tile([1000.0, 1000.0, 500.0, 500.0, 0.1, 0.05, 1.0, 1.0, 1.0, 100.0, 100.0, 100.0], 4)
+    (_, _, _, _, rb), _ = captured(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, verbose=0, bounds=(lo, hi), x_scale=scale,
+                                   ftol=1e-15, xtol=1e-15, gtol=1e-9, max_nfev=600)
+    (_, _, _, _, rc), _ = captured(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, verbose=0, bounds=(lo, hi),
+                                   ftol=1e-15, xtol=1e-15, gtol=1e-9, max_nfev=600)
+    assert rb.status > 0 and rc.status > 0 and rb.active_mask.any()
+    np.testing.assert_array_equal(rb.active_mask, rc.active_mask)
+    assert abs(rb.cost - rc.cost) <= 1e-9 * rc.cost and rb.cost > ru.cost
+    assert np.all(rb.x >= lo) and np.all(rb.x <= hi)
