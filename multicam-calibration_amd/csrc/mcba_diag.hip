@@ -871,8 +871,15 @@ void launch_prefilter_select(hipStream_t st, const double* err, const double* me
   if (median) {
     const int R = C * N, nfb = Fpad / 64, items = nfb * ((R + 16 * PF_ROWS - 1) / (16 * PF_ROWS));
     const int g = std::min(PF_G, items);
-    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prefilter_final_lds_bytes()) == hipSuccess;
-    (void)lds_ok;
+    {  // the dynamic-LDS limit of k_pf_final, raised once per device
+      static bool lds_set[64] = {};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (!lds_set[dev & 63]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prefilter_final_lds_bytes());
+        lds_set[dev & 63] = true;
+      }
+    }
     const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(err);
     k_pf_pass<0><<<dim3(g), dim3(1024), 0, st>>>(keys, mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad, ps);
     k_pf_pass<1><<<dim3(g), dim3(1024), 0, st>>>(keys, mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad, ps);
