@@ -130,7 +130,8 @@ int mcba_copy_params(mcba_handle* h, int dst_slot, int src_slot);  /* device to 
 int mcba_cost(mcba_handle* h, int slot, double* cost, double* n_residuals);
 /* Dense residual array (C,F,N,2), observed - predicted, 0 where the observation is NaN (host). */
 int mcba_residuals(mcba_handle* h, int slot, double* res);
-/* The same array left ON THE DEVICE as an object of its own (it outlives the handle): api.bundle_adjust hands it to the
+/* The same array -- with NaN instead of 0 where the observation is missing, so that it carries its own row mask (ABI 6) -- left
+ * ON THE DEVICE as an object of its own (it outlives the handle): api.bundle_adjust hands it to the
  * OptimizeResult and downloads it when `result.fun` is first read -- scipy materialises `fun` (trf.py:557-560), but 52 MB of
  * device-to-host copy at 6 x 10 000 x 54 for a field few callers read was the largest single item of the call.
  * mcba_buffer_count: doubles in it; mcba_buffer_download: copy to host (synchronises); mcba_buffer_free: back to the pool. */

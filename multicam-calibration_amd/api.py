@@ -90,9 +90,9 @@ class _JacobianSource:
 
     live = _Live()
 
-    def __init__(self, prob, objpoints, x, slot, loss, f_scale, device, robust, nan_bits, shape4):
+    def __init__(self, prob, objpoints, x, slot, loss, f_scale, device, robust, need_mask, shape4):
         self.prob, self.obj, self.x, self.slot = prob, objpoints, x, slot
-        self.loss, self.f_scale, self.device, self.robust, self.nan_bits, self.shape4 = loss, f_scale, device, robust, nan_bits, shape4
+        self.loss, self.f_scale, self.device, self.robust, self.need_mask, self.shape4 = loss, f_scale, device, robust, need_mask, shape4
         self.host_uvs = None
         if hasattr(prob, "trim"):
             prob.trim()
@@ -120,8 +120,13 @@ class _JacobianSource:
         except Exception:  # noqa: BLE001
             pass
 
-    def mask(self):
-        return None if self.nan_bits is None else np.unpackbits(self.nan_bits, count=int(np.prod(self.shape4))).astype(bool).reshape(self.shape4)
+    def mask(self, prob):
+        """Which scalars were observed: from the GPU's copy of the observations (immutable since the call), when it is needed."""
+        if not self.need_mask:
+            return None
+        if hasattr(prob, "seen_bits"):
+            return np.unpackbits(prob.seen_bits(), count=int(np.prod(self.shape4))).astype(bool).reshape(self.shape4)
+        return ~np.isnan(prob.uvs)   # (the CPU test double keeps its observations as an array)
 
     def csr(self):
         try:
@@ -132,7 +137,7 @@ class _JacobianSource:
                 prob = self.prob = ops.Problem(self.host_uvs, self.obj, device=self.device, loss=self.loss, f_scale=self.f_scale)
                 prob.set_params(0, self.x)
                 slot = 0
-            m = self.mask()
+            m = self.mask(prob)
             uvs = np.zeros(self.shape4) if m is None else np.where(m, 0.0, np.nan)   # (jacobian_structure only looks at which scalars are NaN)
             idx, indptr, shape, mask = jacobian_structure(uvs)  # CSR indices: 0.25 s of numpy at 6 x 10k x 54 -- only when asked for
             prob.jacobian_eval(slot, robust_scaled=self.robust)
@@ -513,20 +518,19 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         slot = result.lm["slot"]
         need_mask = not all_seen  # (every selected detection complete -- the pre-filter counted them on the GPU: no NaN mask to apply)
         shape4 = (n_cameras, use_frames.size, all_calib_uvs.shape[2], 2)
-        # which scalars are observed is fixed NOW (one bit each), not when a lazy field is first read: the caller may NaN out
-        # detections of its array in place between this call and that read.  The bits come from the GPU's copy of the
-        # selected frames (k_seen_bits: 0.8 MB of D2H at 6 x 10 000 x 54; the same thing in numpy over the caller's array is 24 ms)
-        if not need_mask:
-            seen_bits = None
-        elif hasattr(prob, "seen_bits"):
-            seen_bits = prob.seen_bits()
-        else:
-            seen_bits = np.packbits(~np.isnan(all_calib_uvs)[:, use_frames])
+        # Which scalars are observed is fixed NOW, not when a lazy field is first read -- the caller may NaN out detections of its array in
+        # place between this call and that read -- and it costs the call nothing: the detached residual vector carries NaN where
+        # a scalar is missing (its own row mask), and `result.jac` takes its mask from the GPU's copy of the observations when it is produced
+        # (ops.Problem.seen_bits; round 4 fetched those bits in every call: 0.1 ms at 6 x 10 000 x 54).
         vec = prob.residuals_detach(slot)
+        own_mask = hasattr(prob, "seen_bits")   # (libmcba: NaN-marked vector; the CPU test double hands back zeros: mask from the caller's array)
+        host_bits = None if (own_mask or not need_mask) else np.packbits(~np.isnan(all_calib_uvs)[:, use_frames])
 
-        def fun(vec=vec, bits=seen_bits, shape4=shape4):
+        def fun(vec=vec, bits=host_bits, shape4=shape4, need_mask=need_mask, own_mask=own_mask):
             r = vec.download()
-            return r.ravel() if bits is None else r[np.unpackbits(bits, count=r.size).astype(bool).reshape(shape4)]
+            if not need_mask:
+                return r.ravel()
+            return r[~np.isnan(r)] if own_mask else r[np.unpackbits(bits, count=r.size).astype(bool).reshape(shape4)]
 
         dict.__setitem__(result, "fun", _Lazy(fun))
         x_local = result.x.copy() if return_jac else None   # this process's frames (a frame-sharded run assembles the global vector below)
@@ -556,7 +560,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             result.grad = grad
         if return_jac:
             # (no reference to the caller's array is kept: a result whose handle has to be released first copies its observations back from the GPU)
-            jsrc = _JacobianSource(prob, calib_objpoints, x_local, slot, kw["loss"], kw.get("f_scale", 1.0), device, kw["loss"] != "linear", seen_bits, shape4)
+            jsrc = _JacobianSource(prob, calib_objpoints, x_local, slot, kw["loss"], kw.get("f_scale", 1.0), device, kw["loss"] != "linear", need_mask, shape4)
             dict.__setitem__(result, "jac", _Lazy(jsrc.csr))
             prob = None   # owned by the lazy `jac` field now (closed when that field is produced, with the result, or under MCBA_JAC_HOLD_MB pressure)
     finally:

@@ -1879,7 +1879,7 @@ int mcba_residuals_detach(mcba_handle* h, int slot, mcba_buffer** out) {
   if (rc) return rc;
   {  // (the residual vector alone: the cost sums of run_cost are not wanted here)
     Scope sc(h, K_COST);
-    mcba::launch_cost(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->cpart, h->res, h->C, h->F, h->N, h->Fpad, h->nch);
+    mcba::launch_cost(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, h->x[slot], h->cpart, h->res, h->C, h->F, h->N, h->Fpad, h->nch, NAN);   // NaN where a scalar is missing: the vector is its own row mask
   }
   if ((rc = check_launch())) return rc;
   mcba_buffer* b = new mcba_buffer{h->res, (size_t)2 * h->C * h->F * h->N, h->device, h->stream, h->res, (size_t)2 * h->C * h->F * h->N};

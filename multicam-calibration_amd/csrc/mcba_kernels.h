@@ -82,7 +82,8 @@ int gram_round_blocks(int C, int nfb, int slots);   // frame blocks (a multiple 
 size_t gram_psplit_lds_bytes(int npw, int cw = 12);  // dynamic LDS of k_gram_psplit
 int gram_psplit_set_lds_limit();             // raises the dynamic-LDS limit of its instances (0 = ok)
 size_t gram_chunk_doubles(int C, int nfb, int nchunk, int slots);   // doubles of that scratch for C cameras x nfb frame blocks
-void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch);
+void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch,
+                 double fill = 0.0);   // what the residual vector holds where a scalar is missing: 0, or NaN (then the vector carries its own row mask)
 size_t syrk_lds_bytes(int C, int FS, int cw = 12);
 void launch_syrk(hipStream_t st, Sel s, const SyrkFuse& fz, const double* rec0, const double* rec1, double* fbuf, double* fpart, const int* tile_i, const int* tile_j, double* spart, int C, int F, int Fpad, int NT, int NP, int G, int sq, int sr, int FS, int ppw,
                  const double* dscale = nullptr,   // dscale: D = 1 / x_scale^2 in the layout of x (numeric x_scale), nullptr: D = diag(J^T J)

@@ -937,7 +937,8 @@ __global__ __launch_bounds__(256) void k_gram_combine(const double2* __restrict_
 // ~4 wavefronts per SIMD are in flight -- the loop body is short and latency-bound at one wave per SIMD.
 template <int LOSS, bool WRITE_RES>
 __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
-                                              double* __restrict__ cpart, double* __restrict__ res, int C, int F, int N, int Fpad, int nfb, int nch, double fs2, double ifs2) {
+                                              double* __restrict__ cpart, double* __restrict__ res, int C, int F, int N, int Fpad, int nfb, int nch, double fs2, double ifs2,
+                                              double fill) {   // fill: what a MISSING scalar's slot of the residual vector gets -- 0 (mcba_residuals), or NaN (the detached vector: its own row mask)
   __shared__ CamConst s_cam;
   const int c = blockIdx.y;
   if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(256) void k_cost(const double2* __restrict__ obs_t,
     }
     if (WRITE_RES && f < F) {
       // (C,F,N,2) order of the reference's residual vector before NaN removal
-      *reinterpret_cast<double2*>(res + (((size_t)c * F + f) * N + p) * 2) = make_double2(vu ? ru : 0.0, vv ? rv : 0.0);
+      *reinterpret_cast<double2*>(res + (((size_t)c * F + f) * N + p) * 2) = make_double2(vu ? ru : fill, vv ? rv : fill);
     }
   };
   int p = p0;
@@ -1881,14 +1882,14 @@ size_t gram_chunk_doubles(int C, int nfb, int nchunk, int slots) {
   return (size_t)C * (nfb - fba) * nchunk * kGramRaw * 64;
 }
 
-void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch) {
+void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, const double* x, double* cpart, double* res, int C, int F, int N, int Fpad, int nch, double fill) {
   int nfb = Fpad / 64;
   dim3 grid((nfb + 3) / 4, C, nch), block(256);
   double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
   if (res) {
-    DISPATCH_LOSS(loss, (k_cost<L, true><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, cpart, res, C, F, N, Fpad, nfb, nch, fs2, ifs2)));
+    DISPATCH_LOSS(loss, (k_cost<L, true><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, cpart, res, C, F, N, Fpad, nfb, nch, fs2, ifs2, fill)));
   } else {
-    DISPATCH_LOSS(loss, (k_cost<L, false><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, cpart, res, C, F, N, Fpad, nfb, nch, fs2, ifs2)));
+    DISPATCH_LOSS(loss, (k_cost<L, false><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, cpart, res, C, F, N, Fpad, nfb, nch, fs2, ifs2, fill)));
   }
 }
 

@@ -26,6 +26,21 @@ MCBA_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace --stats --output-format csv -d 
 find $OUT/${TAG}_dist_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_dist_kernel_stats.csv \;
 echo "forced-dist done"
 python3 scripts/e2e_breakdown.py > $OUT/${TAG}_e2e_breakdown.json 2> $OUT/${TAG}_e2e.err
+# round 5: the user-level call where users are (the reference tutorial's recording, BASELINE configs[0]), its kernels by rocprofv3, and the
+# timelines of the small-shape ticks (what a kernel boundary costs in the stream)
+MCBA_E2E_SHAPE=6,2130,5,7 python3 scripts/e2e_breakdown.py 2130 9 > $OUT/${TAG}_e2e_tutorial.json 2>> $OUT/${TAG}_e2e.err
+MCBA_E2E_SHAPE=2,50,6,9 python3 scripts/e2e_breakdown.py 50 9 > $OUT/${TAG}_e2e_config0.json 2>> $OUT/${TAG}_e2e.err
+MCBA_E2E_MISSING=0.05 python3 scripts/e2e_breakdown.py > $OUT/${TAG}_e2e_missing.json 2>> $OUT/${TAG}_e2e.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_e2e_stats -- python3 scripts/e2e_breakdown.py 10000 5 > /dev/null 2>> $OUT/${TAG}_e2e.err
+find $OUT/${TAG}_e2e_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_e2e_kernel_stats.csv \;
+for S in "config1:6,1000,6,9,1" "config0:2,50,6,9" "tutorial:6,2130,5,7"; do
+  N=${S%%:*}; SH=${S#*:}
+  MCBA_SHAPES="$SH" rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_tl_$N -- python3 scripts/other_shapes.py > /dev/null 2>> $OUT/${TAG}_e2e.err
+  find $OUT/${TAG}_tl_$N -name "*kernel_trace.csv" -exec cp {} $OUT/${TAG}_tl_${N}_trace.csv \;
+  python3 scripts/tick_timeline.py $OUT/${TAG}_tl_${N}_trace.csv > $OUT/${TAG}_tick_timeline_$N.txt
+  rm -rf $OUT/${TAG}_tl_$N $OUT/${TAG}_tl_${N}_trace.csv
+done
+echo "round-5 e2e done"
 python3 scripts/other_shapes.py > $OUT/${TAG}_other_shapes.json 2> $OUT/${TAG}_shapes.err
 MCBA_SHAPES="24,6250,10,20" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_shard5_stats -- python3 scripts/other_shapes.py > $OUT/${TAG}_shard5.json 2> $OUT/${TAG}_shard5.err
 find $OUT/${TAG}_shard5_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_shard5_kernel_stats.csv \;

@@ -22,7 +22,11 @@ def main(tag, rnd):
                  (f"{tag}_shard5_kernel_stats.csv", f"shard5_kernel_stats_{tag}.csv"),
                  (f"{tag}_config1_kernel_stats.csv", f"config1_kernel_stats_{tag}.csv"), (f"{tag}_c1free_kernel_stats.csv", f"shape_6x1000_free_kernel_stats_{tag}.csv"),
                  (f"{tag}_config0_kernel_stats.csv", f"config0_kernel_stats_{tag}.csv"), (f"{tag}_shard4_kernel_stats.csv", f"shard4_kernel_stats_{tag}.csv"),
-                 (f"{tag}_pmc_config1_summary.json", f"pmc_config1_{tag}_summary.json"), (f"{tag}_config5_full.json", f"config5_full_one_gpu_{tag}.json")):
+                 (f"{tag}_pmc_config1_summary.json", f"pmc_config1_{tag}_summary.json"), (f"{tag}_config5_full.json", f"config5_full_one_gpu_{tag}.json"),
+                 (f"{tag}_e2e_tutorial.json", f"e2e_breakdown_{tag}_tutorial.json"), (f"{tag}_e2e_config0.json", f"e2e_breakdown_{tag}_config0.json"),
+                 (f"{tag}_e2e_missing.json", f"e2e_missing_{tag}.json"), (f"{tag}_e2e_kernel_stats.csv", f"e2e_kernel_stats_{tag}.csv"),
+                 (f"{tag}_tick_timeline_config0.txt", f"tick_timeline_config0_{tag}.txt"), (f"{tag}_tick_timeline_config1.txt", f"tick_timeline_config1_{tag}.txt"),
+                 (f"{tag}_tick_timeline_tutorial.txt", f"tick_timeline_tutorial_{tag}.txt")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, b))
         else:
