@@ -374,3 +374,58 @@ def test_lm_run_with_iteration_limits_and_bounded_with_x_scale(mc):
     np.testing.assert_array_equal(rb.active_mask, rc.active_mask)
     assert abs(rb.cost - rc.cost) <= 1e-9 * rc.cost and rb.cost > ru.cost
     assert np.all(rb.x >= lo) and np.all(rb.x <= hi)
+
+
+def test_three_crossing_stub_over_raw_ctypes(mc):
+    """INTEGRATION.md section 2's stub, executed literally through ctypes.CDLL (no ops.py): mcba_prefilter -> mcba_create_subset ->
+    mcba_lm_run -> mcba_lm_history -> mcba_lm_result reproduce api.bundle_adjust's frames, solution and gradient."""
+    import ctypes
+
+    p = mc.synth.make_problem(3, 120, seed=31, missing=0.15, outlier_frames=4)
+    uvs, obj = np.ascontiguousarray(p["uvs"]), np.ascontiguousarray(p["obj"])
+    C, F, N = uvs.shape[:3]
+    lib = ctypes.CDLL(mc.ops.LIB_PATH)
+    dp = ctypes.POINTER(ctypes.c_double)
+    P = lambda a: a.ctypes.data_as(dp)
+    lib.mcba_last_error.restype = ctypes.c_char_p
+    lib.mcba_prefilter.argtypes = [ctypes.c_void_p, dp, dp, dp, ctypes.c_double, ctypes.POINTER(ctypes.c_ubyte), dp]
+    lib.mcba_create_subset.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    lib.mcba_lm_run.argtypes = [ctypes.c_void_p, dp, dp, ctypes.c_char_p, dp]
+    lib.mcba_lm_history.argtypes = [ctypes.c_void_p, dp, ctypes.c_size_t]
+    lib.mcba_lm_result.argtypes = [ctypes.c_void_p, ctypes.c_int, dp, dp, ctypes.POINTER(ctypes.c_void_p)]
+    lib.mcba_destroy.argtypes = [ctypes.c_void_p]
+
+    def check(rc):
+        assert rc == 0, lib.mcba_last_error().decode()
+
+    h = ctypes.c_void_p()
+    check(lib.mcba_create(ctypes.byref(h), C, F, N, 0))
+    x_all = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    status, info = np.empty(F, np.uint8), np.empty(8)
+    check(lib.mcba_prefilter(h, P(uvs), P(obj), P(x_all), float("nan"), status.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), P(info)))
+    use0 = np.flatnonzero(status & 1)
+    use_frames = use0[(status[use0] & 2) == 0]
+    np.random.seed(4)
+    n_frames = 60
+    if not (n_frames is None or n_frames > len(use_frames)):
+        use_frames = np.random.choice(use_frames, n_frames, replace=False)
+    sub = ctypes.c_void_p()
+    idx = np.ascontiguousarray(use_frames, dtype=np.int32)
+    check(lib.mcba_create_subset(ctypes.byref(sub), h, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), len(idx)))
+    n = 12 * C + 6 * len(idx)
+    opt = np.array([1e-4, 1e-8, 1e-8, 1e-3, 1e-9, 1e12, 0.1, 1.0, 1e-2, 100 * n, -1, 2, 0], dtype=np.float64)
+    summary = np.zeros(4)
+    check(lib.mcba_lm_run(sub, None, P(opt), None, P(summary)))
+    rows = np.empty((int(summary[1]), 32))
+    check(lib.mcba_lm_history(sub, P(rows), len(rows)))
+    out = np.empty((2, n))
+    check(lib.mcba_lm_result(sub, int(rows[-1, 3]), P(out), P(out[1]), None))
+    lib.mcba_destroy(sub)
+    lib.mcba_destroy(h)
+    np.random.seed(4)
+    (e, i, ps, use, res), line = captured(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=n_frames, verbose=0)
+    np.testing.assert_array_equal(use, use_frames)
+    assert f"threshold of {info[0]}" in line
+    assert int(summary[0]) == res.status and 1 + int(rows[-1, 17]) == res.nfev
+    np.testing.assert_array_equal(out[0], res.x)
+    np.testing.assert_array_equal(out[1], res.grad)
