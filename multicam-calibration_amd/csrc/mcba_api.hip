@@ -90,6 +90,7 @@ struct mcba_handle {
   // trial_ready = the last tick did so, the next one must not back-substitute again.  The flag word sits behind the camera step.
   bool fuse_backsub = false, trial_ready = false;
   unsigned long long last_solve_seq = 0;  // sequence number of the last mcba_lm_auto_solve / tick (what a timed-out back-substitution of that launch stamps)
+  unsigned long long waited_seq = 0;      // the last tick whose posted state the host has read (mcba_lm_auto_wait): equal to last_solve_seq = nothing posts into the ring any more
   unsigned long long solve_launches = 0;  // k_solve_cam launches so far (SolveArgs.stage_tag)
   int slots = 1024;  // wavefront slots of the device (4 x CUs): where k_gram's launch variants cut this shard into rounds
   int ncu = 256, lds_optin = 160 * 1024;  // compute units and the LDS a workgroup may ask for (hipGetDeviceProperties at create; MI355X: 256 / 160 KiB)
@@ -179,11 +180,19 @@ int check_launch() {
 // Freed buffers are parked here (per device, keyed by their exact size -- repeated calls ask for the same sizes) and handed out
 // again; MCBA_POOL_MB caps what is parked (default 2048 MiB of the 288 GB -- other allocators of the process, torch's or RCCL's, cannot
 // see parked memory --; 0 switches the pool off; pinned host memory: 256 MiB), mcba_pool_trim() returns everything to the driver, and
-// so does an allocation of this library that the driver answers with out-of-memory, before it asks once more.  Re-use is safe without events: every kernel and copy of this library is enqueued on the handle's
-// stream and mcba_destroy synchronises that stream before it parks a buffer.
+// so does an allocation of this library that the driver answers with out-of-memory, before it asks once more.  Re-use is safe without
+// events: every kernel and copy of this library is enqueued on the handle's stream, so a buffer that goes to a handle on the SAME stream
+// is ordered behind whatever its previous owner still had in flight (round 5: mcba_destroy no longer waits for the stream -- a handle
+// was closed while the next stage's kernels were still running, and the host stood still for them); a buffer that goes to another
+// stream, or back to the driver, waits for the stream it was parked with first.
+struct ParkedBuf {
+  void* p;
+  hipStream_t stream;  // work enqueued on this stream may still read / write the buffer (busy) ...
+  bool busy;           // ... or nothing can (the owner synchronised before parking it)
+};
 struct BufferPool {
   std::mutex mu;
-  std::multimap<std::pair<int, size_t>, void*> dev;     // (device, bytes) -> pointer
+  std::multimap<std::pair<int, size_t>, ParkedBuf> dev;     // (device, bytes) -> pointer + who may still be using it
   std::multimap<std::pair<unsigned, size_t>, void*> host;  // (hipHostMalloc flags, bytes) -> pointer
   size_t parked = 0, parked_host = 0;
   const size_t host_cap = (size_t)256 << 20;  // pinned host memory parked at most (state rings and staging buffers: a few hundred KB each)
@@ -195,11 +204,20 @@ struct BufferPool {
 BufferPool g_pool;
 
 void pool_release_all();
-hipError_t pool_malloc(void** p, size_t bytes, int device) {
+hipError_t pool_malloc(void** p, size_t bytes, int device, hipStream_t stream = nullptr, bool any_stream = false) {
   {
-    std::lock_guard<std::mutex> lk(g_pool.mu);
-    auto it = g_pool.dev.find({device, bytes});
-    if (it != g_pool.dev.end()) { *p = it->second; g_pool.dev.erase(it); g_pool.parked -= bytes; return hipSuccess; }
+    ParkedBuf got{nullptr, nullptr, false};
+    {
+      std::lock_guard<std::mutex> lk(g_pool.mu);
+      auto it = g_pool.dev.find({device, bytes});
+      if (it != g_pool.dev.end()) { got = it->second; g_pool.dev.erase(it); g_pool.parked -= bytes; }
+    }
+    if (got.p) {
+      // (any_stream: the caller cannot say which stream will touch the buffer)
+      if (got.busy && (any_stream || got.stream != stream)) (void)hipStreamSynchronize(got.stream);
+      *p = got.p;
+      return hipSuccess;
+    }
   }
   hipError_t e = hipMalloc(p, bytes);
   if (e == hipErrorOutOfMemory) {  // what the pool has parked is memory too: give it back to the driver and ask once more
@@ -209,12 +227,13 @@ hipError_t pool_malloc(void** p, size_t bytes, int device) {
   }
   return e;
 }
-void pool_free(void* p, size_t bytes, int device) {
+void pool_free(void* p, size_t bytes, int device, hipStream_t stream = nullptr, bool busy = false) {
   if (!p) return;
   {
     std::lock_guard<std::mutex> lk(g_pool.mu);
-    if (g_pool.parked + bytes <= g_pool.cap()) { g_pool.dev.insert({{device, bytes}, p}); g_pool.parked += bytes; return; }
+    if (g_pool.parked + bytes <= g_pool.cap()) { g_pool.dev.insert({{device, bytes}, ParkedBuf{p, stream, busy}}); g_pool.parked += bytes; return; }
   }
+  if (busy) (void)hipStreamSynchronize(stream);
   (void)hipFree(p);
 }
 hipError_t pool_host_malloc(void** p, size_t bytes, unsigned flags) {
@@ -236,7 +255,7 @@ void pool_release_all() {
   std::lock_guard<std::mutex> lk(g_pool.mu);
   int cur = 0;
   (void)hipGetDevice(&cur);
-  for (auto& kv : g_pool.dev) { (void)hipSetDevice(kv.first.first); (void)hipFree(kv.second); }
+  for (auto& kv : g_pool.dev) { (void)hipSetDevice(kv.first.first); if (kv.second.busy) (void)hipStreamSynchronize(kv.second.stream); (void)hipFree(kv.second.p); }
   for (auto& kv : g_pool.host) (void)hipHostFree(kv.second);
   g_pool.dev.clear();
   g_pool.host.clear();
@@ -250,7 +269,7 @@ void pool_release_all() {
 template <class T>
 int dalloc(mcba_handle* h, T** p, size_t count, bool zero = true) {
   const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-  HIPCHK(pool_malloc(reinterpret_cast<void**>(p), bytes, h->device));
+  HIPCHK(pool_malloc(reinterpret_cast<void**>(p), bytes, h->device, h->stream));
   h->bufs.push_back({reinterpret_cast<void**>(p), bytes});
   if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
   else if (getenv("MCBA_POISON") && atoi(getenv("MCBA_POISON")) != 0) HIPCHK(hipMemsetAsync(*p, 0xFF, bytes, h->stream));  // (tests: whatever relies on a fill that is no longer made shows)
@@ -547,9 +566,13 @@ static int ensure_solver(mcba_handle* h) {
 int mcba_destroy(mcba_handle* h) {
   if (!h) return MCBA_OK;
   (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream);  // nothing in flight may still touch a buffer that is parked below
+  // Device buffers are parked as "busy on h->stream" and NOT waited for (a later owner on the same stream is ordered behind whatever is
+  // still in flight; pool_malloc waits for anybody else).  What the GPU writes into HOST memory must be quiet, though: the state ring
+  // (ticks that were enqueued but never waited for), profiling events, an RCCL communicator -- then the stream is waited for as before.
+  const bool quiet = h->last_solve_seq == h->waited_seq && h->evs.empty() && !h->comm && !h->prof;
+  if (!quiet) (void)hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.ok) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
-  for (auto& b : h->bufs) { pool_free(*b.slot, b.bytes, h->device); *b.slot = nullptr; }
+  for (auto& b : h->bufs) { pool_free(*b.slot, b.bytes, h->device, h->stream, quiet); *b.slot = nullptr; }
   free(h->obj_host);
   pool_host_free(h->pinned, h->pinned_bytes, hipHostMallocDefault);
   pool_host_free(h->ring, h->ring_bytes, h->ring_flags);
@@ -1098,6 +1121,7 @@ int mcba_lm_auto_config(mcba_handle* h, double ftol, double xtol, double gtol, d
   HIPCHK(hipStreamSynchronize(h->stream));
   h->trial_ready = false;
   h->last_solve_seq = 0;
+  h->waited_seq = 0;
   h->auto_ready = true;
   if (const char* e = getenv("MCBA_SPECULATE")) h->speculate = atoi(e) != 0;
   return MCBA_OK;
@@ -1276,6 +1300,7 @@ int mcba_lm_auto_wait(mcba_handle* h, unsigned long long seq, double* state) {
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   for (int i = 0; i < MCBA_LMS; ++i) state[i] = slot[i];
+  if (seq > h->waited_seq) h->waited_seq = seq;
   if (h->fuse_backsub && const_cast<volatile double*>(h->ring)[(size_t)kRing * MCBA_LMS] != 0.0) {
     // a back-substitution workgroup of k_solve_backsub gave up waiting for the solve (mcba_backsub.h): the ticks already in
     // flight discard their stale trial points on the device; from here on the solve and the back-substitution are two launches
@@ -1333,6 +1358,7 @@ int mcba_lm_run(mcba_handle* h, const double* x0, const double* opt, const unsig
   HIPCHK(hipMemsetAsync(h->dcbuf + h->n, 0, 8 * sizeof(double), h->stream));
   h->trial_ready = false;
   h->last_solve_seq = 0;
+  h->waited_seq = 0;
   h->auto_ready = true;
   if (const char* e = getenv("MCBA_SPECULATE")) h->speculate = atoi(e) != 0;
   // (with <= 9 cameras the first solve's launch already carries the back-substitution of the first trial step, like every later one)
@@ -1901,8 +1927,7 @@ int mcba_buffer_download(mcba_buffer* b, double* host) {
 int mcba_buffer_free(mcba_buffer* b) {
   if (!b) return MCBA_OK;
   (void)hipSetDevice(b->device);
-  (void)hipStreamSynchronize(b->stream);
-  pool_free(b->base, b->base_count * sizeof(double), b->device);
+  pool_free(b->base, b->base_count * sizeof(double), b->device, b->stream, true);   // (the kernel that fills it may still be running: parked as busy on its stream)
   delete b;
   return MCBA_OK;
 }
@@ -1915,7 +1940,7 @@ int mcba_seen_bits(mcba_handle* h, unsigned char* bits) {
   HIPCHK(hipSetDevice(h->device));
   const size_t count = (size_t)2 * h->C * h->F * h->N, words = (count + 63) / 64;
   unsigned long long* d = nullptr;
-  HIPCHK(pool_malloc(reinterpret_cast<void**>(&d), words * 8, h->device));
+  HIPCHK(pool_malloc(reinterpret_cast<void**>(&d), words * 8, h->device, h->stream));
   mcba::launch_seen_bits(h->stream, h->obs_raw, count, d);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(bits, d, (count + 7) / 8, hipMemcpyDeviceToHost, h->stream);
