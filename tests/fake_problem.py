@@ -29,6 +29,29 @@ class OracleProblem:
         self.reduce_tensor = torch.zeros(self.nsys + 8, dtype=torch.float64)
         self._red = self.reduce_tensor.numpy()
 
+    # ---- box constraints and the working set of the bounded loop (ops.Problem.set_bounds / set_frozen), in numpy
+    def set_bounds(self, lo, hi):
+        self.lo = None if lo is None else np.asarray(lo, float)
+        self.hi = None if hi is None else np.asarray(hi, float)
+
+    def set_frozen(self, mask):
+        self.frozen_f = None if mask is None else np.asarray(mask, bool)[self.n:].reshape(self.F, 6)
+
+    def _frozen_blocks(self):
+        """(V, gf, W) with the frozen frame coordinates taken out: identity row / column in V_f, zero gradient entry, zero column of W."""
+        U, gc, V, gf, W, cost = self.lin
+        fr = getattr(self, "frozen_f", None)
+        if fr is None or not fr.any():
+            return V, gf, W
+        V, gf, W = V.copy(), gf.copy(), W.copy()
+        for f, k in zip(*np.nonzero(fr)):
+            V[f, k, :] = 0.0
+            V[f, :, k] = 0.0
+            V[f, k, k] = 1.0
+            gf[f, k] = 0.0
+            W[:, f, :, k] = 0.0
+        return V, gf, W
+
     def set_curvature_floor(self, floor):
         old, self.curv_floor = self.curv_floor, float(floor)
         return old
@@ -51,7 +74,11 @@ class OracleProblem:
         Df2 = np.stack([np.where(np.diag(V[f]) > 0, np.diag(V[f]), 1.0) for f in range(self.F)])
         if self.x_scale is not None:  # numeric x_scale: fixed D = 1 / x_scale^2
             Df2 = 1.0 / self.x_scale[self.n:].reshape(self.F, 6) ** 2
-        S, rhs = orc.schur_reduce(U, gc, V, gf, W, lam, np.zeros((self.C, 12)), Df2)
+        Vm, gfm, Wm = self._frozen_blocks()
+        fr = getattr(self, "frozen_f", None)
+        if fr is not None and fr.any():
+            Df2 = np.where(fr, 0.0, Df2)   # (the frozen coordinates' diagonal entries are the identity's, undamped)
+        S, rhs = orc.schur_reduce(U, gc, Vm, gfm, Wm, lam, np.zeros((self.C, 12)), Df2)
         r = self._red
         r[:] = 0
         r[: n * n] = S.ravel()
@@ -60,7 +87,7 @@ class OracleProblem:
         r[n * n + 2 * n : n * n + 3 * n] = gc.ravel()
         sc = r[n * n + 3 * n : n * n + 3 * n + 16]
         sc[0] = cost
-        sc[4 + rank_slot] = np.abs(gf).max()
+        sc[4 + rank_slot] = np.abs(gfm).max()
         self.Df2, self.lam = Df2, lam
 
     def get_reduced(self):
@@ -71,14 +98,17 @@ class OracleProblem:
     def step(self, dc, lam, src, dst):
         self.calls["step"] += 1
         U, gc, V, gf, W, cost = self.lin
-        df = orc.back_substitute(np.asarray(dc), V, gf, W, lam, self.Df2)
+        Vm, gfm, Wm = self._frozen_blocks()
+        df = orc.back_substitute(np.asarray(dc), Vm, gfm, Wm, lam, self.Df2)
         xs = self.x[src]
         self.x[dst] = xs + np.concatenate([dc, df.ravel()])
+        if getattr(self, "lo", None) is not None:   # the trial point, projected onto the box (ops: k_clip)
+            self.x[dst] = np.minimum(np.maximum(self.x[dst], self.lo), self.hi)
         f = orc.residuals(self.x[dst], self.uvs, self.obj)
         t = self._red[self.nsys :]
         t[:] = 0
         t[0] = orc.robust_cost(f, self.loss, self.f_scale)
-        t[1] = np.sum(df * (lam * self.Df2 * df - gf))
+        t[1] = np.sum(df * (lam * self.Df2 * df - gfm))
         t[2] = np.sum(df * df)
         t[3] = np.sum(xs[self.n :] ** 2)
         t[4] = f.size

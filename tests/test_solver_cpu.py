@@ -1,7 +1,9 @@
 """Host-side LM / Schur driver (multicam-calibration_amd/solver.py) exercised on the CPU through an
 oracle-backed test double of ops.Problem: convergence to the reference's tight optimum, fixed
 intrinsics, termination codes, and the world_size-2 frame-sharded path over gloo."""
+import contextlib
 import datetime
+import io
 import os
 import socket
 import sys
@@ -461,3 +463,21 @@ def test_find_active_constraints_is_scipys():
     x = np.where(rng.random(200) < 0.3, np.where(np.isfinite(ub), ub - rng.choice([0.0, 1e-11, 1e-8], size=200), x), x)
     for rtol in (0.0, 1e-10, 1e-8, 1e-6):
         np.testing.assert_array_equal(solver.find_active_constraints(x, lb, ub, rtol), ref(x, lb, ub, rtol))
+
+
+def test_bounded_loop_on_the_oracle_double_reaches_the_reference_bounded_optimum(monkeypatch):
+    """The active-set loop (solver.BoundedLevenbergMarquardt) on the CPU test double -- its working set, projection and release logic
+    without a GPU -- against the same golden as the GPU test: the reference's own bounded run, polished and certified
+    (tests/golden/make_golden_bounds.py)."""
+    from conftest import GOLDEN, problem_from_npz
+    from multicam_calibration_amd import api, ops
+
+    z = np.load(os.path.join(GOLDEN, "tight_bounds_config1.npz"), allow_pickle=False)
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    monkeypatch.setattr(ops, "Problem", OracleProblem)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, i, p_, use, res = api.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=None, bounds=(z["lo"], z["hi"]), ftol=1e-15, xtol=1e-15, gtol=1e-9, verbose=0, max_nfev=300, return_jac=False)
+    np.testing.assert_array_equal(use, z["use"])
+    assert res.status > 0 and np.all(res.x >= z["lo"]) and np.all(res.x <= z["hi"])
+    assert abs(res.cost - float(z["cost"])) <= 1e-9 * res.cost
+    np.testing.assert_array_equal(res.active_mask, z["active_mask"])
