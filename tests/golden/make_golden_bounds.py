@@ -26,28 +26,32 @@ sys.dont_write_bytecode = True
 from make_golden import load_reference, problem_arrays  # noqa: E402
 
 
-def main():
+def main(tag="config1"):
     from multicam_calibration_amd import synth
     from oracle import ba_oracle as orc
     from scipy.optimize._lsq.common import find_active_constraints
     from scipy.optimize._numdiff import approx_derivative, group_columns
 
     geo, ba = load_reference()
-    q = synth.make_problem(2, 50, seed=0, perturb_seed=1)
+    # config1: BASELINE configs[0]; missing3: three cameras, 30 frames, a quarter of the detections and six single scalars missing (the same
+    # problems as the unconstrained goldens tight_config1.npz / tight_missing3.npz of make_golden.py --slow, whose optima place the bounds)
+    q = synth.make_problem(2, 50, seed=0, perturb_seed=1) if tag == "config1" else synth.make_problem(3, 30, seed=40, missing=0.25, scalar_nans=6, perturb_seed=1)
+    C = q["uvs"].shape[0]
     with contextlib.redirect_stdout(io.StringIO()):
         use = ba.bundle_adjust(q["uvs"], q["extrinsics"], q["intrinsics"], q["obj"], q["poses"], n_frames=None, max_nfev=1, verbose=0)[3]
     uvs = q["uvs"][:, use]
     x0 = ba.serialize_params(q["extrinsics"], q["intrinsics"], q["poses"][use])
-    xu = np.load(os.path.join(HERE, "tight_config1.npz"))["s0_x"]   # the unconstrained tight optimum of the same problem (make_golden.py --slow)
+    xu = np.load(os.path.join(HERE, f"tight_{tag}.npz"))["s0_x"]   # the unconstrained tight optimum of the same problem (make_golden.py --slow)
     assert xu.shape == x0.shape
     n = x0.size
     lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
     # bounds half-way between the start and the unconstrained optimum: feasible at x0, violated at the unconstrained optimum
     # (board poses: ONE bounded pose coordinate can always be evaded through the 6-dimensional gauge freedom -- a rigid motion of all poses
     #  against the cameras costs nothing --, so a dozen of them are bounded, close to the start: more than the gauge can absorb)
-    pose_idx = tuple(24 + 6 * f + 5 for f in range(12)) + (24 + 6 * 20 + 0, 24 + 6 * 31 + 4)
-    for i in (4, 5, 12 + 4, 12 + 5, 12 + 0) + pose_idx:
-        b = x0[i] + (0.5 if i < 24 else 0.1) * (xu[i] - x0[i])
+    nc = 12 * C
+    pose_idx = tuple(nc + 6 * f + 5 for f in range(12)) + (nc + 6 * 20 + 0, nc + 6 * (len(use) - 3) + 4)
+    for i in (4, 5, 12 + 4, 12 + 5, 12 + 0) + ((24 + 1, 24 + 5) if C > 2 else ()) + pose_idx:
+        b = x0[i] + (0.5 if i < nc else 0.1) * (xu[i] - x0[i])
         if xu[i] > x0[i]:
             hi[i] = b
         else:
@@ -56,7 +60,7 @@ def main():
     for i in (0, 1, 2, 3, 12 + 1, 12 + 2, 12 + 3):
         lo[i] = min(lo[i], x0[i] - 500.0) if np.isfinite(lo[i]) else x0[i] - 500.0
         hi[i] = hi[i] if np.isfinite(hi[i]) else x0[i] + 500.0
-    for i in (24 + 6 * 7 + 3, 24 + 6 * 7 + 4, 24 + 6 * 7 + 5):
+    for i in (nc + 6 * 7 + 3, nc + 6 * 7 + 4, nc + 6 * 7 + 5):
         lo[i], hi[i] = x0[i] - 300.0, x0[i] + 300.0
     assert np.all(lo < hi) and np.all(x0 >= lo) and np.all(x0 <= hi)
 
@@ -111,15 +115,19 @@ def main():
     outward = np.all(g_fd[active == -1] > 0) and np.all(g_fd[active == 1] < 0)
     print("polished: cost %.15g (reference run %.15g, unconstrained %.15g)  KKT residual %.2e  FD gradient on the free set %.2e  active %d (lower %d, upper %d), multipliers point outward: %s"
           % (cost, res.cost, orc.robust_cost(ba.residuals(xu, uvs, q["obj"])), r, np.abs(g_fd[active == 0]).max(), int((active != 0).sum()), int((active == -1).sum()), int((active == 1).sum()), outward))
+    print("active indices", np.nonzero(active)[0], "camera block ends at", nc)
     assert outward and (active != 0).sum() >= 2 and np.array_equal(active != 0, work)
-    assert (active[:24] != 0).sum() >= 2 and (active[24:] != 0).sum() >= 1, "want active bounds on camera parameters AND on a board pose"
-    assert np.array_equal(active, find_active_constraints(np.clip(res.x, lo, hi), lo, hi, rtol=1e-6)), "the reference's run and the polish disagree on the active set"
+    assert (active[:nc] != 0).sum() >= 1 and (active[nc:] != 0).sum() >= 1, "want active bounds on camera parameters AND on a board pose"
+    same_set = np.array_equal(active, find_active_constraints(np.clip(res.x, lo, hi), lo, hi, rtol=1e-6))
+    print("the reference's own run (400 evaluations of scipy's bounded TRF + LSMR) has", "the same active set" if same_set else "NOT reached the active set of the optimum (it is far from converged: see its cost)")
+    assert same_set or tag != "config1"
     out = problem_arrays(q)
     out.update(use=use, lo=lo, hi=hi, x=xp, cost=np.array(cost), active_mask=active, kkt_residual=np.array(r), fd_grad_free_inf=np.array(np.abs(g_fd[active == 0]).max()),
                ref_run_x=res.x, ref_run_cost=np.array(res.cost), ref_run_active_mask=res.active_mask, ref_run_nfev=np.array(res.nfev), ref_run_status=np.array(res.status))
-    np.savez_compressed(os.path.join(HERE, "tight_bounds_config1.npz"), **out)
-    print("tight_bounds_config1.npz written")
+    np.savez_compressed(os.path.join(HERE, f"tight_bounds_{tag}.npz"), **out)
+    print(f"tight_bounds_{tag}.npz written")
 
 
 if __name__ == "__main__":
-    main()
+    for t in (sys.argv[1:] or ["config1", "missing3"]):
+        main(t)

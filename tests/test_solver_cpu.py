@@ -465,14 +465,15 @@ def test_find_active_constraints_is_scipys():
         np.testing.assert_array_equal(solver.find_active_constraints(x, lb, ub, rtol), ref(x, lb, ub, rtol))
 
 
-def test_bounded_loop_on_the_oracle_double_reaches_the_reference_bounded_optimum(monkeypatch):
+@pytest.mark.parametrize("tag", ["config1", "missing3"])
+def test_bounded_loop_on_the_oracle_double_reaches_the_reference_bounded_optimum(monkeypatch, tag):
     """The active-set loop (solver.BoundedLevenbergMarquardt) on the CPU test double -- its working set, projection and release logic
     without a GPU -- against the same golden as the GPU test: the reference's own bounded run, polished and certified
     (tests/golden/make_golden_bounds.py)."""
     from conftest import GOLDEN, problem_from_npz
     from multicam_calibration_amd import api, ops
 
-    z = np.load(os.path.join(GOLDEN, "tight_bounds_config1.npz"), allow_pickle=False)
+    z = np.load(os.path.join(GOLDEN, f"tight_bounds_{tag}.npz"), allow_pickle=False)
     uvs, ext, intr, obj, poses = problem_from_npz(z)
     monkeypatch.setattr(ops, "Problem", OracleProblem)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -480,4 +481,10 @@ def test_bounded_loop_on_the_oracle_double_reaches_the_reference_bounded_optimum
     np.testing.assert_array_equal(use, z["use"])
     assert res.status > 0 and np.all(res.x >= z["lo"]) and np.all(res.x <= z["hi"])
     assert abs(res.cost - float(z["cost"])) <= 1e-9 * res.cost
-    np.testing.assert_array_equal(res.active_mask, z["active_mask"])
+    # (the constrained minimiser is a manifold -- one gauge freedom is left --: the active set on the gauge-invariant intrinsics is the
+    #  golden's; on config1 the whole set is)
+    C = uvs.shape[0]
+    intr_idx = np.array([12 * c + k for c in range(C) for k in range(6)])
+    np.testing.assert_array_equal(res.active_mask[intr_idx], z["active_mask"][intr_idx])
+    if tag == "config1":
+        np.testing.assert_array_equal(res.active_mask, z["active_mask"])
