@@ -46,12 +46,13 @@ extern "C" {
 #define MCBA_LOSS_HUBER 2
 #define MCBA_LOSS_CAUCHY 3
 #define MCBA_LOSS_ARCTAN 4
+#define MCBA_LOSS_TABLE 5   /* not a name for mcba_set_loss: what mcba_set_loss_table switches the handle to (least_squares' callable `loss`) */
 
 typedef struct mcba_handle mcba_handle;
 typedef struct mcba_buffer mcba_buffer;   /* a device array that outlives its handle (mcba_residuals_detach) */
 
 /* ---- library ------------------------------------------------------------------------------- */
-int mcba_abi_version(void);            /* 6.  Bumped when this header changes: 6 (round 5) ADDS mcba_prefilter, mcba_lm_run, mcba_lm_history, mcba_lm_result and leaves every
+int mcba_abi_version(void);            /* 6.  Bumped when this header changes: 6 (round 5) ADDS mcba_prefilter, mcba_lm_run, mcba_lm_history, mcba_lm_result, mcba_set_bounds / _frozen, mcba_set_loss_table and leaves every
                                         * ABI-5 entry point as it was.  (ABI 5 gave LM-state slots 25 / 26 -- "reserved" before -- their meaning: curvature floor / switch
                                         * fraction; a caller that zeroes them gets the handle's floor, fixed.) */
 const char* mcba_last_error(void);
@@ -82,6 +83,13 @@ int mcba_set_stream(mcba_handle* h, void* hip_stream);
 int mcba_upload_observations(mcba_handle* h, const double* uvs, const double* objpoints);
 /* Robust loss and f_scale of least_squares (default soft_l1, 1.0: bundle_adjustment.py:301-303). */
 int mcba_set_loss(mcba_handle* h, int loss, double f_scale);
+/* least_squares' CALLABLE `loss` -- rho(z) -> (rho, rho', rho'') (least_squares.py:160-227; the reference forwards it untouched: bundle_adjustment.py:301-313).
+ * The function is the caller's, so are its values: tab3 = three (C,F,N,2) arrays in the order of the observations, evaluated at the residuals
+ * (mcba_residuals) of the point that is linearised next: [0] 0.5 f_scale^2 rho(z), [1] rho'(z), [2] max(rho' + 2 rho'' z, EPS) (scipy's J_scale^2,
+ * common.py:720-731); entries of missing observations are ignored.  mcba_linearize then builds the normal equations with these weights; the
+ * trial cost of mcba_step is the caller's to evaluate (its function on the trial residuals); mcba_jacobian_eval returns unscaled rows;
+ * mcba_step_linearize and the device-resident loops (mcba_lm_iterate, mcba_lm_auto_*, mcba_lm_run) refuse to run.  mcba_set_loss switches back. */
+int mcba_set_loss_table(mcba_handle* h, const double* tab3);
 
 /* Camera block width (round 4, ABI 5).  12 (default): all 12 parameters of every camera are variables, as in the reference
  * (bundle_adjustment.py:113,121-122,149-155).  6: the intrinsics (fx fy cx cy k1 k2) of EVERY camera are held fixed -- BASELINE

@@ -140,9 +140,14 @@ class _JacobianSource:
             m = self.mask(prob)
             uvs = np.zeros(self.shape4) if m is None else np.where(m, 0.0, np.nan)   # (jacobian_structure only looks at which scalars are NaN)
             idx, indptr, shape, mask = jacobian_structure(uvs)  # CSR indices: 0.25 s of numpy at 6 x 10k x 54 -- only when asked for
-            prob.jacobian_eval(slot, robust_scaled=self.robust)
+            own_rho = callable(self.loss)   # least_squares' callable loss: unscaled rows from the GPU, scipy's row scale from the caller's function (common.py:720-731)
+            prob.jacobian_eval(slot, robust_scaled=self.robust and not own_rho)
             data, _ = prob.jacobian_download(want_res=False)
-            return sp.csr_matrix((data[mask].ravel(), idx, indptr), shape=shape)
+            data = data[mask]
+            if own_rho:
+                _, z, rho = prob.loss_values(slot)
+                data *= np.sqrt(np.maximum(rho[1] + 2.0 * rho[2] * z, np.finfo(float).eps))[:, None]
+            return sp.csr_matrix((data.ravel(), idx, indptr), shape=shape)
         finally:
             self.release()
             self.host_uvs = None
@@ -382,8 +387,8 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     kw = dict(verbose=2, x_scale="jac", ftol=1e-4, method="trf", loss="soft_l1")
     kw.update(opt_kwargs)
     box = kw.pop("bounds", None)
-    if callable(kw.get("loss")):
-        raise NotImplementedError("callable losses are not supported by the GPU solver")
+    if callable(kw.get("loss")) and distributed:
+        raise NotImplementedError("a callable loss is not supported with distributed=True")
     unknown = set(kw) - set(_PATH_ONLY) - {"verbose", "ftol", "xtol", "gtol", "max_nfev", "loss", "f_scale", "x_scale"}
     if unknown:
         raise TypeError(f"unsupported least_squares keyword(s) for the GPU solver: {sorted(unknown)}")
@@ -560,7 +565,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             result.grad = grad
         if return_jac:
             # (no reference to the caller's array is kept: a result whose handle has to be released first copies its observations back from the GPU)
-            jsrc = _JacobianSource(prob, calib_objpoints, x_local, slot, kw["loss"], kw.get("f_scale", 1.0), device, kw["loss"] != "linear", need_mask, shape4)
+            jsrc = _JacobianSource(prob, calib_objpoints, x_local, slot, kw["loss"], kw.get("f_scale", 1.0), device, callable(kw["loss"]) or kw["loss"] != "linear", need_mask, shape4)
             dict.__setitem__(result, "jac", _Lazy(jsrc.csr))
             prob = None   # owned by the lazy `jac` field now (closed when that field is produced, with the result, or under MCBA_JAC_HOLD_MB pressure)
     finally:

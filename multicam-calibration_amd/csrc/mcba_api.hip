@@ -78,6 +78,7 @@ struct mcba_handle {
   std::vector<unsigned char> frozen_host;  // coordinates taken out of the system (mcba_set_frozen; empty = none)
   double *blo = nullptr, *bhi = nullptr;   // box constraints (mcba_set_bounds), in the layout of x
   bool have_bounds = false;
+  double* loss_tab = nullptr;   // loss == LOSS_TABLE (mcba_set_loss_table): [3][C][N][Fpad] (u, v) pairs, laid out as obs_t
   int fuse_max_polls = 200000;
   bool strict_sync = false;   // the fused back-substitution's readers acquire the release word with an agent-scope fence (MCBA_STRICT_SYNC=1 / mcba_set_strict_sync)
   unsigned char* fixed = nullptr;
@@ -683,6 +684,36 @@ int mcba_set_loss(mcba_handle* h, int loss, double f_scale) {
   return MCBA_OK;
 }
 
+static int ensure_res(mcba_handle* h);
+
+// least_squares' CALLABLE `loss` (least_squares.py:160-227: rho(z) -> (rho, rho', rho''); the reference forwards it untouched,
+// bundle_adjustment.py:301-313): the function is the caller's, so its values are -- tab3 = three (C,F,N,2) arrays in the order of the
+// observations, evaluated by the caller at the residuals of the point it is about to linearise:
+//   [0] this scalar's share of the cost, 0.5 f_scale^2 rho(z)      [1] rho'(z)      [2] scipy's J_scale^2 = max(rho' + 2 rho'' z, EPS)
+// (entries of missing observations are ignored).  From this call on the handle's loss is MCBA_LOSS_TABLE: mcba_linearize builds the normal
+// equations with these weights (k_gram_table), the trial cost of mcba_step is NOT evaluated with it (the caller evaluates its function
+// on mcba_residuals of the trial point), mcba_jacobian_eval returns unscaled rows, and the device-resident loops refuse to run -- the host
+// must call the function between a step and the next linearisation.  mcba_set_loss with one of the five names switches back.
+int mcba_set_loss_table(mcba_handle* h, const double* tab3) {
+  if (!h || !tab3) return fail(MCBA_ERR_ARG, "mcba_set_loss_table: NULL argument");
+  if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_set_loss_table: upload observations first");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_res(h);
+  if (rc) return rc;
+  const size_t raw = (size_t)2 * h->C * h->F * h->N, plane = (size_t)2 * h->C * h->N * h->Fpad;
+  if (!h->loss_tab && (rc = dalloc(h, &h->loss_tab, 3 * plane, false))) return rc;
+  for (int k = 0; k < 3; ++k) {   // through the residual buffer as staging (the stream orders copy -> re-layout -> next copy)
+    HIPCHK(hipMemcpyAsync(h->res, tab3 + k * raw, raw * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    mcba::launch_transpose_obs(h->stream, h->res, h->loss_tab + k * plane, h->C, h->F, h->N, h->Fpad);
+  }
+  if ((rc = check_launch())) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));   // (tab3 is the caller's pageable memory)
+  h->loss = mcba::LOSS_TABLE;
+  h->f_scale = 1.0;   // (folded into the table by the caller)
+  h->have_lin = h->have_red = false;
+  return MCBA_OK;
+}
+
 // Camera block width: 12 (every camera parameter is a variable: the reference, bundle_adjustment.py:149-155) or 6 = the intrinsics
 // (fx fy cx cy k1 k2) of EVERY camera are held fixed -- BASELINE configs[1]; SURVEY section 8c-8's wrapper around the reference's
 // residuals().  With 6 the solver kernels run role A of the linearisation alone, the camera system is 6C x 6C (row i = parameter
@@ -839,7 +870,7 @@ int mcba_linearize(mcba_handle* h, int slot) {
   NEED_SOLVER(h);
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[slot], h->x[slot], h->rec2[h->lin], h->rec2[h->lin], h->gpart2[h->lin], h->gpart2[h->lin], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots, h->loss_tab);
   }
   int rc = check_launch();
   if (rc) return rc;
@@ -913,13 +944,14 @@ int mcba_step(mcba_handle* h, const double* delta_cam, double lambda, int src, i
 int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, int src, int dst) {
   if (!slot_ok(h, src) || !slot_ok(h, dst) || src == dst || !delta_cam) return fail(MCBA_ERR_ARG, "mcba_step_linearize: bad argument (slots must differ)");
   if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_step_linearize: call mcba_build_reduced first");
+  if (h->loss == mcba::LOSS_TABLE) return fail(MCBA_ERR_ARG, "mcba_step_linearize: a tabulated loss is set -- step (mcba_step), evaluate the function at the trial residuals, mcba_set_loss_table, then mcba_linearize");
   HIPCHK(hipSetDevice(h->device));
   int rc = step_common(h, delta_cam, lambda, src, dst);
   if (rc) return rc;
   const int alt = 1 - h->lin;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[dst], h->x[dst], h->rec2[alt], h->rec2[alt], h->gpart2[alt], h->gpart2[alt], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots, h->loss_tab);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -985,6 +1017,7 @@ int mcba_lm_set_state(mcba_handle* h, const double* state) {
 static int lm_trial_impl(mcba_handle* h, const double* delta_cam, const mcba::DecideArgs& da) {
   if (!h || !delta_cam) return fail(MCBA_ERR_ARG, "mcba_lm_trial: bad argument");
   if (h->have_bounds) return fail(MCBA_ERR_ARG, "box constraints are set (mcba_set_bounds): drive the steps with mcba_step / mcba_step_linearize (the host-driven loop)");
+  if (h->loss == mcba::LOSS_TABLE) return fail(MCBA_ERR_ARG, "a tabulated loss is set (mcba_set_loss_table): the device-resident loops cannot call the caller's function -- use the host-driven loop");
   if (!h->have_lin) return fail(MCBA_ERR_ARG, "mcba_lm_trial: no linearisation");
   HIPCHK(hipSetDevice(h->device));
   mcba::CamStep cs;
@@ -997,7 +1030,7 @@ static int lm_trial_impl(mcba_handle* h, const double* delta_cam, const mcba::De
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);  // trial point = the OTHER slot / buffer
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, dev_sel(h, 1)), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, dev_sel(h, 1)), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots, h->loss_tab);
   }
   if ((rc = check_launch())) return rc;
   {
@@ -1181,6 +1214,7 @@ int mcba_lm_set_decrease_floor(mcba_handle* h, double dec_floor) {
 static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   if (!h || !h->auto_ready) return fail(MCBA_ERR_ARG, "mcba_lm_auto_trial: call mcba_lm_auto_config first");
   if (h->have_bounds) return fail(MCBA_ERR_ARG, "box constraints are set (mcba_set_bounds): the device-resident loop does not project its trial points -- use the host-driven loop");
+  if (h->loss == mcba::LOSS_TABLE) return fail(MCBA_ERR_ARG, "a tabulated loss is set (mcba_set_loss_table): the device-resident loops cannot call the caller's function -- use the host-driven loop");
   if (!h->have_lin) return fail(MCBA_ERR_ARG, "mcba_lm_auto_trial: no linearisation");
   HIPCHK(hipSetDevice(h->device));
   int rc;
@@ -1192,7 +1226,7 @@ static int auto_trial_impl(mcba_handle* h, int decide, bool sum_here) {
   if ((rc = check_launch())) return rc;
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, dev_sel(h, 1)), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, dev_sel(h, 1)), h->x[0], h->x[1], h->rec2[0], h->rec2[1], h->gpart2[0], h->gpart2[1], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots, h->loss_tab);
   }
   if ((rc = check_launch())) return rc;
   if (!sum_here) return MCBA_OK;
@@ -1327,6 +1361,7 @@ int mcba_lm_run(mcba_handle* h, const double* x0, const double* opt, const unsig
   if (!h || !opt || !summary) return fail(MCBA_ERR_ARG, "mcba_lm_run: bad argument");
   if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_lm_run: upload observations first");
   if (h->have_bounds) return fail(MCBA_ERR_ARG, "mcba_lm_run: box constraints are set (mcba_set_bounds) -- use the host-driven loop");
+  if (h->loss == mcba::LOSS_TABLE) return fail(MCBA_ERR_ARG, "mcba_lm_run: a tabulated loss is set (mcba_set_loss_table) -- use the host-driven loop");
   const double lam0 = opt[3], lam_min = opt[4], lam_max = opt[5], cfl = opt[7], cfl_switch = opt[8];
   const int depth = std::max(1, std::min((int)opt[11], 12)), rank_slot = (int)opt[12];
   const double max_nfev = opt[9], max_ticks = opt[10];
@@ -1342,7 +1377,7 @@ int mcba_lm_run(mcba_handle* h, const double* x0, const double* opt, const unsig
   h->lin = 0;   // parameter slot 0 and linearisation buffer 0 belong together (mcba_lm_set_state's convention)
   {
     Scope sc(h, K_GRAM);
-    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[0], h->x[0], h->rec2[0], h->rec2[0], h->gpart2[0], h->gpart2[0], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots);
+    mcba::launch_gram(h->stream, h->loss, h->f_scale, h->obs_t, h->obj, gram_sel(h, host_sel(0)), h->x[0], h->x[0], h->rec2[0], h->rec2[0], h->gpart2[0], h->gpart2[0], h->C, h->N, h->Fpad, h->gram_split, h->planar, h->gchunk, h->gram_nchunk, h->gram_npw, h->cw, h->slots, h->loss_tab);
   }
   if ((rc = check_launch())) return rc;
   h->have_lin = true; h->have_spec = false;
@@ -1574,7 +1609,7 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
   mcba_handle* h = *out;
   if (src->stream != h->stream) HIPCHK(hipStreamSynchronize(h->stream));  // mcba_create's zero fills ran on the creation stream
   h->stream = src->stream;
-  h->loss = src->loss;
+  h->loss = src->loss == mcba::LOSS_TABLE ? MCBA_LOSS_SOFT_L1 : src->loss;   // (a table belongs to its frames: the subset starts from the default)
   h->f_scale = src->f_scale;
   h->strict_sync = src->strict_sync;
   // (the index list lives and dies with the new handle: nothing to free here, so nothing to wait for)

@@ -75,7 +75,8 @@ void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, 
                  double* chunk = nullptr, int nchunk = 0,   // split == 3: scratch for the point-chunk tail (gram_chunk_doubles) and the number of chunks
                  int npw = 4,                               // split == 4 / 5 (point split inside the workgroup): wavefronts per (camera, frame block), 4 or 2
                  int cw = 12,                               // camera block width: 12, or 6 = intrinsics held fixed (role A alone: split 4 = point split, anything else = the role-A half of the split roles)
-                 int slots = 1024);                         // wavefront slots of the device (4 x CUs): where the launch variants cut a shard into rounds
+                 int slots = 1024,                          // wavefront slots of the device (4 x CUs): where the launch variants cut a shard into rounds
+                 const double* ltab = nullptr);             // loss == LOSS_TABLE: three planes [C][N][Fpad] of (u, v) pairs -- 0.5 f_scale^2 rho, rho', J_scale^2 (mcba_set_loss_table)
 void gram_time_next_launch(hipEvent_t start, hipEvent_t stop);  // measurement: the next fused k_gram launch of this thread carries the events on its dispatch (the kernel's own begin / end)
 bool gram_time_pending();                                       // ... still pending after the launch: another variant ran, bracket it the usual way
 int gram_round_blocks(int C, int nfb, int slots);   // frame blocks (a multiple of 4) that whole rounds of the wavefront slots cover; split 2 / 3 / 5 handle the rest as a tail

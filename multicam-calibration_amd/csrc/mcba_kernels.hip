@@ -120,6 +120,14 @@ __device__ __forceinline__ void obs_weights(double r, bool valid, double fs2, do
   g = valid ? gw * r : 0.0;
 }
 
+// LOSS_TABLE: the three numbers come from the caller's table (mcba_set_loss_table: 0.5 f_scale^2 rho, rho', scipy's J_scale^2 -- evaluated
+// by the caller's function at the residuals of the point being linearised), not from r
+__device__ __forceinline__ void obs_weights_table(double r, bool valid, double rh, double gw, double ww, double cfl, double& cost, double& w2, double& g) {
+  cost += valid ? rh : 0.0;
+  w2 = valid ? lm_weight(gw, ww, cfl) : 0.0;
+  g = valid ? gw * r : 0.0;
+}
+
 // ---------------------------------------------------------------- observation re-layout
 // raw (C,F,N,2) -> obs_t [C][N][Fpad] (u,v); frames f >= F are NaN (= missing, contribute nothing).
 // Through an LDS tile of 64 frames x 16 points: reads are 256 contiguous bytes per frame (16 points), writes 1 KB per point (64
@@ -171,7 +179,8 @@ template <int LOSS, int ROLE, bool FAST = false, int MODE = 0, int NPW = 1>
 __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x,
                                           double* __restrict__ rec, double* __restrict__ gpart, int c, int fb, int lane, int C, int N, int Fpad, int nfb, double fs2, double ifs2, double cfl,
                                           const double (&pz0)[6], const double2 (&pre)[4], double* s_cost, int nrun, int p_lo = 0, int p_hi = -1, double2* chunk = nullptr, int nchunk = 1,
-                                          size_t chunk_stride = 0) {
+                                          size_t chunk_stride = 0, const double2* __restrict__ ltab = nullptr) {
+  static_assert(LOSS != LOSS_TABLE || (ROLE != 2 && MODE == 0), "the tabulated loss runs the split-role kernel (k_gram_table)");
   if (p_hi < 0) p_hi = N;
   static_assert(MODE == 0 || ((ROLE == 2 || (MODE == 3 && ROLE == 0)) && MCBA_GRAM_PIPE), "point chunks exist for the pipelined loop only (both roles; role A alone in MODE 3: intrinsics held fixed)");
   static_assert(MODE == 3 ? (NPW == 2 || NPW == 4) : NPW == 1, "NPW wavefronts share a (camera, frame block) in MODE 3 only");
@@ -218,15 +227,23 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     ring[j] = pre[j];
     xring[j][0] = obj[3 * pj]; xring[j][1] = obj[3 * pj + 1]; xring[j][2] = obj[3 * pj + 2];
   }
-  auto point = [&](double2 o2, const double Xo[3]) {
+  auto point = [&](double2 o2, const double Xo[3], int pi) {
     bool vu = is_num(o2.x), vv = is_num(o2.y);
     if (vu || vv) {
       any = true;
       ObsCommon q;
       obs_common(K, pc, Xo, q);
       double wu2, wv2, gu, gv;
+      if constexpr (LOSS == LOSS_TABLE) {
+        // three planes [C][N][Fpad] of (u, v) pairs, laid out as the observations are
+        const size_t plane = (size_t)C * N * Fpad, at = (size_t)c * N * Fpad + (size_t)pi * Fpad + f;
+        const double2 t0 = ltab[at], t1 = ltab[plane + at], t2 = ltab[2 * plane + at];
+        obs_weights_table(o2.x - q.up, vu, t0.x, t1.x, t2.x, cfl, cost, wu2, gu);
+        obs_weights_table(o2.y - q.vp, vv, t0.y, t1.y, t2.y, cfl, cost, wv2, gv);
+      } else {
       obs_weights<LOSS>(o2.x - q.up, vu, fs2, ifs2, cfl, cost, wu2, gu);
       obs_weights<LOSS>(o2.y - q.vp, vv, fs2, ifs2, cfl, cost, wv2, gv);
+      }
       {  // u row, completely, before the v row exists: one [A|P] row live at a time
         double E[6];
         obs_row_cam<0>(q, E);
@@ -402,12 +419,12 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       const int pn = min(p + j + PF, N - 1);
       ring[j] = op[(size_t)pn * Fpad];
       xring[j][0] = obj[3 * pn]; xring[j][1] = obj[3 * pn + 1]; xring[j][2] = obj[3 * pn + 2];
-      point(o2, Xo);
+      point(o2, Xo, p + j);
     }
   }
 #pragma unroll
   for (int j = 0; j < PF; ++j)
-    if (p + j < N) point(ring[j], xring[j]);
+    if (p + j < N) point(ring[j], xring[j], p + j);
   }
 
 #ifdef MCBA_GRAM_TIMING
@@ -826,6 +843,22 @@ __global__ __launch_bounds__(256, 2) void k_gram_split(const double2* __restrict
   const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));  // wavefronts of this workgroup that have a frame block
   if (blockIdx.z == 0) gram_body<LOSS, 0>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, nrun);
   else gram_body<LOSS, 1>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, nrun);
+}
+
+// The caller's loss, tabulated (LOSS_TABLE; least_squares' callable `loss`): the split-role kernel with the table behind one more argument.
+// An off-default path driven from the host (solver.py evaluates the caller's function between the launches): the plain point loop.
+__global__ __launch_bounds__(256, 2) void k_gram_table(const double2* __restrict__ obs_t, const double* __restrict__ obj, Sel sl, const double* __restrict__ x0, const double* __restrict__ x1,
+                                                       double* __restrict__ rec0, double* __restrict__ rec1, double* __restrict__ gp0, double* __restrict__ gp1, int C, int N, int Fpad, int nfb, int fb0, int fb1,
+                                                       const double2* __restrict__ ltab) {
+  __shared__ CamConst s_cam;
+  __shared__ double s_cost[8];
+  GramStart g;
+  gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1);
+  if (!g.run) return;
+  const int c = blockIdx.y;
+  const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));
+  if (blockIdx.z == 0) gram_body<LOSS_TABLE, 0>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, 1.0, 1.0, g.cfl, g.pz, g.pre, s_cost, nrun, 0, -1, nullptr, 1, 0, ltab);
+  else gram_body<LOSS_TABLE, 1>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, c, g.fb, g.lane, C, N, Fpad, nfb, 1.0, 1.0, g.cfl, g.pz, g.pre, s_cost, nrun, 0, -1, nullptr, 1, 0, ltab);
 }
 
 // Both roles in one lane: grid.z = 1, one wave per SIMD (all 87 accumulators + temporaries in the 512-register file).
@@ -1763,9 +1796,13 @@ void gram_time_next_launch(hipEvent_t start, hipEvent_t stop) { t_ext_start = st
 bool gram_time_pending() { return t_ext_start != nullptr; }
 
 void launch_gram(hipStream_t st, int loss, double f_scale, const double* obs_t, const double* obj, Sel s, const double* x0, const double* x1, double* rec0, double* rec1, double* gp0, double* gp1, int C, int N, int Fpad, int split,
-                 int planar, double* chunk, int nchunk, int npw, int cw, int slots) {
+                 int planar, double* chunk, int nchunk, int npw, int cw, int slots, const double* ltab) {
   const int nfb = Fpad / 64;
   dim3 block(256);
+  if (loss == LOSS_TABLE) {   // (the caller's tabulated loss: one launch variant, whatever the shape; the intrinsics held fixed = role A alone)
+    k_gram_table<<<dim3((nfb + 3) / 4, C, cw == 6 ? 1 : 2), block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, s, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, nfb, 0, nfb, reinterpret_cast<const double2*>(ltab));
+    return;
+  }
   const double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
   const double2* o2 = reinterpret_cast<const double2*>(obs_t);
   auto fused = [&](int fb0, int fb1) {
@@ -1886,6 +1923,7 @@ void launch_cost(hipStream_t st, int loss, double f_scale, const double* obs_t, 
   int nfb = Fpad / 64;
   dim3 grid((nfb + 3) / 4, C, nch), block(256);
   double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
+  if (loss == LOSS_TABLE) loss = LOSS_LINEAR;   // (residuals are what this launch is for then: the cost of a tabulated loss is the caller's to evaluate)
   if (res) {
     DISPATCH_LOSS(loss, (k_cost<L, true><<<grid, block, 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, cpart, res, C, F, N, Fpad, nfb, nch, fs2, ifs2, fill)));
   } else {
@@ -2000,6 +2038,7 @@ void launch_decide(hipStream_t st, const double* trial8, DecideArgs da) {
 }
 
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust) {
+  if (loss == LOSS_TABLE) { loss = LOSS_LINEAR; robust = 0; }   // (tabulated loss: the unscaled rows; the caller scales them with its own rho)
   double fs2 = f_scale * f_scale, ifs2 = 1.0 / fs2;
   DISPATCH_LOSS(loss, (k_jacobian<L><<<dim3(F, C), dim3(64), 0, st>>>(reinterpret_cast<const double2*>(obs_raw), obj, x, jac, res, C, F, N, Fpad, robust, fs2, ifs2)));
 }

@@ -26,7 +26,8 @@
 
 namespace mcba {
 
-enum Loss { LOSS_LINEAR = 0, LOSS_SOFT_L1 = 1, LOSS_HUBER = 2, LOSS_CAUCHY = 3, LOSS_ARCTAN = 4 };
+enum Loss { LOSS_LINEAR = 0, LOSS_SOFT_L1 = 1, LOSS_HUBER = 2, LOSS_CAUCHY = 3, LOSS_ARCTAN = 4,
+            LOSS_TABLE = 5 };  // the caller's rho, tabulated per observed scalar at the point being linearised (mcba_set_loss_table: least_squares' callable `loss`)
 
 constexpr double MCBA_EPS = 2.220446049250313e-16;
 // Resolution of the robust cost as the kernels evaluate it (a sum over up to ~1e7 terms, reduced per wavefront, per workgroup, per

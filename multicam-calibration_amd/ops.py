@@ -41,6 +41,7 @@ SYMBOLS = [
     ("mcba_set_stream", ctypes.c_int, [_h, ctypes.c_void_p]),
     ("mcba_upload_observations", ctypes.c_int, [_h, _dp, _dp]),
     ("mcba_set_loss", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_double]),
+    ("mcba_set_loss_table", ctypes.c_int, [_h, _dp]),
     ("mcba_set_camera_block", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_get_camera_block", ctypes.c_int, [_h]),
     ("mcba_set_params", ctypes.c_int, [_h, ctypes.c_int, _dp]),
@@ -343,10 +344,54 @@ class Problem:
             return np.arange(12 * self.C)
         return (12 * np.arange(self.C)[:, None] + 6 + np.arange(6)[None, :]).ravel()
 
+    _loss_fn = None   # least_squares' callable `loss`, if that is what set_loss was given
+
     def set_loss(self, loss, f_scale=1.0):
+        """One of least_squares' five names, or its CALLABLE form rho(z) -> array (3, m) = (rho, rho', rho'') (least_squares.py:160-227; the
+        reference forwards `loss` untouched: bundle_adjustment.py:301-313).  A callable is evaluated HERE, on the residuals the GPU computed, each
+        time a point is linearised or a trial cost is asked for; its values go to the GPU as a table (include/mcba.h: mcba_set_loss_table).
+        Host-driven loop only (solver.py)."""
+        if callable(loss):
+            if not f_scale > 0:
+                raise ValueError("`f_scale` must be positive.")
+            self._loss_fn, self._loss_fs, self._loss_valid = loss, float(f_scale), None
+            return
         if loss not in LOSSES:
-            raise ValueError(f"loss must be one of {sorted(LOSSES)} (callable losses are not supported on the GPU path)")
+            raise ValueError(f"loss must be one of {sorted(LOSSES)} or a callable")
+        self._loss_fn = None
         self._chk(self.lib.mcba_set_loss(self.handle, LOSSES[loss], float(f_scale)))
+
+    @property
+    def loss_is_callable(self):
+        return self._loss_fn is not None
+
+    def loss_values(self, slot):
+        """The caller's rho at the residuals of x[slot], as scipy's loss_function wrapper hands it to the solver (least_squares.py: construct_loss_function):
+        (valid (C,F,N,2) bool, z (m,), rho (3, m)) over the observed scalars in the reference's row order; rho is None if a residual is not finite."""
+        if self._loss_valid is None:
+            self._loss_valid = np.unpackbits(self.seen_bits(), count=2 * self.C * self.F * self.N).astype(bool).reshape(self.C, self.F, self.N, 2)
+        f = self.residuals(slot)[self._loss_valid]
+        if not np.isfinite(f).all():
+            return self._loss_valid, None, None
+        z = (f / self._loss_fs) ** 2
+        rho = np.asarray(self._loss_fn(z), dtype=np.float64)
+        if rho.shape != (3, f.size):
+            raise ValueError("The return value of `loss` callable has wrong shape.")
+        return self._loss_valid, z, rho
+
+    def _callable_cost(self, slot):
+        _, _, rho = self.loss_values(slot)
+        return np.inf if rho is None else 0.5 * self._loss_fs**2 * float(np.sum(rho[0]))
+
+    def _refresh_loss_table(self, slot):
+        valid, z, rho = self.loss_values(slot)
+        if rho is None:
+            raise ValueError("Residuals are not finite in the initial point.")
+        tab = np.zeros((3,) + valid.shape)
+        tab[0][valid] = 0.5 * self._loss_fs**2 * rho[0]
+        tab[1][valid] = rho[1]
+        tab[2][valid] = np.maximum(rho[1] + 2.0 * rho[2] * z, np.finfo(float).eps)   # scipy's J_scale^2 (common.py:720-731; rho''/f_scale^2 * f^2 = rho'' z)
+        self._chk(self.lib.mcba_set_loss_table(self.handle, _p(tab)))
 
     def set_params(self, slot, x):
         x = _f64(x)
@@ -365,6 +410,8 @@ class Problem:
     def cost(self, slot):
         c, n = ctypes.c_double(), ctypes.c_double()
         self._chk(self.lib.mcba_cost(self.handle, slot, ctypes.byref(c), ctypes.byref(n)))
+        if self._loss_fn is not None:
+            return self._callable_cost(slot), n.value
         return c.value, n.value
 
     def residuals(self, slot):
@@ -450,6 +497,8 @@ class Problem:
         return jac, res
 
     def linearize(self, slot):
+        if self._loss_fn is not None:
+            self._refresh_loss_table(slot)   # the caller's rho at THIS point
         self._chk(self.lib.mcba_linearize(self.handle, slot))
 
     def build_reduced(self, lam, rank_slot=0):
@@ -481,9 +530,13 @@ class Problem:
     def step_fetch(self, delta_cam, lam, src, dst, linearize):
         """step / step_linearize + get_trial in one ABI crossing; returns a view of the 8 trial scalars."""
         self._dc[:] = delta_cam
+        if self._loss_fn is not None and linearize:
+            raise ValueError("a callable loss cannot linearise its trial point speculatively (its table is not known before the step): use speculative=False")
         rc = self.lib.mcba_step_fetch(self.handle, self._dc_p, lam, src, dst, 1 if linearize else 0, self._trial_p)
         if rc:
             self._chk(rc)
+        if self._loss_fn is not None:
+            self._trial[0] = self._callable_cost(dst)   # the trial cost is the caller's function on the trial residuals
         return self._trial
 
     def step(self, delta_cam, lam, src, dst):
@@ -500,6 +553,8 @@ class Problem:
 
     def get_trial(self):
         self._chk(self.lib.mcba_get_trial(self.handle, _p(self._trial)))
+        if self._loss_fn is not None:
+            raise ValueError("a callable loss: the trial cost comes with step_fetch (single process, host-driven loop)")
         return self._trial.copy()
 
     # ---- device-resident LM iteration (one host synchronisation per iteration)

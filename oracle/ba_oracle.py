@@ -225,8 +225,14 @@ def jacobian_csr(x, all_calib_uvs, calib_objpoints):
 
 # --------------------------------------------------------------------------- robust loss (scipy/optimize/_lsq/least_squares.py:160-227, common.py:720-731)
 def loss_rho(z, loss):
-    """rho(z), rho'(z), rho''(z) for scipy's built-in losses, z = (f/f_scale)^2."""
+    """rho(z), rho'(z), rho''(z) for scipy's built-in losses, z = (f/f_scale)^2 -- or from least_squares' CALLABLE form, a function
+    z -> array (3, m) (least_squares.py:160-227; construct_loss_function applies the f_scale factors exactly as for the names)."""
     z = np.asarray(z, dtype=float)
+    if callable(loss):
+        rho = np.asarray(loss(z), dtype=float)
+        if rho.shape != (3,) + z.shape:
+            raise ValueError("The return value of `loss` callable has wrong shape.")
+        return rho[0], rho[1], rho[2]
     if loss == "linear":
         return z.copy(), np.ones_like(z), np.zeros_like(z)
     if loss == "soft_l1":

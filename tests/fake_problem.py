@@ -134,6 +134,10 @@ class OracleProblem:
     def set_loss(self, loss, f_scale=1.0):
         self.loss, self.f_scale = loss, f_scale
 
+    @property
+    def loss_is_callable(self):
+        return callable(self.loss)
+
     # ---- the pre-filter interface of ops.Problem (api.select_frames), in numpy
     def _errors(self, slot):
         r = self.uvs - orc.predict_from_x(self.x[slot], self.C, self.obj)

@@ -16,6 +16,7 @@ Files written
   default_run.npz   default bundle_adjust() on config 1 (2 x 50 x 54)         (golden 5)
   robust.npz        scipy's soft_l1/huber/cauchy/arctan rho + rescale         (golden 7)
   tight_*.npz       (--slow) tight-optimum runs, SURVEY.md section 7 protocol (golden 6)
+  tight_config1_callable.npz  (--callable) the same recipe with a callable `loss` (tests/losses.py) + the reference's default run with it
   tight_edge_*.npz  (--edge) the same recipe on degenerate inputs (blind camera, 3 frames, 9 / 10 cameras with 40 % missing);
                     (--many) 24 and 27 cameras
 """
@@ -56,7 +57,7 @@ def problem_arrays(p):
     return dict(uvs=p["uvs"], obj=p["obj"], extrinsics=p["extrinsics"], K=K, dist=dist, poses=p["poses"])
 
 
-def main(slow, edge=False, many=False):
+def main(slow, edge=False, many=False, callable_loss=False):
     from multicam_calibration_amd import synth
     from scipy.optimize._numdiff import approx_derivative, group_columns
     from scipy.optimize._lsq.least_squares import construct_loss_function
@@ -171,7 +172,7 @@ def main(slow, edge=False, many=False):
     np.savez_compressed(os.path.join(HERE, "robust.npz"), **out)
     print("robust.npz")
 
-    if not (slow or edge or many):
+    if not (slow or edge or many or callable_loss):
         return
 
     # ---------------------------------------------------------------- golden 6: tight optimum (hard part 1)
@@ -246,6 +247,20 @@ def main(slow, edge=False, many=False):
         tight(dict(n_cameras=2, n_frames=50, seed=0), "config1", (1, 2))
         tight(dict(n_cameras=3, n_frames=30, seed=40, missing=0.25, scalar_nans=6), "missing3", (1, 2))
         tight(dict(n_cameras=2, n_frames=50, seed=0), "config1_cauchy", (1, 2), loss="cauchy", f_scale=0.5)
+    if callable_loss:
+        # least_squares' CALLABLE loss (the reference forwards `loss` untouched: bundle_adjustment.py:301-313): the same recipe with a function that is
+        # not one of the five names (tests/losses.py), + what the reference's own bundle_adjust(..., loss=function) returns with its default tolerances
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from losses import charbonnier_quarter
+
+        tight(dict(n_cameras=2, n_frames=50, seed=0), "config1_callable", (1, 2), loss=charbonnier_quarter, f_scale=0.7)
+        q = synth.make_problem(perturb_seed=1, n_cameras=2, n_frames=50, seed=0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = ba.bundle_adjust(q["uvs"], q["extrinsics"], q["intrinsics"], q["obj"], q["poses"], n_frames=None, loss=charbonnier_quarter, f_scale=0.7, verbose=0)
+        z = dict(np.load(os.path.join(HERE, "tight_config1_callable.npz")))
+        z.update(ref_default_x=r[4].x, ref_default_cost=np.array(r[4].cost), ref_default_nfev=np.array(r[4].nfev), ref_default_status=np.array(r[4].status))
+        np.savez_compressed(os.path.join(HERE, "tight_config1_callable.npz"), **z)
+        print("reference bundle_adjust(loss=<function>) default run: cost %.12g nfev %d status %d" % (r[4].cost, r[4].nfev, r[4].status))
     if edge:
         # degenerate inputs (SURVEY 8c edge cases) through the same recipe: a camera that never sees the board (its twelve
         # columns of the Jacobian vanish: the minimum-norm polish leaves its parameters where they started), fewer frames than
@@ -265,4 +280,4 @@ def main(slow, edge=False, many=False):
 
 
 if __name__ == "__main__":
-    main("--slow" in sys.argv, "--edge" in sys.argv, "--many" in sys.argv)
+    main("--slow" in sys.argv, "--edge" in sys.argv, "--many" in sys.argv, "--callable" in sys.argv)

@@ -441,3 +441,122 @@ def test_three_crossing_stub_over_raw_ctypes(mc):
     assert int(summary[0]) == res.status and 1 + int(rows[-1, 17]) == res.nfev
     np.testing.assert_array_equal(out[0], res.x)
     np.testing.assert_array_equal(out[1], res.grad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# least_squares' CALLABLE `loss` (the reference forwards `loss` untouched: bundle_adjustment.py:301-313; scipy least_squares.py:160-227)
+def test_callable_loss_builds_the_builtin_normal_equations(mc):
+    """soft_l1 written as a callable must give the normal equations, cost and gradient of the built-in name (the table of the caller's
+    rho values against the kernel's own rho: two routes to the same numbers), free and with the intrinsics held fixed."""
+    from losses import soft_l1_as_callable
+
+    p = mc.synth.make_problem(3, 70, seed=5, perturb_seed=2, missing=0.2, scalar_nans=4)
+    x0 = mc.api.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    for width in (12, 6):
+        got = []
+        for loss in ("soft_l1", soft_l1_as_callable):
+            prob = mc.ops.Problem(p["uvs"], p["obj"], loss=loss, f_scale=0.8)
+            if width == 6:
+                assert prob.set_camera_block(6)
+            prob.set_params(0, x0)
+            prob.linearize(0)
+            red = {k: v.copy() for k, v in prob.reduce_fetch(0.0).items()}
+            got.append((red, prob.frame_gradient().copy(), prob.cost(0)[0]))
+            if callable(loss):   # the device-resident loops cannot call back: they refuse
+                with pytest.raises(mc.ops.McbaError, match="tabulated loss"):
+                    prob.lm_run(None, 1e-8, 1e-8, 1e-8, 1e-3, 1e-12, 1e12, 0.1, 1.0, 0.01, 10, 10, 2)
+            prob.close()
+        (ra, ga, ca), (rb, gb, cb) = got
+        assert abs(ca - cb) <= 1e-13 * ca and abs(ra["scal"][0] - rb["scal"][0]) <= 1e-13 * ca
+        for k in ("S0", "rhs", "diagU", "gc"):
+            np.testing.assert_allclose(rb[k], ra[k], rtol=0, atol=1e-11 * np.abs(ra[k]).max(), err_msg=f"{k} width {width}")
+        np.testing.assert_allclose(gb, ga, rtol=0, atol=1e-11 * np.abs(ga).max())
+
+
+def test_callable_loss_reaches_the_reference_optimum(mc, golden):
+    """Golden = the reference's residual function minimised with a callable loss that is none of scipy's five names (generalised Charbonnier,
+    exponent 1/4, f_scale 0.7: tests/losses.py) to a tight, FD-certified optimum from two starts (tests/golden/make_golden.py --callable), + what
+    the reference's own bundle_adjust(..., loss=<function>) returns with its default tolerances.  bundle_adjust here with the same function:
+    cost to 1e-9, parameters to 1e-6; fun / jac / grad are scipy's (unscaled residuals, robust-rescaled rows, J^T f of the rescaled pair)."""
+    from conftest import problem_from_npz
+    from losses import charbonnier_quarter
+
+    z = golden("tight_config1_callable.npz")
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    (e, i, p_, use, res), out = captured(mc.bundle_adjust, uvs, ext, intr, obj, poses, n_frames=None, loss=charbonnier_quarter, f_scale=0.7, ftol=1e-14, xtol=1e-14, gtol=1e-9, verbose=2, max_nfev=300)
+    np.testing.assert_array_equal(use, z["s0_use"])
+    assert res.status in (1, 2, 3, 4), out
+    assert "Iteration" in out and res.lm["reduced_solver"] == "host"
+    assert abs(res.cost - float(z["s0_cost"])) <= 1e-9 * res.cost, (res.cost, float(z["s0_cost"]))
+    xg, C = z["s0_x"], uvs.shape[0]
+    cam, cam_g = res.x[:12 * C].reshape(C, 12), xg[:12 * C].reshape(C, 12)
+    assert (np.abs(cam[:, :6] - cam_g[:, :6]) / np.abs(cam_g[:, :6])).max() < 1e-6
+    ext_a, _, poses_a = orc.deserialize_params(res.x, C)
+    ext_g, _, poses_g = orc.deserialize_params(xg, C)
+    (cc, cb), (cc_g, cb_g) = orc.invariants(ext_a, poses_a), orc.invariants(ext_g, poses_g)
+    for a, b in ((cc, cc_g), (cb, cb_g)):
+        assert np.abs(a - b)[..., :3, :3].max() < 1e-6
+        assert (np.abs(a - b)[..., :3, 3] / np.abs(b[..., :3, 3]).max()).max() < 1e-6
+    # the oracle's view of the returned point (scipy's own arithmetic with the same function)
+    f = orc.residuals(res.x, uvs[:, use], obj)
+    assert abs(orc.robust_cost(f, charbonnier_quarter, 0.7) - res.cost) <= 1e-10 * res.cost
+    js, fs = orc.robust_scales(f, charbonnier_quarter, 0.7)
+    J = orc.jacobian_csr(res.x, uvs[:, use], obj)
+    g = J.T @ (js * fs)
+    np.testing.assert_allclose(res.fun, f, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res.grad, g, rtol=0, atol=1e-11 * (abs(J).T @ np.abs(js * fs)).max())   # (at the optimum the entries are what cancellation leaves of their terms)
+    Js = J.multiply(js[:, None]).tocsr()
+    assert res.jac.shape == Js.shape and np.array_equal(res.jac.indptr, Js.indptr)
+    assert abs(res.jac - Js).max() <= 1e-9 * abs(Js).max()
+    # ... and with the reference's default tolerances: at least as low as the reference's own run with this function (which stops early: ftol 1e-4)
+    (_, _, _, _, r1), _ = captured(mc.bundle_adjust, uvs, ext, intr, obj, poses, n_frames=None, loss=charbonnier_quarter, f_scale=0.7, verbose=0)
+    assert r1.cost <= float(z["ref_default_cost"]) * (1 + 1e-9) and r1.cost >= float(z["s0_cost"]) * (1 - 1e-9)
+
+
+def test_callable_loss_contract_and_combinations(mc):
+    """scipy's message for a function that returns the wrong shape; a callable with fix_intrinsics and with (inactive and active) bounds."""
+    from losses import charbonnier_quarter, soft_l1_as_callable
+
+    p = mc.synth.make_problem(2, 40, seed=3, perturb_seed=1)
+    args = (p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    with pytest.raises(ValueError, match="The return value of `loss` callable has wrong shape."):
+        captured(mc.bundle_adjust, *args, n_frames=None, loss=lambda z: np.ones((2, z.size)), verbose=0)
+    tol = dict(ftol=1e-13, xtol=1e-13, gtol=1e-9, verbose=0, n_frames=None, max_nfev=300)
+    # the callable form of soft_l1 ends where the name does (different drivers: host-driven table loop / device-resident loop)
+    (_, ia, _, _, ra), _ = captured(mc.bundle_adjust, *args, loss="soft_l1", **tol)
+    (_, ib, _, _, rb), _ = captured(mc.bundle_adjust, *args, loss=soft_l1_as_callable, **tol)
+    assert abs(ra.cost - rb.cost) <= 1e-10 * ra.cost
+    for (Ka, da), (Kb, db) in zip(ia, ib):
+        np.testing.assert_allclose(Kb, Ka, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(db, da, rtol=1e-5, atol=1e-9)
+    # fix_intrinsics: the 6-wide camera block with the table
+    (_, ic, _, _, rc), _ = captured(mc.bundle_adjust, *args, loss=charbonnier_quarter, fix_intrinsics=True, **tol)
+    (_, id_, _, _, rd), _ = captured(mc.bundle_adjust, *args, loss=charbonnier_quarter, fix_intrinsics=True, **dict(tol, ftol=1e-15, xtol=1e-15))
+    for (Kc, dc), (K0, d0) in zip(ic, p["intrinsics"]):
+        np.testing.assert_array_equal(Kc, K0)
+        np.testing.assert_array_equal(dc[:2], np.asarray(d0)[:2])
+    assert rc.x.size == 12 * 2 + 6 * 40   # (every frame is used: no detection is missing and none is an outlier)
+    f = orc.residuals(rc.x, p["uvs"], p["obj"])
+    assert abs(orc.robust_cost(f, charbonnier_quarter) - rc.cost) <= 1e-10 * rc.cost and abs(rc.cost - rd.cost) <= 1e-9 * rc.cost
+    # bounds: a box nothing touches changes nothing but the driver; a box on k1 that the optimum violates ends ON it
+    (_, _, _, _, r_free), _ = captured(mc.bundle_adjust, *args, loss=charbonnier_quarter, **tol)
+    n = r_free.x.size
+    lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
+    lo[0], hi[0] = r_free.x[0] - 1e4, r_free.x[0] + 1e4
+    (_, _, _, _, r_wide), _ = captured(mc.bundle_adjust, *args, loss=charbonnier_quarter, bounds=(lo, hi), **tol)
+    assert abs(r_wide.cost - r_free.cost) <= 1e-9 * r_free.cost and not r_wide.active_mask.any()
+    x0 = mc.api.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    k = 4   # k1 of camera 0: a bound half-way between the start and the free optimum
+    b = x0[k] + 0.5 * (r_free.x[k] - x0[k])
+    lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
+    if r_free.x[k] > x0[k]:
+        hi[k] = b
+    else:
+        lo[k] = b
+    (_, _, _, _, r_box), _ = captured(mc.bundle_adjust, *args, loss=charbonnier_quarter, bounds=(lo, hi), **tol)
+    assert r_box.x[k] == b and r_box.active_mask[k] != 0 and r_box.cost > r_free.cost
+    f = orc.residuals(r_box.x, p["uvs"], p["obj"])
+    js, fs = orc.robust_scales(f, charbonnier_quarter)
+    g = orc.jacobian_csr(r_box.x, p["uvs"], p["obj"]).T @ (js * fs)
+    free = r_box.active_mask == 0
+    assert np.abs(g[free]).max() < 1e-5 * max(1.0, abs(g[k]))

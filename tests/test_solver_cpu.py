@@ -488,3 +488,22 @@ def test_bounded_loop_on_the_oracle_double_reaches_the_reference_bounded_optimum
     np.testing.assert_array_equal(res.active_mask[intr_idx], z["active_mask"][intr_idx])
     if tag == "config1":
         np.testing.assert_array_equal(res.active_mask, z["active_mask"])
+
+
+def test_callable_loss_on_the_oracle_double_reaches_the_reference_optimum():
+    """least_squares' callable `loss` through solver.lm_solve on the oracle-backed double (the host-driven, non-speculative loop the GPU path runs
+    with a callable): the golden of tests/golden/make_golden.py --callable (the reference's residual function, a generalised Charbonnier loss)."""
+    from conftest import problem_from_npz
+    from losses import charbonnier_quarter
+
+    z = np.load(os.path.join(GOLDEN, "tight_config1_callable.npz"))
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    use = z["s0_use"]
+    prob = OracleProblem(uvs[:, use], obj, loss=charbonnier_quarter, f_scale=0.7)
+    assert prob.loss_is_callable
+    x0 = orc.serialize_params(ext, intr, poses[use])
+    lm = solver.LevenbergMarquardt(prob)
+    assert lm.speculative is False and not lm.device_decide
+    res = solver.lm_solve(prob, x0, ftol=1e-14, xtol=1e-14, gtol=1e-9, max_nfev=300)
+    assert res.status in (1, 2, 3, 4)
+    assert abs(res.cost - float(z["s0_cost"])) <= 1e-9 * res.cost
