@@ -451,24 +451,24 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         if box is not None:
             from scipy.optimize import Bounds
 
+            nx_all = 12 * n_cameras + 6 * all_use.size   # the bounds are those of the WHOLE parameter vector (every selected frame), on every rank
             if isinstance(box, Bounds):
                 lb, ub = np.asarray(box.lb, dtype=np.float64), np.asarray(box.ub, dtype=np.float64)
-                lb, ub = (np.resize(lb, nx_local) if lb.ndim == 0 else lb), (np.resize(ub, nx_local) if ub.ndim == 0 else ub)
             elif len(box) == 2:
                 lb, ub = (np.asarray(b, dtype=np.float64) for b in box)
-                lb, ub = (np.resize(lb, nx_local) if lb.ndim == 0 else lb), (np.resize(ub, nx_local) if ub.ndim == 0 else ub)
             else:
                 raise ValueError("`bounds` must contain 2 elements.")
-            if lb.shape != (nx_local,) or ub.shape != (nx_local,):
+            lb, ub = (np.resize(lb, nx_all) if lb.ndim == 0 else lb), (np.resize(ub, nx_all) if ub.ndim == 0 else ub)
+            if lb.shape != (nx_all,) or ub.shape != (nx_all,):
                 raise ValueError("Inconsistent shapes between bounds and `x0`.")
             if np.any(lb >= ub):
                 raise ValueError("Each lower bound must be strictly less than each upper bound.")
-            if np.any(_X0.get() < lb) or np.any(_X0.get() > ub):
+            x0_all = _X0.get() if not distributed else serialize_params(all_extrinsics, all_intrinsics, calib_poses[all_use])   # (every rank checks the whole start vector: they raise together)
+            if np.any(x0_all < lb) or np.any(x0_all > ub):
                 raise ValueError("Initial guess is outside of provided bounds")
             if np.isfinite(lb).any() or np.isfinite(ub).any():
-                if distributed:
-                    raise NotImplementedError("bounds are not supported with distributed=True")
-                lohi = (lb, ub)
+                # this shard's part: the camera block and its own frames' blocks
+                lohi = tuple(np.concatenate([b[: 12 * n_cameras], b[12 * n_cameras:].reshape(-1, 6)[positions].ravel()]) for b in (lb, ub))
         if use_frames.size == 0:
             # nothing to fit: scipy's least_squares on an empty residual vector returns x0 with status 1 (gtol) after one
             # evaluation (what the reference then returns: bundle_adjustment.py:307-327)
@@ -550,14 +550,16 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         if distributed:
             # assemble the global vectors in selection order: cameras are identical on every rank, poses / frame gradients are gathered
             parts = [None] * world
-            dist.all_gather_object(parts, (positions, result.x[12 * n_cameras:].reshape(-1, 6), grad[12 * n_cameras:].reshape(-1, 6)))
-            poses_all, gradf_all = np.empty((all_use.size, 6)), np.empty((all_use.size, 6))
-            for pos, po, gr in parts:
-                poses_all[pos], gradf_all[pos] = po, gr
+            am = np.asarray(result.active_mask)
+            dist.all_gather_object(parts, (positions, result.x[12 * n_cameras:].reshape(-1, 6), grad[12 * n_cameras:].reshape(-1, 6), am[12 * n_cameras:].reshape(-1, 6)))
+            poses_all, gradf_all, amf_all = np.empty((all_use.size, 6)), np.empty((all_use.size, 6)), np.zeros((all_use.size, 6), dtype=am.dtype)
+            for pos, po, gr, af in parts:
+                poses_all[pos], gradf_all[pos], amf_all[pos] = po, gr, af
             result.x = np.concatenate([result.x[: 12 * n_cameras], poses_all.ravel()])
             grad = np.concatenate([grad[: 12 * n_cameras], gradf_all.ravel()])
-            result.active_mask = np.zeros_like(result.x)
-            result.optimality = float(np.abs(grad).max())
+            result.active_mask = np.concatenate([am[: 12 * n_cameras], amf_all.ravel()])   # (zeros without bounds; the cameras' entries are the same on every rank)
+            if lohi is None:   # (bounded: the KKT residual the loop ended with -- gradient entries of the working set do not count)
+                result.optimality = float(np.abs(grad).max())
             result.lm["frame_positions"] = positions
         if isinstance(grad, ops.DeviceArray):   # left on the GPU (mcba_lm_result): downloaded when `result.grad` is first read
             dict.__setitem__(result, "grad", _Lazy(grad.download))

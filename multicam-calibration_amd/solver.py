@@ -710,7 +710,9 @@ class BoundedLevenbergMarquardt(LevenbergMarquardt):
       * optimality = the largest gradient entry outside the working set (the KKT residual), the termination tests scipy's.
     It minimises the same cost over the same box, so it ends at the same constrained minimiser as scipy's trust-region-reflective
     iteration (the iterates differ, as in the unbounded case).  The decision runs on the host (one synchronisation per iteration): this is
-    an off-default path, built for exactness, not for the bench."""
+    an off-default path, built for exactness, not for the bench.  Frame-sharded runs: lo / hi are this shard's (cameras first, then its own
+    frames); every quantity a decision looks at is all-reduced (trial scalars, camera system, the per-rank gradient maxima), so every shard
+    takes the same decisions; the working set of a shard's frame coordinates is its own business."""
 
     def __init__(self, problem, lo, hi, **kw):
         kw["reduced_solver"] = "host"
@@ -744,10 +746,14 @@ class BoundedLevenbergMarquardt(LevenbergMarquardt):
             frozen = (on_lo & (g > 0)) | (on_hi & (g < 0))
         frames_changed = bool((frozen[ncam:] != self.frozen[ncam:]).any())
         self.frozen = frozen
-        self.free = self.user_free & ~frozen[:ncam][self.cam_index]
+        self.free = self.user_free & ~frozen[:ncam][self.cam_index]   # (camera coordinates: x and g_c are the same on every shard, so is this)
         self.all_free = bool(self.free.all())
-        if frames_changed:   # the frame blocks of the reduced system change with the set: build it again (the linearisation stays)
-            self.p.set_frozen(frozen if frozen[ncam:].any() else None)
+        # the frame blocks of the reduced system change with the set: build it again (the linearisation stays).  Frame-sharded: whether a
+        # frame coordinate changed sides is known to its own shard only, and the rebuild is a collective -- every shard rebuilds after every
+        # iteration (one more all-reduce of the camera system per iteration: an off-default path)
+        if frames_changed or self.comm.world > 1:
+            if frames_changed:
+                self.p.set_frozen(frozen if frozen[ncam:].any() else None)
             self._refresh_system()
         else:
             self.g_inf = max(float(np.abs(self.red["gc"][self.free]).max()) if self.free.any() else 0.0, float(self.red["scal"][4:16].max()))
@@ -775,8 +781,6 @@ def lm_solve(problem, x0, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, verbos
     `fun` / `jac` / `grad` of the OptimizeResult are attached by api.bundle_adjust.
     x0_on_device: parameter slot 0 of the problem already holds x0 (ops.Problem.subset gathered it on the GPU): nothing is uploaded."""
     if bounds is not None:   # (lo, hi) in the layout of x: the active-set loop
-        if comm is not None and not isinstance(comm, SingleProcess):
-            raise NotImplementedError("bounds are not supported in frame-sharded runs")
         lm = BoundedLevenbergMarquardt(problem, bounds[0], bounds[1], comm=comm, free_cam_mask=free_cam_mask, ftol=ftol, xtol=xtol, gtol=gtol, lam0=lam0, speculative=speculative, x_scale=x_scale,
                                        dec_floor=dec_floor, curvature=curvature)
     else:

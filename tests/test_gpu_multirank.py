@@ -476,3 +476,57 @@ def test_a_poll_timeout_on_one_shard_is_seen_by_all():
     assert abs(hit[0][0].cost - calm[0][0].cost) <= 1e-9 * calm[0][0].cost
     xa = lambda out: np.concatenate([out[0][0].x[: 12 * C]] + [o[0].x[12 * C:] for o in out])
     assert np.abs(orc.predict_from_x(xa(hit), C, p["obj"]) - orc.predict_from_x(xa(calm), C, p["obj"])).max() < 1e-5
+
+
+# ------------------------------------------------------------------ bounds in a frame-sharded run (round 5)
+def _bounds_worker(rank, world, port, out_dir, tag):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import contextlib
+    import faulthandler
+    import io
+
+    faulthandler.dump_traceback_later(int(os.environ.get("MCBA_TEST_WATCHDOG_S", "150")), exit=True)
+    import torch.distributed as dist
+
+    import multicam_calibration_amd as m
+    from conftest import GOLDEN, problem_from_npz
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    z = np.load(os.path.join(GOLDEN, f"tight_bounds_{tag}.npz"))
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = m.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=None, device=0, bounds=(z["lo"], z["hi"]), ftol=1e-15, xtol=1e-15, gtol=1e-9, max_nfev=400,
+                                              verbose=0, distributed=True, return_jac=False)
+    np.savez(os.path.join(out_dir, f"b{rank}.npz"), x=res.x, cost=res.cost, active_mask=res.active_mask, use=use, status=res.status, nfev=res.nfev,
+             collectives=np.array(res.lm["collectives"]), n_local=len(res.lm["frame_positions"]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tag", ["config1", "missing3"])
+def test_bounds_in_a_frame_sharded_run_two_ranks(tmp_path, tag):
+    """bundle_adjust(distributed=True, bounds=...) as two gloo ranks sharing the GPU: the bounds are those of the whole parameter vector,
+    each rank takes its cameras' and its own frames' part (k_clip, frozen frame coordinates in k_syrk / k_backsub per shard); the same
+    decisions on both ranks, the reference's bounded optimum (tests/golden/tight_bounds_*.npz), the assembled active_mask."""
+    import torch.multiprocessing as mp
+
+    from conftest import GOLDEN
+
+    mp.spawn(_bounds_worker, args=(2, _free_port(), str(tmp_path), tag), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "b0.npz"), np.load(tmp_path / "b1.npz")
+    for k in ("x", "active_mask", "use"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    assert float(r0["cost"]) == float(r1["cost"]) and int(r0["nfev"]) == int(r1["nfev"]) and int(r0["status"]) in (1, 2, 3, 4)
+    assert str(r0["collectives"]) == "HostStagedGloo" and int(r0["n_local"]) > 0 and int(r1["n_local"]) > 0
+    z = np.load(os.path.join(GOLDEN, f"tight_bounds_{tag}.npz"))
+    np.testing.assert_array_equal(r0["use"], z["use"])
+    assert abs(float(r0["cost"]) - float(z["cost"])) <= 1e-9 * float(z["cost"])
+    C = z["uvs"].shape[0] if "uvs" in z.files else int(r0["x"].size - 6 * r0["use"].size) // 12
+    intr_idx = np.array([12 * c + k for c in range(C) for k in range(6)])
+    np.testing.assert_array_equal(r0["active_mask"][intr_idx], z["active_mask"][intr_idx])
+    if tag == "config1":
+        np.testing.assert_array_equal(r0["active_mask"], z["active_mask"])
+    am = r0["active_mask"]
+    assert np.all(r0["x"] >= z["lo"]) and np.all(r0["x"] <= z["hi"])
+    np.testing.assert_array_equal(r0["x"][am == 1], z["hi"][am == 1])
+    np.testing.assert_array_equal(r0["x"][am == -1], z["lo"][am == -1])

@@ -507,3 +507,43 @@ def test_callable_loss_on_the_oracle_double_reaches_the_reference_optimum():
     res = solver.lm_solve(prob, x0, ftol=1e-14, xtol=1e-14, gtol=1e-9, max_nfev=300)
     assert res.status in (1, 2, 3, 4)
     assert abs(res.cost - float(z["s0_cost"])) <= 1e-9 * res.cost
+
+
+# ------------------------------------------------------------------ bounds in a frame-sharded run, world_size 2 over gloo
+def _bounds_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from multicam_calibration_amd import ops
+
+    ops.Problem = OracleProblem   # this process only
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    z = np.load(os.path.join(GOLDEN, "tight_bounds_config1.npz"))
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = api.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=None, bounds=(z["lo"], z["hi"]), ftol=1e-15, xtol=1e-15, gtol=1e-9, max_nfev=400, verbose=0,
+                                                 distributed=True, return_jac=False)
+    np.savez(os.path.join(out_dir, f"b{rank}.npz"), x=res.x, cost=res.cost, active_mask=res.active_mask, use=use, status=res.status, nfev=res.nfev, collectives=np.array(res.lm["collectives"]))
+    dist.destroy_process_group()
+
+
+def test_bounds_in_a_frame_sharded_run_two_ranks(tmp_path):
+    """bundle_adjust(distributed=True, bounds=...) on two gloo ranks (the oracle-backed double): the bounds are those of the whole parameter
+    vector, every rank takes its cameras' and its own frames' part; same decisions on both ranks, the reference's bounded optimum
+    (tests/golden/tight_bounds_config1.npz), the assembled active_mask."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_bounds_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "b0.npz"), np.load(tmp_path / "b1.npz")
+    for k in ("x", "active_mask", "use"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    assert float(r0["cost"]) == float(r1["cost"]) and int(r0["nfev"]) == int(r1["nfev"]) and int(r0["status"]) in (1, 2, 3, 4)
+    z = np.load(os.path.join(GOLDEN, "tight_bounds_config1.npz"))
+    np.testing.assert_array_equal(r0["use"], z["use"])
+    assert abs(float(r0["cost"]) - float(z["cost"])) <= 1e-9 * float(z["cost"])
+    np.testing.assert_array_equal(r0["active_mask"], z["active_mask"])
+    assert np.all(r0["x"] >= z["lo"]) and np.all(r0["x"] <= z["hi"])
+    np.testing.assert_array_equal(r0["x"][z["active_mask"] == 1], z["hi"][z["active_mask"] == 1])
+    np.testing.assert_array_equal(r0["x"][z["active_mask"] == -1], z["lo"][z["active_mask"] == -1])
