@@ -721,6 +721,8 @@ class BoundedLevenbergMarquardt(LevenbergMarquardt):
         self.lo, self.hi = np.ascontiguousarray(lo, dtype=np.float64), np.ascontiguousarray(hi, dtype=np.float64)
         self.user_free = self.free.copy()
         self.frozen = np.zeros(problem.nx, dtype=bool)
+        self.forced = np.zeros(problem.nx, dtype=bool)   # on a bound, gradient inward, but the coupled LM step bent outward: held until the next accepted step
+        self.releases = 0
         self.ncam = 12 * problem.C
 
     def start(self, x0):
@@ -743,7 +745,7 @@ class BoundedLevenbergMarquardt(LevenbergMarquardt):
             gcam = np.zeros(ncam)
             gcam[self.cam_index] = self.red["gc"]
             g = np.concatenate([gcam, self.p.frame_gradient().ravel()])
-            frozen = (on_lo & (g > 0)) | (on_hi & (g < 0))
+            frozen = (on_lo & (g > 0)) | (on_hi & (g < 0)) | (self.forced & (on_lo | on_hi))
         frames_changed = bool((frozen[ncam:] != self.frozen[ncam:]).any())
         self.frozen = frozen
         self.free = self.user_free & ~frozen[:ncam][self.cam_index]   # (camera coordinates: x and g_c are the same on every shard, so is this)
@@ -759,13 +761,38 @@ class BoundedLevenbergMarquardt(LevenbergMarquardt):
             self.g_inf = max(float(np.abs(self.red["gc"][self.free]).max()) if self.free.any() else 0.0, float(self.red["scal"][4:16].max()))
 
     def iterate(self, always_linearize=False):
+        lam_b, nu_b, tried = self.lam, self.nu, len(self.history)
         status = super().iterate(always_linearize)
         if getattr(self, "accepted", False):
             self.x_host = self.p.get_params(self.cur)   # (the projected point: what the GPU holds)
             self.x_cam = self.x_host[self.cam_index].copy()
+            self.forced[:] = False
+        elif len(self.history) > tried and self.comm.world == 1:
+            # A rejected step.  Was it BENT?  A coordinate that sits on a bound with the gradient pointing inward is free, but the coupled LM
+            # step may still push it outward (the step is -(H + lam D)^-1 g, not -g): the projection then cuts that one component out of a
+            # step whose other components were computed with it -- for strongly coupled coordinates (a near-rigid motion of the rig) not a
+            # descent step at any length, and raising the damping does not help.  Such coordinates join the working set until the next
+            # accepted step (the others' steps are then computed with them held), and the damping stays where it was: the step failed for
+            # its bend, not for its length.  (Frame-sharded runs keep the plain projection: the bend of a shard's frames is known to it alone.)
+            xt = self.p.get_params(1 - self.cur)
+            on_lo, on_hi = self.x_host <= self.lo, self.x_host >= self.hi
+            bent = ~self.frozen & ((on_lo & (xt <= self.lo)) | (on_hi & (xt >= self.hi)))
+            bent[: self.ncam][self.cam_index[~self.user_free]] = False
+            if bent.any():
+                self.forced |= bent
+                self.lam, self.nu = lam_b, nu_b
+                if status == 3:
+                    status = None
         self._update_working_set()
         if status is None and self.g_inf < self.gtol:
             status = 1
+        if status is not None and status > 0 and self.forced.any() and self.releases < 8:
+            # converged with coordinates held for a bend: release them and look again (at a minimiser of the held problem the step of a released
+            # coordinate points inward: the diagonal of an SPD inverse is positive)
+            self.releases += 1
+            self.forced[:] = False
+            self._update_working_set()
+            status = 1 if self.g_inf < self.gtol else None
         return status
 
     def result(self, status, lazy_grad=False):

@@ -208,3 +208,102 @@ def test_frame_selection_matches_the_oracle_prefilter(mc, capsys):
         head_o, _, t_want = line.rpartition(" ")
         assert head == head_o, (tag, out, line)
         assert (t_got == t_want == "nan") or abs(float(t_got) - float(t_want)) <= 1e-12 * abs(float(t_want)), (tag, out, line)
+
+
+@pytest.mark.parametrize("it", list(range(36)))
+def test_bounded_runs_end_at_kkt_points_of_the_oracle_objective(mc, it):
+    """bundle_adjust(..., bounds=(lo, hi)) on random problems with random boxes: bounds between the start and the UNCONSTRAINED optimum on a
+    random tenth of all coordinates, on a quarter of the intrinsics, or on those + 14-23 board-pose coordinates (the optimum violates them); wide ones on a tenth of everything.  Judged with the
+    oracle at the returned point: feasible, the cost between the unconstrained optimum's and the start's, scipy's active_mask, active
+    coordinates exactly on their bounds, and the KKT conditions of the oracle's objective -- its gradient vanishes on the free coordinates
+    (relative to the gradient at the start) and points outward on the active ones.  Sometimes with the intrinsics held fixed, with a
+    callable loss, with a numeric x_scale."""
+    from scipy.optimize._lsq.common import find_active_constraints
+
+    sys_path_tests = os.path.dirname(os.path.abspath(__file__))
+    import sys
+    if sys_path_tests not in sys.path:
+        sys.path.insert(0, sys_path_tests)
+    from losses import charbonnier_quarter
+
+    rng = np.random.default_rng(12000 + it)
+    C = int(rng.choice([2, 3, 4, 6, 9, 14]))
+    F = int(rng.integers(6, 30)) if C > 6 else int(rng.integers(8, 120))
+    loss = [("soft_l1", 1.0), ("linear", 1.0), ("huber", 2.5), ("soft_l1", 0.5), (charbonnier_quarter, 0.7)][int(rng.integers(5))]
+    mk = dict(n_cameras=C, n_frames=F, rows=int(rng.integers(2, 5)), cols=int(rng.integers(3, 6)), seed=1700 + it, perturb_seed=1800 + it,
+              missing=float(rng.choice([0.0, 0.15])), scalar_nans=int(rng.choice([0, 5])))
+    fixed = bool(rng.random() < 0.3)
+    p = mc.synth.make_problem(**mk)
+    args = (p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    kw = dict(n_frames=None, ftol=1e-14, xtol=1e-14, gtol=1e-11, verbose=0, max_nfev=500, fix_intrinsics=fixed, loss=loss[0], f_scale=loss[1])
+    tag = f"case {it}: {mk} loss={loss} fixed={fixed}"
+    _, _, _, use, free = quiet(mc.bundle_adjust, *args, **kw)
+    assert free.status > 0, tag
+    x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"][use])
+    xu, n, nc = free.x, x0.size, 12 * C
+    lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
+    # Which coordinates get a bound the optimum violates: a tenth of ALL that moved (camera parameters and board poses alike -- boxes on
+    # extrinsics / poses couple through the rig's gauge freedom: the projected steps of such runs bend, solver.py's working set handles it),
+    # a quarter of the intrinsics (gauge-invariant: "k2 >= 0", "fx within 5 %"), or intrinsics + 14-23 pose coordinates close to the start
+    moved = np.abs(xu - x0) > 1e-6 * np.maximum(1.0, np.abs(x0))
+    if fixed:
+        moved[:nc] &= (np.arange(nc) % 12) >= 6
+    intr_c = np.nonzero(moved[:nc] & ((np.arange(nc) % 12) < 6))[0]
+    pose_c = nc + np.nonzero(moved[nc:])[0]
+    kind = it % 3 if not fixed else 2 * (it % 2)
+    if kind == 0:
+        cand = np.nonzero(moved)[0]
+        pick = list(rng.choice(cand, size=max(2, cand.size // 10), replace=False))
+        frac = {i: float(rng.uniform(0.2, 0.8)) for i in pick}
+    else:
+        pick = [] if fixed else list(rng.choice(intr_c, size=min(intr_c.size, max(2, intr_c.size // 4)), replace=False))
+        frac = {i: float(rng.uniform(0.2, 0.8)) for i in pick}
+        if kind == 2:
+            extra = rng.choice(pose_c, size=min(pose_c.size, int(rng.integers(14, 24))), replace=False)
+            pick += list(extra)
+            frac.update({i: 0.1 for i in extra})
+    for i in pick:
+        b = x0[i] + frac[i] * (xu[i] - x0[i])
+        if xu[i] > x0[i]:
+            hi[i] = b
+        else:
+            lo[i] = b
+    for i in rng.choice(n, size=max(2, n // 10), replace=False):   # ... and bounds nothing should touch (some on coordinates bounded above already)
+        lo[i] = min(lo[i], min(x0[i], xu[i]) - 50.0) if np.isfinite(lo[i]) else min(x0[i], xu[i]) - 50.0
+        hi[i] = hi[i] if np.isfinite(hi[i]) else max(x0[i], xu[i]) + 50.0
+    assert np.all(lo < hi) and np.all(x0 >= lo) and np.all(x0 <= hi)
+    xs = None
+    if rng.random() < 0.25:   # least_squares' numeric x_scale (a fixed damping matrix instead of Marquardt's)
+        xs = np.concatenate([np.tile([100.0, 100.0, 100.0, 100.0, 0.1, 0.1, 0.1, 0.1, 0.1, 10.0, 10.0, 10.0], C), np.tile([0.1, 0.1, 0.1, 10.0, 10.0, 10.0], use.size)])
+    _, _, _, use2, res = quiet(mc.bundle_adjust, *args, **kw, bounds=(lo, hi), **({} if xs is None else dict(x_scale=xs)))
+    np.testing.assert_array_equal(use2, use)
+    assert res.status > 0, (tag, res.status, res.nfev)
+    x = res.x
+    assert np.all(x >= lo) and np.all(x <= hi), tag
+    uvs = p["uvs"][:, use]
+    lname, fs = loss
+    f = orc.residuals(x, uvs, p["obj"])
+    cost = orc.robust_cost(f, lname, fs)
+    c0 = orc.robust_cost(orc.residuals(x0, uvs, p["obj"]), lname, fs)
+    assert abs(res.cost - cost) <= 1e-11 * cost + 1e-14, tag
+    assert free.cost * (1 - 1e-9) <= cost <= c0 * (1 + 1e-12), (tag, free.cost, cost, c0)
+    am = find_active_constraints(x, lo, hi, rtol=1e-14)
+    np.testing.assert_array_equal(res.active_mask, am, err_msg=tag)
+    np.testing.assert_array_equal(x[am == -1], lo[am == -1])
+    np.testing.assert_array_equal(x[am == 1], hi[am == 1])
+    # KKT with the oracle's gradient
+    js, fsc = orc.robust_scales(f, lname, fs)
+    J = orc.jacobian_csr(x, uvs, p["obj"])
+    g = J.T @ (js * fsc)
+    js0, fsc0 = orc.robust_scales(orc.residuals(x0, uvs, p["obj"]), lname, fs)
+    g0 = np.abs(orc.jacobian_csr(x0, uvs, p["obj"]).T @ (js0 * fsc0))
+    held = np.zeros(n, bool)
+    if fixed:
+        held[:nc] = (np.arange(nc) % 12) < 6
+        g0 = g0[~held]
+        np.testing.assert_array_equal(x[held], x0[held], err_msg=tag)
+    scale = g0.max()
+    off = (am == 0) & ~held
+    assert np.abs(g[off]).max() <= 1e-6 * scale + 1e-8, (tag, np.abs(g[off]).max(), scale, res.status, res.nfev)
+    assert np.all(g[am == -1] >= -1e-6 * scale - 1e-8) and np.all(g[am == 1] <= 1e-6 * scale + 1e-8), tag
+    np.testing.assert_allclose(res.grad[~held], g[~held], rtol=0, atol=1e-6 * max(scale, np.abs(g).max()) + 1e-7, err_msg=tag)
