@@ -365,6 +365,13 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
 /* undistort_points (geometry.py:328-358 = cv2.undistortPoints(uvs, K, dist, None, K)): n_points (u,v) pairs, K4 = (fx fy cx cy),
  * dist5 = (k1 k2 p1 p2 k3) or NULL; fixed-point iteration, `iterations` rounds (OpenCV's default: 5).  NaN rows stay NaN. */
 int mcba_undistort_points(size_t n_points, const double* uvs, const double* K4, const double* dist5, int iterations, int device, double* out);
+/* Single-camera calibration with OpenCV's FIVE-coefficient distortion model (k1 k2 p1 p2 k3) -- what the reference's get_intrinsics() asks of
+ * cv2.calibrateCamera when fix_k3 / zero_tangent_dist are False (calibration.py:11-71) and of cv2.solvePnP when such coefficients come back
+ * (:74-113).  Stateless: uvs (V,N,2) detections of V views (NaN = missing), objpoints (N,3), intr9 = fx fy cx cy k1 k2 p1 p2 k3, poses (V,6)
+ * board -> camera (rotation vector, translation).  out (V,136) per view: the upper triangle (row by row, 120) of the Gauss-Newton block J^T J over
+ * the parameters [intr9 | pose6], the gradient J^T r (15), the cost 0.5 sum r^2, with r = observed - predicted.  Rows are differentiated by
+ * forward-mode automatic differentiation on the GPU (csrc/mcba_calib.hip); the LM iteration around it is calibration.py's. */
+int mcba_calib_normal_equations(int n_views, int n_points, const double* uvs, const double* objpoints, const double* intr9, const double* poses, int device, double* out);
 /* Numeric core of plot_residuals (viz.py:166-186) at x[slot]: per (camera, frame) with a complete detection the
  * least-squares homography from the undistorted detections to the board plane, the distortion-free reprojection of the
  * board mapped through it, and per camera the median distance to the board points (board units).

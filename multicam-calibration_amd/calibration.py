@@ -15,6 +15,11 @@ served -- this image has no cv2, and a GPU is there anyway:
       is numpy and is restated here; tests/golden/calibration_graph.npz pins it to the reference's own outputs
       (including networkx's tie-breaking in the spanning tree, reproduced without networkx).
 
+  get_intrinsics(fix_k3=False | zero_tangent_dist=False), estimate_pose with tangential / k3 coefficients
+      OpenCV's five-coefficient model (k1 k2 p1 p2 k3), which the bundle-adjustment kernels do not have: per-view normal equations
+      from csrc/mcba_calib.hip (forward-mode automatic differentiation), the reduced 9 x 9 system and the damping here
+      (_refine_five_coefficients).
+
 Parity of the two OpenCV-backed pieces cannot be pinned to cv2 numbers in this container ("parity unpinned" for them);
 they minimise the same reprojection error over the same parameters, and the tests check recovery of the synthetic truth
 and that `bundle_adjust` started from `calibrate()` ends in the same optimum as from any other start.
@@ -223,14 +228,18 @@ def poses_from_homographies(H, K):
 
 
 def undistort_normalized(uv, K, dist, iterations=8):
-    """Pixel -> undistorted normalised coordinates for the (k1, k2) radial model (fixed-point iteration on x = x_d / d(x))."""
+    """Pixel -> undistorted normalised coordinates for OpenCV's (k1, k2, p1, p2, k3) model: the fixed-point iteration of its undistortPoints,
+    x <- (x_d - tangential(x)) / radial(x)."""
+    k1, k2, p1, p2, k3 = (list(np.ravel(dist)) + [0.0] * 5)[:5]
     xd = (uv[..., 0] - K[0, 2]) / K[0, 0]
     yd = (uv[..., 1] - K[1, 2]) / K[1, 1]
     x, y = xd.copy(), yd.copy()
     for _ in range(iterations):
         s = x * x + y * y
-        d = 1 + dist[0] * s + dist[1] * s * s
-        x, y = xd / d, yd / d
+        d = 1 + s * (k1 + s * (k2 + s * k3))
+        dx = 2 * p1 * x * y + p2 * (s + 2 * x * x)
+        dy = p1 * (s + 2 * y * y) + 2 * p2 * x * y
+        x, y = (xd - dx) / d, (yd - dy) / d
     return np.stack([x, y], -1)
 
 
@@ -247,12 +256,95 @@ def _refine_single_camera(uvs, obj, cam12, poses, free_cam, device, max_nfev=200
     return res.x[:12], res.x[12:].reshape(-1, 6), res
 
 
+# ------------------------------------------------------------------ the five-coefficient model (k1 k2 p1 p2 k3): get_intrinsics(fix_k3=False | zero_tangent_dist=False)
+def _refine_five_coefficients(uvs, obj, intr9, poses, free9, device, max_evaluations=300):
+    """Levenberg-Marquardt on calibrateCamera's objective (sum of squared reprojection errors over the views) with OpenCV's five-coefficient
+    model: the per-view Gauss-Newton blocks, gradients and costs come from the GPU (ops.calib_normal_equations: forward-mode automatic
+    differentiation, one wavefront per view); the Schur complement over the views' 6 x 6 pose blocks and the damping live here (a 9 x 9 system).
+    free9: which of fx fy cx cy k1 k2 p1 p2 k3 are variables; none = every view is an independent 6-parameter problem (estimate_pose) with
+    its own damping.  Returns (intr9, poses, cost)."""
+    from . import ops
+
+    k, ps = np.array(intr9, dtype=np.float64), np.array(poses, dtype=np.float64)
+    free9 = np.asarray(free9, dtype=bool)
+    nf, V = int(free9.sum()), len(ps)
+    H, g, c = ops.calib_normal_equations(uvs, obj, k, ps, device)
+    if not np.isfinite(c).all():
+        raise ValueError("Residuals are not finite in the initial point.")
+    per_view = nf == 0
+    lam, nu = (np.full(V, 1e-3), np.full(V, 2.0)) if per_view else (1e-3, 2.0)
+    done = np.zeros(V, dtype=bool)
+    eye6 = np.eye(6)
+    for _ in range(max_evaluations):
+        Vv, gv = H[:, 9:, 9:], g[:, 9:]
+        Dv = np.maximum(np.einsum("vii->vi", Vv), 1e-300)
+        lam_v = lam if per_view else np.full(V, lam)
+        Vinv = np.linalg.inv(Vv + (lam_v[:, None] * Dv)[:, :, None] * eye6)
+        dc = np.zeros(9)
+        if nf:
+            U, gc = H[:, :9, :9].sum(0)[np.ix_(free9, free9)], g[:, :9].sum(0)[free9]
+            W = H[:, :9, 9:][:, free9, :]                                   # (V, nf, 6)
+            WVi = W @ Vinv
+            S = U + lam * np.diag(np.maximum(np.diag(U), 1e-300)) - (WVi @ W.transpose(0, 2, 1)).sum(0)
+            dc[free9] = np.linalg.solve(S, -gc + np.einsum("vij,vj->i", WVi, gv))
+            dv = -np.einsum("vij,vj->vi", Vinv, gv + np.einsum("vij,i->vj", W, dc[free9]))
+        else:
+            dv = -np.einsum("vij,vj->vi", Vinv, gv)
+        dv[done] = 0.0
+        d15 = np.concatenate([np.broadcast_to(dc, (V, 9)), dv], axis=1)
+        pred_v = -np.einsum("vi,vi->v", g, d15) - 0.5 * np.einsum("vi,vij,vj->v", d15, H, d15)   # per view; their sum is the model's reduction
+        H2, g2, c2 = ops.calib_normal_equations(uvs, obj, k + dc, ps + dv, device)
+        if per_view:
+            gain = c - c2
+            ok = np.isfinite(c2) & (gain >= 0) & ~done
+            ratio = np.where(pred_v > 0, gain / np.where(pred_v > 0, pred_v, 1.0), -1.0)
+            conv = ok & (gain <= 1e-14 * np.maximum(c, 1e-300))
+            ps[ok], H[ok], g[ok], c[ok] = (ps + dv)[ok], H2[ok], g2[ok], c2[ok]
+            lam = np.where(ok, np.maximum(lam * np.maximum(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3), 1e-12), lam * nu)
+            nu = np.where(ok, 2.0, nu * 2.0)
+            done |= conv | (lam > 1e12)
+            if done.all():
+                break
+        else:
+            gain, pred = c.sum() - c2.sum(), pred_v.sum()
+            if np.isfinite(c2).all() and gain >= 0:
+                ratio = gain / pred if pred > 0 else 1.0
+                small = gain <= 1e-14 * max(c.sum(), 1e-300)
+                k, ps, H, g, c = k + dc, ps + dv, H2, g2, c2
+                lam, nu = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3), 1e-12), 2.0
+                if small:
+                    break
+            else:
+                lam, nu = lam * nu, nu * 2.0
+                if lam > 1e12:
+                    break
+    return k, ps, float(c.sum())
+
+
+def _zhang_start(uvs, obj, image_size):
+    H = homographies(obj[:, :2], uvs)
+    K0 = intrinsics_from_homographies(H, image_size)
+    return K0, poses_from_homographies(H, K0)
+
+
 def get_intrinsics(calib_uvs, calib_objpoints, image_size, n_samples=100, fix_k3=True, zero_tangent_dist=True, device=0):
-    """Camera matrix (3,3) and distortion (k1, k2, 0, 0, 0) from complete detections of a planar board
-    (calibration.py:11-71; the model of cv2.calibrateCamera under CALIB_FIX_K3 | CALIB_ZERO_TANGENT_DIST)."""
-    if not (fix_k3 and zero_tangent_dist):
-        raise NotImplementedError("only the (k1, k2) radial model of the reference's calibrate() is implemented (fix_k3=True, zero_tangent_dist=True)")
+    """Camera matrix (3,3) and distortion (k1, k2, p1, p2, k3) from complete detections of a planar board (calibration.py:11-71: the model
+    of cv2.calibrateCamera under flags = CALIB_FIX_K3 * fix_k3 + CALIB_ZERO_TANGENT_DIST * zero_tangent_dist).  The reference's default --
+    both flags: the (k1, k2) radial model, which is also all bundle_adjust optimises -- is refined by the library's own bundle-adjustment
+    loop; with a flag off, the five-coefficient model by _refine_five_coefficients (GPU normal equations, 9 x 9 reduced system here)."""
     obj = _require_planar(calib_objpoints)
+    if not (fix_k3 and zero_tangent_dist):
+        calib_uvs = np.asarray(calib_uvs, dtype=np.float64)
+        calib_uvs = calib_uvs[~np.isnan(calib_uvs).any((1, 2))]
+        n_samples = min(n_samples, len(calib_uvs))
+        if n_samples < 1:
+            raise ValueError("no complete detection of the calibration board for this camera")
+        uvs = calib_uvs[np.random.choice(len(calib_uvs), n_samples, replace=False)]  # same draw from the global RNG as the reference
+        K0, poses0 = _zhang_start(uvs, obj, image_size)
+        free9 = np.array([1, 1, 1, 1, 1, 1, not zero_tangent_dist, not zero_tangent_dist, not fix_k3], dtype=bool)
+        k9, _, _ = _refine_five_coefficients(uvs, obj, [K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], poses0, free9, device)
+        K = np.array([[k9[0], 0, k9[2]], [0, k9[1], k9[3]], [0, 0, 1.0]])
+        return K, k9[4:].copy()
     calib_uvs = np.asarray(calib_uvs, dtype=np.float64)
     calib_uvs = calib_uvs[~np.isnan(calib_uvs).any((1, 2))]
     n_samples = min(n_samples, len(calib_uvs))
@@ -283,8 +375,11 @@ def estimate_pose(calib_uvs, calib_objpoints, camera_matrix, dist_coeffs, device
     uvs = calib_uvs[ok]
     H = homographies(obj[:, :2], undistort_normalized(uvs, K, dist))
     poses0 = poses_from_homographies(H, np.eye(3))
-    cam = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2], dist[0], dist[1], 0, 0, 0, 0, 0, 0])
-    _, refined, _ = _refine_single_camera(uvs, obj, cam, poses0, np.zeros(12, bool), device)
+    if dist[2] != 0.0 or dist[3] != 0.0 or dist[4] != 0.0:   # tangential / k3 coefficients (get_intrinsics with a flag off): the five-coefficient model
+        _, refined, _ = _refine_five_coefficients(uvs, obj, [K[0, 0], K[1, 1], K[0, 2], K[1, 2], *dist], poses0, np.zeros(9, bool), device)
+    else:
+        cam = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2], dist[0], dist[1], 0, 0, 0, 0, 0, 0])
+        _, refined, _ = _refine_single_camera(uvs, obj, cam, poses0, np.zeros(12, bool), device)
     poses[ok] = refined
     return poses
 

@@ -1785,6 +1785,34 @@ int mcba_triangulate(int n_cameras, size_t n_points, const double* uvs, const do
   return MCBA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Single-camera calibration with OpenCV's five-coefficient model (reference calibration.py:11-71 -> cv2.calibrateCamera without
+// CALIB_FIX_K3 / CALIB_ZERO_TANGENT_DIST; :74-113 -> cv2.solvePnP with such coefficients): stateless; per view the Gauss-Newton block of
+// (fx fy cx cy k1 k2 p1 p2 k3 | w t), the gradient and the cost at the given parameters.  calibration.py drives the LM iteration.
+int mcba_calib_normal_equations(int n_views, int n_points, const double* uvs, const double* objpoints, const double* intr9, const double* poses, int device, double* out) {
+  if (n_views < 1 || n_points < 1 || !uvs || !objpoints || !intr9 || !poses || !out) return fail(MCBA_ERR_ARG, "mcba_calib_normal_equations: views >= 1, points >= 1, non-NULL arrays required");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MCBA_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(MCBA_ERR_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  const size_t nuv = (size_t)2 * n_views * n_points, nobj = (size_t)3 * n_points, npose = (size_t)6 * n_views, nout = (size_t)136 * n_views;
+  const size_t total = nuv + nobj + 9 + npose + nout;
+  double* d = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), total * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(d, uvs, nuv * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + nuv, objpoints, nobj * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + nuv + nobj, intr9, 9 * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + nuv + nobj + 9, poses, npose * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    mcba::launch_calib_views(nullptr, d, d + nuv, d + nuv + nobj, d + nuv + nobj + 9, n_views, n_points, d + nuv + nobj + 9 + npose);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d + nuv + nobj + 9 + npose, nout * sizeof(double), hipMemcpyDeviceToHost);
+  if (d) (void)hipFree(d);
+  if (e != hipSuccess) { g_err = std::string("mcba_calib_normal_equations: ") + hipGetErrorString(e); return MCBA_ERR_HIP; }
+  return MCBA_OK;
+}
+
 int mcba_comm_unique_id(unsigned char* out128) {
   if (!out128) return fail(MCBA_ERR_ARG, "mcba_comm_unique_id: NULL");
   int rc = load_rccl();

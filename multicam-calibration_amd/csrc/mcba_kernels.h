@@ -138,6 +138,8 @@ struct TriCams {
   double K[8][4];
   double dist[8][5];
 };
+// single-camera calibration with the 5-coefficient model (mcba_calib.hip): per view the 15 x 15 Gauss-Newton block (upper triangle, 120), the gradient (15), the cost
+void launch_calib_views(hipStream_t st, const double* uvs, const double* obj, const double* intr9, const double* poses, int V, int N, double* out);
 int launch_triangulate(hipStream_t st, int C, const double* uvs, const TriCams& cams, double* out, size_t npts, int iters);
 // 9 .. 64 cameras: cams_dev = C x {P[12], K[4], dist[5]} doubles in device memory; one wavefront per point
 int launch_triangulate_wave(hipStream_t st, int C, const double* uvs, const void* cams_dev, double* out, size_t npts, int iters);

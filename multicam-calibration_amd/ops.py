@@ -93,6 +93,7 @@ SYMBOLS = [
     ("mcba_lm_history", ctypes.c_int, [_h, _dp, ctypes.c_size_t]),
     ("mcba_lm_result", ctypes.c_int, [_h, ctypes.c_int, _dp, _dp, ctypes.POINTER(_h)]),
     ("mcba_undistort_points", ctypes.c_int, [ctypes.c_size_t, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp]),
+    ("mcba_calib_normal_equations", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, ctypes.c_int, _dp]),
     ("mcba_reprojection_diagnostics", ctypes.c_int, [_h, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp, _dp]),
     ("mcba_triangulate", ctypes.c_int, [ctypes.c_int, ctypes.c_size_t, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
     ("mcba_profile_enable", ctypes.c_int, [_h, ctypes.c_int]),
@@ -771,3 +772,23 @@ def undistort_points(uvs, K4, dist5=None, iterations=5, device=0):
     if rc != OK:
         raise McbaError(rc, lib.mcba_last_error().decode())
     return out
+
+
+def calib_normal_equations(uvs, objpoints, intr9, poses, device=0):
+    """Single-camera calibration with the five-coefficient model (include/mcba.h: mcba_calib_normal_equations): uvs (V,N,2), objpoints (N,3),
+    intr9 = fx fy cx cy k1 k2 p1 p2 k3, poses (V,6) -> (H (V,15,15) symmetric Gauss-Newton blocks over [intr9 | pose6], g (V,15), cost (V,)),
+    residuals observed - predicted."""
+    lib = load_library()
+    uvs, obj, k, ps = _f64(uvs), _f64(objpoints), _f64(intr9), _f64(poses)
+    V, N = uvs.shape[:2]
+    if uvs.shape != (V, N, 2) or obj.shape != (N, 3) or k.shape != (9,) or ps.shape != (V, 6):
+        raise ValueError("uvs (V,N,2), objpoints (N,3), intr9 (9,), poses (V,6) required")
+    out = np.empty((V, 136))
+    rc = lib.mcba_calib_normal_equations(V, N, _p(uvs), _p(obj), _p(k), _p(ps), int(device), _p(out))
+    if rc != OK:
+        raise McbaError(rc, lib.mcba_last_error().decode())
+    H = np.zeros((V, 15, 15))
+    iu = np.triu_indices(15)
+    H[:, iu[0], iu[1]] = out[:, :120]
+    H[:, iu[1], iu[0]] = out[:, :120]
+    return H, out[:, 120:135].copy(), out[:, 135].copy()
