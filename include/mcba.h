@@ -189,6 +189,7 @@ int mcba_step(mcba_handle* h, const double* delta_cam, double lambda, int src_sl
 int mcba_step_linearize(mcba_handle* h, const double* delta_cam, double lambda, int src_slot, int dst_slot);
 int mcba_accept_linearization(mcba_handle* h);
 int mcba_get_trial(mcba_handle* h, double* host8);
+int mcba_set_trial(mcba_handle* h, const double* host8);   /* the eight trial scalars, written back (a tabulated loss in a frame-sharded run: [the caller's cost of THIS shard's trial point, the step's other scalars], before the all-reduce) */
 /* Convenience for the single-GPU loop (one ABI crossing instead of two):
  *   mcba_reduce_fetch     = mcba_build_reduced + mcba_get_reduced
  *   mcba_step_fetch       = mcba_step (linearize == 0) or mcba_step_linearize (linearize != 0) + mcba_get_trial */

@@ -387,8 +387,6 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     kw = dict(verbose=2, x_scale="jac", ftol=1e-4, method="trf", loss="soft_l1")
     kw.update(opt_kwargs)
     box = kw.pop("bounds", None)
-    if callable(kw.get("loss")) and distributed:
-        raise NotImplementedError("a callable loss is not supported with distributed=True")
     unknown = set(kw) - set(_PATH_ONLY) - {"verbose", "ftol", "xtol", "gtol", "max_nfev", "loss", "f_scale", "x_scale"}
     if unknown:
         raise TypeError(f"unsupported least_squares keyword(s) for the GPU solver: {sorted(unknown)}")

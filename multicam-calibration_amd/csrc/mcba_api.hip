@@ -977,6 +977,18 @@ int mcba_get_trial(mcba_handle* h, double* host8) {
   return fetch_trial(h, host8);
 }
 
+// Write the eight trial scalars back into the reduce buffer: with a tabulated loss (mcba_set_loss_table) the cost of this shard's trial point
+// is the caller's function on its residuals -- a frame-sharded run fetches the scalars of mcba_step (mcba_get_trial), evaluates the function
+// (mcba_residuals, which reuses the scalars' slots), and puts [its cost, the step's other scalars] here BEFORE the all-reduce.
+int mcba_set_trial(mcba_handle* h, const double* host8) {
+  if (!h || !host8 || !h->red) return fail(MCBA_ERR_ARG, "mcba_set_trial: bad argument, or no reduce buffer yet (call mcba_step first)");
+  HIPCHK(hipSetDevice(h->device));
+  memcpy(h->pinned + h->nsys, host8, 8 * sizeof(double));
+  HIPCHK(hipMemcpyAsync(h->red + h->nsys, h->pinned + h->nsys, 8 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
 int mcba_reduce_fetch(mcba_handle* h, double lambda, int rank_slot, double* host) {
   int rc = mcba_build_reduced(h, lambda, rank_slot);
   if (rc) return rc;

@@ -42,6 +42,7 @@ SYMBOLS = [
     ("mcba_upload_observations", ctypes.c_int, [_h, _dp, _dp]),
     ("mcba_set_loss", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_double]),
     ("mcba_set_loss_table", ctypes.c_int, [_h, _dp]),
+    ("mcba_set_trial", ctypes.c_int, [_h, _dp]),
     ("mcba_set_camera_block", ctypes.c_int, [_h, ctypes.c_int]),
     ("mcba_get_camera_block", ctypes.c_int, [_h]),
     ("mcba_set_params", ctypes.c_int, [_h, ctypes.c_int, _dp]),
@@ -543,6 +544,12 @@ class Problem:
     def step(self, delta_cam, lam, src, dst):
         d = _f64(delta_cam)
         self._chk(self.lib.mcba_step(self.handle, _p(d), float(lam), src, dst))
+        if self._loss_fn is not None:
+            # the trial cost of THIS shard's frames is the caller's function on their residuals: put in place of the kernel's BEFORE the all-reduce
+            # of the trial scalars (mcba_residuals reuses the scalars' slots: the step's other scalars are fetched first and written back)
+            t = self.get_trial()
+            t[0] = self._callable_cost(dst)
+            self._chk(self.lib.mcba_set_trial(self.handle, _p(t)))
 
     def step_linearize(self, delta_cam, lam, src, dst):
         """Back-substitute, then linearise x[dst] speculatively (its cost becomes trial scalar 0)."""
@@ -554,8 +561,6 @@ class Problem:
 
     def get_trial(self):
         self._chk(self.lib.mcba_get_trial(self.handle, _p(self._trial)))
-        if self._loss_fn is not None:
-            raise ValueError("a callable loss: the trial cost comes with step_fetch (single process, host-driven loop)")
         return self._trial.copy()
 
     # ---- device-resident LM iteration (one host synchronisation per iteration)

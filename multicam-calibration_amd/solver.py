@@ -292,9 +292,7 @@ class LevenbergMarquardt:
         if getattr(problem, "loss_is_callable", False):
             # least_squares' callable `loss`: the function runs here, between a step and the next linearisation -- nothing is linearised before
             # its trial cost is known, and the decision stays on the host (the device-resident loops cannot call back)
-            if not isinstance(self.comm, SingleProcess):
-                raise NotImplementedError("a callable loss is not supported in frame-sharded runs")
-            self.speculative = False
+            self.speculative = False   # (frame-sharded: every shard evaluates the function on its own residuals, the costs meet in the all-reduce of the trial scalars)
         # device_decide: accept/reject and the damping update run on the GPU (k_decide) so that one LM iteration is a
         # single stream-ordered chain with ONE host synchronisation; needs a backend with lm_iterate (libmcba).
         self.device_decide = self.speculative and hasattr(problem, "lm_iterate")

@@ -530,3 +530,48 @@ def test_bounds_in_a_frame_sharded_run_two_ranks(tmp_path, tag):
     assert np.all(r0["x"] >= z["lo"]) and np.all(r0["x"] <= z["hi"])
     np.testing.assert_array_equal(r0["x"][am == 1], z["hi"][am == 1])
     np.testing.assert_array_equal(r0["x"][am == -1], z["lo"][am == -1])
+
+
+# ------------------------------------------------------------------ a callable loss in a frame-sharded run (round 5)
+def _callable_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import contextlib
+    import faulthandler
+    import io
+
+    faulthandler.dump_traceback_later(int(os.environ.get("MCBA_TEST_WATCHDOG_S", "150")), exit=True)
+    import torch.distributed as dist
+
+    import multicam_calibration_amd as m
+    from conftest import GOLDEN, problem_from_npz
+    from losses import charbonnier_quarter
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    z = np.load(os.path.join(GOLDEN, "tight_config1_callable.npz"))
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = m.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=None, device=0, loss=charbonnier_quarter, f_scale=0.7, ftol=1e-14, xtol=1e-14, gtol=1e-9, max_nfev=300,
+                                              verbose=0, distributed=True, return_jac=False)
+    hist = np.array([(h[0], h[1], h[2], h[5]) for h in res.lm["history"]])
+    np.savez(os.path.join(out_dir, f"c{rank}.npz"), x=res.x, cost=res.cost, use=use, status=res.status, nfev=res.nfev, hist=hist, K=np.stack([k for k, _ in it]))
+    dist.destroy_process_group()
+
+
+def test_callable_loss_in_a_frame_sharded_run_two_ranks(tmp_path):
+    """bundle_adjust(distributed=True, loss=<function>) as two gloo ranks sharing the GPU: every rank evaluates the function on the residuals of
+    its own frames (table + trial cost), the costs meet in the all-reduce of the trial scalars: identical decisions, the golden optimum."""
+    import torch.multiprocessing as mp
+
+    from conftest import GOLDEN
+
+    mp.spawn(_callable_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "c0.npz"), np.load(tmp_path / "c1.npz")
+    for k in ("x", "use", "hist", "K"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    assert float(r0["cost"]) == float(r1["cost"]) and int(r0["status"]) in (1, 2, 3, 4)
+    z = np.load(os.path.join(GOLDEN, "tight_config1_callable.npz"))
+    np.testing.assert_array_equal(r0["use"], z["s0_use"])
+    assert abs(float(r0["cost"]) - float(z["s0_cost"])) <= 1e-9 * float(z["s0_cost"])
+    cam, cam_g = r0["x"][:24].reshape(2, 12), z["s0_x"][:24].reshape(2, 12)
+    assert (np.abs(cam[:, :6] - cam_g[:, :6]) / np.abs(cam_g[:, :6])).max() < 1e-6

@@ -547,3 +547,34 @@ def test_bounds_in_a_frame_sharded_run_two_ranks(tmp_path):
     assert np.all(r0["x"] >= z["lo"]) and np.all(r0["x"] <= z["hi"])
     np.testing.assert_array_equal(r0["x"][z["active_mask"] == 1], z["hi"][z["active_mask"] == 1])
     np.testing.assert_array_equal(r0["x"][z["active_mask"] == -1], z["lo"][z["active_mask"] == -1])
+
+
+def _callable_sharded_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from losses import charbonnier_quarter
+    from multicam_calibration_amd import ops
+
+    ops.Problem = OracleProblem   # this process only
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    z = np.load(os.path.join(GOLDEN, "tight_config1_callable.npz"))
+    uvs, ext, intr, obj, poses = problem_from_npz(z)
+    with contextlib.redirect_stdout(io.StringIO()):
+        e, it, ps, use, res = api.bundle_adjust(uvs, ext, intr, obj, poses, n_frames=None, loss=charbonnier_quarter, f_scale=0.7, ftol=1e-14, xtol=1e-14, gtol=1e-9, max_nfev=300, verbose=0,
+                                                 distributed=True, return_jac=False)
+    np.savez(os.path.join(out_dir, f"c{rank}.npz"), x=res.x, cost=res.cost, use=use, status=res.status, nfev=res.nfev)
+    dist.destroy_process_group()
+
+
+def test_callable_loss_in_a_frame_sharded_run_two_ranks(tmp_path):
+    """bundle_adjust(distributed=True, loss=<function>) on two gloo ranks (the oracle-backed double): same decisions on both ranks, the golden optimum."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_callable_sharded_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "c0.npz"), np.load(tmp_path / "c1.npz")
+    np.testing.assert_array_equal(r0["x"], r1["x"])
+    assert float(r0["cost"]) == float(r1["cost"]) and int(r0["nfev"]) == int(r1["nfev"]) and int(r0["status"]) in (1, 2, 3, 4)
+    z = np.load(os.path.join(GOLDEN, "tight_config1_callable.npz"))
+    assert abs(float(r0["cost"]) - float(z["s0_cost"])) <= 1e-9 * float(z["s0_cost"])
