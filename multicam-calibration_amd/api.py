@@ -246,19 +246,19 @@ def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         try:
             # (a NaN threshold compares False with everything -- nothing is excluded --: +inf does the same and leaves NaN free to mean "5 x median" at the ABI)
             thr_in = None if outlier_threshold is None else (float("inf") if np.isnan(float(outlier_threshold)) else float(outlier_threshold))
-            status, thr, _ = prob.prefilter(serialize_params(all_extrinsics, all_intrinsics, calib_poses), thr_in)
+            status, thr, info = prob.prefilter(serialize_params(all_extrinsics, all_intrinsics, calib_poses), thr_in)
         except BaseException:
             prob.close()
             raise
-        use0 = np.flatnonzero(status & 1)
-        excluded = (status[use0] & 2) != 0
-        use_frames = use0[~excluded]
+        use_frames = np.flatnonzero((status & 3) == 1)   # used (:266) and not excluded (:285); the counts come with the call (info 4..6)
         shown = thr if outlier_threshold is None else outlier_threshold
-        print(f"Excluding {int(excluded.sum())} out of {len(use_frames)} frames based on an outlier threshold of {shown}")
+        print(f"Excluding {int(info[5])} out of {len(use_frames)} frames based on an outlier threshold of {shown}")
+        all_seen = info[6] == 0.0   # no kept frame is incomplete in any camera
         if not (n_frames is None or n_frames > len(use_frames)):
             use_frames = np.random.choice(use_frames, n_frames, replace=False)
+            all_seen = all_seen or bool((status[use_frames] & 4).all())
         if keep_problem:
-            return use_frames, prob, bool((status[use_frames] & 4).all()), 0
+            return use_frames, prob, bool(all_seen), 0
         prob.close()
         return use_frames
     dist, rank, world = None, 0, 1

@@ -866,6 +866,7 @@ int mcba_jacobian_download(mcba_handle* h, double* jac, double* res) {
 int mcba_linearize(mcba_handle* h, int slot) {
   if (!slot_ok(h, slot)) return fail(MCBA_ERR_ARG, "mcba_linearize: bad argument");
   if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_linearize: upload observations first");
+  if (h->loss == mcba::LOSS_TABLE && !h->loss_tab) return fail(MCBA_ERR_ARG, "mcba_linearize: the loss table was released (mcba_trim): call mcba_set_loss_table again");
   HIPCHK(hipSetDevice(h->device));
   NEED_SOLVER(h);
   {
