@@ -286,7 +286,13 @@ def _refine_five_coefficients(uvs, obj, intr9, poses, free9, device, max_evaluat
             W = H[:, :9, 9:][:, free9, :]                                   # (V, nf, 6)
             WVi = W @ Vinv
             S = U + lam * np.diag(np.maximum(np.diag(U), 1e-300)) - (WVi @ W.transpose(0, 2, 1)).sum(0)
-            dc[free9] = np.linalg.solve(S, -gc + np.einsum("vij,vj->i", WVi, gv))
+            try:
+                dc[free9] = np.linalg.solve(S, -gc + np.einsum("vij,vj->i", WVi, gv))
+            except np.linalg.LinAlgError:   # (views that do not constrain the intrinsics: more damping)
+                lam, nu = lam * nu, nu * 2.0
+                if lam > 1e12:
+                    break
+                continue
             dv = -np.einsum("vij,vj->vi", Vinv, gv + np.einsum("vij,i->vj", W, dc[free9]))
         else:
             dv = -np.einsum("vij,vj->vi", Vinv, gv)
