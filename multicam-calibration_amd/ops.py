@@ -14,7 +14,7 @@ LOSSES = {"linear": 0, "soft_l1": 1, "huber": 2, "cauchy": 3, "arctan": 4}
 OK, ERR_HIP, ERR_ARG, ERR_NONFINITE, ERR_NODEVICE = 0, 1, 2, 3, 4
 
 # every symbol include/mcba.h declares: (name, restype, argtypes)
-_dp = ctypes.POINTER(ctypes.c_double)
+_dp = ctypes.c_void_p   # double* (passed as the array's address: numpy's data_as(POINTER(c_double)) costs 2.8 us per argument, .ctypes.data 1.2 -- a call has 17 of them)
 _ip = ctypes.POINTER(ctypes.c_int)
 _h = ctypes.c_void_p
 SYMBOLS = [
@@ -142,7 +142,7 @@ def load_library():
 
 
 def _p(a):
-    return a.ctypes.data_as(_dp)
+    return a.ctypes.data
 
 
 def _f64(a):
@@ -217,7 +217,6 @@ class Problem:
         else:
             self._pending = (uvs, objpoints)
         self.set_loss(loss, f_scale)
-        self._init_host_views()
 
     def prefilter(self, x, outlier_threshold=None):
         """The reference's pre-filter (bundle_adjustment.py:265-285) in one C-ABI crossing and one host synchronisation
@@ -235,6 +234,16 @@ class Problem:
                                           status.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), _p(info)))
         self._pending = None
         return status, float(info[0]), info
+
+    _HOST_VIEWS = frozenset(("nsys", "_all", "_red", "_trial", "_state", "_all_p", "_red_p", "_trial_p", "_red_views", "_dc", "_dc_p"))
+
+    def __getattr__(self, name):
+        # the host-side images of the reduce buffer / trial scalars / LM state are made when first touched: the handle that only pre-filters
+        # (api.select_frames) never needs them
+        if name in Problem._HOST_VIEWS and "n" in self.__dict__:
+            self._init_host_views()
+            return self.__dict__[name]
+        raise AttributeError(name)
 
     def _init_host_views(self):
         self.nsys = self.n * self.n + 3 * self.n + 16
@@ -282,7 +291,6 @@ class Problem:
         self._chk(self.lib.mcba_create_subset(ctypes.byref(new.handle), self.handle, idx.ctypes.data_as(_ip), int(idx.size)))
         if loss is not None:
             new.set_loss(loss, 1.0 if f_scale is None else f_scale)
-        new._init_host_views()
         return new
 
     def reprojection_diagnostics(self, slot, dist5=None, undistort_iterations=5, arrays=True):
