@@ -492,11 +492,12 @@ def main():
         dom_bytes = algorithmic_bytes(dom, C, F, N)
         # HBM bytes from the PMC counters are NOT measured in this run (counter passes need rocprofv3): the figure printed is the
         # one of the committed profile named next to it, collected at the default shard size with the same kernels
-        traffic = jtraffic = traffic_source = None
+        traffic = jtraffic = traffic_source = rocprof_stats = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_file) and F == F_PER_GPU:
             with open(pmc_file) as fh:
                 pmc = json.load(fh)
+            rocprof_stats = pmc.get("_rocprofv3_kernel_stats")
             traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
             jtraffic = pmc.get("k_jacobian", {}).get("hbm_bytes_per_launch")
             traffic_source = "profiles/pmc_traffic.json <- " + str(pmc.get("_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier gpurun call")) + " (not measured in this run)"
@@ -525,6 +526,12 @@ def main():
                         "live_issue_ceiling": {"tflops": live_ceiling, "frac_issue_slots": (tfs / live_ceiling) if live_ceiling else None,
                                                "what": "independent v_fma_f64 with three distinct register pairs each, one wavefront per SIMD on every CU (mcba_fp64_issue_rate), measured in this run"},
                         "instructions_per_point_observation": mix, "hbm": hbm,
+                        # rocprofv3's average of the same kernel in the committed profile of the same command (another process, another box): what
+                        # the line's own figure should be read against -- the dispatch events of a plain run read 1-3 % above it
+                        "rocprofv3": ({"avg_launch_us": rocprof_stats["kernels"][dom]["avg_us"], "calls": rocprof_stats["kernels"][dom]["calls"],
+                                       "frac": real / (rocprof_stats["kernels"][dom]["avg_us"] * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                       "this_run_over_profile": dom_ms * 1e3 / rocprof_stats["kernels"][dom]["avg_us"], "source": rocprof_stats["source"] + " (not measured in this run)"}
+                                      if rocprof_stats and dom in rocprof_stats.get("kernels", {}) else None),
                         "note": "frac = real FP64 flops (2 x FMA + MUL + ADD) / 78.6 TFLOP/s; frac_issue_slots counts every FP64 instruction as an FMA; avg_launch_us = mean of 50 launches right after the timed region, "
                                 "timed by events attached to the kernel's dispatch (its own begin / end: the figure rocprofv3 reports); avg_launch_us_by_events_raw = the same launches with event records AROUND them"}
         tick_bytes = TICK_ALGORITHMIC_BYTES_10K * F / F_PER_GPU

@@ -36,6 +36,18 @@ def main(tag, rnd):
     traffic = {k: {q: v[q] for q in keys if q in v} for k, v in summary.items()}
     traffic["_source"] = (f"profiles/{rnd}/pmc_{tag}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
                           "scripts/profile_kernels.py; reads = 2 x FETCH_SIZE x 1024 per the gfx950 rule)")
+    # rocprofv3's own average durations of the bench command's kernels in this set (bench.py prints them next to what it measures itself)
+    stats = os.path.join(dst, f"bench_default_kernel_stats_{tag}.csv")
+    if os.path.exists(stats):
+        import csv
+        import re
+
+        avg = {}
+        for row in csv.DictReader(open(stats)):
+            mm = re.search(r"mcba::(k_[a-z0-9_]+)", row["Name"])
+            if mm and mm.group(1) not in avg:   # (rows are sorted by total time: the first instance of a kernel is the loop's)
+                avg[mm.group(1)] = {"avg_us": float(row["AverageNs"]) / 1e3, "calls": int(row["Calls"])}
+        traffic["_rocprofv3_kernel_stats"] = {"kernels": avg, "source": f"profiles/{rnd}/bench_default_kernel_stats_{tag}.csv (rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline --no-end-to-end --no-other-configs`)"}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
         f.write("\n")
