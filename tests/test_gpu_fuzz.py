@@ -186,7 +186,7 @@ def test_frame_selection_matches_the_oracle_prefilter(mc, capsys):
     threshold (or the caller's), the random subsample drawn from the global numpy RNG when n_frames is smaller than what is left --
     the same frames in the same order as the oracle, and the reference's printed line (threshold to 1e-12)."""
     rng = np.random.default_rng(77)
-    for it in range(40):
+    for it in range(40 + EXTRA):
         C = int(rng.choice([2, 3, 5, 8]))
         F = int(rng.choice([1, 5, 63, 64, 65, 200, 333]))
         p = mc.synth.make_problem(C, F, rows=int(rng.integers(1, 4)), cols=int(rng.integers(2, 5)), seed=300 + it, missing=float(rng.choice([0.0, 0.2, 0.6])),
