@@ -746,6 +746,8 @@ class BoundedLevenbergMarquardt(LevenbergMarquardt):
             natural = (on_lo & (g > 0)) | (on_hi & (g < 0))
             self.forced &= (on_lo | on_hi) & ~natural   # (a held coordinate that left its bound, or whose gradient now holds it there by itself, is no longer held for a bend)
             frozen = natural | self.forced
+        else:
+            self.forced[:] = False
         frames_changed = bool((frozen[ncam:] != self.frozen[ncam:]).any())
         self.frozen = frozen
         self.free = self.user_free & ~frozen[:ncam][self.cam_index]   # (camera coordinates: x and g_c are the same on every shard, so is this)
