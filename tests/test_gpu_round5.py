@@ -560,3 +560,43 @@ def test_callable_loss_contract_and_combinations(mc):
     g = orc.jacobian_csr(r_box.x, p["uvs"], p["obj"]).T @ (js * fs)
     free = r_box.active_mask == 0
     assert np.abs(g[free]).max() < 1e-5 * max(1.0, abs(g[k]))
+
+
+def test_bounds_at_a_thousand_frames(mc):
+    """The bounded loop where the frozen frame coordinates span many workgroups (6 x 1 000 x 54: 16 frame blocks per camera, the XS instances of
+    k_syrk / k_backsub over all of them, k_clip over 6 072 coordinates): bounds on four intrinsics and on forty pose coordinates that the free optimum
+    violates; judged by the oracle's KKT conditions at the returned point."""
+    from scipy.optimize._lsq.common import find_active_constraints
+
+    p = mc.synth.make_problem(6, 1000, seed=0, perturb_seed=1)
+    args = (p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    tol = dict(n_frames=None, ftol=1e-13, xtol=1e-13, gtol=1e-10, verbose=0, max_nfev=300)
+    (_, _, _, use, free), _ = captured(mc.bundle_adjust, *args, **tol)
+    assert use.size == 1000 and free.status > 0
+    x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    xu, n, nc = free.x, x0.size, 72
+    rng = np.random.default_rng(3)
+    lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
+    pick = [4, 12 + 5, 24 + 0, 36 + 4] + list(nc + rng.choice(6000, 40, replace=False))
+    for i in pick:
+        b = x0[i] + (0.5 if i < nc else 0.1) * (xu[i] - x0[i])
+        if xu[i] > x0[i]:
+            hi[i] = b
+        else:
+            lo[i] = b
+    (_, _, _, use2, res), _ = captured(mc.bundle_adjust, *args, bounds=(lo, hi), **tol)
+    assert res.status > 0 and np.array_equal(use2, use)
+    x = res.x
+    assert np.all(x >= lo) and np.all(x <= hi) and res.cost >= free.cost * (1 - 1e-12)
+    am = find_active_constraints(x, lo, hi, rtol=1e-13)
+    np.testing.assert_array_equal(res.active_mask, am)
+    assert (am[:nc] != 0).sum() >= 2 and (am[nc:] != 0).sum() >= 6
+    f = orc.residuals(x, p["uvs"], p["obj"])
+    assert abs(orc.robust_cost(f) - res.cost) <= 1e-10 * res.cost
+    js, fs = orc.robust_scales(f)
+    g = orc.jacobian_csr(x, p["uvs"], p["obj"]).T @ (js * fs)
+    js0, fs0 = orc.robust_scales(orc.residuals(x0, p["uvs"], p["obj"]))
+    scale = np.abs(orc.jacobian_csr(x0, p["uvs"], p["obj"]).T @ (js0 * fs0)).max()
+    assert np.abs(g[am == 0]).max() <= 1e-6 * scale, (np.abs(g[am == 0]).max(), scale)
+    assert np.all(g[am == -1] >= -1e-6 * scale) and np.all(g[am == 1] <= 1e-6 * scale)
+    np.testing.assert_allclose(res.grad, g, rtol=0, atol=1e-6 * scale)
