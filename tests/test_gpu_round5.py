@@ -445,12 +445,14 @@ def test_three_crossing_stub_over_raw_ctypes(mc):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # least_squares' CALLABLE `loss` (the reference forwards `loss` untouched: bundle_adjustment.py:301-313; scipy least_squares.py:160-227)
-def test_callable_loss_builds_the_builtin_normal_equations(mc):
+@pytest.mark.parametrize("shape", [(3, 70), (6, 1000), (14, 130)])
+def test_callable_loss_builds_the_builtin_normal_equations(mc, shape):
     """soft_l1 written as a callable must give the normal equations, cost and gradient of the built-in name (the table of the caller's
-    rho values against the kernel's own rho: two routes to the same numbers), free and with the intrinsics held fixed."""
+    rho values against the kernel's own rho: two routes to the same numbers), free and with the intrinsics held fixed; 3 x 70, 6 x 1 000 (16 frame
+    blocks per camera), 14 cameras (the 16-tile k_syrk)."""
     from losses import soft_l1_as_callable
 
-    p = mc.synth.make_problem(3, 70, seed=5, perturb_seed=2, missing=0.2, scalar_nans=4)
+    p = mc.synth.make_problem(shape[0], shape[1], seed=5, perturb_seed=2, missing=0.2, scalar_nans=4)
     x0 = mc.api.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
     for width in (12, 6):
         got = []
