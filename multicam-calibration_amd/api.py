@@ -13,7 +13,6 @@ exact Schur solve instead of scipy's TRF/LSMR on a finite-difference Jacobian.  
 cost, so it converges to the same minimiser (gauge aside); the iterate sequence is not reproduced.
 """
 import os
-import warnings
 import weakref
 
 import numpy as np
