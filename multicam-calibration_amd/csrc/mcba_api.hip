@@ -1396,14 +1396,13 @@ int mcba_lm_run(mcba_handle* h, const double* x0, const double* opt, const unsig
   h->have_lin = true; h->have_spec = false;
   if ((rc = mcba_build_reduced(h, lam0, rank_slot))) return rc;
   if (h->comm && (rc = mcba_comm_allreduce(h, 0, h->nsys))) return rc;
-  mcba::launch_lm_init(h->stream, h->red + (size_t)h->n * h->n + 3 * (size_t)h->n, h->red + h->nsys + 8, lam0, 0, cfl, cfl_switch);
+  mcba::launch_lm_init(h->stream, h->red + (size_t)h->n * h->n + 3 * (size_t)h->n, h->red + h->nsys + 8, lam0, 0, cfl, cfl_switch, h->dcbuf + h->n);
   if ((rc = check_launch())) return rc;
   // mcba_lm_auto_config, without its two waits
   h->ftol = opt[0]; h->xtol = opt[1]; h->gtol = opt[2]; h->lam_min = lam_min; h->lam_max = lam_max;
   h->have_fixed = fixed != nullptr;
   if (fixed) HIPCHK(hipMemcpyAsync(h->fixed, fixed, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
   memset(h->ring, 0, (size_t)kRing * MCBA_LMS * sizeof(double));
-  HIPCHK(hipMemsetAsync(h->dcbuf + h->n, 0, 8 * sizeof(double), h->stream));
   h->trial_ready = false;
   h->last_solve_seq = 0;
   h->waited_seq = 0;
@@ -1534,8 +1533,8 @@ int mcba_prefilter(mcba_handle* h, const double* uvs, const double* objpoints, c
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(h->x[0], x, ((size_t)12 * h->C + (size_t)6 * h->F) * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (uvs && (rc = upload_impl(h, uvs, objpoints, false))) return rc;
-  mcba::launch_frame_err(h->stream, h->obs_t, h->obj, h->x[0], h->err, h->dmean, h->dfull, h->C, h->F, h->N, h->Fpad);
-  mcba::launch_prefilter_select(h->stream, h->err, h->dmean, h->dfull, h->fmask, h->pf_status, h->pf_worst, h->pf_state, h->pf_packed, h->C, h->F, h->N, h->Fpad, outlier_threshold);
+  mcba::launch_frame_err(h->stream, h->obs_t, h->obj, h->x[0], h->err, h->dmean, h->dfull, h->C, h->F, h->N, h->Fpad, h->pf_state);
+  mcba::launch_prefilter_select(h->stream, h->err, h->dmean, h->dfull, h->fmask, h->pf_status, h->pf_worst, h->pf_state, h->pf_packed, h->C, h->F, h->N, h->Fpad, outlier_threshold, true);
   if ((rc = check_launch())) return rc;
   const size_t nb = 64 + (size_t)h->F;
   auto fetch = [&]() -> int {

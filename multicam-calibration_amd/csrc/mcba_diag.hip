@@ -34,7 +34,12 @@ __device__ __forceinline__ double diag_uni(double v) {
 
 // ---------------------------------------------------------------- pre-filter errors
 __global__ __launch_bounds__(256) void k_frame_err(const double2* __restrict__ obs_t, const double* __restrict__ obj, const double* __restrict__ x, double* __restrict__ err,
-                                                   double* __restrict__ mean_cf, double* __restrict__ full_cf, int C, int F, int N, int Fpad, int nfb) {
+                                                   double* __restrict__ mean_cf, double* __restrict__ full_cf, int C, int F, int N, int Fpad, int nfb,
+                                                   unsigned long long* __restrict__ clear, unsigned nclear) {
+  // (mcba_prefilter: the selection's state is zeroed HERE, by the launch that precedes its first pass anyway -- a hipMemsetAsync of its own is two
+  //  fill kernels of ~5 us each between this launch and the next)
+  if (clear)
+    for (unsigned i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nclear; i += gridDim.x * gridDim.y * 256) clear[i] = 0ull;
   __shared__ CamConst s_cam;
   const int c = blockIdx.y;
   if (threadIdx.x == 0) make_cam_const(x + 12 * c, s_cam);
@@ -778,9 +783,11 @@ __global__ __launch_bounds__(256) void k_reproj_diag(const double2* __restrict__
 }
 
 // ---------------------------------------------------------------- launch wrappers
-void launch_frame_err(hipStream_t st, const double* obs_t, const double* obj, const double* x, double* err, double* mean_cf, double* full_cf, int C, int F, int N, int Fpad) {
+void launch_frame_err(hipStream_t st, const double* obs_t, const double* obj, const double* x, double* err, double* mean_cf, double* full_cf, int C, int F, int N, int Fpad, void* prefilter_state) {
   const int nfb = Fpad / 64;
-  k_frame_err<<<dim3((nfb + 3) / 4, C), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, err, mean_cf, full_cf, C, F, N, Fpad, nfb);
+  static_assert(offsetof(PrefState, partB) % 8 == 0, "the cleared part of the selection's state is whole 64-bit words");
+  k_frame_err<<<dim3((nfb + 3) / 4, C), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(obs_t), obj, x, err, mean_cf, full_cf, C, F, N, Fpad, nfb,
+                                                            static_cast<unsigned long long*>(prefilter_state), (unsigned)(prefilter_state_clear_bytes() / 8));
 }
 
 size_t select_state_bytes(int groups) { return (size_t)groups * sizeof(SelState); }
@@ -864,9 +871,9 @@ double measure_fp64_issue_rate(int ncu) {
 // 5 x nanmedian of the used frames' per-point errors (three passes over err), else the caller's.  The result [info 8 doubles | status]
 // lands in `packed` (64 + F bytes) for one device-to-host copy.  No synchronisation.
 void launch_prefilter_select(hipStream_t st, const double* err, const double* mean_cf, const double* full_cf, unsigned char* fmask, unsigned char* status, double* worst, void* state,
-                             unsigned char* packed, int C, int F, int N, int Fpad, double threshold) {
+                             unsigned char* packed, int C, int F, int N, int Fpad, double threshold, bool state_cleared) {
   PrefState* ps = static_cast<PrefState*>(state);
-  (void)hipMemsetAsync(ps, 0, prefilter_state_clear_bytes(), st);
+  if (!state_cleared) (void)hipMemsetAsync(ps, 0, prefilter_state_clear_bytes(), st);   // (mcba_prefilter: launch_frame_err cleared it)
   const bool median = threshold != threshold;
   if (median) {
     const int R = C * N, nfb = Fpad / 64, items = nfb * ((R + 16 * PF_ROWS - 1) / (16 * PF_ROWS));

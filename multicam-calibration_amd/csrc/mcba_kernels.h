@@ -109,19 +109,20 @@ void launch_solve_backsub(hipStream_t st, const SolveArgs& a, Sel sl, const doub
                           int strict = 0);  // != 0: the waiting workgroups acquire the release word with an agent-scope fence (mcba_backsub.h: release_word_acquired)
 void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp1, int cstride, int cinner, size_t couter, int ncp, const double* bpart, int nbp, double* out, DecideArgs da);
 void launch_decide(hipStream_t st, const double* trial8, DecideArgs da);
-void launch_lm_init(hipStream_t st, const double* red_scal, double* lms, double lam0, int sel, double cfl, double cfl_switch);  // mcba_lm_run: the start state, on the device
+void launch_lm_init(hipStream_t st, const double* red_scal, double* lms, double lam0, int sel, double cfl, double cfl_switch, double* clear8 = nullptr);  // mcba_lm_run: the start state, on the device
 void launch_pack_result(hipStream_t st, const double* x, const double* gc, const double* fbuf, const unsigned char* fixed, double* out, int C, int F, int cw);  // mcba_lm_result
 void launch_jacobian(hipStream_t st, int loss, double f_scale, const double* obs_raw, const double* obj, const double* x, double* jac, double* res, int C, int F, int N, int Fpad, int robust);
 int syrk_set_lds_limit(size_t bytes);
 // pre-filter, frame subsets, undistortion, reprojection diagnostics (mcba_diag.hip)
-void launch_frame_err(hipStream_t st, const double* obs_t, const double* obj, const double* x, double* err, double* mean_cf, double* full_cf, int C, int F, int N, int Fpad);
+void launch_frame_err(hipStream_t st, const double* obs_t, const double* obj, const double* x, double* err, double* mean_cf, double* full_cf, int C, int F, int N, int Fpad,
+                      void* prefilter_state = nullptr);   // non-NULL: the launch also zeroes the selection's state (launch_prefilter_select(..., state_cleared = true) follows)
 size_t select_state_bytes(int groups);  // per group: u64 prefix, rank, count, value (bit pattern of the selected double) + a 256-bin histogram
 void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int groups, int Fpad, void* sel, int upper);
 int launch_select_hist(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int Fpad, void* sel, unsigned long long prefix, int pass, unsigned int* hist256);
 // the pre-filter's selection on the device (mcba_prefilter): see mcba_diag.hip
 size_t prefilter_state_bytes();
 void launch_prefilter_select(hipStream_t st, const double* err, const double* mean_cf, const double* full_cf, unsigned char* fmask, unsigned char* status, double* worst, void* state,
-                             unsigned char* packed, int C, int F, int N, int Fpad, double threshold);
+                             unsigned char* packed, int C, int F, int N, int Fpad, double threshold, bool state_cleared = false);
 void launch_prefilter_status(hipStream_t st, unsigned char* status, const double* worst, void* state, unsigned char* packed, int F, double threshold, int from_state);
 void launch_gather_params(hipStream_t st, const double* x_src, const int* frames, double* x_dst, int C, int Fdst);
 void launch_clip(hipStream_t st, double* x, const double* lo, const double* hi, size_t n);  // x <- min(max(x, lo), hi): the trial point of a bounded step

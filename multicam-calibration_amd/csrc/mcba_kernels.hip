@@ -1994,8 +1994,9 @@ void launch_sum_trial(hipStream_t st, Sel s, const double* cp0, const double* cp
 
 // mcba_lm_run: the LM state a fresh solve starts from, written on the device -- its cost is scalar 0 of the reduced system that was
 // just built (and all-reduced) at the start point, so no host round trip separates that build from the first solve
-__global__ void k_lm_init(const double* __restrict__ red_scal, double* __restrict__ lms, double lam0, double sel, double cfl, double cfl_switch) {
+__global__ void k_lm_init(const double* __restrict__ red_scal, double* __restrict__ lms, double lam0, double sel, double cfl, double cfl_switch, double* __restrict__ clear8) {
   const int i = threadIdx.x;
+  if (clear8 && i >= 56) clear8[i - 56] = 0.0;   // (the release words of the fused back-substitution: what a memset of their own did)
   if (i >= MCBA_LMS) return;
   double v = 0.0;
   if (i == 0) v = red_scal[0];
@@ -2006,8 +2007,9 @@ __global__ void k_lm_init(const double* __restrict__ red_scal, double* __restric
   else if (i == MCBA_LM_CFL_SWITCH) v = cfl_switch;
   lms[i] = v;
 }
-void launch_lm_init(hipStream_t st, const double* red_scal, double* lms, double lam0, int sel, double cfl, double cfl_switch) {
-  k_lm_init<<<dim3(1), dim3(64), 0, st>>>(red_scal, lms, lam0, (double)sel, cfl, cfl_switch);
+void launch_lm_init(hipStream_t st, const double* red_scal, double* lms, double lam0, int sel, double cfl, double cfl_switch, double* clear8) {
+  static_assert(MCBA_LMS <= 56, "threads 56..63 of k_lm_init clear the eight release words");
+  k_lm_init<<<dim3(1), dim3(64), 0, st>>>(red_scal, lms, lam0, (double)sel, cfl, cfl_switch, clear8);
 }
 
 // mcba_lm_result: [x (12C + 6F) | gradient (12C + 6F)] of the current point in one buffer -- the camera gradient g_c of the reduced system
