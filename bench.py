@@ -111,7 +111,7 @@ def end_to_end(m, p, reps=5, full=True):
         return w
 
     saved = []
-    for owner, names in ((ops.Problem, ["__init__", "prefilter", "subset", "close", "lm_run", "lm_result", "residuals_detach", "set_x_scale"]),
+    for owner, names in ((ops.Problem, ["__init__", "prefilter", "prefilter_subset", "subset", "close", "lm_run", "lm_result", "residuals_detach", "set_x_scale"]),
                          (api, ["select_frames", "deserialize_params", "serialize_params"]), (solver, ["lm_solve"])):
         for n in names:
             saved.append((owner, n, getattr(owner, n)))
@@ -159,12 +159,28 @@ def end_to_end(m, p, reps=5, full=True):
                 o = m.bundle_adjust(uvs_m, p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=F, verbose=0, return_jac=False)
             miss.append(1e3 * (time.perf_counter() - t0))
             del o
+        # n_frames larger than the recording (the reference's default n_frames=10000 on anything shorter; its tutorial passes 5000 for 2 130 frames):
+        # no random draw stands between the selection and its gather (bundle_adjustment.py:292-296) -- every frame kept = no gather at all
+        nodraw = []
+        for _ in range(4 if full else 3):
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                o = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=2 * F, verbose=0, return_jac=False)
+            nodraw.append(1e3 * (time.perf_counter() - t0))
+            del o
+        nodraw_m = []
+        for _ in range(4 if full else 3):
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                o = m.bundle_adjust(uvs_m, p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=2 * F, verbose=0, return_jac=False)
+            nodraw_m.append(1e3 * (time.perf_counter() - t0))
+            del o
     finally:
         for owner, n, f in saved:
             setattr(owner, n, f)
     ms = {k: 1e3 * v / reps for k, v in acc_main.items()}
     total = float(np.median(times))
-    pre = ms.get("ops.prefilter", 0.0) + ms.get("ops.__init__", 0.0)
+    pre = ms.get("ops.prefilter", 0.0) + ms.get("ops.prefilter_subset", 0.0) + ms.get("ops.__init__", 0.0)
     sel = ms.get("api.select_frames", 0.0) - pre
     lm = ms.get("solver.lm_solve", 0.0)
     gather = ms.get("ops.subset", 0.0)
@@ -176,7 +192,8 @@ def end_to_end(m, p, reps=5, full=True):
                             "lm_solve_total": lm, "of_which_lm_run_one_crossing": ms.get("ops.lm_run", 0.0), "of_which_lm_result_d2h": ms.get("ops.lm_result", 0.0),
                             "residual_vector_left_on_device": detach, "handle_teardown": close, "python_rest": total - (pre + sel + gather + lm + detach + close)},
            "result_fun_first_read_ms": t_fun, "result_fun_size": nres, "missing_detections_call_ms": float(np.median(miss[1:])),
-           "note": "three C-ABI crossings carry the call (mcba_prefilter, mcba_lm_run, mcba_lm_result); result.fun / result.grad stay on the GPU until first read (LazyOptimizeResult) -- the download of fun is timed separately above and is not part of `ms`; missing_detections_call_ms = the same call with 5 % of the (camera, frame) detections NaN"}
+           "n_frames_above_recording_call_ms": float(np.median(nodraw[1:])), "n_frames_above_recording_missing_detections_call_ms": float(np.median(nodraw_m[1:])),
+           "note": "three C-ABI crossings carry the call (mcba_prefilter, mcba_lm_run, mcba_lm_result); result.fun / result.grad stay on the GPU until first read (LazyOptimizeResult) -- the download of fun is timed separately above and is not part of `ms`; missing_detections_call_ms = the same call with 5 % of the (camera, frame) detections NaN; n_frames_above_recording_call_ms = the same call with n_frames larger than the recording (the reference's default 10000 on a shorter recording; its tutorial's 5000 for 2 130 frames): no random draw, the kept frames are gathered inside the pre-filter's crossing (mcba_prefilter_subset) or, all kept, not at all"}
     if full:
         out["default_call_ms"] = float(np.median(dflt))
         out["note"] += "; default_call_ms = the same call without return_jac=False (result.jac lazy, the result holds the handle)"

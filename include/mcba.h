@@ -52,7 +52,7 @@ typedef struct mcba_handle mcba_handle;
 typedef struct mcba_buffer mcba_buffer;   /* a device array that outlives its handle (mcba_residuals_detach) */
 
 /* ---- library ------------------------------------------------------------------------------- */
-int mcba_abi_version(void);            /* 6.  Bumped when this header changes: 6 (round 5) ADDS mcba_prefilter, mcba_lm_run, mcba_lm_history, mcba_lm_result, mcba_set_bounds / _frozen, mcba_set_loss_table and leaves every
+int mcba_abi_version(void);            /* 6.  Bumped when this header changes: 6 (round 5) ADDS mcba_prefilter, mcba_prefilter_subset, mcba_lm_run, mcba_lm_history, mcba_lm_result, mcba_set_bounds / _frozen, mcba_set_loss_table and leaves every
                                         * ABI-5 entry point as it was.  (ABI 5 gave LM-state slots 25 / 26 -- "reserved" before -- their meaning: curvature floor / switch
                                         * fraction; a caller that zeroes them gets the handle's floor, fixed.) */
 const char* mcba_last_error(void);
@@ -356,6 +356,12 @@ int mcba_error_histogram(mcba_handle* h, const unsigned char* frame_mask, unsign
  * 6 kept frames that are incomplete in some camera.  The per-point errors and per-(camera, frame) statistics stay on the device as
  * after mcba_frame_errors(h, 0, ...). */
 int mcba_prefilter(mcba_handle* h, const double* uvs, const double* objpoints, const double* x, double outlier_threshold, unsigned char* status, double* info8);
+/* mcba_prefilter + the gather of the frames it kept, when no random draw stands in between (bundle_adjustment.py:292-296 draws the subsample from the
+ * caller's global numpy RNG only if n_frames <= the number of frames kept; n_frames < 0 = None).  info8[7]: 0 nothing kept, 1 the caller must draw
+ * (*sub stays NULL: mcba_create_subset of its draw), 2 every frame kept, in order (solve on h itself), 3 *sub = a new handle holding the kept frames
+ * in order (as mcba_create_subset makes it: observations, board and the parameters of slot 0 gathered on the device).  The caller owns *sub. */
+int mcba_prefilter_subset(mcba_handle* h, const double* uvs, const double* objpoints, const double* x, double outlier_threshold, int n_frames, unsigned char* status, double* info8,
+                          mcba_handle** sub);
 /* New handle on the same device / stream holding the observations of n_frames frames of `src` (indices into its frames,
  * any order, repeats allowed) -- gathered device to device: what bundle_adjust solves on after the pre-filter, without
  * a second host upload (the reference slices all_calib_uvs[:, use_frames]: bundle_adjustment.py:298,312).  Parameter slot 0 of the

@@ -227,7 +227,7 @@ def _median_from_histograms(hist):
     return float(0.5 * (vals[0] + vals[-1]))
 
 
-def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device=0, keep_problem=False, group=None, **problem_kw):
+def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device=0, keep_problem=False, group=None, subset_loss=None, **problem_kw):
     """The reference's pre-filter (bundle_adjustment.py:265-296) on the GPU: the frames are uploaded once, the reprojection
     errors, their per-(camera, frame) nan-means, the completeness counts (k_frame_err) and the exact nan-median (radix
     select) are computed there; the host sees 2 x (C,F) doubles.  Returns use_frames, or (use_frames, problem, complete, lo)
@@ -245,7 +245,12 @@ def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
         try:
             # (a NaN threshold compares False with everything -- nothing is excluded --: +inf does the same and leaves NaN free to mean "5 x median" at the ABI)
             thr_in = None if outlier_threshold is None else (float("inf") if np.isnan(float(outlier_threshold)) else float(outlier_threshold))
-            status, thr, info = prob.prefilter(serialize_params(all_extrinsics, all_intrinsics, calib_poses), thr_in)
+            sub = None
+            if keep_problem and subset_loss is not None and hasattr(prob, "prefilter_subset") and os.environ.get("MCBA_PREFILTER_SUBSET", "1") != "0":   # (0: gather in a crossing of its own, for A/B)
+                # bundle_adjust: the frames kept are gathered in the same crossing unless the reference's random draw stands in between (:292-296)
+                status, thr, info, sub = prob.prefilter_subset(serialize_params(all_extrinsics, all_intrinsics, calib_poses), thr_in, n_frames, *subset_loss)
+            else:
+                status, thr, info = prob.prefilter(serialize_params(all_extrinsics, all_intrinsics, calib_poses), thr_in)
         except BaseException:
             prob.close()
             raise
@@ -257,6 +262,8 @@ def select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             use_frames = np.random.choice(use_frames, n_frames, replace=False)
             all_seen = all_seen or bool((status[use_frames] & 4).all())
         if keep_problem:
+            if subset_loss is not None:
+                return use_frames, prob, bool(all_seen), 0, sub
             return use_frames, prob, bool(all_seen), 0
         prob.close()
         return use_frames
@@ -411,8 +418,10 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             # torch orders its collectives against torch's CURRENT stream: the library must launch on that same stream
             # (the torch.distributed fallback of solver.make_comm all-reduces the library's reduce buffer in place)
             pkw["stream"] = torch.cuda.current_stream(device).cuda_stream
-    all_use, prob_all, all_seen, lo = select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device,
-                                                    keep_problem=True, group=group, **pkw)
+    sel = select_frames(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints, calib_poses, n_frames, outlier_threshold, device, keep_problem=True, group=group,
+                        subset_loss=None if distributed else (kw["loss"], kw.get("f_scale", 1.0)), **pkw)
+    all_use, prob_all, all_seen, lo = sel[:4]
+    pre_sub = sel[4] if len(sel) > 4 else None   # (one GPU, no random draw: the kept frames were gathered in the pre-filter's own crossing)
     prob = None
     try:
         # ---- which of the selected frames this process solves: all of them, or (frame-sharded) those of its own slice -- they are
@@ -484,7 +493,7 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
             prob.set_loss(kw["loss"], kw.get("f_scale", 1.0))
             x0_on_device = True
         elif local:        # the frames are already on the GPU (pre-filter): gather the selection there, no second upload
-            prob = prob_all.subset(use_frames - lo, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0))
+            prob, pre_sub = (pre_sub, None) if pre_sub is not None else (prob_all.subset(use_frames - lo, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0)), None)
             x0_on_device = hasattr(prob, "lm_run")   # (mcba_create_subset gathers the parameters of the chosen frames as well)
         else:
             prob = ops.Problem(np.ascontiguousarray(all_calib_uvs[:, use_frames]), calib_objpoints, device=device, loss=kw["loss"], f_scale=kw.get("f_scale", 1.0), **pkw)
@@ -570,6 +579,8 @@ def bundle_adjust(all_calib_uvs, all_extrinsics, all_intrinsics, calib_objpoints
     finally:
         if prob_all is not None:
             prob_all.close()
+        if pre_sub is not None:
+            pre_sub.close()
         if prob is not None:
             prob.close()
 

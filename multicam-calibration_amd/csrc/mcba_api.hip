@@ -1566,6 +1566,30 @@ int mcba_prefilter(mcba_handle* h, const double* uvs, const double* objpoints, c
   return MCBA_OK;
 }
 
+// mcba_prefilter + what bundle_adjust does with its answer when no random draw stands in between (bundle_adjustment.py:292-296: the
+// subsample is drawn from the caller's global numpy RNG only if n_frames <= the number of frames kept): the kept frames are gathered into a
+// new handle right here, with the status bytes still warm -- the host round trip between "the selection is known" and "its gather is enqueued"
+// was a Python function and a second crossing.  info8[7]: 0 nothing kept, 1 the caller must draw (no handle made), 2 every frame kept in
+// order (solve on h itself), 3 *sub holds the kept frames (mcba_create_subset of them, in order).  n_frames < 0: no cap (None).
+int mcba_prefilter_subset(mcba_handle* h, const double* uvs, const double* objpoints, const double* x, double outlier_threshold, int n_frames, unsigned char* status, double* info8,
+                          mcba_handle** sub) {
+  if (!sub) return fail(MCBA_ERR_ARG, "mcba_prefilter_subset: bad argument");
+  *sub = nullptr;
+  int rc = mcba_prefilter(h, uvs, objpoints, x, outlier_threshold, status, info8);
+  if (rc) return rc;
+  const int kept = (int)(info8[4] - info8[5]);
+  if (kept == 0) { info8[7] = 0.0; return MCBA_OK; }
+  if (n_frames >= 0 && n_frames <= kept) { info8[7] = 1.0; return MCBA_OK; }
+  if (kept == h->F) { info8[7] = 2.0; return MCBA_OK; }
+  std::vector<int> frames;
+  frames.reserve((size_t)kept);
+  for (int f = 0; f < h->F; ++f)
+    if ((status[f] & 3) == 1) frames.push_back(f);
+  if ((rc = mcba_create_subset(sub, h, frames.data(), (int)frames.size()))) return rc;
+  info8[7] = 3.0;
+  return MCBA_OK;
+}
+
 int mcba_frame_errors(mcba_handle* h, int slot, double* mean_cf, double* full_cf) {
   if (!slot_ok(h, slot) || !mean_cf || !full_cf) return fail(MCBA_ERR_ARG, "mcba_frame_errors: bad argument");
   if (!h->have_obs) return fail(MCBA_ERR_ARG, "mcba_frame_errors: upload observations first");

@@ -90,6 +90,7 @@ SYMBOLS = [
     ("mcba_error_median", ctypes.c_int, [_h, ctypes.c_char_p, _dp, _dp]),
     ("mcba_create_subset", ctypes.c_int, [ctypes.POINTER(_h), _h, _ip, ctypes.c_int]),
     ("mcba_prefilter", ctypes.c_int, [_h, _dp, _dp, _dp, ctypes.c_double, ctypes.POINTER(ctypes.c_ubyte), _dp]),
+    ("mcba_prefilter_subset", ctypes.c_int, [_h, _dp, _dp, _dp, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte), _dp, ctypes.POINTER(_h)]),
     ("mcba_lm_run", ctypes.c_int, [_h, _dp, _dp, ctypes.c_char_p, _dp]),
     ("mcba_lm_history", ctypes.c_int, [_h, _dp, ctypes.c_size_t]),
     ("mcba_lm_result", ctypes.c_int, [_h, ctypes.c_int, _dp, _dp, ctypes.POINTER(_h)]),
@@ -244,6 +245,33 @@ class Problem:
             self._init_host_views()
             return self.__dict__[name]
         raise AttributeError(name)
+
+    def prefilter_subset(self, x, outlier_threshold=None, n_frames=None, loss=None, f_scale=None):
+        """`prefilter` + the gather of the kept frames in the same crossing when no random draw stands in between (include/mcba.h:
+        mcba_prefilter_subset).  Returns (status, threshold, info, sub): info[7] = 0 nothing kept, 1 the caller must draw its subsample
+        (sub None), 2 every frame kept in order (sub None: solve on this handle), 3 sub = a new Problem holding the kept frames in order."""
+        x = _f64(x)
+        if x.shape != (self.nx,):
+            raise ValueError(f"x must have {self.nx} entries")
+        status = np.empty(self.F, np.uint8)
+        info = np.empty(8)
+        uvs, obj = getattr(self, "_pending", None) or (None, None)
+        thr = float("nan") if outlier_threshold is None else float(outlier_threshold)
+        sub = _h()
+        self._chk(self.lib.mcba_prefilter_subset(self.handle, None if uvs is None else _p(uvs), None if obj is None else _p(obj), _p(x), thr, -1 if n_frames is None else int(n_frames),
+                                                 status.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), _p(info), ctypes.byref(sub)))
+        self._pending = None
+        new = None
+        if sub:
+            new = Problem.__new__(Problem)
+            new.lib = self.lib
+            new.C, new.N, new.F = self.C, self.N, int(info[4] - info[5])
+            new.cw, new.n = 12, 12 * self.C
+            new.nx = 12 * new.C + 6 * new.F
+            new.handle = sub
+            if loss is not None:
+                new.set_loss(loss, 1.0 if f_scale is None else f_scale)
+        return status, float(info[0]), info, new
 
     def _init_host_views(self):
         self.nsys = self.n * self.n + 3 * self.n + 16

@@ -602,3 +602,46 @@ def test_bounds_at_a_thousand_frames(mc):
     assert np.abs(g[am == 0]).max() <= 1e-6 * scale, (np.abs(g[am == 0]).max(), scale)
     assert np.all(g[am == -1] >= -1e-6 * scale) and np.all(g[am == 1] <= 1e-6 * scale)
     np.testing.assert_allclose(res.grad, g, rtol=0, atol=1e-6 * scale)
+
+
+@pytest.mark.parametrize("shape", [(3, 70, dict(missing=0.2, outlier_frames=4)), (6, 300, dict(outlier_frames=7)), (2, 40, {})])
+def test_prefilter_subset_equals_the_two_crossings(mc, shape):
+    """mcba_prefilter_subset (the kept frames gathered inside the pre-filter's crossing when no random draw stands in between: n_frames None or
+    larger than what is kept) against mcba_prefilter + mcba_create_subset (MCBA_PREFILTER_SUBSET=0): the same frames, printed line, iterates and
+    solution to the bit; with n_frames <= the frames kept the reference's draw from the global RNG comes first and the old path runs (same result,
+    same RNG state); nothing kept: no handle."""
+    C, F, kw = shape
+    p = mc.synth.make_problem(C, F, seed=21, perturb_seed=3, **kw)
+    args = (p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    for nf in (None, 10 * F, F // 2):
+        outs = []
+        for flag in ("1", "0"):
+            with env(MCBA_PREFILTER_SUBSET=flag):
+                np.random.seed(5)
+                (e, i, ps, use, res), out = captured(mc.bundle_adjust, *args, n_frames=nf, verbose=2, return_jac=False)
+                outs.append((use, res.x, res.cost, res.nfev, out, np.random.randint(1 << 30)))
+        a, b = outs
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and a[5] == b[5]
+    # the crossing itself: which case it reports, and the handle it makes
+    x = mc.api.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    prob = mc.ops.Problem(p["uvs"], p["obj"], upload=False)
+    status, thr, info, sub = prob.prefilter_subset(x, None, None, "soft_l1", 1.0)
+    kept = np.flatnonzero((status & 3) == 1)
+    if kept.size == F:
+        assert info[7] == 2 and sub is None
+    else:
+        assert info[7] == 3 and sub is not None and sub.F == kept.size
+        np.testing.assert_array_equal(sub.get_params(0), np.concatenate([x[:12 * C], x[12 * C:].reshape(F, 6)[kept].ravel()]))
+        np.testing.assert_array_equal(sub.download_observations(), p["uvs"][:, kept])
+        sub.close()
+    status2, thr2, info2, sub2 = prob.prefilter_subset(x, None, max(1, kept.size // 2), "soft_l1", 1.0)
+    assert info2[7] == 1 and sub2 is None and np.array_equal(status2, status)
+    prob.close()
+    q = mc.synth.make_problem(2, 12, seed=3)
+    q["uvs"][1] = np.nan   # no frame is complete in two cameras
+    prob = mc.ops.Problem(q["uvs"], q["obj"], upload=False)
+    st, _, info3, sub3 = prob.prefilter_subset(mc.api.serialize_params(q["extrinsics"], q["intrinsics"], q["poses"]), None, None, "soft_l1", 1.0)
+    assert info3[7] == 0 and sub3 is None and not (st & 1).any()
+    prob.close()
