@@ -624,6 +624,18 @@ def test_prefilter_subset_equals_the_two_crossings(mc, shape):
         np.testing.assert_array_equal(a[0], b[0])
         np.testing.assert_array_equal(a[1], b[1])
         assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and a[5] == b[5]
+    # ... with the options that take other drivers: a callable loss, bounds, the intrinsics held fixed
+    from losses import charbonnier_quarter
+
+    for extra in (dict(loss=charbonnier_quarter, f_scale=0.7), dict(fix_intrinsics=True), dict(bounds=(-1e9, 1e9), x_scale=2.0)):
+        outs = []
+        for flag in ("1", "0"):
+            with env(MCBA_PREFILTER_SUBSET=flag):
+                (e, i, ps, use, res), out = captured(mc.bundle_adjust, *args, n_frames=None, verbose=0, return_jac=False, max_nfev=30, **extra)
+                outs.append((use, res.x, res.cost))
+        np.testing.assert_array_equal(outs[0][0], outs[1][0])
+        np.testing.assert_array_equal(outs[0][1], outs[1][1])
+        assert outs[0][2] == outs[1][2]
     # the crossing itself: which case it reports, and the handle it makes
     x = mc.api.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
     prob = mc.ops.Problem(p["uvs"], p["obj"], upload=False)
