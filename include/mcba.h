@@ -52,7 +52,7 @@ typedef struct mcba_handle mcba_handle;
 typedef struct mcba_buffer mcba_buffer;   /* a device array that outlives its handle (mcba_residuals_detach) */
 
 /* ---- library ------------------------------------------------------------------------------- */
-int mcba_abi_version(void);            /* 6.  Bumped when this header changes: 6 (round 5) ADDS mcba_prefilter, mcba_prefilter_subset, mcba_lm_run, mcba_lm_history, mcba_lm_result, mcba_set_bounds / _frozen, mcba_set_loss_table and leaves every
+int mcba_abi_version(void);            /* 6.  Bumped when this header changes: 6 (round 5) ADDS mcba_prefilter, mcba_prefilter_subset, mcba_lm_run, mcba_lm_history, mcba_lm_result, mcba_set_bounds / _frozen, mcba_set_loss_table, mcba_set_trial, mcba_calib_normal_equations (and the diagnostics / life-cycle helpers declared below as ABI 6) and leaves every
                                         * ABI-5 entry point as it was.  (ABI 5 gave LM-state slots 25 / 26 -- "reserved" before -- their meaning: curvature floor / switch
                                         * fraction; a caller that zeroes them gets the handle's floor, fixed.) */
 const char* mcba_last_error(void);
