@@ -52,7 +52,7 @@ typedef struct mcba_handle mcba_handle;
 typedef struct mcba_buffer mcba_buffer;   /* a device array that outlives its handle (mcba_residuals_detach) */
 
 /* ---- library ------------------------------------------------------------------------------- */
-int mcba_abi_version(void);            /* 6.  Bumped when this header changes: 6 (round 5) ADDS mcba_prefilter, mcba_prefilter_subset, mcba_lm_run, mcba_lm_history, mcba_lm_result, mcba_set_bounds / _frozen, mcba_set_loss_table, mcba_set_trial, mcba_calib_normal_equations (and the diagnostics / life-cycle helpers declared below as ABI 6) and leaves every
+int mcba_abi_version(void);            /* 7.  Bumped when this header changes: 7 (round 6) ADDS the mcba_calib_* / mcba_pose_* / mcba_create_views block below (calibrate() on the device) and leaves every ABI-6 entry point as it was; 6 (round 5) ADDED mcba_prefilter, mcba_prefilter_subset, mcba_lm_run, mcba_lm_history, mcba_lm_result, mcba_set_bounds / _frozen, mcba_set_loss_table, mcba_set_trial, mcba_calib_normal_equations (and the diagnostics / life-cycle helpers declared below as ABI 6) and leaves every
                                         * ABI-5 entry point as it was.  (ABI 5 gave LM-state slots 25 / 26 -- "reserved" before -- their meaning: curvature floor / switch
                                         * fraction; a caller that zeroes them gets the handle's floor, fixed.) */
 const char* mcba_last_error(void);
@@ -64,14 +64,15 @@ int mcba_create(mcba_handle** out, int n_cameras, int n_frames, int n_points, in
 int mcba_destroy(mcba_handle* h);
 /* Device and pinned buffers of destroyed handles are parked in a per-process pool and handed out again (hipMalloc / hipFree are
  * synchronising driver calls: 4 ms of a 16 ms bundle_adjust() at 6 x 10 000 x 54 before the pool).  MCBA_POOL_MB caps what is
- * parked (default 8192; 0 = no pool); this returns everything to the driver.  The solver's own buffers (records, partial sums,
+ * parked (default 2048; 0 = no pool); this returns everything to the driver.  The solver's own buffers (records, partial sums,
  * reduce buffer, state ring) are allocated on the first call that needs them: a handle that only runs the pre-filter over all
  * frames of a long recording holds the observations and nothing else. */
 int mcba_pool_trim(void);
 /* Bytes of device memory the handle holds right now. */
 size_t mcba_device_bytes(const mcba_handle* h);
-/* Returns every device buffer to the pool except what defines the problem (observations in both layouts, board, parameter slots): solver
- * buffers, pre-filter scores, Jacobian / residual blocks.  Calls that need them allocate them again.  For handles that are parked so that
+/* Returns every device buffer to the pool except what defines the problem (observations in both layouts, board, parameter slots, the box of
+ * mcba_set_bounds): solver buffers, pre-filter scores, Jacobian / residual blocks, calibrate()'s poses.  Calls that need them allocate them
+ * again; a numeric x_scale / frozen set given before the trim is put back into the new buffers.  For handles that are parked so that
  * something can be produced from them later (the lazily attached result.jac): 0.26 -> 0.11 GB at 6 x 10 000 x 54.  Synchronises. */
 int mcba_trim(mcba_handle* h);
 /* The observations the handle holds, (C,F,N,2) doubles, back to the host (the values the solve saw). */
@@ -367,6 +368,47 @@ int mcba_prefilter_subset(mcba_handle* h, const double* uvs, const double* objpo
  * a second host upload (the reference slices all_calib_uvs[:, use_frames]: bundle_adjustment.py:298,312).  Parameter slot 0 of the
  * new handle = the camera blocks of src's slot 0 + the poses of the chosen frames (ABI 6).  Does not synchronise. */
 int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, int n_frames);
+
+/* ---- calibrate() on the device (ABI 7, round 6) ------------------------------------------------------------------------
+ * The initialiser that produces bundle_adjust()'s inputs: reference multicam_calibration/calibration.py:280-373.  Its two OpenCV calls per
+ * view (cv2.calibrateCamera :68 on <= 100 sampled views per camera, cv2.solvePnP :108 on every complete view) and its pose graph
+ * (:116-277) run on the detections a handle already holds (mcba_upload_observations).  A call of calibrate() is
+ *   mcba_calib_complete -> [host: np.random.choice per camera, as the reference draws it :57-60] -> mcba_calib_homographies (sampled views)
+ *   -> [host: Zhang's closed form for K, a 6-unknown null vector per camera] -> mcba_calib_view_poses (sampled views, K0, no distortion)
+ *   -> mcba_create_views + mcba_lm_run + mcba_lm_result (EVERY camera's fx fy cx cy k1 k2 and its views' poses in one device-resident LM run)
+ *   -> mcba_calib_poses (every (camera, frame): one launch, the poses stay on the device) -> [host: maximum spanning tree of the C x C
+ *   co-detection counts :146-197] -> mcba_calib_pairwise (tree edges) -> [host: chain C - 1 transforms :230-235] -> mcba_calib_consensus.
+ * Views are (camera, frame) int pairs.  intr9 = C x (fx fy cx cy k1 k2 p1 p2 k3) (OpenCV's five-coefficient model; the reference's defaults
+ * leave p1 = p2 = k3 = 0).  Poses are board -> camera 6-vectors (rotation vector, translation), NaN rows where there is none.  The board must
+ * be planar (z = 0), as the reference's chessboards are.  cv2 is absent from the build image: parity with OpenCV's numbers is unpinned; the
+ * kernels are checked against numpy restatements (oracle/calibration_oracle.py) and against exact recovery of synthetic truth. */
+/* complete_cf (C, F) bytes: 1 = all 2 N scalars of the detection are present (what :55 samples from and :107 solves). */
+int mcba_calib_complete(mcba_handle* h, unsigned char* complete_cf);
+/* Board-plane -> pixel homographies, H[2][2] = 1, of the listed views (Hartley-normalised DLT, the smallest singular vector of the 2N x 9
+ * system): H_out n_views x 9 row-major (NaN for an incomplete view), ok_out n_views bytes or NULL. */
+int mcba_calib_homographies(mcba_handle* h, const int* views, int n_views, double* H_out, unsigned char* ok_out);
+/* cv2.solvePnP's job for the listed views: undistort (undistort_iterations rounds of OpenCV's fixed point), homography start, pose from it,
+ * Levenberg-Marquardt on the pixel reprojection error (at most max_evaluations linearisations per view, every view its own damping).
+ * poses_out n_views x 6, ok_out n_views bytes or NULL. */
+int mcba_calib_view_poses(mcba_handle* h, const int* views, int n_views, const double* intr9, int undistort_iterations, int max_evaluations, double* poses_out, unsigned char* ok_out);
+/* estimate_pose (:74-113) of EVERY camera at once.  The poses stay on the device for the two calls below; poses_out (C,F,6), ok_out (C,F)
+ * bytes, evals_out (C,F) bytes (linearisations a view took) are optional -- with all three NULL the call does not synchronise. */
+int mcba_calib_poses(mcba_handle* h, const double* intr9, int undistort_iterations, int max_evaluations, double* poses_out, unsigned char* ok_out, unsigned char* evals_out);
+/* estimate_pairwise_camera_transform (:116-143) for camera pairs edges = n_edges x (c1, c2): transforms_out (n_edges, 6) = component-wise
+ * median over the frames both cameras have a pose for of T2 T1^-1 (exact order statistics: radix select on the device; NaN if the pair shares
+ * no frame); counts_out (n_edges) = frames shared, or NULL. */
+int mcba_calib_pairwise(mcba_handle* h, const int* edges, int n_edges, double* transforms_out, double* counts_out);
+/* consensus_calib_poses (:239-277): extrinsics (C,6) world -> camera; poses_out (F,6) = per-coordinate nan-median over the cameras of
+ * T_ext^-1 T_pose; NaN rows for frames no camera has a pose for. */
+int mcba_calib_consensus(mcba_handle* h, const double* extrinsics, double* poses_out);
+/* A new handle of C cameras x n_views frames: frame j holds view j's detection in ITS camera alone (NaN in the others) -- the sampled views of
+ * every camera side by side, so that one LM run (12 C camera parameters of which the extrinsics are held fixed at 0, 6 per view) is
+ * get_intrinsics of every camera.  Gathered device to device; does not synchronise. */
+int mcba_create_views(mcba_handle** out, mcba_handle* src, const int* views, int n_views);
+/* The two pose-graph steps for a caller's own pose array (C,F,6) (NaN rows = none): the reference's public functions of the same names take
+ * exactly that.  Stateless: host arrays in, host arrays out. */
+int mcba_pose_pairwise(int n_cameras, int n_frames, const double* poses, const int* edges, int n_edges, int device, double* transforms_out, double* counts_out);
+int mcba_pose_consensus(int n_cameras, int n_frames, const double* poses, const double* extrinsics, int device, double* poses_out);
 
 /* ---- geometry helpers and diagnostics around the solver ---------------------------------------- */
 /* undistort_points (geometry.py:328-358 = cv2.undistortPoints(uvs, K, dist, None, K)): n_points (u,v) pairs, K4 = (fx fy cx cy),

@@ -1,28 +1,33 @@
 """`calibrate()` without OpenCV: the initialiser that produces `bundle_adjust`'s inputs.
 
 Reference: multicam_calibration/calibration.py.  Same signatures, same return values, same use of the global numpy
-RNG, same printed progress lines (the tqdm bars are not reproduced).  What differs is how the two OpenCV calls are
-served -- this image has no cv2, and a GPU is there anyway:
+RNG, same printed progress lines (the tqdm bars are not reproduced).  This image has no cv2, and a GPU is there anyway: everything
+per view and per frame runs in libmcba.so (include/mcba.h: the mcba_calib_* block, csrc/mcba_pnp.hip); the host keeps what is a
+handful of numbers per CAMERA.
 
   get_intrinsics (calibration.py:11-71, cv2.calibrateCamera with CALIB_FIX_K3 | CALIB_ZERO_TANGENT_DIST)
-      closed-form start (Zhang 2000: one homography per view -> image of the absolute conic -> K; per-view pose from the
-      homography) + joint refinement of (fx, fy, cx, cy, k1, k2) and all view poses by the library's own LM on the GPU:
-      it is the bundle adjustment of ONE camera whose extrinsics are held at the identity, plain least squares.
+      per sampled view the board-plane homography (GPU: normalised DLT, lane = view) -> Zhang's closed form for K (host: the null vector
+      of a 6-column system per camera) -> per-view pose (GPU: cv2.solvePnP's job with K0) -> joint refinement of (fx, fy, cx, cy, k1, k2)
+      and the views' poses by the library's own device-resident LM loop: the bundle adjustment of cameras whose extrinsics are held at
+      the identity, plain least squares.  calibrate() refines EVERY camera in one such run (the sampled views of all cameras side by
+      side: the normal equations are block-diagonal over the cameras).
   estimate_pose (calibration.py:74-113, cv2.solvePnP, iterative)
-      homography start on undistorted normalised coordinates + the same GPU LM with ALL camera parameters held fixed
-      (every frame is then an independent 6-parameter problem; the reduced camera system is the identity).
+      ONE kernel launch for every (camera, frame): undistort, homography on normalised coordinates, pose from it, Levenberg-Marquardt
+      on the pixel reprojection error with the five-coefficient model, every view its own damping and stopping test.
   the pose-graph part (calibration.py:116-277: pairwise medians, maximum spanning tree, chaining, consensus median)
-      is numpy and is restated here; tests/golden/calibration_graph.npz pins it to the reference's own outputs
-      (including networkx's tie-breaking in the spanning tree, reproduced without networkx).
+      pairwise transforms and their exact medians (radix select) and the consensus median over cameras on the GPU; the spanning tree
+      (C x C co-detection counts; networkx's tie-breaking reproduced without networkx) and the chaining of C - 1 transforms on the host.
+      tests/golden/calibration_graph.npz pins all of it to the reference's own outputs.
 
-  get_intrinsics(fix_k3=False | zero_tangent_dist=False), estimate_pose with tangential / k3 coefficients
+  get_intrinsics(fix_k3=False | zero_tangent_dist=False)
       OpenCV's five-coefficient model (k1 k2 p1 p2 k3), which the bundle-adjustment kernels do not have: per-view normal equations
       from csrc/mcba_calib.hip (forward-mode automatic differentiation), the reduced 9 x 9 system and the damping here
       (_refine_five_coefficients).
 
 Parity of the two OpenCV-backed pieces cannot be pinned to cv2 numbers in this container ("parity unpinned" for them);
-they minimise the same reprojection error over the same parameters, and the tests check recovery of the synthetic truth
-and that `bundle_adjust` started from `calibrate()` ends in the same optimum as from any other start.
+they minimise the same reprojection error over the same parameters, and the tests check the kernels against numpy restatements
+(oracle/calibration_oracle.py), recovery of the synthetic truth and that `bundle_adjust` started from `calibrate()` ends in the same
+optimum as from any other start.
 """
 import numpy as np
 
@@ -65,24 +70,24 @@ def get_transformation_vector(T):
 
 
 # ------------------------------------------------------------------ pose graph (calibration.py:116-277)
-def estimate_pairwise_camera_transform(camera1_poses, camera2_poses):
-    """Median over the common frames of T2 T1^-1, component-wise on the 6-vectors (calibration.py:116-143)."""
-    camera1_poses, camera2_poses = np.asarray(camera1_poses), np.asarray(camera2_poses)
-    common = ~np.isnan([camera1_poses, camera2_poses]).any((0, 2))
-    T1 = get_transformation_matrix(camera1_poses[common])
-    T2 = get_transformation_matrix(camera2_poses[common])
-    return np.median(get_transformation_vector(T2 @ np.linalg.inv(T1)), axis=0)
+def estimate_pairwise_camera_transform(camera1_poses, camera2_poses, device=0):
+    """Median over the common frames of T2 T1^-1, component-wise on the 6-vectors (calibration.py:116-143).  On the GPU: one lane per
+    frame, exact medians by radix select (include/mcba.h: mcba_pose_pairwise)."""
+    from . import ops
+
+    poses = np.stack([np.asarray(camera1_poses, dtype=np.float64), np.asarray(camera2_poses, dtype=np.float64)])
+    return ops.pose_pairwise(poses, [(0, 1)], device)[0][0]
 
 
-def get_camera_spanning_tree(all_calib_poses, root=0):
-    """Maximum spanning tree of the co-detection graph, edges ordered by distance from `root` (calibration.py:146-197).
+def _spanning_tree(detected, root=0):
+    """Maximum spanning tree of the co-detection graph from the (C,F) detection flags, edges ordered by distance from `root`.
 
     The reference delegates to networkx (Kruskal on a stably sorted edge list, then `Graph.edges` iteration order); both
     are reproduced here so that ties between equally populated camera pairs resolve identically."""
-    all_calib_poses = np.asarray(all_calib_poses)
-    C = len(all_calib_poses)
-    detected = ~np.isnan(all_calib_poses).any(2)
-    edges = [(i, j, int((detected[i] & detected[j]).sum())) for i in range(C) for j in range(i + 1, C)]
+    detected = np.asarray(detected, dtype=bool)
+    C = len(detected)
+    counts = detected.astype(np.int64) @ detected.T.astype(np.int64)
+    edges = [(i, j, int(counts[i, j])) for i in range(C) for j in range(i + 1, C)]
     parent = list(range(C))
 
     def find(a):
@@ -118,63 +123,45 @@ def get_camera_spanning_tree(all_calib_poses, root=0):
     return sorted(tree, key=lambda e: dist[e[0]])
 
 
-def estimate_all_extrinsics(all_calib_poses, root=0):
-    """Chain the pairwise transforms down the spanning tree (calibration.py:200-236)."""
-    all_calib_poses = np.asarray(all_calib_poses)
-    ext = [None] * len(all_calib_poses)
+def get_camera_spanning_tree(all_calib_poses, root=0):
+    """Maximum spanning tree of the co-detection graph, edges ordered by distance from `root` (calibration.py:146-197)."""
+    return _spanning_tree(~np.isnan(np.asarray(all_calib_poses)).any(2), root=root)
+
+
+def _chain_extrinsics(n_cameras, tree, transforms, root):
+    """World -> camera 6-vectors from the tree's pairwise transforms (calibration.py:226-235); the root's is the exact zero vector."""
+    ext = [None] * n_cameras
     ext[root] = np.eye(4)
-    tree = get_camera_spanning_tree(all_calib_poses, root=root)
-    for c1, c2 in tree:
-        ext[c2] = get_transformation_matrix(estimate_pairwise_camera_transform(all_calib_poses[c1], all_calib_poses[c2])) @ ext[c1]
-    return np.array([get_transformation_vector(T) for T in ext]), tree
+    for (c1, c2), t in zip(tree, transforms):
+        ext[c2] = get_transformation_matrix(t) @ ext[c1]
+    return np.array([get_transformation_vector(T) for T in ext])
 
 
-def consensus_calib_poses(all_calib_poses, all_extrinsics):
-    """Per-camera board poses mapped to world coordinates, nan-median over cameras (calibration.py:239-277)."""
-    import warnings
+def estimate_all_extrinsics(all_calib_poses, root=0, device=0):
+    """Chain the pairwise transforms down the spanning tree (calibration.py:200-236)."""
+    from . import ops
 
     all_calib_poses = np.asarray(all_calib_poses, dtype=np.float64)
-    world = np.full_like(all_calib_poses, np.nan)
-    for i, (poses, transform) in enumerate(zip(all_calib_poses, all_extrinsics)):
-        det = ~np.isnan(poses).any(axis=-1)
-        T = np.linalg.inv(get_transformation_matrix(transform)) @ get_transformation_matrix(poses[det])
-        world[i, det] = get_transformation_vector(T)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", category=RuntimeWarning)
-        return np.nanmedian(world, axis=0)
+    tree = get_camera_spanning_tree(all_calib_poses, root=root)
+    transforms = ops.pose_pairwise(all_calib_poses, tree, device)[0] if tree else []
+    return _chain_extrinsics(len(all_calib_poses), tree, transforms, root), tree
 
 
-# ------------------------------------------------------------------ closed-form starts (Zhang 2000, sections 3.1, 3.2 and appendix A)
+def consensus_calib_poses(all_calib_poses, all_extrinsics, device=0):
+    """Per-camera board poses mapped to world coordinates, nan-median over cameras (calibration.py:239-277): lane = frame on the GPU."""
+    from . import ops
+
+    return ops.pose_consensus(np.asarray(all_calib_poses, dtype=np.float64), all_extrinsics, device)
+
+
+# ------------------------------------------------------------------ closed-form start of the intrinsics (Zhang 2000, section 3.1 and appendix B)
 def _require_planar(obj):
     obj = np.asarray(obj, dtype=np.float64)
     if obj.ndim != 2 or obj.shape[1] != 3 or np.abs(obj[:, 2]).max() > 1e-9 * max(1.0, np.abs(obj[:, :2]).max()):
         raise NotImplementedError("the closed-form initialisation needs a planar calibration board (z = 0), as the reference's boards are")
+    obj = obj.copy()
+    obj[:, 2] = 0.0
     return obj
-
-
-def homographies(XY, uv):
-    """Normalised DLT, batched: XY (N,2) board coordinates, uv (F,N,2) -> H (F,3,3) with uv ~ H [X, Y, 1]."""
-    def norm(P):
-        c = P.mean(-2, keepdims=True)
-        s = np.sqrt(2.0) / np.sqrt(((P - c) ** 2).sum(-1).mean(-1))[..., na, na]
-        T = np.zeros(P.shape[:-2] + (3, 3))
-        T[..., 0, 0] = T[..., 1, 1] = s[..., 0, 0]
-        T[..., 0, 2], T[..., 1, 2] = -s[..., 0, 0] * c[..., 0, 0], -s[..., 0, 0] * c[..., 0, 1]
-        T[..., 2, 2] = 1
-        return (P - c) * s, T
-
-    uv = np.asarray(uv, dtype=np.float64)
-    Xn, TX = norm(np.asarray(XY, dtype=np.float64))
-    un, Tu = norm(uv)
-    F, N = uv.shape[:2]
-    X, Y = np.broadcast_to(Xn[:, 0], (F, N)), np.broadcast_to(Xn[:, 1], (F, N))
-    u, v = un[..., 0], un[..., 1]
-    z, o = np.zeros((F, N)), np.ones((F, N))
-    A = np.concatenate([np.stack([X, Y, o, z, z, z, -u * X, -u * Y, -u], -1), np.stack([z, z, z, X, Y, o, -v * X, -v * Y, -v], -1)], axis=1)
-    _, _, Vt = np.linalg.svd(A)
-    Hn = Vt[:, -1].reshape(F, 3, 3)
-    H = np.linalg.inv(Tu) @ Hn @ TX
-    return H / H[:, 2:3, 2:3]
 
 
 def intrinsics_from_homographies(H, image_size):
@@ -182,6 +169,8 @@ def intrinsics_from_homographies(H, image_size):
     the views do not constrain it (fewer than 2 usable views, or a non-positive-definite estimate)."""
     w, h = float(image_size[0]), float(image_size[1])
     fallback = np.array([[max(w, h), 0, (w - 1) / 2], [0, max(w, h), (h - 1) / 2], [0, 0, 1.0]])
+    H = np.asarray(H, dtype=np.float64)
+    H = H[np.isfinite(H).all((1, 2))] if len(H) else H
     if len(H) < 2:
         return fallback
 
@@ -211,49 +200,52 @@ def intrinsics_from_homographies(H, image_size):
     return K / K[2, 2]
 
 
-def poses_from_homographies(H, K):
-    """Board pose (F,6) from H = K [r1 r2 t] up to scale, rotation re-orthonormalised, board in front of the camera."""
-    M = np.linalg.inv(K) @ H
-    lam = 2.0 / (np.linalg.norm(M[:, :, 0], axis=1) + np.linalg.norm(M[:, :, 1], axis=1))
-    lam = np.where(M[:, 2, 2] < 0, -lam, lam)  # t_z > 0
-    M = M * lam[:, na, na]
-    R = np.stack([M[:, :, 0], M[:, :, 1], np.cross(M[:, :, 0], M[:, :, 1])], axis=-1)
-    U, _, Vt = np.linalg.svd(R)
-    R = U @ Vt
-    neg = np.linalg.det(R) < 0
-    if neg.any():
-        U[neg, :, 2] *= -1
-        R = U @ Vt
-    return np.concatenate([rodrigues_inv(R), M[:, :, 2]], axis=-1)
+def _intr9(K, dist=None):
+    d = np.zeros(5)
+    if dist is not None:
+        d[: np.size(dist)] = np.ravel(dist)
+    return np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2], *d])
 
 
-def undistort_normalized(uv, K, dist, iterations=8):
-    """Pixel -> undistorted normalised coordinates for OpenCV's (k1, k2, p1, p2, k3) model: the fixed-point iteration of its undistortPoints,
-    x <- (x_d - tangential(x)) / radial(x)."""
-    k1, k2, p1, p2, k3 = (list(np.ravel(dist)) + [0.0] * 5)[:5]
-    xd = (uv[..., 0] - K[0, 2]) / K[0, 0]
-    yd = (uv[..., 1] - K[1, 2]) / K[1, 1]
-    x, y = xd.copy(), yd.copy()
-    for _ in range(iterations):
-        s = x * x + y * y
-        d = 1 + s * (k1 + s * (k2 + s * k3))
-        dx = 2 * p1 * x * y + p2 * (s + 2 * x * x)
-        dy = p1 * (s + 2 * y * y) + 2 * p2 * x * y
-        x, y = (xd - dx) / d, (yd - dy) / d
-    return np.stack([x, y], -1)
+def _draw_samples(complete, n_samples):
+    """The reference's draw (calibration.py:55-60): one np.random.choice without replacement over the camera's complete detections, from
+    the GLOBAL numpy RNG.  complete: (F,) bool.  Returns the sampled frame indices in draw order."""
+    frames = np.flatnonzero(complete)
+    n = min(n_samples, len(frames))
+    if n < 1:
+        raise ValueError("no complete detection of the calibration board for this camera")
+    return frames[np.random.choice(len(frames), n, replace=False)]
 
 
-# ------------------------------------------------------------------ GPU refinement: the library's LM with a parameter mask
-def _refine_single_camera(uvs, obj, cam12, poses, free_cam, device, max_nfev=200):
-    from . import ops, solver
+def _start_on_device(prob, views, image_sizes):
+    """Closed-form start for the cameras of `prob` from their sampled views ((V,2) int: camera, frame): per-view homographies on the GPU,
+    Zhang's K per camera on the host, per-view poses with that K on the GPU.  Returns (K0 list, poses0 (V,6))."""
+    H = prob.calib_homographies(views)
+    K0 = [intrinsics_from_homographies(H[views[:, 0] == c], image_sizes[c]) for c in range(prob.C)]
+    poses0 = prob.calib_view_poses(views, np.array([_intr9(K) for K in K0]))
+    return K0, poses0
 
-    prob = ops.Problem(np.ascontiguousarray(uvs[na]), obj, device=device, loss="linear")
+
+def _refine_intrinsics_on_device(prob, views, K0, poses0):
+    """get_intrinsics' refinement for every camera of `prob` at once: the library's device-resident LM loop on the sampled views side by
+    side (ops.Problem.view_subset), camera extrinsics held at the identity, plain least squares.  Returns cam (C,12)."""
+    from . import solver
+
+    ok = np.isfinite(poses0).all(1)
+    views, poses0 = views[ok], poses0[ok]
+    cam0 = np.zeros((prob.C, 12))
+    for c, K in enumerate(K0):
+        cam0[c, :4] = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    if not len(views):
+        return cam0
+    free = np.tile(np.r_[np.ones(6, bool), np.zeros(6, bool)], prob.C)  # each camera IS the coordinate frame of its own views
+    free.reshape(prob.C, 12)[~np.isin(np.arange(prob.C), views[:, 0])] = False   # (a camera without a usable view keeps its start)
+    sub = prob.view_subset(views, loss="linear")
     try:
-        x0 = np.concatenate([cam12, np.asarray(poses, dtype=np.float64).ravel()])
-        res = solver.lm_solve(prob, x0, ftol=1e-12, xtol=1e-12, gtol=1e-10, max_nfev=max_nfev, verbose=0, free_cam_mask=free_cam)
+        res = solver.lm_solve(sub, np.concatenate([cam0.ravel(), poses0.ravel()]), ftol=1e-12, xtol=1e-12, gtol=1e-10, max_nfev=200, verbose=0, free_cam_mask=free)
     finally:
-        prob.close()
-    return res.x[:12], res.x[12:].reshape(-1, 6), res
+        sub.close()
+    return res.x[: 12 * prob.C].reshape(prob.C, 12)
 
 
 # ------------------------------------------------------------------ the five-coefficient model (k1 k2 p1 p2 k3): get_intrinsics(fix_k3=False | zero_tangent_dist=False)
@@ -275,6 +267,7 @@ def _refine_five_coefficients(uvs, obj, intr9, poses, free9, device, max_evaluat
     lam, nu = (np.full(V, 1e-3), np.full(V, 2.0)) if per_view else (1e-3, 2.0)
     done = np.zeros(V, dtype=bool)
     eye6 = np.eye(6)
+    flat = 0
     for _ in range(max_evaluations):
         Vv, gv = H[:, 9:, 9:], g[:, 9:]
         Dv = np.maximum(np.einsum("vii->vi", Vv), 1e-300)
@@ -313,12 +306,16 @@ def _refine_five_coefficients(uvs, obj, intr9, poses, free9, device, max_evaluat
                 break
         else:
             gain, pred = c.sum() - c2.sum(), pred_v.sum()
-            if np.isfinite(c2).all() and gain >= 0:
+            if np.isfinite(c2).all() and gain >= -1e-13 * c.sum():   # (a loss inside the cost's own rounding level is not an uphill step)
                 ratio = gain / pred if pred > 0 else 1.0
-                small = gain <= 1e-14 * max(c.sum(), 1e-300)
+                # a gain at the rounding level of the cost does not mean the weakly determined coefficients (k2 against k3) have settled: the
+                # step is computed from the gradient, which is far more exact than a difference of costs -- stop on the step, or after a
+                # few such steps in a row
+                flat = flat + 1 if gain <= 1e-14 * max(c.sum(), 1e-300) else 0
+                settled = np.max(np.abs(dc[free9]) / (np.abs(k[free9]) + 1e-4)) <= 1e-9 if nf else True
                 k, ps, H, g, c = k + dc, ps + dv, H2, g2, c2
                 lam, nu = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3), 1e-12), 2.0
-                if small:
+                if flat and (settled or flat >= 6):
                     break
             else:
                 lam, nu = lam * nu, nu * 2.0
@@ -327,10 +324,17 @@ def _refine_five_coefficients(uvs, obj, intr9, poses, free9, device, max_evaluat
     return k, ps, float(c.sum())
 
 
-def _zhang_start(uvs, obj, image_size):
-    H = homographies(obj[:, :2], uvs)
-    K0 = intrinsics_from_homographies(H, image_size)
-    return K0, poses_from_homographies(H, K0)
+def _zhang_start(uvs, obj, image_size, device=0):
+    """Closed-form start (K0, per-view poses) from complete views uvs (V,N,2) of one camera."""
+    from . import ops
+
+    prob = ops.Problem(np.ascontiguousarray(uvs[na]), obj, device=device, loss="linear")
+    try:
+        views = np.stack([np.zeros(len(uvs), np.int32), np.arange(len(uvs), dtype=np.int32)], 1)
+        K0, poses0 = _start_on_device(prob, views, [image_size])
+    finally:
+        prob.close()
+    return K0[0], poses0
 
 
 def get_intrinsics(calib_uvs, calib_objpoints, image_size, n_samples=100, fix_k3=True, zero_tangent_dist=True, device=0):
@@ -338,73 +342,80 @@ def get_intrinsics(calib_uvs, calib_objpoints, image_size, n_samples=100, fix_k3
     of cv2.calibrateCamera under flags = CALIB_FIX_K3 * fix_k3 + CALIB_ZERO_TANGENT_DIST * zero_tangent_dist).  The reference's default --
     both flags: the (k1, k2) radial model, which is also all bundle_adjust optimises -- is refined by the library's own bundle-adjustment
     loop; with a flag off, the five-coefficient model by _refine_five_coefficients (GPU normal equations, 9 x 9 reduced system here)."""
+    from . import ops
+
     obj = _require_planar(calib_objpoints)
-    if not (fix_k3 and zero_tangent_dist):
-        calib_uvs = np.asarray(calib_uvs, dtype=np.float64)
-        calib_uvs = calib_uvs[~np.isnan(calib_uvs).any((1, 2))]
-        n_samples = min(n_samples, len(calib_uvs))
-        if n_samples < 1:
-            raise ValueError("no complete detection of the calibration board for this camera")
-        uvs = calib_uvs[np.random.choice(len(calib_uvs), n_samples, replace=False)]  # same draw from the global RNG as the reference
-        K0, poses0 = _zhang_start(uvs, obj, image_size)
-        free9 = np.array([1, 1, 1, 1, 1, 1, not zero_tangent_dist, not zero_tangent_dist, not fix_k3], dtype=bool)
-        k9, _, _ = _refine_five_coefficients(uvs, obj, [K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0, 0, 0, 0, 0], poses0, free9, device)
-        K = np.array([[k9[0], 0, k9[2]], [0, k9[1], k9[3]], [0, 0, 1.0]])
-        return K, k9[4:].copy()
-    calib_uvs = np.asarray(calib_uvs, dtype=np.float64)
-    calib_uvs = calib_uvs[~np.isnan(calib_uvs).any((1, 2))]
-    n_samples = min(n_samples, len(calib_uvs))
-    if n_samples < 1:
-        raise ValueError("no complete detection of the calibration board for this camera")
-    uvs = calib_uvs[np.random.choice(len(calib_uvs), n_samples, replace=False)]  # same draw from the global RNG as the reference
-    H = homographies(obj[:, :2], uvs)
-    K0 = intrinsics_from_homographies(H, image_size)
-    poses0 = poses_from_homographies(H, K0)
-    cam0 = np.array([K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], 0.0, 0.0, 0, 0, 0, 0, 0, 0])
-    free = np.r_[np.ones(6, bool), np.zeros(6, bool)]  # the camera IS the coordinate frame
-    cam, _, _ = _refine_single_camera(uvs, obj, cam0, poses0, free, device)
-    K = np.array([[cam[0], 0, cam[2]], [0, cam[1], cam[3]], [0, 0, 1.0]])
-    return K, np.array([cam[4], cam[5], 0.0, 0.0, 0.0])
+    calib_uvs = np.ascontiguousarray(calib_uvs, dtype=np.float64)
+    prob = ops.Problem(calib_uvs[na], obj, device=device, loss="linear")
+    try:
+        frames = _draw_samples(prob.calib_complete()[0], n_samples)  # same draw from the global RNG as the reference
+        views = np.stack([np.zeros(len(frames), np.int32), frames.astype(np.int32)], 1)
+        K0, poses0 = _start_on_device(prob, views, [image_size])
+        if fix_k3 and zero_tangent_dist:
+            cam = _refine_intrinsics_on_device(prob, views, K0, poses0)[0]
+            return np.array([[cam[0], 0, cam[2]], [0, cam[1], cam[3]], [0, 0, 1.0]]), np.array([cam[4], cam[5], 0.0, 0.0, 0.0])
+    finally:
+        prob.close()
+    ok = np.isfinite(poses0).all(1)
+    free9 = np.array([1, 1, 1, 1, 1, 1, not zero_tangent_dist, not zero_tangent_dist, not fix_k3], dtype=bool)
+    k9, _, _ = _refine_five_coefficients(calib_uvs[frames[ok]], obj, _intr9(K0[0]), poses0[ok], free9, device)
+    K = np.array([[k9[0], 0, k9[2]], [0, k9[1], k9[3]], [0, 0, 1.0]])
+    return K, k9[4:].copy()
 
 
 def estimate_pose(calib_uvs, calib_objpoints, camera_matrix, dist_coeffs, device=0):
-    """Board pose (board -> camera) per frame, NaN rows where the detection is incomplete (calibration.py:74-113)."""
+    """Board pose (board -> camera) per frame, NaN rows where the detection is incomplete (calibration.py:74-113).  One kernel launch
+    (include/mcba.h: mcba_calib_poses); tangential / k3 coefficients (get_intrinsics with a flag off) are part of its model."""
+    from . import ops
+
     obj = _require_planar(calib_objpoints)
-    calib_uvs = np.asarray(calib_uvs, dtype=np.float64)
-    K = np.asarray(camera_matrix, dtype=np.float64)
-    dist = np.zeros(5)
-    dist[: np.size(dist_coeffs)] = np.ravel(dist_coeffs)
-    poses = np.full((len(calib_uvs), 6), np.nan)
-    ok = ~np.isnan(calib_uvs).any((1, 2))
-    if not ok.any():
-        return poses
-    uvs = calib_uvs[ok]
-    H = homographies(obj[:, :2], undistort_normalized(uvs, K, dist))
-    poses0 = poses_from_homographies(H, np.eye(3))
-    if dist[2] != 0.0 or dist[3] != 0.0 or dist[4] != 0.0:   # tangential / k3 coefficients (get_intrinsics with a flag off): the five-coefficient model
-        _, refined, _ = _refine_five_coefficients(uvs, obj, [K[0, 0], K[1, 1], K[0, 2], K[1, 2], *dist], poses0, np.zeros(9, bool), device)
-    else:
-        cam = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2], dist[0], dist[1], 0, 0, 0, 0, 0, 0])
-        _, refined, _ = _refine_single_camera(uvs, obj, cam, poses0, np.zeros(12, bool), device)
-    poses[ok] = refined
-    return poses
+    calib_uvs = np.ascontiguousarray(calib_uvs, dtype=np.float64)
+    prob = ops.Problem(calib_uvs[na], obj, device=device, loss="linear")
+    try:
+        _, poses, _ = prob.calib_poses(_intr9(np.asarray(camera_matrix, dtype=np.float64), dist_coeffs)[na], want_poses=True)
+    finally:
+        prob.close()
+    return poses[0]
+
+
+def _sample_all_cameras(complete, n_samples):
+    """(V,2) int32 (camera, frame): every camera's sampled views, drawn camera by camera as the reference's loop does (calibration.py:341-350;
+    nothing else consumes the global RNG in between)."""
+    return np.concatenate([np.stack([np.full(len(fr), c, np.int32), fr.astype(np.int32)], 1) for c, fr in ((c, _draw_samples(row, n_samples)) for c, row in enumerate(complete))])
+
+
+def _pose_graph_on_device(prob, detected, root):
+    """calibration.py:200-277 on the poses prob.calib_poses left on the device: (all_extrinsics, consensus poses, spanning tree)."""
+    tree = _spanning_tree(detected, root=root)
+    transforms = prob.calib_pairwise(tree)[0] if tree else []
+    ext = _chain_extrinsics(prob.C, tree, transforms, root)
+    return ext, tree
 
 
 def calibrate(all_calib_uvs, img_sizes, calib_objpoints, root=0, verbose=True, n_samples_for_intrinsics=100, device=0):
     """Reference signature and return tuple (calibration.py:280-373):
-    (all_extrinsics (C,6), all_intrinsics [(K, dist5)] * C, consensus board poses (F,6), spanning_tree)."""
-    all_intrinsics = []
-    if verbose:
-        print("Estimating camera intrinsics")
-    for uvs, img_size in zip(all_calib_uvs, img_sizes):
-        all_intrinsics.append(get_intrinsics(uvs, calib_objpoints, img_size, n_samples=n_samples_for_intrinsics, device=device))
-    if verbose:
-        print("Initializing calibration object poses")
-    all_calib_poses = np.array([estimate_pose(uvs, calib_objpoints, *intr, device=device) for uvs, intr in zip(all_calib_uvs, all_intrinsics)])
-    if verbose:
-        print("Estimating camera extrinsics")
-    all_extrinsics, spanning_tree = estimate_all_extrinsics(all_calib_poses, root=root)
-    if verbose:
-        print("Merging calibration object poses")
-    calib_poses = consensus_calib_poses(all_calib_poses, all_extrinsics)
+    (all_extrinsics (C,6), all_intrinsics [(K, dist5)] * C, consensus board poses (F,6), spanning_tree).
+    The detections go to the GPU once; every stage works on that copy (module docstring)."""
+    from . import ops
+
+    obj = _require_planar(calib_objpoints)
+    prob = ops.Problem(np.ascontiguousarray(all_calib_uvs, dtype=np.float64), obj, device=device, loss="linear")
+    try:
+        if verbose:
+            print("Estimating camera intrinsics")
+        views = _sample_all_cameras(prob.calib_complete(), n_samples_for_intrinsics)
+        K0, poses0 = _start_on_device(prob, views, img_sizes)
+        cam = _refine_intrinsics_on_device(prob, views, K0, poses0)
+        all_intrinsics = [(np.array([[q[0], 0, q[2]], [0, q[1], q[3]], [0, 0, 1.0]]), np.array([q[4], q[5], 0.0, 0.0, 0.0])) for q in cam]
+        if verbose:
+            print("Initializing calibration object poses")
+        detected, _, _ = prob.calib_poses(np.array([_intr9(K, d) for K, d in all_intrinsics]))
+        if verbose:
+            print("Estimating camera extrinsics")
+        all_extrinsics, spanning_tree = _pose_graph_on_device(prob, detected, root)
+        if verbose:
+            print("Merging calibration object poses")
+        calib_poses = prob.calib_consensus(all_extrinsics)
+    finally:
+        prob.close()
     return all_extrinsics, all_intrinsics, calib_poses, spanning_tree

@@ -56,6 +56,13 @@ struct mcba_handle {
   unsigned char* solver_arena = nullptr;   // ensure_solver: the one allocation the solver buffers below are pieces of
   int* sub_frames = nullptr;   // mcba_create_subset: the frame indices on the device (kept with the handle: no synchronisation to free them)
   double* outbuf = nullptr;    // mcba_lm_result: [x | gradient] packed for one device-to-host copy
+  // calibrate() on the device (mcba_calib_*): intrinsics [C][9], every view's board pose [C][6][Fpad] (NaN = none), per-view flags, and
+  // scratch that grows with the call (view lists, outputs, pairwise transforms, select states, world-frame poses)
+  double *cal_intr = nullptr, *cal_poses_t = nullptr, *cal_out = nullptr, *cal_rel = nullptr, *cal_world = nullptr;
+  unsigned char *cal_valid = nullptr, *cal_nit = nullptr, *cal_sel = nullptr;
+  int* cal_views = nullptr;
+  size_t cal_out_cap = 0, cal_rel_cap = 0, cal_sel_cap = 0, cal_views_cap = 0;
+  bool have_cal_poses = false;
   double* obj_host = nullptr;  // board points as uploaded (diagnostics normalise them on the host)
   int planar = 0;              // every board point has z = 0 exactly (the fused k_gram then runs its planar instance)
   int *tile_i = nullptr, *tile_j = nullptr;
@@ -444,7 +451,7 @@ static int derive_geometry(mcba_handle* h) {
 
 extern "C" {
 
-int mcba_abi_version(void) { return 6; }  // 6 (round 5): mcba_prefilter, mcba_lm_run / _history / _result -- whole stages of bundle_adjust() per crossing; additions only: every ABI-5 entry point is unchanged
+int mcba_abi_version(void) { return 7; }  // 7 (round 6): calibrate() on the device (mcba_calib_*, mcba_pose_*, mcba_create_views); 6 (round 5): mcba_prefilter, mcba_lm_run / _history / _result -- whole stages of bundle_adjust() per crossing; additions only: every ABI-5 entry point is unchanged
 const char* mcba_last_error(void) { return g_err.c_str(); }
 const char* mcba_profile_names(void) { return kKernelNames; }
 
@@ -501,6 +508,7 @@ static bool poison_enabled() {   // MCBA_POISON=1 (tests): buffers that are hand
   static const bool on = [] { const char* e = getenv("MCBA_POISON"); return e && atoi(e) != 0; }();
   return on;
 }
+static int compose_dscale(mcba_handle* h);
 static int ensure_solver(mcba_handle* h) {
   if (h->have_solver) return MCBA_OK;
   const int C = h->C;
@@ -560,6 +568,8 @@ static int ensure_solver(mcba_handle* h) {
     if (mcba::syrk_set_lds_limit(lds) != 0) return fail(MCBA_ERR_HIP, "cannot raise the dynamic LDS limit of k_syrk");
   }
   h->have_solver = true;
+  // a numeric x_scale / a frozen set given before an mcba_trim are still the caller's: put them back into the new buffers
+  if (!h->xs_host.empty() || !h->frozen_host.empty()) return compose_dscale(h);
   return MCBA_OK;
 }
 #define NEED_SOLVER(h) do { int rc_ = ensure_solver(h); if (rc_) return rc_; } while (0)
@@ -600,7 +610,9 @@ int mcba_trim(mcba_handle* h) {
   if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
-  void** keep[] = {reinterpret_cast<void**>(&h->obs_t), reinterpret_cast<void**>(&h->obs_raw), reinterpret_cast<void**>(&h->core_arena), reinterpret_cast<void**>(&h->sub_frames)};
+  // (the box of mcba_set_bounds stays as well: it is part of what defines the problem, and the steps after a trim must still be projected onto it)
+  void** keep[] = {reinterpret_cast<void**>(&h->obs_t), reinterpret_cast<void**>(&h->obs_raw), reinterpret_cast<void**>(&h->core_arena), reinterpret_cast<void**>(&h->sub_frames),
+                   reinterpret_cast<void**>(&h->blo), reinterpret_cast<void**>(&h->bhi)};
   std::vector<DevBuf> kept;
   for (auto& b : h->bufs) {
     bool k = false;
@@ -613,6 +625,8 @@ int mcba_trim(mcba_handle* h) {
   // the pieces of the solver arena
   h->rec2[0] = h->rec2[1] = h->gpart2[0] = h->gpart2[1] = h->fbuf = h->fpart = h->spart = h->cpart = h->bpart = h->red_own = h->red = h->dcbuf = h->swork = h->dscale = h->gchunk = nullptr;
   h->fixed = nullptr;
+  h->cal_out_cap = h->cal_rel_cap = h->cal_sel_cap = h->cal_views_cap = 0;
+  h->have_cal_poses = false;
   h->have_solver = h->have_lin = h->have_red = h->have_spec = h->have_jac = h->auto_ready = h->have_xscale = h->have_fixed = h->trial_ready = false;
   return MCBA_OK;
 }
@@ -1474,6 +1488,7 @@ int mcba_lm_result(mcba_handle* h, int slot, double* x_out, double* grad_out, mc
   if (!h->have_red) return fail(MCBA_ERR_ARG, "mcba_lm_result: no reduced system");
   HIPCHK(hipSetDevice(h->device));
   const size_t nx = (size_t)12 * h->C + (size_t)6 * h->F;
+  if (grad_out && grad_out != x_out + nx) return fail(MCBA_ERR_ARG, "mcba_lm_result: grad_out must directly follow x_out (x_out + 12C + 6F): both arrive in one copy");
   int rc;
   if (!h->outbuf && (rc = dalloc(h, &h->outbuf, 2 * nx, false))) return rc;
   mcba::launch_pack_result(h->stream, h->x[slot], h->red + (size_t)h->n * h->n + 2 * (size_t)h->n, h->fbuf, h->have_fixed ? h->fixed : nullptr, h->outbuf, h->C, h->F, h->cw);
@@ -1635,11 +1650,12 @@ int mcba_error_median(mcba_handle* h, const unsigned char* frame_mask, double* m
   return median_of_err(h, (size_t)h->C * h->N * h->Fpad, 1, frame_mask != nullptr, median, count);
 }
 
-int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, int n_frames) {
+// only_cam != nullptr (mcba_create_views): destination frame j keeps the detection of camera only_cam[j] alone
+static int create_subset_impl(mcba_handle** out, mcba_handle* src, const int* frames, const int* only_cam, int n_frames) {
   if (!out || !src || !frames || n_frames < 1) return fail(MCBA_ERR_ARG, "mcba_create_subset: bad argument");
   if (!src->have_obs) return fail(MCBA_ERR_ARG, "mcba_create_subset: the source handle has no observations");
   for (int i = 0; i < n_frames; ++i)
-    if (frames[i] < 0 || frames[i] >= src->F) return fail(MCBA_ERR_ARG, "mcba_create_subset: frame index out of range");
+    if (frames[i] < 0 || frames[i] >= src->F || (only_cam && (only_cam[i] < 0 || only_cam[i] >= src->C))) return fail(MCBA_ERR_ARG, "mcba_create_subset: frame / camera index out of range");
   int rc = mcba_create(out, src->C, n_frames, src->N, src->device);
   if (rc) return rc;
   mcba_handle* h = *out;
@@ -1649,11 +1665,12 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
   h->f_scale = src->f_scale;
   h->strict_sync = src->strict_sync;
   // (the index list lives and dies with the new handle: nothing to free here, so nothing to wait for)
-  if ((rc = dalloc(h, &h->sub_frames, (size_t)n_frames, false)) != MCBA_OK) { mcba_destroy(h); *out = nullptr; return rc; }
+  if ((rc = dalloc(h, &h->sub_frames, (size_t)n_frames * (only_cam ? 2 : 1), false)) != MCBA_OK) { mcba_destroy(h); *out = nullptr; return rc; }
   int* d_frames = h->sub_frames;
   hipError_t e = hipMemcpyAsync(d_frames, frames, (size_t)n_frames * sizeof(int), hipMemcpyHostToDevice, h->stream);  // (pageable source: staged before the call returns)
+  if (e == hipSuccess && only_cam) e = hipMemcpyAsync(d_frames + n_frames, only_cam, (size_t)n_frames * sizeof(int), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) {
-    mcba::launch_gather_frames(h->stream, src->obs_raw, d_frames, h->obs_raw, h->C, src->F, h->F, h->N);
+    mcba::launch_gather_frames(h->stream, src->obs_raw, d_frames, h->obs_raw, h->C, src->F, h->F, h->N, only_cam ? d_frames + n_frames : nullptr);
     // ... and the parameters of the source's slot 0: the camera blocks + the poses of the chosen frames (what bundle_adjust starts from)
     mcba::launch_gather_params(h->stream, src->x[0], d_frames, h->x[0], h->C, h->F);
     e = hipGetLastError();
@@ -1676,6 +1693,264 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
     h->planar = src->planar;
   }
   h->have_obs = true;
+  return MCBA_OK;
+}
+
+int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, int n_frames) { return create_subset_impl(out, src, frames, nullptr, n_frames); }
+
+// A handle of C cameras x n_views frames whose frame j holds the detection of view j = (camera, frame) of `src` in ITS camera alone (NaN in
+// the others): the <= 100 sampled views of every camera side by side, so that ONE device-resident LM run refines every camera's intrinsics
+// with its own views' poses (get_intrinsics, reference calibration.py:11-71) -- the normal equations are block-diagonal over the cameras.
+int mcba_create_views(mcba_handle** out, mcba_handle* src, const int* views, int n_views) {
+  if (!out || !src || !views || n_views < 1) return fail(MCBA_ERR_ARG, "mcba_create_views: bad argument");
+  std::vector<int> frames((size_t)n_views), cams((size_t)n_views);
+  for (int i = 0; i < n_views; ++i) { cams[i] = views[2 * i]; frames[i] = views[2 * i + 1]; }
+  return create_subset_impl(out, src, frames.data(), cams.data(), n_views);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// calibrate() on the device (reference calibration.py:11-113 -- the two OpenCV calls per view -- and :116-277 -- the pose graph).
+// The handle holds every detection (mcba_upload_observations); a call of calibrate() is: mcba_calib_complete -> [host: the reference's
+// RNG draw] -> mcba_calib_homographies (sampled views) -> [host: Zhang's closed form, a 6-vector] -> mcba_calib_view_poses ->
+// mcba_create_views + mcba_lm_run (all cameras' intrinsics in one run) -> mcba_calib_poses (every view, ONE launch; the poses stay on the
+// device) -> [host: spanning tree] -> mcba_calib_pairwise -> [host: chain C - 1 transforms] -> mcba_calib_consensus.
+}  // extern "C"
+namespace {
+// a scratch buffer of the handle that grows with the call
+template <class T>
+int dgrow(mcba_handle* h, T** p, size_t* cap, size_t count) {
+  if (*p && *cap >= count) return MCBA_OK;
+  if (*p) {
+    for (size_t i = 0; i < h->bufs.size(); ++i)
+      if (h->bufs[i].slot == reinterpret_cast<void**>(p)) { pool_free(*p, h->bufs[i].bytes, h->device, h->stream, true); h->bufs.erase(h->bufs.begin() + i); break; }
+    *p = nullptr;
+  }
+  *cap = 0;
+  int rc = dalloc(h, p, count, false);
+  if (rc == MCBA_OK) *cap = count;
+  return rc;
+}
+// Hartley normalisation of the board's XY as calibration.py's closed-form start uses it: centroid, sqrt(2) / rms distance
+void board_normalisation(const double* obj, int N, double* bn) {
+  bn[0] = bn[1] = 0.0; bn[2] = 1.0;
+  for (int p = 0; p < N; ++p) { bn[0] += obj[3 * p]; bn[1] += obj[3 * p + 1]; }
+  bn[0] /= N; bn[1] /= N;
+  double ms = 0.0;
+  for (int p = 0; p < N; ++p) ms += (obj[3 * p] - bn[0]) * (obj[3 * p] - bn[0]) + (obj[3 * p + 1] - bn[1]) * (obj[3 * p + 1] - bn[1]);
+  if (ms > 0.0) bn[2] = sqrt(2.0) / sqrt(ms / N);
+}
+int calib_ready(mcba_handle* h, const char* who) {
+  if (!h) return fail(MCBA_ERR_ARG, "NULL handle");
+  if (!h->have_obs || !h->obj_host) { g_err = std::string(who) + ": upload observations first"; return MCBA_ERR_ARG; }
+  for (int p = 0; p < h->N; ++p)
+    if (h->obj_host[3 * p + 2] != 0.0) { g_err = std::string(who) + ": the closed-form start needs a planar calibration board (z = 0)"; return MCBA_ERR_ARG; }
+  HIPCHK(hipSetDevice(h->device));
+  return MCBA_OK;
+}
+int upload_views(mcba_handle* h, const int* views, int n_views, const char* who) {
+  for (int i = 0; i < n_views; ++i)
+    if (views[2 * i] < 0 || views[2 * i] >= h->C || views[2 * i + 1] < 0 || views[2 * i + 1] >= h->F) { g_err = std::string(who) + ": view (camera, frame) out of range"; return MCBA_ERR_ARG; }
+  int rc = dgrow(h, &h->cal_views, &h->cal_views_cap, (size_t)2 * n_views);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h->cal_views, views, (size_t)2 * n_views * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  return MCBA_OK;
+}
+int upload_intr(mcba_handle* h, const double* intr9) {
+  int rc;
+  if (!h->cal_intr && (rc = dalloc(h, &h->cal_intr, (size_t)9 * h->C, false))) return rc;
+  HIPCHK(hipMemcpyAsync(h->cal_intr, intr9, (size_t)9 * h->C * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return MCBA_OK;
+}
+struct SelRecord { unsigned long long prefix, rank, count, value; unsigned int hist[256]; };   // = SelState of mcba_diag.hip
+
+// medians of the pairwise transforms (calibration.py:143): rel [E][6][Fpad] -> out (E, 6), counts (E) = frames the pair shares
+int pairwise_medians(hipStream_t st, const double* rel, int n_edges, int Fpad, unsigned char* sel_dev, double* out, double* counts) {
+  const int groups = 6 * n_edges;
+  mcba::launch_select(st, rel, nullptr, (size_t)Fpad, groups, Fpad, sel_dev, 2, 1);
+  int rc = check_launch();
+  if (rc) return rc;
+  std::vector<unsigned long long> head((size_t)4 * 2 * groups);   // prefix rank count value of every state
+  HIPCHK(hipMemcpy2DAsync(head.data(), 32, sel_dev, sizeof(SelRecord), 32, (size_t)2 * groups, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int g = 0; g < groups; ++g) {
+    double a, b;
+    memcpy(&a, &head[4 * (2 * g) + 3], 8);
+    memcpy(&b, &head[4 * (2 * g + 1) + 3], 8);
+    out[g] = head[4 * (2 * g) + 2] ? 0.5 * (a + b) : NAN;   // np.median: the mean of the two middle values; no common frame: NaN
+    if (counts && g % 6 == 0) counts[g / 6] = (double)head[4 * (2 * g) + 2];
+  }
+  return MCBA_OK;
+}
+struct TempDevice {   // one device allocation for a stateless call, freed on every way out
+  unsigned char* p = nullptr;
+  ~TempDevice() { if (p) (void)hipFree(p); }
+};
+int stateless_device(int device, const char* who) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MCBA_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) { g_err = std::string(who) + ": device ordinal out of range"; return MCBA_ERR_ARG; }
+  HIPCHK(hipSetDevice(device));
+  return MCBA_OK;
+}
+size_t up256(size_t b) { return (b + 255) / 256 * 256; }
+}  // namespace
+extern "C" {
+
+// complete_cf (C, F) bytes: 1 = every scalar of the detection is present (what get_intrinsics samples from and estimate_pose solves: :55, :107)
+int mcba_calib_complete(mcba_handle* h, unsigned char* complete_cf) {
+  int rc = calib_ready(h, "mcba_calib_complete");
+  if (rc) return rc;
+  if (!complete_cf) return fail(MCBA_ERR_ARG, "mcba_calib_complete: NULL output");
+  if (!h->cal_valid && (rc = dalloc(h, &h->cal_valid, (size_t)h->C * h->F, false))) return rc;
+  mcba::launch_view_complete(h->stream, h->obs_t, h->cal_valid, h->C, h->F, h->N, h->Fpad);
+  if ((rc = check_launch())) return rc;
+  HIPCHK(hipMemcpyAsync(complete_cf, h->cal_valid, (size_t)h->C * h->F, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+// Board-plane -> pixel homographies (H[2][2] = 1) of the listed (camera, frame) views: normalised DLT.  H_out n_views x 9; ok_out n_views bytes or NULL
+int mcba_calib_homographies(mcba_handle* h, const int* views, int n_views, double* H_out, unsigned char* ok_out) {
+  int rc = calib_ready(h, "mcba_calib_homographies");
+  if (rc) return rc;
+  if (!views || n_views < 1 || !H_out) return fail(MCBA_ERR_ARG, "mcba_calib_homographies: bad argument");
+  if ((rc = upload_views(h, views, n_views, "mcba_calib_homographies"))) return rc;
+  if ((rc = dgrow(h, &h->cal_out, &h->cal_out_cap, (size_t)10 * n_views + 8))) return rc;
+  unsigned char* okd = reinterpret_cast<unsigned char*>(h->cal_out + (size_t)9 * n_views);
+  double bn[3];
+  board_normalisation(h->obj_host, h->N, bn);
+  mcba::launch_pnp(h->stream, 0, h->obs_t, h->obj, nullptr, h->cal_views, n_views, bn, h->C, h->F, h->N, h->Fpad, 0, 0, h->cal_out, nullptr, okd, nullptr);
+  if ((rc = check_launch())) return rc;
+  HIPCHK(hipMemcpyAsync(H_out, h->cal_out, (size_t)9 * n_views * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (ok_out) HIPCHK(hipMemcpyAsync(ok_out, okd, (size_t)n_views, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+// cv2.solvePnP's job (calibration.py:108) for the listed views: intr9 = C x (fx fy cx cy k1 k2 p1 p2 k3); poses_out n_views x 6 (NaN = none)
+int mcba_calib_view_poses(mcba_handle* h, const int* views, int n_views, const double* intr9, int undistort_iterations, int max_evaluations, double* poses_out, unsigned char* ok_out) {
+  int rc = calib_ready(h, "mcba_calib_view_poses");
+  if (rc) return rc;
+  if (!views || n_views < 1 || !intr9 || !poses_out || undistort_iterations < 0 || max_evaluations < 1) return fail(MCBA_ERR_ARG, "mcba_calib_view_poses: bad argument");
+  if ((rc = upload_views(h, views, n_views, "mcba_calib_view_poses"))) return rc;
+  if ((rc = upload_intr(h, intr9))) return rc;
+  if ((rc = dgrow(h, &h->cal_out, &h->cal_out_cap, (size_t)10 * n_views + 8))) return rc;
+  unsigned char* okd = reinterpret_cast<unsigned char*>(h->cal_out + (size_t)9 * n_views);
+  double bn[3];
+  board_normalisation(h->obj_host, h->N, bn);
+  mcba::launch_pnp(h->stream, 1, h->obs_t, h->obj, h->cal_intr, h->cal_views, n_views, bn, h->C, h->F, h->N, h->Fpad, undistort_iterations, max_evaluations, h->cal_out, nullptr, okd, nullptr);
+  if ((rc = check_launch())) return rc;
+  HIPCHK(hipMemcpyAsync(poses_out, h->cal_out, (size_t)6 * n_views * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (ok_out) HIPCHK(hipMemcpyAsync(ok_out, okd, (size_t)n_views, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+// estimate_pose (calibration.py:74-113) of EVERY camera in one launch: the board pose of every (camera, frame) with a complete detection.
+// The poses stay on the device for mcba_calib_pairwise / mcba_calib_consensus; poses_out (C, F, 6) (NaN rows = no pose), ok_out (C, F) bytes
+// and evals_out (C, F) bytes (LM evaluations a view took) are optional.
+int mcba_calib_poses(mcba_handle* h, const double* intr9, int undistort_iterations, int max_evaluations, double* poses_out, unsigned char* ok_out, unsigned char* evals_out) {
+  int rc = calib_ready(h, "mcba_calib_poses");
+  if (rc) return rc;
+  if (!intr9 || undistort_iterations < 0 || max_evaluations < 1) return fail(MCBA_ERR_ARG, "mcba_calib_poses: bad argument");
+  if ((rc = upload_intr(h, intr9))) return rc;
+  const size_t CF = (size_t)h->C * h->F;
+  if (!h->cal_poses_t && (rc = dalloc(h, &h->cal_poses_t, (size_t)6 * h->C * h->Fpad, false))) return rc;
+  if (!h->cal_valid && (rc = dalloc(h, &h->cal_valid, CF, false))) return rc;
+  if (!h->cal_nit && (rc = dalloc(h, &h->cal_nit, CF, false))) return rc;
+  if (poses_out && (rc = dgrow(h, &h->cal_out, &h->cal_out_cap, 6 * CF))) return rc;
+  double bn[3];
+  board_normalisation(h->obj_host, h->N, bn);
+  mcba::launch_pnp(h->stream, 1, h->obs_t, h->obj, h->cal_intr, nullptr, 0, bn, h->C, h->F, h->N, h->Fpad, undistort_iterations, max_evaluations, poses_out ? h->cal_out : nullptr, h->cal_poses_t, h->cal_valid,
+                   h->cal_nit);
+  if ((rc = check_launch())) return rc;
+  h->have_cal_poses = true;
+  if (poses_out) HIPCHK(hipMemcpyAsync(poses_out, h->cal_out, 6 * CF * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (ok_out) HIPCHK(hipMemcpyAsync(ok_out, h->cal_valid, CF, hipMemcpyDeviceToHost, h->stream));
+  if (evals_out) HIPCHK(hipMemcpyAsync(evals_out, h->cal_nit, CF, hipMemcpyDeviceToHost, h->stream));
+  if (poses_out || ok_out || evals_out) HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+// estimate_pairwise_camera_transform (calibration.py:116-143) for a list of camera pairs (c1, c2) over the poses mcba_calib_poses left on
+// the device: transforms_out (n_edges, 6) = component-wise median over the common frames of T2 T1^-1; counts_out (n_edges) or NULL
+int mcba_calib_pairwise(mcba_handle* h, const int* edges, int n_edges, double* transforms_out, double* counts_out) {
+  int rc = calib_ready(h, "mcba_calib_pairwise");
+  if (rc) return rc;
+  if (!edges || n_edges < 1 || !transforms_out) return fail(MCBA_ERR_ARG, "mcba_calib_pairwise: bad argument");
+  if (!h->have_cal_poses) return fail(MCBA_ERR_ARG, "mcba_calib_pairwise: call mcba_calib_poses first");
+  for (int i = 0; i < 2 * n_edges; ++i)
+    if (edges[i] < 0 || edges[i] >= h->C) return fail(MCBA_ERR_ARG, "mcba_calib_pairwise: camera index out of range");
+  if ((rc = dgrow(h, &h->cal_views, &h->cal_views_cap, (size_t)2 * n_edges))) return rc;
+  if ((rc = dgrow(h, &h->cal_rel, &h->cal_rel_cap, (size_t)6 * n_edges * h->Fpad))) return rc;
+  if ((rc = dgrow(h, &h->cal_sel, &h->cal_sel_cap, mcba::select_state_bytes(12 * n_edges)))) return rc;
+  HIPCHK(hipMemcpyAsync(h->cal_views, edges, (size_t)2 * n_edges * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  mcba::launch_pose_pairs(h->stream, h->cal_poses_t, (size_t)6 * h->Fpad, 1, (size_t)h->Fpad, h->cal_views, n_edges, h->F, h->Fpad, h->cal_rel);
+  if ((rc = check_launch())) return rc;
+  return pairwise_medians(h->stream, h->cal_rel, n_edges, h->Fpad, h->cal_sel, transforms_out, counts_out);
+}
+
+// consensus_calib_poses (calibration.py:239-277): extrinsics (C, 6) world -> camera; poses_out (F, 6) = nan-median over the cameras of
+// T_ext^-1 T_pose, NaN rows for frames no camera has a pose for
+int mcba_calib_consensus(mcba_handle* h, const double* extrinsics, double* poses_out) {
+  int rc = calib_ready(h, "mcba_calib_consensus");
+  if (rc) return rc;
+  if (!extrinsics || !poses_out) return fail(MCBA_ERR_ARG, "mcba_calib_consensus: bad argument");
+  if (!h->have_cal_poses) return fail(MCBA_ERR_ARG, "mcba_calib_consensus: call mcba_calib_poses first");
+  if (!h->cal_world && (rc = dalloc(h, &h->cal_world, (size_t)6 * h->C * h->Fpad, false))) return rc;
+  if ((rc = dgrow(h, &h->cal_out, &h->cal_out_cap, (size_t)6 * h->F + (size_t)6 * h->C))) return rc;
+  double* d_ext = h->cal_out + (size_t)6 * h->F;
+  HIPCHK(hipMemcpyAsync(d_ext, extrinsics, (size_t)6 * h->C * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  mcba::launch_pose_consensus(h->stream, h->cal_poses_t, (size_t)6 * h->Fpad, 1, (size_t)h->Fpad, d_ext, h->C, h->F, h->Fpad, h->cal_world, h->cal_out);
+  if ((rc = check_launch())) return rc;
+  HIPCHK(hipMemcpyAsync(poses_out, h->cal_out, (size_t)6 * h->F * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
+// The same two pose-graph steps for a caller's own (C, F, 6) pose array (NaN rows = no detection): what the reference's public
+// estimate_pairwise_camera_transform / consensus_calib_poses take.  Stateless; host arrays in, host arrays out.
+int mcba_pose_pairwise(int n_cameras, int n_frames, const double* poses, const int* edges, int n_edges, int device, double* transforms_out, double* counts_out) {
+  if (n_cameras < 1 || n_frames < 1 || !poses || !edges || n_edges < 1 || !transforms_out) return fail(MCBA_ERR_ARG, "mcba_pose_pairwise: bad argument");
+  for (int i = 0; i < 2 * n_edges; ++i)
+    if (edges[i] < 0 || edges[i] >= n_cameras) return fail(MCBA_ERR_ARG, "mcba_pose_pairwise: camera index out of range");
+  int rc = stateless_device(device, "mcba_pose_pairwise");
+  if (rc) return rc;
+  const int Fpad = (n_frames + 63) / 64 * 64;
+  const size_t b_pose = up256((size_t)6 * n_cameras * n_frames * sizeof(double)), b_edge = up256((size_t)2 * n_edges * sizeof(int)), b_rel = up256((size_t)6 * n_edges * Fpad * sizeof(double)),
+               b_sel = up256(mcba::select_state_bytes(12 * n_edges));
+  TempDevice t;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&t.p), b_pose + b_edge + b_rel + b_sel));
+  double* d_pose = reinterpret_cast<double*>(t.p);
+  int* d_edge = reinterpret_cast<int*>(t.p + b_pose);
+  double* d_rel = reinterpret_cast<double*>(t.p + b_pose + b_edge);
+  unsigned char* d_sel = t.p + b_pose + b_edge + b_rel;
+  HIPCHK(hipMemcpyAsync(d_pose, poses, (size_t)6 * n_cameras * n_frames * sizeof(double), hipMemcpyHostToDevice, nullptr));
+  HIPCHK(hipMemcpyAsync(d_edge, edges, (size_t)2 * n_edges * sizeof(int), hipMemcpyHostToDevice, nullptr));
+  mcba::launch_pose_pairs(nullptr, d_pose, (size_t)6 * n_frames, 6, 1, d_edge, n_edges, n_frames, Fpad, d_rel);
+  if ((rc = check_launch())) return rc;
+  return pairwise_medians(nullptr, d_rel, n_edges, Fpad, d_sel, transforms_out, counts_out);
+}
+
+int mcba_pose_consensus(int n_cameras, int n_frames, const double* poses, const double* extrinsics, int device, double* poses_out) {
+  if (n_cameras < 1 || n_cameras > 64 || n_frames < 1 || !poses || !extrinsics || !poses_out) return fail(MCBA_ERR_ARG, "mcba_pose_consensus: 1..64 cameras, non-NULL arrays required");
+  int rc = stateless_device(device, "mcba_pose_consensus");
+  if (rc) return rc;
+  const int Fpad = (n_frames + 63) / 64 * 64;
+  const size_t b_pose = up256((size_t)6 * n_cameras * n_frames * sizeof(double)), b_ext = up256((size_t)6 * n_cameras * sizeof(double)), b_world = up256((size_t)6 * n_cameras * Fpad * sizeof(double)),
+               b_out = up256((size_t)6 * n_frames * sizeof(double));
+  TempDevice t;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&t.p), b_pose + b_ext + b_world + b_out));
+  double* d_pose = reinterpret_cast<double*>(t.p);
+  double* d_ext = reinterpret_cast<double*>(t.p + b_pose);
+  double* d_world = reinterpret_cast<double*>(t.p + b_pose + b_ext);
+  double* d_out = reinterpret_cast<double*>(t.p + b_pose + b_ext + b_world);
+  HIPCHK(hipMemcpyAsync(d_pose, poses, (size_t)6 * n_cameras * n_frames * sizeof(double), hipMemcpyHostToDevice, nullptr));
+  HIPCHK(hipMemcpyAsync(d_ext, extrinsics, (size_t)6 * n_cameras * sizeof(double), hipMemcpyHostToDevice, nullptr));
+  mcba::launch_pose_consensus(nullptr, d_pose, (size_t)6 * n_frames, 6, 1, d_ext, n_cameras, n_frames, Fpad, d_world, d_out);
+  if ((rc = check_launch())) return rc;
+  HIPCHK(hipMemcpyAsync(poses_out, d_out, (size_t)6 * n_frames * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+  HIPCHK(hipStreamSynchronize(nullptr));
   return MCBA_OK;
 }
 

@@ -112,7 +112,12 @@ struct SelState {
 // values: [groups][stride] doubles with the frame index = i % Fpad; mask (per frame) may be nullptr; group g selects the
 // slice [g * per_group, (g + 1) * per_group) (per-camera medians) -- blockIdx.y = group, one SelState per group
 // dual != 0: two states per group (2 g: the lower middle rank, 2 g + 1: the upper one) walk the same slice in the same passes
-__global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ v, const unsigned char* __restrict__ fmask, size_t per_group, int Fpad, SelState* __restrict__ sts, int pass, int dual) {
+// skey != 0: the values may be negative -- they are compared through an order-preserving key (sign bit flipped for values >= +0, every bit
+// for negative ones: unsigned order of the keys = numeric order of the values); the errors of the pre-filter are >= +0 and need none
+__device__ __forceinline__ unsigned long long sel_key(unsigned long long k, int skey) {
+  return skey ? ((k >> 63) ? ~k : (k | 0x8000000000000000ull)) : k;
+}
+__global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ v, const unsigned char* __restrict__ fmask, size_t per_group, int Fpad, SelState* __restrict__ sts, int pass, int dual, int skey) {
   __shared__ unsigned int s_h[256];
   SelState* st = sts + blockIdx.y;
   s_h[threadIdx.x] = 0;
@@ -121,8 +126,9 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ v, 
   const int shift_hi = 64 - 8 * pass, shift = 56 - 8 * pass;
   const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(v) + (size_t)(dual ? blockIdx.y >> 1 : blockIdx.y) * per_group;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per_group; i += (size_t)gridDim.x * 256) {
-    const unsigned long long k = keys[i];
-    const double d = __longlong_as_double((long long)k);
+    const unsigned long long kraw = keys[i];
+    const double d = __longlong_as_double((long long)kraw);
+    const unsigned long long k = sel_key(kraw, skey);
     bool ok = d == d;
     if (fmask) ok = ok && fmask[i % (size_t)Fpad] != 0;
     if (ok && (pass == 0 || (k >> shift_hi) == prefix)) atomicAdd(&s_h[(unsigned)(k >> shift) & 255u], 1u);
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ v, 
 }
 
 // one thread per group: which byte holds the wanted rank; upper == 0 selects rank (n-1)/2, upper == 1 rank n/2
-__global__ void k_sel_pick(SelState* __restrict__ sts, int pass, int upper, int dual) {
+__global__ void k_sel_pick(SelState* __restrict__ sts, int pass, int upper, int dual, int skey) {
   SelState* st = sts + blockIdx.x;
   if (threadIdx.x != 0) return;
   if (dual) upper = blockIdx.x & 1;
@@ -153,7 +159,7 @@ __global__ void k_sel_pick(SelState* __restrict__ sts, int pass, int upper, int 
   }
   st->rank = r - below;
   st->prefix = (st->prefix << 8) | (unsigned long long)digit;
-  if (pass == 7) st->value = st->prefix;
+  if (pass == 7) st->value = skey ? ((st->prefix >> 63) ? (st->prefix & 0x7FFFFFFFFFFFFFFFull) : ~st->prefix) : st->prefix;   // (the key back to the value's bits)
   for (int b = 0; b < 256; ++b) st->hist[b] = 0;
 }
 
@@ -527,14 +533,15 @@ __global__ __launch_bounds__(256) void k_gather_params(const double* __restrict_
 }
 
 // ---------------------------------------------------------------- frame subsets, device to device
-__global__ void k_gather_frames(const double2* __restrict__ src, const int* __restrict__ frames, double2* __restrict__ dst, int C, int Fsrc, int Fdst, int N) {
+__global__ void k_gather_frames(const double2* __restrict__ src, const int* __restrict__ frames, double2* __restrict__ dst, int C, int Fsrc, int Fdst, int N, const int* __restrict__ only_cam) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)C * Fdst * N;
   if (i >= total) return;
   const int p = (int)(i % N);
   const size_t cf = i / N;
   const int f = (int)(cf % Fdst), c = (int)(cf / Fdst);
-  dst[i] = src[((size_t)c * Fsrc + frames[f]) * N + p];
+  const double nan = __builtin_nan("");
+  dst[i] = (only_cam && only_cam[f] != c) ? double2{nan, nan} : src[((size_t)c * Fsrc + frames[f]) * N + p];
 }
 
 // ---------------------------------------------------------------- presence bits of the observation scalars
@@ -796,14 +803,14 @@ size_t select_state_bytes(int groups) { return (size_t)groups * sizeof(SelState)
 // sel[g].value (bit pattern of the order statistic) are valid.  16 tiny launches per call, no host synchronisation.
 // upper = 0 / 1: one order statistic per group; upper = 2: BOTH middle ranks in the same eight passes (states 2 g and 2 g + 1:
 // `sel` must hold 2 x groups states) -- half the launches and one host synchronisation instead of two for a median
-void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int groups, int Fpad, void* sel, int upper) {
+void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int groups, int Fpad, void* sel, int upper, int skey) {
   SelState* s = static_cast<SelState*>(sel);
   const int dual = upper == 2 ? 1 : 0, nst = dual ? 2 * groups : groups;
   (void)hipMemsetAsync(s, 0, select_state_bytes(nst), st);
   const unsigned bx = (unsigned)std::min<size_t>((per_group + 255) / 256, 1024);
   for (int pass = 0; pass < 8; ++pass) {
-    k_sel_hist<<<dim3(bx, nst), dim3(256), 0, st>>>(v, fmask, per_group, Fpad, s, pass, dual);
-    k_sel_pick<<<dim3(nst), dim3(64), 0, st>>>(s, pass, upper, dual);
+    k_sel_hist<<<dim3(bx, nst), dim3(256), 0, st>>>(v, fmask, per_group, Fpad, s, pass, dual, skey);
+    k_sel_pick<<<dim3(nst), dim3(64), 0, st>>>(s, pass, upper, dual, skey);
   }
 }
 
@@ -815,7 +822,7 @@ int launch_select_hist(hipStream_t st, const double* v, const unsigned char* fma
   init.prefix = prefix;
   if (hipMemcpyAsync(s, &init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return 1;
   const unsigned bx = (unsigned)std::min<size_t>((per_group + 255) / 256, 1024);
-  k_sel_hist<<<dim3(bx, 1), dim3(256), 0, st>>>(v, fmask, per_group, Fpad, s, pass, 0);
+  k_sel_hist<<<dim3(bx, 1), dim3(256), 0, st>>>(v, fmask, per_group, Fpad, s, pass, 0, 0);
   if (hipMemcpyAsync(hist256, s->hist, 256 * sizeof(unsigned int), hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
   return hipStreamSynchronize(st) == hipSuccess ? 0 : 1;
 }
@@ -932,9 +939,9 @@ void launch_gather_params(hipStream_t st, const double* x_src, const int* frames
   k_gather_params<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(x_src, frames, x_dst, C, Fdst);
 }
 
-void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N) {
+void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N, const int* only_cam) {
   const size_t total = (size_t)C * Fdst * N;
-  k_gather_frames<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(src_raw), frames, reinterpret_cast<double2*>(dst_raw), C, Fsrc, Fdst, N);
+  k_gather_frames<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(src_raw), frames, reinterpret_cast<double2*>(dst_raw), C, Fsrc, Fdst, N, only_cam);
 }
 
 void launch_seen_bits(hipStream_t st, const double* obs_raw, size_t count, unsigned long long* words) {

@@ -117,7 +117,8 @@ int syrk_set_lds_limit(size_t bytes);
 void launch_frame_err(hipStream_t st, const double* obs_t, const double* obj, const double* x, double* err, double* mean_cf, double* full_cf, int C, int F, int N, int Fpad,
                       void* prefilter_state = nullptr);   // non-NULL: the launch also zeroes the selection's state (launch_prefilter_select(..., state_cleared = true) follows)
 size_t select_state_bytes(int groups);  // per group: u64 prefix, rank, count, value (bit pattern of the selected double) + a 256-bin histogram
-void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int groups, int Fpad, void* sel, int upper);
+void launch_select(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int groups, int Fpad, void* sel, int upper,
+                   int skey = 0);   // != 0: values of either sign (compared through an order-preserving key); 0: values >= +0 (the pre-filter's errors)
 int launch_select_hist(hipStream_t st, const double* v, const unsigned char* fmask, size_t per_group, int Fpad, void* sel, unsigned long long prefix, int pass, unsigned int* hist256);
 // the pre-filter's selection on the device (mcba_prefilter): see mcba_diag.hip
 size_t prefilter_state_bytes();
@@ -128,11 +129,20 @@ void launch_gather_params(hipStream_t st, const double* x_src, const int* frames
 void launch_clip(hipStream_t st, double* x, const double* lo, const double* hi, size_t n);  // x <- min(max(x, lo), hi): the trial point of a bounded step
 bool launch_store_small(hipStream_t st, double* dst, const double* src_host, size_t n);  // <= 480 doubles through the kernel-argument segment (no blocking copy); false: too many
 double measure_fp64_issue_rate(int ncu);  // TFLOP/s of independent v_fma_f64 at one wavefront per SIMD on `ncu` compute units (measurement aid)
-void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N);
+void launch_gather_frames(hipStream_t st, const double* src_raw, const int* frames, double* dst_raw, int C, int Fsrc, int Fdst, int N,
+                          const int* only_cam = nullptr);   // non-NULL: destination frame j keeps the detection of camera only_cam[j] alone (NaN for the others)
 void launch_seen_bits(hipStream_t st, const double* obs_raw, size_t count, unsigned long long* words);  // words: ceil(count / 64) of them
 void launch_undistort(hipStream_t st, const double* uv, double* out, size_t n, const double* K4, const double* dist5, int iters);
 void launch_reproj_diag(hipStream_t st, const double* obs_t, const double* obj, const double* x, const double* dist5, const double* bn, double* und, double* repro, double* trans, double* err, int C, int F, int N,
                         int Fpad, int iters, int lm_iters);
+// calibrate()'s per-view work and pose graph (mcba_pnp.hip).  mode 0: homographies of the listed views (out: nviews x 9); mode 1: board poses --
+// views != nullptr: of the listed (camera, frame) views (out: nviews x 6), else of every (camera, frame) (out (C,F,6) and / or poses_t [C][6][Fpad])
+void launch_view_complete(hipStream_t st, const double* obs_t, unsigned char* out, int C, int F, int N, int Fpad);
+void launch_pnp(hipStream_t st, int mode, const double* obs_t, const double* obj, const double* intr9, const int* views, int nviews, const double* bn3, int C, int F, int N, int Fpad, int und_iters, int lm_iters,
+                double* out, double* poses_t, unsigned char* valid, unsigned char* nit);
+// poses addressed as p[c * sc + f * sf + k * sk]; rel [n_edges][6][Fpad]; world [C][6][Fpad] scratch; out (F, 6)
+void launch_pose_pairs(hipStream_t st, const double* poses, size_t sc, size_t sf, size_t sk, const int* edges, int n_edges, int F, int Fpad, double* rel);
+void launch_pose_consensus(hipStream_t st, const double* poses, size_t sc, size_t sf, size_t sk, const double* ext, int C, int F, int Fpad, double* world, double* out);
 // triangulation (mcba_triangulate.hip): up to 8 cameras; P = K [R | t] row-major 3x4, K = (fx, fy, cx, cy), dist = (k1 k2 p1 p2 k3)
 struct TriCams {
   double P[8][12];

@@ -89,6 +89,15 @@ SYMBOLS = [
     ("mcba_frame_errors", ctypes.c_int, [_h, ctypes.c_int, _dp, _dp]),
     ("mcba_error_median", ctypes.c_int, [_h, ctypes.c_char_p, _dp, _dp]),
     ("mcba_create_subset", ctypes.c_int, [ctypes.POINTER(_h), _h, _ip, ctypes.c_int]),
+    ("mcba_create_views", ctypes.c_int, [ctypes.POINTER(_h), _h, _ip, ctypes.c_int]),
+    ("mcba_calib_complete", ctypes.c_int, [_h, ctypes.POINTER(ctypes.c_ubyte)]),
+    ("mcba_calib_homographies", ctypes.c_int, [_h, _ip, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte)]),
+    ("mcba_calib_view_poses", ctypes.c_int, [_h, _ip, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte)]),
+    ("mcba_calib_poses", ctypes.c_int, [_h, _dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_ubyte)]),
+    ("mcba_calib_pairwise", ctypes.c_int, [_h, _ip, ctypes.c_int, _dp, _dp]),
+    ("mcba_calib_consensus", ctypes.c_int, [_h, _dp, _dp]),
+    ("mcba_pose_pairwise", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _ip, ctypes.c_int, ctypes.c_int, _dp, _dp]),
+    ("mcba_pose_consensus", ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_int, _dp]),
     ("mcba_prefilter", ctypes.c_int, [_h, _dp, _dp, _dp, ctypes.c_double, ctypes.POINTER(ctypes.c_ubyte), _dp]),
     ("mcba_prefilter_subset", ctypes.c_int, [_h, _dp, _dp, _dp, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte), _dp, ctypes.POINTER(_h)]),
     ("mcba_lm_run", ctypes.c_int, [_h, _dp, _dp, ctypes.c_char_p, _dp]),
@@ -320,6 +329,73 @@ class Problem:
         if loss is not None:
             new.set_loss(loss, 1.0 if f_scale is None else f_scale)
         return new
+
+    # ---- calibrate() on the device (include/mcba.h: the mcba_calib_* block; reference calibration.py:11-277)
+    def _sibling(self, handle, F):
+        new = Problem.__new__(Problem)
+        new.lib = self.lib
+        new.C, new.N, new.F = self.C, self.N, int(F)
+        new.cw, new.n = 12, 12 * self.C
+        new.nx = 12 * new.C + 6 * new.F
+        new.handle = handle
+        return new
+
+    def view_subset(self, views, loss=None, f_scale=None):
+        """A new Problem of C cameras x len(views) frames: frame j holds the detection of view j = (camera, frame) in its camera alone."""
+        v = np.ascontiguousarray(views, dtype=np.int32).reshape(-1, 2)
+        sub = _h()
+        self._chk(self.lib.mcba_create_views(ctypes.byref(sub), self.handle, v.ctypes.data_as(_ip), len(v)))
+        new = self._sibling(sub, len(v))
+        if loss is not None:
+            new.set_loss(loss, 1.0 if f_scale is None else f_scale)
+        return new
+
+    def calib_complete(self):
+        """(C,F) bool: every scalar of the detection present."""
+        out = np.empty((self.C, self.F), np.uint8)
+        self._chk(self.lib.mcba_calib_complete(self.handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))))
+        return out.view(np.bool_)
+
+    def calib_homographies(self, views):
+        """(V,3,3) board-plane -> pixel homographies of the (camera, frame) views, H[2,2] = 1; NaN for incomplete views."""
+        v = np.ascontiguousarray(views, dtype=np.int32).reshape(-1, 2)
+        H = np.empty((len(v), 3, 3))
+        self._chk(self.lib.mcba_calib_homographies(self.handle, v.ctypes.data_as(_ip), len(v), _p(H), None))
+        return H
+
+    def calib_view_poses(self, views, intr9, undistort_iterations=8, max_evaluations=60):
+        """(V,6) board poses of the listed views with the cameras' intrinsics intr9 (C,9); NaN rows where none came out."""
+        v = np.ascontiguousarray(views, dtype=np.int32).reshape(-1, 2)
+        k = _f64(intr9).reshape(self.C, 9)
+        out = np.empty((len(v), 6))
+        self._chk(self.lib.mcba_calib_view_poses(self.handle, v.ctypes.data_as(_ip), len(v), _p(k), int(undistort_iterations), int(max_evaluations), _p(out), None))
+        return out
+
+    def calib_poses(self, intr9, undistort_iterations=8, max_evaluations=60, want_poses=False, want_evals=False):
+        """Board pose of every (camera, frame) with a complete detection, left on the device for calib_pairwise / calib_consensus.
+        Returns (ok (C,F) bool, poses (C,F,6) or None, evaluations (C,F) uint8 or None)."""
+        k = _f64(intr9).reshape(self.C, 9)
+        ok = np.empty((self.C, self.F), np.uint8)
+        poses = np.empty((self.C, self.F, 6)) if want_poses else None
+        ev = np.empty((self.C, self.F), np.uint8) if want_evals else None
+        ub = ctypes.POINTER(ctypes.c_ubyte)
+        self._chk(self.lib.mcba_calib_poses(self.handle, _p(k), int(undistort_iterations), int(max_evaluations), None if poses is None else _p(poses), ok.ctypes.data_as(ub),
+                                            None if ev is None else ev.ctypes.data_as(ub)))
+        return ok.view(np.bool_), poses, ev
+
+    def calib_pairwise(self, edges):
+        """(E,6) median relative transforms T2 T1^-1 of the camera pairs `edges` (E,2), and the number of frames each pair shares."""
+        e = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+        out, cnt = np.empty((len(e), 6)), np.empty(len(e))
+        self._chk(self.lib.mcba_calib_pairwise(self.handle, e.ctypes.data_as(_ip), len(e), _p(out), _p(cnt)))
+        return out, cnt
+
+    def calib_consensus(self, extrinsics):
+        """(F,6) consensus board poses in world coordinates for the extrinsics (C,6)."""
+        ext = _f64(extrinsics).reshape(self.C, 6)
+        out = np.empty((self.F, 6))
+        self._chk(self.lib.mcba_calib_consensus(self.handle, _p(ext), _p(out)))
+        return out
 
     def reprojection_diagnostics(self, slot, dist5=None, undistort_iterations=5, arrays=True):
         """(median_error (C,), reprojections (C,F,N,2), transformed_reprojections (C,F,N,2)) as plot_residuals computes them
@@ -810,6 +886,30 @@ def undistort_points(uvs, K4, dist5=None, iterations=5, device=0):
     k = _f64(K4)
     d = None if dist5 is None else _f64(dist5)
     rc = lib.mcba_undistort_points(a.size // 2, _p(a), _p(k), None if d is None else _p(d), int(iterations), int(device), _p(out))
+    if rc != OK:
+        raise McbaError(rc, lib.mcba_last_error().decode())
+    return out
+
+
+def pose_pairwise(poses, edges, device=0):
+    """Median relative transforms of camera pairs over a caller's pose array (C,F,6) (include/mcba.h: mcba_pose_pairwise)."""
+    lib = load_library()
+    ps = _f64(poses)
+    e = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+    out, cnt = np.empty((len(e), 6)), np.empty(len(e))
+    rc = lib.mcba_pose_pairwise(ps.shape[0], ps.shape[1], _p(ps), e.ctypes.data_as(_ip), len(e), int(device), _p(out), _p(cnt))
+    if rc != OK:
+        raise McbaError(rc, lib.mcba_last_error().decode())
+    return out, cnt
+
+
+def pose_consensus(poses, extrinsics, device=0):
+    """Consensus board poses (F,6) of a caller's pose array (C,F,6) under the extrinsics (C,6) (include/mcba.h: mcba_pose_consensus)."""
+    lib = load_library()
+    ps = _f64(poses)
+    ext = _f64(extrinsics).reshape(ps.shape[0], 6)
+    out = np.empty((ps.shape[1], 6))
+    rc = lib.mcba_pose_consensus(ps.shape[0], ps.shape[1], _p(ps), _p(ext), int(device), _p(out))
     if rc != OK:
         raise McbaError(rc, lib.mcba_last_error().decode())
     return out

@@ -70,3 +70,147 @@ def refine(uvs, obj, intr9, poses, free9):
     res = least_squares(fun, z0, method="trf", x_scale="jac", ftol=1e-15, xtol=1e-15, gtol=1e-12, max_nfev=200)
     k, ps = unpack(res.x)
     return k, ps, res.cost
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# calibrate()'s per-view closed-form starts and its pose graph, in numpy (round 6: the product runs them on the GPU -- csrc/mcba_pnp.hip --
+# and these are what its kernels are checked against).
+#   pose graph: restates multicam_calibration/calibration.py:116-143 (estimate_pairwise_camera_transform) and :239-277
+#   (consensus_calib_poses) with geometry.py:38-56,155-196 (rodrigues_inv, the 6-vector <-> 4x4 maps); PINNED to the reference's own
+#   outputs by tests/golden/calibration_graph.npz (tests/test_calibration_cpu.py).
+#   homographies / poses_from_homographies / undistort_normalized: the steps OpenCV takes inside cv2.calibrateCamera / cv2.solvePnP for a
+#   planar board (Hartley-normalised DLT -- Zhang 2000 appendix A --, pose from H = K [r1 r2 t], undistortPoints' fixed point); cv2 is absent:
+#   parity with its numbers is unpinned, the tests check exact recovery on noise-free synthetic views.
+na = np.newaxis
+
+
+def rodrigues_batch(r):
+    """geometry.py:8-35 for an array of rotation vectors (..., 3) -> (..., 3, 3)."""
+    r = np.asarray(r, dtype=np.float64)
+    theta = np.linalg.norm(r, axis=-1)[..., na, na]
+    safe = np.where(theta == 0, 1.0, theta)
+    A = np.zeros(r.shape[:-1] + (3, 3))
+    A[..., 0, 1], A[..., 0, 2] = -r[..., 2], r[..., 1]
+    A[..., 1, 0], A[..., 1, 2] = r[..., 2], -r[..., 0]
+    A[..., 2, 0], A[..., 2, 1] = -r[..., 1], r[..., 0]
+    A = A / safe
+    return np.eye(3) + np.sin(theta) * A + (1 - np.cos(theta)) * (A @ A)
+
+
+def rodrigues_inv(R):
+    R = np.asarray(R, dtype=np.float64)
+    v = np.stack([R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]], axis=-1)
+    theta = np.arccos((np.trace(R, axis1=-2, axis2=-1) - 1) / 2)[..., na]
+    n = np.linalg.norm(v, axis=-1, keepdims=True)
+    n = n + (n == 0)
+    return v * theta / n
+
+
+def get_transformation_matrix(t):
+    t = np.asarray(t, dtype=np.float64)
+    T = np.zeros(t.shape[:-1] + (4, 4))
+    T[..., :3, :3] = rodrigues_batch(t[..., :3])
+    T[..., :3, 3] = t[..., 3:]
+    T[..., 3, 3] = 1
+    return T
+
+
+def get_transformation_vector(T):
+    return np.concatenate([rodrigues_inv(T[..., :3, :3]), T[..., :3, 3]], axis=-1)
+
+
+def estimate_pairwise_camera_transform(camera1_poses, camera2_poses):
+    """Median over the common frames of T2 T1^-1, component-wise on the 6-vectors (calibration.py:116-143)."""
+    camera1_poses, camera2_poses = np.asarray(camera1_poses), np.asarray(camera2_poses)
+    common = ~np.isnan([camera1_poses, camera2_poses]).any((0, 2))
+    T1 = get_transformation_matrix(camera1_poses[common])
+    T2 = get_transformation_matrix(camera2_poses[common])
+    return np.median(get_transformation_vector(T2 @ np.linalg.inv(T1)), axis=0)
+
+
+def consensus_calib_poses(all_calib_poses, all_extrinsics):
+    """Per-camera board poses mapped to world coordinates, nan-median over cameras (calibration.py:239-277)."""
+    import warnings
+
+    all_calib_poses = np.asarray(all_calib_poses, dtype=np.float64)
+    world = np.full_like(all_calib_poses, np.nan)
+    for i, (poses, transform) in enumerate(zip(all_calib_poses, all_extrinsics)):
+        det = ~np.isnan(poses).any(axis=-1)
+        T = np.linalg.inv(get_transformation_matrix(transform)) @ get_transformation_matrix(poses[det])
+        world[i, det] = get_transformation_vector(T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)
+        return np.nanmedian(world, axis=0)
+
+
+def homographies(XY, uv):
+    """Normalised DLT, batched: XY (N,2) board coordinates, uv (F,N,2) -> H (F,3,3) with uv ~ H [X, Y, 1]."""
+    def norm(P):
+        c = P.mean(-2, keepdims=True)
+        s = np.sqrt(2.0) / np.sqrt(((P - c) ** 2).sum(-1).mean(-1))[..., na, na]
+        T = np.zeros(P.shape[:-2] + (3, 3))
+        T[..., 0, 0] = T[..., 1, 1] = s[..., 0, 0]
+        T[..., 0, 2], T[..., 1, 2] = -s[..., 0, 0] * c[..., 0, 0], -s[..., 0, 0] * c[..., 0, 1]
+        T[..., 2, 2] = 1
+        return (P - c) * s, T
+
+    uv = np.asarray(uv, dtype=np.float64)
+    Xn, TX = norm(np.asarray(XY, dtype=np.float64))
+    un, Tu = norm(uv)
+    F, N = uv.shape[:2]
+    X, Y = np.broadcast_to(Xn[:, 0], (F, N)), np.broadcast_to(Xn[:, 1], (F, N))
+    u, v = un[..., 0], un[..., 1]
+    z, o = np.zeros((F, N)), np.ones((F, N))
+    A = np.concatenate([np.stack([X, Y, o, z, z, z, -u * X, -u * Y, -u], -1), np.stack([z, z, z, X, Y, o, -v * X, -v * Y, -v], -1)], axis=1)
+    _, _, Vt = np.linalg.svd(A, full_matrices=False)   # (2N >= 9 rows: Vt is 9 x 9 either way; the 2N x 2N U is not needed)
+    Hn = Vt[:, -1].reshape(F, 3, 3)
+    H = np.linalg.inv(Tu) @ Hn @ TX
+    return H / H[:, 2:3, 2:3]
+
+
+def poses_from_homographies(H, K):
+    """Board pose (F,6) from H = K [r1 r2 t] up to scale, rotation re-orthonormalised, board in front of the camera."""
+    M = np.linalg.inv(K) @ H
+    lam = 2.0 / (np.linalg.norm(M[:, :, 0], axis=1) + np.linalg.norm(M[:, :, 1], axis=1))
+    lam = np.where(M[:, 2, 2] < 0, -lam, lam)  # t_z > 0
+    M = M * lam[:, na, na]
+    R = np.stack([M[:, :, 0], M[:, :, 1], np.cross(M[:, :, 0], M[:, :, 1])], axis=-1)
+    U, _, Vt = np.linalg.svd(R)
+    R = U @ Vt
+    neg = np.linalg.det(R) < 0
+    if neg.any():
+        U[neg, :, 2] *= -1
+        R = U @ Vt
+    return np.concatenate([rodrigues_inv(R), M[:, :, 2]], axis=-1)
+
+
+def undistort_normalized(uv, K, dist, iterations=8):
+    """Pixel -> undistorted normalised coordinates for OpenCV's (k1, k2, p1, p2, k3) model: the fixed-point iteration of its undistortPoints,
+    x <- (x_d - tangential(x)) / radial(x)."""
+    k1, k2, p1, p2, k3 = (list(np.ravel(dist)) + [0.0] * 5)[:5]
+    xd = (uv[..., 0] - K[0, 2]) / K[0, 0]
+    yd = (uv[..., 1] - K[1, 2]) / K[1, 1]
+    x, y = xd.copy(), yd.copy()
+    for _ in range(iterations):
+        s = x * x + y * y
+        d = 1 + s * (k1 + s * (k2 + s * k3))
+        dx = 2 * p1 * x * y + p2 * (s + 2 * x * x)
+        dy = p1 * (s + 2 * y * y) + 2 * p2 * x * y
+        x, y = (xd - dx) / d, (yd - dy) / d
+    return np.stack([x, y], -1)
+
+
+def estimate_all_extrinsics(all_calib_poses, tree, root=0):
+    """calibration.py:226-235 for a given spanning tree: chain the pairwise medians from the root (whose transform is the identity)."""
+    ext = [None] * len(all_calib_poses)
+    ext[root] = np.eye(4)
+    for c1, c2 in tree:
+        ext[c2] = get_transformation_matrix(estimate_pairwise_camera_transform(all_calib_poses[c1], all_calib_poses[c2])) @ ext[c1]
+    return np.array([get_transformation_vector(T) for T in ext])
+
+
+def solve_pnp(uv, obj, intr9, pose0):
+    """The minimiser cv2.solvePnP (iterative) looks for: least squares of the pixel reprojection error of one view over its 6 pose coordinates,
+    by scipy from the given start."""
+    res = least_squares(lambda p: (np.asarray(uv, dtype=float) - project5(obj, p, intr9)).ravel(), np.asarray(pose0, dtype=float), xtol=1e-15, ftol=1e-15, gtol=1e-12)
+    return res.x, res.cost

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in include/mcba.h but not exported by libmcba.so"
     bound = {s[0] for s in ops.SYMBOLS}
     assert bound == set(names), (sorted(bound - set(names)), sorted(set(names) - bound))
-    assert ops.load_library().mcba_abi_version() == 6
+    assert ops.load_library().mcba_abi_version() == 7
 
 
 def test_no_gpu_is_a_loud_error_not_a_fallback():
@@ -40,6 +40,14 @@ def test_no_gpu_is_a_loud_error_not_a_fallback():
     p = synth.make_problem(2, 3)
     with pytest.raises(ops.McbaError):
         ops.Problem(p["uvs"], p["obj"])
+    # ... and so must calibrate()'s public pieces (round 6: pose graph and per-view starts are GPU kernels, not numpy)
+    from multicam_calibration_amd import calibration as cal
+
+    poses = np.zeros((2, 5, 6))
+    for call in (lambda: cal.estimate_pairwise_camera_transform(poses[0], poses[1]), lambda: cal.consensus_calib_poses(poses, np.zeros((2, 6))),
+                 lambda: cal.estimate_pose(p["uvs"][0], p["obj"], np.eye(3), np.zeros(5)), lambda: cal.calibrate(p["uvs"], [(640, 480)] * 2, p["obj"], verbose=False)):
+        with pytest.raises(ops.McbaError):
+            call()
 
 
 def test_product_never_imports_the_oracle():

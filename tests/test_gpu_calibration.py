@@ -188,9 +188,15 @@ def test_get_intrinsics_five_coefficient_model(mc, fix_k3, zero_tangent):
     k_o, ps_o, cost_o = co.refine(sel, obj, np.r_[K0[0, 0], K0[1, 1], K0[0, 2], K0[1, 2], np.zeros(5)], poses0, free9)
     got = np.r_[K[0, 0], K[1, 1], K[0, 2], K[1, 2], dist]
     np.testing.assert_allclose(got[:4], k_o[:4], rtol=1e-6)
-    np.testing.assert_allclose(got[4:], k_o[4:], rtol=1e-4, atol=1e-7)
-    cost_here = sum(0.5 * np.sum((sel[v] - co.project5(obj, ps, got)) ** 2) for v, ps in enumerate(cal._refine_five_coefficients(sel, obj, got, ps_o, np.zeros(9, bool), 0)[1]))
+    np.testing.assert_allclose(got[4:], k_o[4:], rtol=1e-3, atol=1e-7)   # (k2 against k3 is a flat direction of 25 noisy views: scipy's own stopping point moves by 2e-4 with the start)
+    ps_here = cal._refine_five_coefficients(sel, obj, got, ps_o, np.zeros(9, bool), 0)[1]
+    cost_here = sum(0.5 * np.sum((sel[v] - co.project5(obj, ps, got)) ** 2) for v, ps in enumerate(ps_here))
     assert abs(cost_here - cost_o) <= 1e-8 * cost_o
+    # ... and the answer is a stationary point of the oracle's objective: scipy started AT it stays there and gains nothing
+    k_s, _, cost_s = co.refine(sel, obj, got, ps_here, free9)
+    assert cost_s >= cost_here * (1 - 1e-11)
+    np.testing.assert_allclose(k_s[:4], got[:4], rtol=1e-8)
+    np.testing.assert_allclose(k_s[4:], got[4:], rtol=2e-5, atol=1e-9)
 
 
 def test_estimate_pose_with_five_coefficients(mc):
@@ -214,3 +220,184 @@ def test_estimate_pose_with_five_coefficients(mc):
         ref = least_squares(lambda p: (uvs[v] - co.project5(obj, p, TRUE9)).ravel(), poses[v], xtol=1e-15, ftol=1e-15, gtol=1e-12)
         c_here = 0.5 * np.sum((uvs[v] - co.project5(obj, got[v], TRUE9)) ** 2)
         assert abs(c_here - ref.cost) <= 1e-9 * ref.cost, v
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# round 6: calibrate()'s per-view starts and its pose graph on the GPU (csrc/mcba_pnp.hip) against their numpy restatements
+# (oracle/calibration_oracle.py) and against the reference's own pose-graph outputs (tests/golden/calibration_graph.npz)
+def _all_complete_views(uvs):
+    c, f = np.nonzero(~np.isnan(uvs).any((2, 3)))
+    return np.stack([c, f], 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.2, 3.0])
+def test_homographies_on_device_match_the_numpy_dlt(mc, noise):
+    """mcba_calib_homographies = the smallest singular vector of the Hartley-normalised 2N x 9 DLT system (numpy: SVD) to 1e-9, on every complete
+    view; NaN for an incomplete one."""
+    from oracle import calibration_oracle as co
+
+    p = mc.synth.make_problem(3, 150, seed=60, noise=noise, missing=0.2, scalar_nans=3)
+    prob = mc.ops.Problem(p["uvs"], p["obj"], loss="linear")
+    complete = prob.calib_complete()
+    assert np.array_equal(complete, ~np.isnan(p["uvs"]).any((2, 3)))
+    views = _all_complete_views(p["uvs"])
+    H = prob.calib_homographies(views)
+    want = co.homographies(p["obj"][:, :2], p["uvs"][views[:, 0], views[:, 1]])
+    assert (np.abs(H - want) / np.maximum(1.0, np.abs(want))).max() < 1e-9
+    assert np.all(H[:, 2, 2] == 1.0)
+    gone = np.stack(np.nonzero(~complete), 1).astype(np.int32)[:5]
+    assert np.isnan(prob.calib_homographies(gone)).all()
+    prob.close()
+
+
+def test_view_poses_are_the_reprojection_minimisers(mc):
+    """mcba_calib_view_poses / mcba_calib_poses = cv2.solvePnP's minimiser per view: the truth on noise-free detections, scipy's optimum of the same
+    objective with noise (two-coefficient and five-coefficient intrinsics), NaN rows exactly where the detection is incomplete; the homography
+    start itself against the numpy restatement."""
+    from multicam_calibration_amd import calibration as cal
+    from oracle import calibration_oracle as co
+
+    p = mc.synth.make_problem(3, 90, seed=61, noise=0.25, missing=0.25)
+    intr9 = np.c_[p["true_cam"][:, :6], np.zeros((3, 3))]
+    prob = mc.ops.Problem(p["uvs"], p["obj"], loss="linear")
+    ok, poses, evals = prob.calib_poses(intr9, want_poses=True, want_evals=True)
+    complete = ~np.isnan(p["uvs"]).any((2, 3))
+    assert np.array_equal(ok, complete) and np.array_equal(np.isnan(poses).any(2), ~complete)
+    assert evals[complete].min() >= 2 and evals[complete].max() < 40 and np.all(evals[~complete] == 0)
+    views = _all_complete_views(p["uvs"])
+    listed = prob.calib_view_poses(views, intr9)
+    np.testing.assert_array_equal(listed, poses[views[:, 0], views[:, 1]])   # the list form and the dense form run the same arithmetic
+    rng = np.random.default_rng(0)
+    for c, f in views[rng.choice(len(views), 25, replace=False)]:
+        uv = p["uvs"][c, f]
+        K = np.array([[intr9[c, 0], 0, intr9[c, 2]], [0, intr9[c, 1], intr9[c, 3]], [0, 0, 1.0]])
+        start = co.poses_from_homographies(co.homographies(p["obj"][:, :2], co.undistort_normalized(uv[None], K, intr9[c, 4:])), np.eye(3))[0]
+        x, cost = co.solve_pnp(uv, p["obj"], intr9[c], start)
+        mine = 0.5 * np.sum((uv - co.project5(p["obj"], poses[c, f], intr9[c])) ** 2)
+        assert abs(mine - cost) <= 1e-9 * cost, (c, f)
+        assert np.abs(co.project5(p["obj"], poses[c, f], intr9[c]) - co.project5(p["obj"], x, intr9[c])).max() < 1e-6
+    # one evaluation only = the start: pose from the homography of the undistorted detections (polar factor, rodrigues_inv) as numpy computes it
+    start_dev = prob.calib_view_poses(views[:40], intr9, max_evaluations=1)
+    for (c, f), got in zip(views[:40], start_dev):
+        K = np.array([[intr9[c, 0], 0, intr9[c, 2]], [0, intr9[c, 1], intr9[c, 3]], [0, 0, 1.0]])
+        want = co.poses_from_homographies(co.homographies(p["obj"][:, :2], co.undistort_normalized(p["uvs"][c, f][None], K, intr9[c, 4:])), np.eye(3))[0]
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-8 * max(1.0, np.abs(want).max()))
+    prob.close()
+
+    # noise-free: the truth (board -> camera c = T_ext T_pose)
+    q = mc.synth.make_problem(3, 60, seed=61, noise=0.0, missing=0.25)
+    prob = mc.ops.Problem(q["uvs"], q["obj"], loss="linear")
+    ok, poses, _ = prob.calib_poses(intr9, want_poses=True)
+    prob.close()
+    for c in range(3):
+        want = cal.get_transformation_vector(cal.get_transformation_matrix(q["true_cam"][c, 6:])[None] @ cal.get_transformation_matrix(q["true_poses"]))
+        er, et = _pose_err(poses[c][ok[c]], want[ok[c]])
+        assert er < 1e-8 and et < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["a", "ties", "full"])
+def test_pose_graph_on_device_matches_the_reference(mc, golden, tag):
+    """estimate_pairwise_camera_transform / estimate_all_extrinsics / consensus_calib_poses (GPU: mcba_pose_pairwise, mcba_pose_consensus) against the
+    reference's own outputs -- medians of components of either sign through the order-preserving radix select."""
+    from multicam_calibration_amd import calibration as cal
+
+    z = golden("calibration_graph.npz")
+    poses = z[f"{tag}_poses"]
+    np.testing.assert_allclose(cal.estimate_pairwise_camera_transform(poses[0], poses[1]), z[f"{tag}_pair01"], rtol=0, atol=1e-11)
+    for root in (0, 2):
+        ext, tree = cal.estimate_all_extrinsics(poses, root=root)
+        np.testing.assert_array_equal(np.array(tree), z[f"{tag}_tree_r{root}"])
+        np.testing.assert_allclose(ext, z[f"{tag}_ext_r{root}"], rtol=0, atol=1e-10)
+        cons = cal.consensus_calib_poses(poses, ext)
+        want = z[f"{tag}_consensus_r{root}"]
+        assert np.array_equal(np.isnan(cons), np.isnan(want))
+        np.testing.assert_allclose(cons[~np.isnan(want)], want[~np.isnan(want)], rtol=0, atol=1e-9)
+
+
+def test_pairwise_medians_even_odd_empty_and_many_cameras(mc):
+    """The exact median for odd and even counts (np.median: the mean of the two middle values), NaN for a pair without a common frame; the
+    consensus median over 1 .. 9 cameras per frame."""
+    from multicam_calibration_amd import calibration as cal
+    from oracle import calibration_oracle as co
+
+    rng = np.random.default_rng(7)
+    C, F = 9, 301
+    poses = np.concatenate([rng.normal(0, 0.5, (C, F, 3)), rng.normal(0, 80, (C, F, 3))], -1)
+    poses[rng.uniform(size=(C, F)) < 0.45] = np.nan
+    poses[7, :150] = np.nan
+    poses[8, 150:] = np.nan     # cameras 7 and 8 never see the board together
+    poses[:, 17] = np.nan       # a frame nobody sees
+    edges = [(0, 1), (1, 2), (2, 0), (3, 5), (7, 8), (4, 6)]
+    got, cnt = mc.ops.pose_pairwise(poses, edges)
+    for (a, b), g, n in zip(edges, got, cnt):
+        common = ~np.isnan(poses[[a, b]]).any((0, 2))
+        assert n == common.sum()
+        if common.any():
+            np.testing.assert_allclose(g, co.estimate_pairwise_camera_transform(poses[a], poses[b]), rtol=0, atol=1e-11)
+        else:
+            assert np.isnan(g).all()
+    ext = np.concatenate([rng.normal(0, 0.4, (C, 3)), rng.normal(0, 300, (C, 3))], -1)
+    ext[0] = 0.0
+    cons = cal.consensus_calib_poses(poses, ext)
+    want = co.consensus_calib_poses(poses, ext)
+    assert np.array_equal(np.isnan(cons), np.isnan(want)) and np.isnan(cons[17]).all()
+    np.testing.assert_allclose(cons[~np.isnan(want)], want[~np.isnan(want)], rtol=0, atol=1e-9)
+
+
+def test_calibrate_equals_its_stages_in_numpy(mc):
+    """calibrate() end to end against the same stages composed from the numpy restatements, given the intrinsics it found: every camera's
+    poses -> spanning tree -> pairwise medians -> chained extrinsics -> consensus poses."""
+    from multicam_calibration_amd import calibration as cal
+    from oracle import calibration_oracle as co
+
+    p = mc.synth.make_problem(5, 260, seed=62, noise=0.2, missing=0.3)
+    np.random.seed(9)
+    ext, intr, poses, tree = mc.calibrate(p["uvs"], [(1280, 1024)] * 5, p["obj"], root=1, verbose=False, n_samples_for_intrinsics=60)
+    # the RNG: one draw per camera over its complete detections, in camera order
+    after = np.random.randint(1 << 30)
+    np.random.seed(9)
+    for c in range(5):
+        n = int((~np.isnan(p["uvs"][c]).any((1, 2))).sum())
+        np.random.choice(n, min(60, n), replace=False)
+    assert after == np.random.randint(1 << 30)
+    per_cam = np.array([mc.estimate_pose(p["uvs"][c], p["obj"], *intr[c]) for c in range(5)])
+    want_tree = cal.get_camera_spanning_tree(per_cam, root=1)
+    assert tree == want_tree and np.all(ext[1] == 0)
+    want_ext = co.estimate_all_extrinsics(per_cam, want_tree, root=1)
+    np.testing.assert_allclose(ext, want_ext, rtol=0, atol=1e-9)
+    want = co.consensus_calib_poses(per_cam, want_ext)
+    assert np.array_equal(np.isnan(poses), np.isnan(want))
+    np.testing.assert_allclose(poses[~np.isnan(want)], want[~np.isnan(want)], rtol=0, atol=1e-8)
+    # every camera's intrinsics: the same as get_intrinsics alone on the same draw (the joint run is block-diagonal over the cameras)
+    np.random.seed(9)
+    for c in range(5):
+        K, dist = mc.get_intrinsics(p["uvs"][c], p["obj"], (1280, 1024), n_samples=60)
+        np.testing.assert_allclose(np.r_[K[0, 0], K[1, 1], K[0, 2], K[1, 2], dist[:2]], np.r_[intr[c][0][0, 0], intr[c][0][1, 1], intr[c][0][0, 2], intr[c][0][1, 2], intr[c][1][:2]], rtol=1e-7)
+
+
+def test_trim_keeps_the_box_and_restores_the_scaling(mc):
+    """after mcba_trim a handle with bounds still projects its steps (the box is part of the problem) and a numeric x_scale / frozen set
+    is put back into the re-allocated solver buffers."""
+    p = mc.synth.make_problem(2, 40, seed=63)
+    x0 = mc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    lo, hi = x0 - 0.05 * (1 + np.abs(x0)), x0 + 0.05 * (1 + np.abs(x0))
+    xs = 1.0 + np.abs(x0)
+
+    def one_step(trim):
+        prob = mc.ops.Problem(p["uvs"], p["obj"])
+        prob.set_params(0, x0)
+        prob.set_bounds(lo, hi)
+        prob.set_x_scale(xs)
+        if trim:
+            prob.trim()
+        prob.linearize(0)
+        r = prob.reduce_fetch(1e-3)
+        dc = np.linalg.solve(r["S0"] + 1e-3 * np.diag(r["diagU"]), r["rhs"]) * 40.0   # far enough to leave the box
+        prob.step(dc, 1e-3, 0, 1)
+        x1 = prob.get_params(1)
+        prob.close()
+        return x1
+
+    a, b = one_step(False), one_step(True)
+    np.testing.assert_array_equal(a, b)
+    assert np.all(a >= lo) and np.all(a <= hi) and (np.isclose(a, lo) | np.isclose(a, hi)).any()
