@@ -200,6 +200,123 @@ def end_to_end(m, p, reps=5, full=True):
     return out
 
 
+def calibrate_timing(m, p, reps=5):
+    """calibrate() -- the call that produces bundle_adjust()'s inputs (reference calibration.py:280-373; its tutorial: 60 s of intrinsics + 2.7 s of
+    PnP for 6 cameras x 2 130 frames) -- warm, median of `reps`, with its stages, and the pipeline a user runs: calibrate() -> bundle_adjust()."""
+    import contextlib
+    import functools
+    import io
+
+    from multicam_calibration_amd import calibration as cal, ops
+
+    acc = {}
+
+    def timed(name, fn):
+        @functools.wraps(fn)
+        def w(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+        return w
+
+    stages = {"upload": [(ops.Problem, "__init__"), (ops.Problem, "calib_complete")],
+              "intrinsics_sampled_views": [(cal, "_sample_all_cameras"), (cal, "_start_on_device"), (cal, "_refine_intrinsics_on_device")],
+              "poses_every_view": [(ops.Problem, "calib_poses")],
+              "pose_graph_and_consensus": [(cal, "_pose_graph_on_device"), (ops.Problem, "calib_consensus")]}
+    extra = [(ops.Problem, "calib_homographies"), (ops.Problem, "calib_view_poses"), (cal, "intrinsics_from_homographies"), (ops.Problem, "lm_run"), (ops.Problem, "calib_pairwise")]
+    saved = []
+    for owner, n in [x for v in stages.values() for x in v] + extra:
+        saved.append((owner, n, getattr(owner, n)))
+        setattr(owner, n, timed(n, getattr(owner, n)))
+    Cc, F, Nn = p["uvs"].shape[:3]
+    sizes = [(1280, 1024)] * Cc
+
+    def run():
+        np.random.seed(0)
+        return cal.calibrate(p["uvs"], sizes, p["obj"], verbose=False)
+
+    try:
+        run()
+        run()
+        acc.clear()
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ext, intr, poses, tree = run()
+            times.append(1e3 * (time.perf_counter() - t0))
+        acc_main = dict(acc)
+    finally:
+        for owner, n, f in saved:
+            setattr(owner, n, f)
+    ok = ~np.isnan(poses).any(1)
+    uv_ok = p["uvs"] if ok.all() else np.ascontiguousarray(p["uvs"][:, ok])   # (frames no camera saw have no start pose)
+    poses_ok = poses[ok]
+    ba = []
+    for _ in range(reps + 1):
+        np.random.seed(0)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = m.bundle_adjust(uv_ok, ext, intr, p["obj"], poses_ok, n_frames=int(ok.sum()), verbose=0, return_jac=False)
+        ba.append(1e3 * (time.perf_counter() - t0))
+    ms = {k: 1e3 * v / reps for k, v in acc_main.items()}
+    total = float(np.median(times))
+    br = {name: sum(ms.get(n, 0.0) for _, n in members) for name, members in stages.items()}
+    br["python_rest"] = total - sum(br.values())
+    br["of_which"] = {"homographies_kernel_crossing": ms.get("calib_homographies", 0.0), "zhang_closed_form_host": ms.get("intrinsics_from_homographies", 0.0),
+                      "view_poses_kernel_crossing": ms.get("calib_view_poses", 0.0), "joint_refinement_lm_run": ms.get("lm_run", 0.0), "pairwise_medians_crossing": ms.get("calib_pairwise", 0.0)}
+    ba_ms = float(np.median(ba[1:]))
+    return {"calibrate_ms": total, "calibrate_ms_min": float(min(times)), "reps": reps, "breakdown_ms": br, "bundle_adjust_from_calibrate_ms": ba_ms, "pipeline_ms": total + ba_ms,
+            "bundle_adjust_from_calibrate": {"nfev": int(out[4].nfev), "status": int(out[4].status), "cost": float(out[4].cost), "frames": int(ok.sum())},
+            "what": f"calibrate(host array ({Cc},{F},{Nn},2), image sizes, board) -> (extrinsics, intrinsics, consensus poses, spanning tree), n_samples_for_intrinsics=100, warm, median of {reps}; "
+                    "then bundle_adjust() on its outputs (n_frames = all, return_jac=False, default tolerances); pipeline_ms = the sum",
+            "reference": "docs/source/calibration_tutorial.ipynb:89,103: 60 s (intrinsics, 6 cameras) + 2.7 s (PnP) with OpenCV at 6 x 2 130 x 35; round 5 of this repository (host numpy starts): 478 ms / 9 888 ms at 6 x 2 130 x 35 / 6 x 10 000 x 54 on the same GPU box (profiles/round6/calibrate_baseline_r5.json)"}
+
+
+def off_default_calls(m, p, reps=3):
+    """The two off-default solver paths of the user-level call, timed: `bounds=` (k2 >= 0 on two cameras + a box on 20 poses; the reference's
+    bounded solver is scipy's trf_bounds, bundle_adjustment.py:301-313) and a callable `loss=` (soft_l1 written as a function)."""
+    import contextlib
+    import io
+
+    Cc, F, Nn = p["uvs"].shape[:3]
+    x0 = m.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"])
+    lo, hi = np.full(x0.size, -np.inf), np.full(x0.size, np.inf)
+    for c in (1, 3 % Cc):
+        lo[12 * c + 5] = 0.0   # k2 >= 0
+    rng = np.random.default_rng(11)
+    for f in rng.choice(F, min(20, F), replace=False):
+        sl = slice(12 * Cc + 6 * f, 12 * Cc + 6 * f + 6)
+        lo[sl], hi[sl] = x0[sl] - np.r_[0.002, 0.002, 0.002, 1.0, 1.0, 1.0], x0[sl] + np.r_[0.002, 0.002, 0.002, 1.0, 1.0, 1.0]
+    x_in = np.clip(x0, lo, hi)
+
+    def soft_l1(z):
+        t = 1.0 + z
+        r = np.empty((3,) + z.shape)
+        r[0], r[1], r[2] = 2.0 * (np.sqrt(t) - 1.0), t ** -0.5, -0.5 * t ** -1.5
+        return r
+
+    def call(**kw):
+        ts, res = [], None
+        for _ in range(reps + 1):
+            np.random.seed(0)
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = m.bundle_adjust(p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=2 * F, verbose=0, return_jac=False, **kw)[4]
+            ts.append(1e3 * (time.perf_counter() - t0))
+        return float(np.median(ts[1:])), res
+
+    t_plain, r_plain = call()
+    t_b, r_b = call(bounds=(lo, hi))
+    t_c, r_c = call(loss=soft_l1)
+    return {"unbounded_call_ms": t_plain, "unbounded_nfev": int(r_plain.nfev),
+            "bounds_call_ms": t_b, "bounds_nfev": int(r_b.nfev), "bounds_active": int(np.count_nonzero(r_b.active_mask)), "bounds_ms_per_evaluation": t_b / max(int(r_b.nfev), 1),
+            "callable_loss_call_ms": t_c, "callable_loss_nfev": int(r_c.nfev), "callable_loss_ms_per_evaluation": t_c / max(int(r_c.nfev), 1),
+            "what": f"bundle_adjust at ({Cc},{F},{Nn},2), n_frames above the recording, return_jac=False, default tolerances, warm, median of {reps}: plain; bounds = k2 >= 0 on two cameras + a box "
+                    "(+-0.002 rad, +-1 mm) around the start pose of 20 frames; loss = soft_l1 as a Python callable (scipy's rho(z) -> (rho, rho', rho'') contract)"}
+
+
 def cpu_baseline(sample_frames=1000, max_nfev=12):
     """the oracle's CPU path (vectorised numpy residual + the reference's own scipy.least_squares call:
     trf, soft_l1, x_scale='jac', ftol=1e-4, 2-point finite differences through jac_sparsity) on a bounded sample of the
@@ -339,6 +456,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--windows", type=int, default=5, help="timed regions of --steps steps each; `value` = the median window (all are printed)")
     ap.add_argument("--frames", type=int, default=F_PER_GPU, help="frames per GPU, weak scaling (default = BASELINE config 3 per GPU)")
     ap.add_argument("--frames-total", type=int, default=0, help="strong scaling: this many frames of ONE rig sharded over the ranks (100000 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -426,20 +544,32 @@ def main():
     DOMINANT = "k_gram"
     prob.profile_enable(True, only=[DOMINANT], stride=8)  # every 8th launch: the event records must not pace the stream
     prob.profile_read()
-    barrier()
-    nfev0 = lm.nfev
-    t0 = time.perf_counter()
-    ticks = 0
-    while lm.nfev - nfev0 < args.steps:
-        # a step = an LM iteration that evaluated (and linearised) a trial point.  Frame-sharded runs with one collective
-        # per iteration occasionally need an extra rebuild-only pass (mispredicted damping): it is timed, not counted.
-        status = lm.iterate(always_linearize=True)
-        ticks += 1
-        assert status is None, f"the LM loop stopped inside the timed region (status {status})"
-        assert ticks <= 2 * args.steps, "too many rebuild-only passes"
-    barrier()
-    dt = time.perf_counter() - t0
-    assert lm.nfev - nfev0 == args.steps, f"{lm.nfev - nfev0} trial evaluations in {args.steps} timed steps"
+    # `--windows` timed regions of EXACTLY `--steps` steps each, every one bracketed by barrier + synchronize on both sides and reduced by MAX
+    # over the ranks; `value` comes from the MEDIAN window, all of them are printed (a single 2 ms window at the driver's --steps 20 is one
+    # sample of a box's clock state, not a measurement)
+    window_dts, ticks = [], 0
+    for _w in range(max(1, args.windows)):
+        barrier()
+        nfev0 = lm.nfev
+        t0 = time.perf_counter()
+        wticks = 0
+        while lm.nfev - nfev0 < args.steps:
+            # a step = an LM iteration that evaluated (and linearised) a trial point.  Frame-sharded runs with one collective
+            # per iteration occasionally need an extra rebuild-only pass (mispredicted damping): it is timed, not counted.
+            status = lm.iterate(always_linearize=True)
+            wticks += 1
+            assert status is None, f"the LM loop stopped inside the timed region (status {status})"
+            assert wticks <= 2 * args.steps, "too many rebuild-only passes"
+        barrier()
+        dtw = time.perf_counter() - t0
+        assert lm.nfev - nfev0 == args.steps, f"{lm.nfev - nfev0} trial evaluations in {args.steps} timed steps"
+        if dist is not None:
+            tmax = torch.tensor([dtw], dtype=torch.float64, device="cpu" if backend == "gloo" else f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dtw = float(tmax.item())
+        window_dts.append(dtw)
+        ticks += wticks
+    dt = float(np.median(window_dts))
     prof_timed = prob.profile_read()
     prob.profile_enable(True)
     for _ in range(min(args.steps, 50)):
@@ -460,13 +590,14 @@ def main():
     prof_exact = prob.profile_read()[DOMINANT]
     prob.profile_enable(False)
     bracket_us = prob.profile_bracket_overhead(200)
-    # what the formally complete reader of the solve's release word costs (MCBA_STRICT_SYNC=1 / mcba_set_strict_sync: an agent-scope acquire
-    # fence in every waiting workgroup of k_solve_backsub instead of relying on gfx950's ordering): alternating blocks of 200 iterations
+    # what the relaxed reader of the solve's release word would save (MCBA_STRICT_SYNC=0 / mcba_set_strict_sync(h, 0): relaxed agent-scope loads
+    # relying on gfx950's in-order issue instead of the acquire fence that is the default since round 6): alternating blocks of 200 iterations
     strict = None
     if hasattr(prob, "set_strict_sync") and dist is None:
+        default_mode = bool(prob.lib.mcba_get_strict_sync(prob.handle))
         per = {False: [], True: []}
         for rep in range(3):
-            for mode in (False, True):
+            for mode in (True, False):
                 prob.set_strict_sync(mode)
                 for _ in range(10):
                     lm.iterate(always_linearize=True)
@@ -478,18 +609,13 @@ def main():
                 lm.finalize()
                 prob.synchronize()
                 per[mode].append(1e6 * (time.perf_counter() - t0s) / max(lm.nfev - n0, 1))
-        prob.set_strict_sync(False)
-        strict = {"default_us_per_iteration": min(per[False]), "strict_us_per_iteration": min(per[True]), "delta_us": min(per[True]) - min(per[False]),
-                  "what": "LM iteration with the back-substitution workgroups ACQUIRING the solve's release word (agent-scope fence; the HIP memory model's form) against the default (relaxed agent-scope loads + in-order issue); best of 3 alternating blocks of 200 iterations each"}
+        prob.set_strict_sync(default_mode)
+        strict = {"default": "acquire" if default_mode else "relaxed", "acquire_us_per_iteration": min(per[True]), "relaxed_us_per_iteration": min(per[False]), "delta_us": min(per[True]) - min(per[False]),
+                  "what": "LM iteration with the back-substitution workgroups ACQUIRING the solve's release word (agent-scope fence: the HIP memory model's form, the default -- `value` is measured with it) against the relaxed form (agent-scope relaxed loads + in-order issue; MCBA_STRICT_SYNC=0); best of 3 alternating blocks of 200 iterations each"}
     if prof_exact[1]:
         prof[DOMINANT] = prof_exact
     else:   # (a launch variant without dispatch events: the bracketed figure)
         prof[DOMINANT] = prof_dom
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
     # ---- second figure of the metric: one materialised Jacobian evaluation (not part of the timed steps)
     prob.profile_enable(True)
     for _ in range(3):
@@ -575,6 +701,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
+            "windows": len(window_dts),
+            "value_windows": [(args.steps * units / w) if scaling == "weak" else (args.steps / w) for w in window_dts],
+            "ms_per_step_windows": [1e3 * w / args.steps for w in window_dts],
+            "value_is": "the median of the windows",
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -610,9 +740,22 @@ def main():
             out["end_to_end"] = e2e
             # ... and where users are: the one recording the reference documents (docs/source/calibration_tutorial.ipynb: 6 cameras x 2 130
             # frames x 35 points) and BASELINE configs[0]
+            p_tut, p_c0 = m.synth.make_problem(6, 2130, rows=5, cols=7, seed=0), m.synth.make_problem(2, 50, rows=ROWS, cols=COLS, seed=0)
             out["end_to_end_other_shapes"] = {
-                "reference tutorial 6 x 2130 x 35": end_to_end(m, m.synth.make_problem(6, 2130, rows=5, cols=7, seed=0), reps=7, full=False),
-                "configs[0] 2 x 50 x 54": end_to_end(m, m.synth.make_problem(2, 50, rows=ROWS, cols=COLS, seed=0), reps=7, full=False)}
+                "reference tutorial 6 x 2130 x 35": end_to_end(m, p_tut, reps=7, full=False),
+                "configs[0] 2 x 50 x 54": end_to_end(m, p_c0, reps=7, full=False)}
+            # the call that produces bundle_adjust()'s inputs, and the pipeline calibrate() -> bundle_adjust()
+            cal_main = calibrate_timing(m, p)
+            e2e["calibrate_ms"], e2e["pipeline_ms"], e2e["calibrate"] = cal_main["calibrate_ms"], cal_main["pipeline_ms"], cal_main
+            for key, pp in (("reference tutorial 6 x 2130 x 35", p_tut), ("configs[0] 2 x 50 x 54", p_c0)):
+                ct = calibrate_timing(m, pp, reps=7)
+                o = out["end_to_end_other_shapes"][key]
+                o["calibrate_ms"], o["pipeline_ms"], o["calibrate"] = ct["calibrate_ms"], ct["pipeline_ms"], ct
+            p_miss = m.synth.make_problem(C, F_PER_GPU, rows=ROWS, cols=COLS, seed=0, missing=0.3)
+            e2e["calibrate_30pct_missing_detections"] = calibrate_timing(m, p_miss, reps=3)
+            del p_miss
+            # the off-default solver paths of the same call: bounds=, callable loss=
+            e2e["off_default_paths"] = off_default_calls(m, p)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline"]["reference_measured_in_survey_container"] = {"value": 0.0098, "unit": "it/s", "ms_per_jacobian_eval": 68679, "source": "BASELINE.md section 2 (the reference itself, 6x10kx54)"}

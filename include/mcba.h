@@ -300,10 +300,11 @@ int mcba_lm_result(mcba_handle* h, int slot, double* x_out, double* grad_out, mc
  * k_backsub) for good.  *timeouts = number of the last tick in which that happened (0: never), *fused = the fused launch is still
  * in use.  MCBA_FUSE_MAX_POLLS=0 forces the event (tests). */
 int mcba_lm_fuse_status(mcba_handle* h, double* timeouts, int* fused);
-/* The waiting side of that protocol.  Default (0): the readers poll and read with agent-scope relaxed atomic loads and rely on gfx950's
- * in-order issue -- measured faster, stress-tested bit-identical, but a data race under the HIP memory model.  on != 0: the readers
- * ACQUIRE the release word with an agent-scope fence (the formally complete form), chosen at run time per handle; a new handle takes
- * MCBA_STRICT_SYNC from the environment (mcba_create_subset inherits its source's setting).  Results are identical to the bit. */
+/* The waiting side of that protocol.  Default since round 6 (on != 0): the readers ACQUIRE the release word with an agent-scope fence -- the
+ * form the HIP memory model asks for.  on == 0: the readers poll and read with agent-scope relaxed atomic loads and rely on gfx950's in-order
+ * issue -- measured ~1.3 us per iteration faster (1.3 % at 6 x 10 000 x 54), stress-tested bit-identical, but a data race under the HIP
+ * memory model.  Chosen at run time per handle; a new handle takes MCBA_STRICT_SYNC from the environment (unset = 1; mcba_create_subset /
+ * mcba_create_views inherit their source's setting).  Results are identical to the bit. */
 int mcba_set_strict_sync(mcba_handle* h, int on);
 int mcba_get_strict_sync(const mcba_handle* h);
 /* The camera step (12C doubles) the last mcba_lm_auto_solve left on the device; synchronises. */

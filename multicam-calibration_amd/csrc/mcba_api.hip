@@ -87,7 +87,7 @@ struct mcba_handle {
   bool have_bounds = false;
   double* loss_tab = nullptr;   // loss == LOSS_TABLE (mcba_set_loss_table): [3][C][N][Fpad] (u, v) pairs, laid out as obs_t
   int fuse_max_polls = 200000;
-  bool strict_sync = false;   // the fused back-substitution's readers acquire the release word with an agent-scope fence (MCBA_STRICT_SYNC=1 / mcba_set_strict_sync)
+  bool strict_sync = true;    // the fused back-substitution's readers ACQUIRE the release word with an agent-scope fence: the HIP memory model's form, the default since round 6 (MCBA_STRICT_SYNC=0 / mcba_set_strict_sync(h, 0): relaxed loads + gfx950's in-order issue, ~1.3 us per iteration faster)
   unsigned char* fixed = nullptr;
   bool have_fixed = false, auto_ready = false;
   bool speculate = true;       // frame-sharded ticks: one collective (speculative Schur reduction) instead of two
@@ -527,7 +527,7 @@ static int ensure_solver(mcba_handle* h) {
                       {&h->dcbuf, (size_t)h->n + 8},  // + the word k_solve_backsub's solve releases, + the poll-timeout stamp
                       {&h->swork, n_swork}, {&h->dscale, h->nx}, {reinterpret_cast<double**>(&h->fixed), ((size_t)h->n + 7) / 8}};
     Piece plain[] = {{&h->rec2[0], (size_t)h->Fpad * C * MCBA_REC}, {&h->rec2[1], (size_t)h->Fpad * C * MCBA_REC},
-                     {&h->spart, (size_t)h->G * h->NP * 256 + 64 + 12 * (size_t)h->G},  // + per-workgroup stamps of MCBA_SYRK_TIMING builds
+                     {&h->spart, (size_t)h->G * h->NP * 256 + 64},
                      {&h->gchunk, h->gram_split == 3 ? mcba::gram_chunk_doubles(C, h->nfb, h->gram_nchunk, h->slots) : 0}};
     auto padded = [](size_t count) { return (std::max<size_t>(count, 1) * sizeof(double) + 255) / 256 * 256; };
     size_t zero_bytes = 0, total = 0;
@@ -1304,31 +1304,6 @@ int mcba_lm_auto_tick(mcba_handle* h, unsigned long long seq, int rank_slot) {
   if ((rc = mcba_lm_auto_reduce(h, 1, rank_slot))) return rc;
   if ((rc = mcba_comm_allreduce(h, 0, h->nsys))) return rc;
   return mcba_lm_auto_solve(h, seq, 0);
-}
-
-int mcba_debug_syrk_stamps(mcba_handle* h, double* host) {  // development only (MCBA_SYRK_TIMING builds): host[0] = G, then [G][12] from host[12]
-  if (!h || !host) return fail(MCBA_ERR_ARG, "bad argument");
-  HIPCHK(hipDeviceSynchronize());
-  host[0] = (double)h->G;
-  HIPCHK(hipMemcpy(host + 12, h->spart + (size_t)h->G * h->NP * 256 + 64, 12 * (size_t)h->G * sizeof(double), hipMemcpyDeviceToHost));
-  return MCBA_OK;
-}
-
-int mcba_debug_fuse_stamps(mcba_handle* h, double* host8) {  // development only (MCBA_FUSE_TIMING builds): the 8 doubles behind the camera step
-  if (!h || !host8) return fail(MCBA_ERR_ARG, "bad argument");
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(host8, h->dcbuf + h->n, 8 * sizeof(double), hipMemcpyDeviceToHost));
-  return MCBA_OK;
-}
-
-int mcba_debug_gram_stamps(mcba_handle* h, double* host) {  // development only (MCBA_GRAM_TIMING builds): [C][nfb][32] (the fused kernel fills 8 per wavefront, the point split 8 per part)
-  if (!h || !host) return fail(MCBA_ERR_ARG, "bad argument");
-  HIPCHK(hipDeviceSynchronize());
-  for (int c = 0; c < h->C; ++c)
-    for (int fb = 0; fb < h->nfb; ++fb)
-      HIPCHK(hipMemcpy2D(host + ((size_t)c * h->nfb + fb) * 32, sizeof(double), h->rec2[h->lin] + ((size_t)c * h->nfb + fb) * (MCBA_REC * 64) + (size_t)(49 * 64) * 2 + 1, 2 * sizeof(double),
-                         sizeof(double), 32, hipMemcpyDeviceToHost));
-  return MCBA_OK;
 }
 
 int mcba_get_cam_step(mcba_handle* h, double* host) {

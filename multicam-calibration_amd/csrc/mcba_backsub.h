@@ -46,7 +46,7 @@ struct BacksubWait {
   double* timeout_dev;
   double* timeout_host;
   double dec_floor;     // spec != 0: floor of Nielsen's factor the prediction assumes
-  int strict;           // != 0: the reader acquires the release word with an agent-scope fence (release_word_acquired; MCBA_STRICT_SYNC=1 / mcba_set_strict_sync)
+  int strict;           // != 0 (the default): the reader acquires the release word with an agent-scope fence (release_word_acquired; MCBA_STRICT_SYNC=0 / mcba_set_strict_sync(h, 0) for the relaxed form)
 };
 
 __device__ __forceinline__ void backsub_stamp_timeout(const BacksubWait* w) {
@@ -59,18 +59,19 @@ __device__ __forceinline__ double load_coherent(const double* p) { return __hip_
 // ---- the READER SIDE of the release word, in one place.
 // The solve releases the word with an agent-scope release store after a fence (mcba_solve.hip: post_state).  A reader polls it with
 // release_word_poll and then calls release_word_acquired() ONCE before it touches anything the word guards.  What that does:
-//   default            a COMPILER barrier only.  Everything read behind the word -- the camera step, DONE / SKIP of the LM state -- is
-//                      fetched with load_coherent (agent-scope relaxed atomic loads: they bypass the per-XCD L2, which is not coherent
-//                      across XCDs, so no stale line can be served and no invalidation is needed), the hardware issues a wavefront's
-//                      loads in order, and only ONE wavefront per workgroup reads (the others get the values through LDS behind a
-//                      barrier).  Under the HIP memory model this is still a data race (relaxed loads do not synchronise with the
-//                      release): it relies on gfx950 behaviour, and tests/test_gpu_parity_large.py::test_fused_backsub_full_size_bit_identical
-//                      stresses it at more than one waiting workgroup per CU (157 / 469 workgroups x 150 ticks, bit-identical iterates).
-//   strict             the formally complete form, selected AT RUN TIME per handle (MCBA_STRICT_SYNC=1 in the environment when the handle is
-//                      created, or mcba_set_strict_sync): an agent-scope acquire fence (= an L2 invalidation) in the polling wavefront --
-//                      157 of them per launch at 6 x 10 000: k_solve_backsub 28.3 -> 31.0 us, +2.5 us per iteration (three alternations
-//                      on one box, round 3; this round's figure: profiles/round5).  Not the default; both forms run the same tests
-//                      (tests/test_gpu_parity_large.py, tests/test_gpu_round5.py: bit-identical iterates).
+//   strict (DEFAULT    an agent-scope ACQUIRE fence (= an L2 invalidation) in the polling wavefront: the form the HIP memory model asks for --
+//   since round 6)     the relaxed poll + this fence synchronise with the solve's release store, everything read afterwards is ordered behind
+//                      it.  157 fences per launch at 6 x 10 000: +1.3 us per iteration (profiles/round5/bench_r5h.json: 102.5 -> 103.8 us;
+//                      round 3 measured +2.5).  Round 6 made it what ships: 1.3 % of an iteration buys a product that is race-free by the
+//                      model it is written in, and a driver test run that exercises what users run.
+//   relaxed            selected AT RUN TIME per handle (MCBA_STRICT_SYNC=0 in the environment when the handle is created, or
+//                      mcba_set_strict_sync(h, 0)): a COMPILER barrier only.  Everything read behind the word -- the camera step, DONE / SKIP
+//                      of the LM state -- is fetched with load_coherent (agent-scope relaxed atomic loads: they bypass the per-XCD L2, which
+//                      is not coherent across XCDs, so no stale line can be served and no invalidation is needed), the hardware issues a
+//                      wavefront's loads in order, and only ONE wavefront per workgroup reads (the others get the values through LDS behind
+//                      a barrier).  Under the HIP memory model this is a data race (relaxed loads do not synchronise with the release): it
+//                      relies on gfx950 behaviour; tests/test_gpu_parity_large.py::test_fused_backsub_full_size_bit_identical stresses both
+//                      forms at more than one waiting workgroup per CU (157 / 469 workgroups x 150 ticks, bit-identical iterates).
 __device__ __forceinline__ void release_word_acquired(int strict) {
   if (strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   else asm volatile("" ::: "memory");
@@ -98,14 +99,7 @@ __device__ __forceinline__ void backsub_body(Sel sl, const double* __restrict__ 
   if (wave >= nw) return;  // (k_solve_backsub launches more wavefronts than a small rig has cameras)
   const int f = block * 64 + lane;
   const bool fin = wave == 0 && f < F;
-#ifdef MCBA_FUSE_TIMING
-  const bool stamp = wait && block == 1 && threadIdx.x == 0;
-  double* dbg = wait ? const_cast<double*>(wait->flag) : nullptr;
-  if (stamp) dbg[2] = (double)wall_clock64();  // ([0] is the release word)
-#define FSTAMP(k) do { if (stamp) dbg[(k) + 1] = (double)wall_clock64(); } while (0)
-#else
 #define FSTAMP(k) do { } while (0)
-#endif
   double2 v[NR];
   double xv[6], Lp[21], gf[6], D[6];
   unsigned frozen = 0;

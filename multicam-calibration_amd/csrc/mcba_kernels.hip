@@ -31,9 +31,6 @@
 #ifndef MCBA_GRAM_PIPE
 #define MCBA_GRAM_PIPE 1
 #endif
-#ifndef MCBA_GRAM_GLDS
-#define MCBA_GRAM_GLDS 0   // experiment: depth of an LDS-resident observation ring filled by LDS-DMA (0 = off)
-#endif
 
 namespace mcba {
 
@@ -187,10 +184,6 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
   // pz0: this lane's frame pose, pre: its first four observations -- loaded by the kernel before the camera constants were
   // staged (those loads, the LM state and the camera rows are all in flight together: one memory round trip at the start)
   const int f = fb * 64 + lane;
-#ifdef MCBA_GRAM_TIMING
-  const long long gt0 = clock64();
-  const long long gw0 = wall_clock64();
-#endif
   Intr K;
   K.fx = uni(s_cam.fx); K.fy = uni(s_cam.fy); K.cx = uni(s_cam.cx); K.cy = uni(s_cam.cy); K.k1 = uni(s_cam.k1); K.k2 = uni(s_cam.k2);
   double Rc[9], tc[3];
@@ -258,91 +251,12 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       }
     }
   };
-#ifdef MCBA_GRAM_TIMING
-  const long long gt1 = clock64();
-#endif
-#if MCBA_GRAM_GLDS
-  if constexpr (MODE == 0 && ROLE == 2) {
-    // EXPERIMENT (round 4): the observation ring lives in LDS, filled by LDS-DMA (global_load_lds_dwordx4: no VGPR destination), GD
-    // points deep; registers hold the current and the next point only
-    constexpr int GD = MCBA_GRAM_GLDS;
-    typedef __attribute__((address_space(3))) double2 lds_d2;
-    typedef __attribute__((address_space(1))) const void gvoid;
-    lds_d2* rl = (lds_d2*)chunk;   // [GD][64] double2 of this wavefront
-    auto issue = [&](int pt, int slot) {
-      const double2* src = op + (size_t)min(pt, N - 1) * Fpad;
-      __builtin_amdgcn_global_load_lds((gvoid*)src, (__attribute__((address_space(3))) void*)(rl + slot * 64), 16, 0, 0);
-    };
-#pragma unroll
-    for (int j = 0; j < GD; ++j) issue(j, j);
-    double xc[3] = {obj[0], obj[1], obj[2]};
-    const int p1 = min(1, N - 1);
-    double xn[3] = {obj[3 * p1], obj[3 * p1 + 1], obj[3 * p1 + 2]};
-    // LDS reads of the ring as opaque instructions: a ds_read the compiler can see is preceded by an s_waitcnt vmcnt(0) (it may alias
-    // an LDS-DMA in flight), which would drain the ring at every point.  The waits are placed by hand: vmcnt(GD - 2) before a slot is
-    // read (the DMAs retire in order), lgkmcnt(0) one iteration later, just before the value is used.
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    auto lds_read = [&](int slot) {
-      v2d r;
-      const unsigned addr = (unsigned)(unsigned long)(rl + slot * 64 + lane);
-      asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-      return r;
-    };
-    auto landed = [&](v2d& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)::"memory"); };
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD - 2) : "memory");
-    v2d o_cur = lds_read(0), o_nxt = lds_read(1);
-    landed(o_cur);
-    ObsLead qc;
-    obs_lead<true, FAST>(pc, xc, qc, is_num(o_cur[0]) || is_num(o_cur[1]));
-    auto accumulate = [&](v2d o2, const double Xo[3], const ObsLead& ql) {
-      ObsCommon q;
-      obs_finish(K, ql, q);
-      const bool vu = is_num(o2[0]), vv = is_num(o2[1]);
-      any = any || vu || vv;
-      double wu2, wv2, gu, gv;
-      obs_weights<LOSS, FAST>(o2[0] - q.up, vu, fs2, ifs2, cfl, cost, wu2, gu);
-      obs_weights<LOSS, FAST>(o2[1] - q.vp, vv, fs2, ifs2, cfl, cost, wv2, gv);
-      {
-        double E[6];
-        obs_row_cam<0>(q, E);
-        gram_add_row<0>(ga, E, wu2, gu);
-        double l4 = q.fa * q.s;
-        gram_add_row<0>(gb, E, wu2, gu, q.a * q.d, l4, l4 * q.s);
-      }
-      {
-        double E[6];
-        obs_row_cam<1>(q, E);
-        gram_add_row<1>(ga, E, wv2, gv);
-        double l4 = q.fb * q.s;
-        gram_add_row<1>(gb, E, wv2, gv, q.b * q.d, l4, l4 * q.s);
-      }
-    };
-    for (int p = 0; p < N; ++p) {
-      landed(o_nxt);                                                 // (read from LDS an iteration ago)
-      issue(p + GD, p & (GD - 1));                                   // the slot of point p (now in o_cur) takes point p + GD
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD - 2) : "memory");  // point p + 2 has landed
-      v2d o_nn = lds_read((p + 2) & (GD - 1));
-      const int p2 = min(p + 2, N - 1);
-      const double xnn[3] = {obj[3 * p2], obj[3 * p2 + 1], obj[3 * p2 + 2]};
-      ObsLead qn;
-      obs_lead<true, FAST>(pc, xn, qn, is_num(o_nxt[0]) || is_num(o_nxt[1]));
-      accumulate(o_cur, xc, qc);
-      qc = qn; o_cur = o_nxt; o_nxt = o_nn;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { xc[i] = xn[i]; xn[i] = xnn[i]; }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else
-#endif
   if constexpr ((ROLE == 2 || MODE == 3) && MCBA_GRAM_PIPE) {
     // Software-pipelined, branch-free point loop (fused variant, one wavefront per SIMD): the projection of point p + 1 --
     // a serial chain (rotate, reciprocal, distortion polynomial) -- is issued next to the 180 independent accumulator
     // updates of point p, which is what fills the FP64 pipe when no second wavefront is there to do it.  Lanes without
     // an observation project a harmless point and add exact zeros.
-#ifndef MCBA_GRAM_RD
-#define MCBA_GRAM_RD 4
-#endif
-    constexpr int RD = MCBA_GRAM_RD;  // observation ring: points p .. p + RD - 1 resident
+    constexpr int RD = 4;  // observation ring: points p .. p + RD - 1 resident
     double2 r4[RD];
     double x4[RD][3];
 #pragma unroll
@@ -427,9 +341,6 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     if (p + j < N) point(ring[j], xring[j], p + j);
   }
 
-#ifdef MCBA_GRAM_TIMING
-  const long long gt2 = clock64();
-#endif
   if constexpr (MODE == 1) {  // point chunk: the raw sums, [k / 2][lane] double2 rows (1 KiB each), nothing else
     double raw[kGramRaw];
 #pragma unroll
@@ -484,9 +395,6 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
     // ---- the wavefronts of the group meet in LDS (see the head of this function): xs = [group][A: NPW - 1 sources][29][64] then
     // [group][B: NPW - 1 sources][59][64] doubles; every access is 64 consecutive doubles (conflict-free ds_*_b64)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), part = wv % NPW, grp = wv / NPW;
-#ifdef MCBA_GRAM_TIMING
-    long long gt2b = 0;
-#endif
     if constexpr (NPW == 4) {
       // FOUR finishing roles, one per wavefront, so that the expansion and the cross-lane reduction of the 92 per-wavefront sums --
       // about a third of this kernel's time on a 54-point board when one or two wavefronts do it -- are spread over the four SIMDs:
@@ -531,9 +439,6 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #pragma unroll
       for (int i = 0; i < 6; ++i) pz[i] = pose[i];
       __syncthreads();
-#ifdef MCBA_GRAM_TIMING
-      gt2b = clock64();
-#endif
       if (!DO_B && (part == 1 || part == 2)) return;  // intrinsics held fixed: role A alone (no timing stamps from these two)
       ChainConst ch;
       {
@@ -671,9 +576,6 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       for (int i = 0; i < 6; ++i) d[(53 + i) * 64] = gb.hi[i];
     }
     __syncthreads();  // (wavefronts past the last frame block have ended: the barrier does not wait for them)
-#ifdef MCBA_GRAM_TIMING
-    gt2b = clock64();
-#endif
     if (part == 0) {  // parts 0, 1, 2, ... in order
 #pragma unroll
       for (int j = 1; j < NPW; ++j) {
@@ -729,22 +631,6 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
       }
     }
     }
-#ifdef MCBA_GRAM_TIMING
-    {  // every wavefront of the group: set-up, point loop, LDS exchange + barrier, finish (shader cycles), begin / end (100 MHz), where it ran
-      double* s_stamp = reinterpret_cast<double*>(chunk) + gram_xch_doubles(NPW, DO_B);  // behind the exchange area
-      const long long gt3 = clock64(), gw3 = wall_clock64();
-      if (lane == 0) {
-        double* d = s_stamp + 8 * wv;
-        d[0] = (double)(gt1 - gt0); d[1] = (double)(gt2 - gt1); d[2] = (double)(gt2b - gt2); d[3] = (double)(gt3 - gt2b); d[4] = (double)gw0; d[5] = (double)gw3;
-        d[6] = s_stamp[32 + wv]; d[7] = (double)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // [6]: the kernel's entry (100 MHz)
-      }
-      __syncthreads();
-      if (part == 0 && lane < 8 * NPW) {
-        double2* r2 = reinterpret_cast<double2*>(rec + ((size_t)c * nfb + fb) * (MCBA_REC * 64)) + lane;
-        r2[49 * 64].y = s_stamp[8 * (wv / NPW) * NPW + lane];  // pad slot of the record
-      }
-    }
-#endif
     return;
   }
 #define GF_ROLE ROLE
@@ -756,17 +642,6 @@ __device__ __forceinline__ void gram_body(const CamConst& s_cam, const double2* 
 #undef GF_A
 #undef GF_B
 #undef GF_PRESUM
-#ifdef MCBA_GRAM_TIMING
-  if (lane < 8) {  // every wavefront: phase lengths in shader cycles, begin / end on the 100 MHz wall clock, where it ran
-    const long long gt3 = clock64();
-    const long long gw3 = wall_clock64();
-    unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
-    unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // XCC_ID
-    const double v = lane == 0 ? (double)(gt1 - gt0) : lane == 1 ? (double)(gt2 - gt1) : lane == 2 ? (double)(gt3 - gt2) : lane == 3 ? (double)gw0 : lane == 4 ? (double)gw3
-                   : lane == 5 ? (double)hwid : lane == 6 ? (double)xcc : 0.0;
-    r2[49 * 64].y = v;  // pad slot of the record
-  }
-#endif
 }
 
 // Common start of the two k_gram kernels.  Which parameter slot / record buffer is the current one lives in the device LM
@@ -872,11 +747,6 @@ __global__ __launch_bounds__(256) void k_gram(const double2* __restrict__ obs_t,
   gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1);
   if (!g.run) return;
   const int nrun = min(4, fb1 - (fb0 + (int)blockIdx.x * 4));  // wavefronts of this workgroup that have a frame block
-#if MCBA_GRAM_GLDS
-  __shared__ __align__(16) double2 s_ring[4][MCBA_GRAM_GLDS][64];
-  gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, nrun, 0, -1, &s_ring[threadIdx.x >> 6][0][0]);
-  return;
-#endif
   gram_body<LOSS, 2, FAST>(s_cam, obs_t, obj, g.x, g.rec, g.gpart, blockIdx.y, g.fb, g.lane, C, N, Fpad, nfb, fs2, ifs2, g.cfl, g.pz, g.pre, s_cost, nrun);
 }
 
@@ -893,9 +763,6 @@ __global__ __launch_bounds__(256) void k_gram_psplit(const double2* __restrict__
   extern __shared__ __align__(16) double s_xch[];
   const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) % NPW;
   const int p_lo = (int)(((long long)N * part) / NPW), p_hi = (int)(((long long)N * (part + 1)) / NPW);
-#ifdef MCBA_GRAM_TIMING
-  if ((threadIdx.x & 63) == 0) s_xch[gram_xch_doubles(NPW, ROLE != 0) + 32 + (threadIdx.x >> 6)] = (double)wall_clock64();
-#endif
   GramStart g;
   gram_start(g, s_cam, obs_t, sl, x0, x1, rec0, rec1, gp0, gp1, C, N, Fpad, fb0, fb1, p_lo, max(p_hi, p_lo + 1), NPW);  // (an empty piece -- fewer points than wavefronts -- still prefetches a valid point)
   if (!g.run) return;
@@ -1103,9 +970,6 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
   __shared__ double s_tw;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: keeps the tile bookkeeping out of the exec mask
-#ifdef MCBA_SYRK_TIMING
-  const long long t_entry = clock64(), w_entry = wall_clock64();
-#endif
   const bool have_state = sl.lms != nullptr;
   if (have_state && t < MCBA_LMS) s_st[t] = sl.lms[t];
   if (DECIDE && t == MCBA_LMS) s_tw = fz.timeout_word ? *fz.timeout_word : -1.0;  // (in flight with the state: not a round trip of its own before the decision)
@@ -1139,9 +1003,6 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
     if (lane == 63) { s_sum[wave] = sa; s_sum[4 + wave] = sb; }
   }
   __syncthreads();
-#ifdef MCBA_SYRK_TIMING
-  const long long t_summed = clock64();
-#endif
   if (have_state && s_st[MCBA_LM_DONE] != 0.0) {  // terminated: nothing left to do (uniform) -- but the rest of the tick reads
     if (DECIDE && bx == 0 && by == 0 && t < MCBA_LMS) fz.lms_post[t] = s_st[t];  // the state from the second buffer
     return;
@@ -1167,9 +1028,6 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
       if (t < 4) fz.trial_out[t] = s_sum[t];
     }
   }
-#ifdef MCBA_SYRK_TIMING
-  const long long t_decided = clock64();
-#endif
   int sidx;
   double lambda;
   if (have_state) {
@@ -1325,13 +1183,7 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
     }
   };
 
-#ifdef MCBA_SYRK_TIMING
-  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tl = clock64();
-  const long long tstart = tl;
-#define SLAP(i) do { long long tn = clock64(); tacc[i] += tn - tl; tl = tn; } while (0)
-#else
 #define SLAP(i) do { } while (0)
-#endif
   prefetch(f0);
   for (int s0 = f0; s0 < f1; s0 += kSyrkSuper) {
     const int s1 = min(f1, s0 + kSyrkSuper);
@@ -1403,9 +1255,6 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
       SLAP(3);
     }
   }
-#ifdef MCBA_SYRK_TIMING
-  const long long t_loop_end = clock64();
-#endif
   if (wave == 0 && by == 0) {
     const double wm = wave_max(gmax), wn = wave_sum63(nfail);
     if (lane == 63) { fpart[2 * bx] = wm; fpart[2 * bx + 1] = wn; }
@@ -1418,16 +1267,6 @@ __global__ __launch_bounds__(256, PPW <= 4 ? 2 : 1) void k_syrk(Sel sl, SyrkFuse
       o[0] = acc[k][0]; o[G * 64] = acc[k][1]; o[2 * G * 64] = acc[k][2]; o[3 * G * 64] = acc[k][3];
     }
   }
-#ifdef MCBA_SYRK_TIMING
-  if (t == 0 && by == 0) {  // per workgroup, shader cycles: entry -> trial scalars summed -> decided -> stages; V sums, factor, Y build, MFMA, barrier, tile store
-    double* dbg = spart + (size_t)gx * NP * 256 + 64 + 12 * (size_t)bx;
-    dbg[0] = (double)(t_summed - t_entry); dbg[1] = (double)(t_decided - t_summed); dbg[2] = (double)(tstart - t_decided);
-    dbg[3] = (double)tacc[4]; dbg[4] = (double)tacc[0]; dbg[5] = (double)tacc[1]; dbg[6] = (double)tacc[2]; dbg[7] = (double)tacc[3];
-    dbg[8] = (double)(clock64() - t_loop_end);
-    dbg[9] = (double)w_entry; dbg[10] = (double)wall_clock64();  // 100 MHz
-    dbg[11] = (double)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // XCC_ID
-  }
-#endif
 }
 
 // ---------------------------------------------------------------- k_reduce_system: fixed-order second stage
@@ -1783,9 +1622,6 @@ void launch_transpose_obs(hipStream_t st, const double* raw, double* obs_t, int 
 int gram_round_blocks(int C, int nfb, int slots) { return std::min(nfb, (((C * nfb) / slots) * slots / C) & ~3); }
 size_t gram_psplit_lds_bytes(int npw, int cw) {
   size_t b = (size_t)gram_xch_doubles(npw == 4 ? 4 : 2, cw != 6) * sizeof(double);
-#ifdef MCBA_GRAM_TIMING
-  b += 40 * sizeof(double);
-#endif
   return b;
 }
 

@@ -226,12 +226,7 @@ MCBA_HD void make_chain_const(const double* Rc, const double* Jrc, const double*
 //      w2 = max(rho' + 2 rho'' f^2, EPS) (scipy's J_scale^2: J~^T J~ = sum w2 j^T j)
 // lm_weight() turns (gw, w2) into the curvature weight the LM normal equations use.
 MCBA_HD double lm_weight(double gw, double w2, double floor) {
-#ifdef MCBA_LM_IRLS_ONLY  // (measurement aid: the Triggs term compiled out of the LM kernels -- what its FP64 instructions cost k_gram; NOTES_round4 section 13)
-  (void)w2; (void)floor;
-  return gw;
-#else
   return fmax(w2, floor * gw);
-#endif
 }
 // UNIT: f_scale == 1 (the reference's default), known at compile time: the two multiplications by 1.0 disappear (and 1 + r^2
 // becomes one fused multiply-add: results agree with the general code to the last bit or two)

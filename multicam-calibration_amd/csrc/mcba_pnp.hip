@@ -289,9 +289,9 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
       H[3 + j] = G[3 + j] * is + my * G[6 + j];
       H[6 + j] = G[6 + j];
     }
-    const double i22 = 1.0 / H[8];
+    const double h22 = H[8];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) H[i] *= i22;
+    for (int i = 0; i < 9; ++i) H[i] /= h22;   // (a division, as numpy's H / H[2, 2]: H22 comes out as exactly 1)
   }
   const double nan = __builtin_nan("");
   if (MODE == MODE_HOMOGRAPHY) {

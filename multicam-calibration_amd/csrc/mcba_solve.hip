@@ -96,20 +96,13 @@ __device__ __forceinline__ void post_state(const SolveArgs& a, const double* st,
     if (a.host_state) *reinterpret_cast<volatile double*>(a.host_state + MCBA_LMS - 1) = a.seq;  // (the end of the kernel releases it)
     // k_solve_backsub: the back-substitution workgroups of the same launch are polling this word; the camera step (a.dc) and
     // the state were written by other threads of this workgroup before the fence and the barrier above
-#ifdef MCBA_FUSE_TIMING
-    if (a.flag) a.flag[7] = (double)wall_clock64();
-#endif
     // ONE word, three values per tick: 4 seq + 1 camera step in memory, 4 seq + 2 state final (after a step), 4 seq + 3 state
     // final and no step this tick -- a poll is one cache-bypassing load, not two
     if (a.flag) __hip_atomic_store(a.flag, 4.0 * a.seq + (stepped ? 2.0 : 3.0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-#ifdef MCBA_SOLVE_TIMING
-#define STAMP(k) do { if (tid == 0) lst[25 + (k)] = (double)(clock64() - t_begin); } while (0)
-#else
 #define STAMP(k) do { } while (0)
-#endif
 
 // look-ahead panel products (LDS-resident factor): one more npad x 17 buffer -- there is room for it up to 8 cameras next to
 // k_solve_backsub's back-substitution scratch (160 KB per workgroup)
@@ -329,14 +322,8 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
     for (int r = 0; r < 4; ++r) dtile[li * 17 + 4 * lg + r] = v[r];
   }
   __syncthreads();
-#ifdef MCBA_SOLVE_TIMING
-  long long t_a = 0, t_b = 0;
-#endif
   for (int k = 0; k < nblk; ++k) {
     const int r0 = 16 * k;
-#ifdef MCBA_SOLVE_TIMING
-    const long long t0 = clock64();
-#endif
     // ---- A: pivots of block k (wavefront 0)  ||  the others: trailing update with panel k - 1 of the columns >= k + 1
     if (wave == 0) {
       double r[16];
@@ -481,10 +468,6 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
         if ((gone >> b) & 1) rl_stage_offdiag(a, b * NW + wave, nsh * NW, lane, wave);
       __syncthreads();
     }
-#ifdef MCBA_SOLVE_TIMING
-    const long long t1 = clock64();
-    if (k == (int)a.seq - 1) t_a = t1 - t0;
-#endif
     // ---- B: my tiles of panel k:  L_(I,k) = Z L_kk^-T,  then the look-ahead at once: my tiles of column k + 1 updated with panel k.
     // The one operand that is not mine -- L_(k+1,k) -- every wavefront forms for itself (four MFMAs on the tile its owner left in
     // LDS a step ago, read with the A operand's lane order): no barrier between the two.
@@ -529,14 +512,8 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
       }
     }
     __syncthreads();
-#ifdef MCBA_SOLVE_TIMING
-    if (k == (int)a.seq - 1) t_b = clock64() - t1;
-#endif
   }
   // (the last panel has no tiles below its diagonal block: nothing is left in Pop to bring to T2)
-#ifdef MCBA_SOLVE_TIMING
-  const long long t_sw = clock64();
-#endif
   // ---- backward sweep  L^T d = y  with the inverse diagonal blocks; thread j owns column j.  The rows of the factor a step needs
   // (block row k, column j) are requested one step ahead: a round trip to the scratch costs more than the step's arithmetic.
   {
@@ -577,9 +554,6 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
       if (k >= 1) step(k - 1, wn, wc);
     }
   }
-#ifdef MCBA_SOLVE_TIMING
-  if (tid == 0) { tstamp[29] = (double)t_a; tstamp[30] = (double)t_b; tstamp[27] = (double)(clock64() - t_sw); }  // of block step k = seq - 1: 29 interval A, 30 interval B; 27 the backward sweep
-#endif
 }
 
 // Staging of the reduce buffer: thread (rr, cc) = (tid / 16, tid % 16) owns the elements (rr + RS a, cc + 16 b) --
@@ -611,9 +585,6 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
   const bool lookahead = LDSW && NW == 4 && solve_lookahead(npad);
   double* Bs = lst + MCBA_LMS;                         // !LDSW: the right-looking variant's LDS (16 (npad + 2) doubles: the panel as MFMA operands; + 16 x 17 + 2 x 256 behind)
   const int bst = npad + 2;
-#ifdef MCBA_SOLVE_TIMING
-  const long long t_begin = clock64();
-#endif
 
   const double* __restrict__ S0 = a.red;               // rhs follows S0: it is "row n" of the same stride-n array
   const double* __restrict__ diagU = a.red + (size_t)n * n + n;
@@ -738,12 +709,7 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
     // entries are what v_readlane broadcasts), lanes 16..63 hold 48 further rows of the panel each.
     const int q = lane < 16 ? lane : 16 + 48 * wave + (lane - 16);  // row inside the panel
     STAMP(1);
-#ifdef MCBA_SOLVE_TIMING
-    long long acc_t[3] = {0, 0, 0}, tl = clock64();
-#define LAP(i) do { long long tn = clock64(); acc_t[i] += tn - tl; tl = tn; } while (0)
-#else
 #define LAP(i) do { } while (0)
-#endif
     // ---- factorisation
     for (int k = 0; k < nblk; ++k) {
       const int r0 = 16 * k, ntile = nblk - k;
@@ -852,9 +818,6 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
       __syncthreads();
       LAP(1);
     }
-#ifdef MCBA_SOLVE_TIMING
-    if (tid == 0) { lst[30] = (double)acc_t[0]; lst[29] = (double)acc_t[1]; }
-#endif
 
     STAMP(2);
     // ---- backward sweep  L^T d = y,  y = row n of the factor

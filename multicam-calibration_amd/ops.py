@@ -568,8 +568,9 @@ class Problem:
         self._chk(rc)
 
     def set_strict_sync(self, on=True):
-        """The fused back-substitution's readers acquire the solve's release word with an agent-scope fence (the form the HIP memory model
-        asks for) instead of relying on gfx950's ordering (include/mcba.h: mcba_set_strict_sync).  Returns the setting in force before."""
+        """on (the default of a new handle): the fused back-substitution's readers acquire the solve's release word with an agent-scope fence,
+        the form the HIP memory model asks for; off: relaxed loads relying on gfx950's ordering (include/mcba.h: mcba_set_strict_sync).
+        Returns the setting in force before."""
         old = bool(self.lib.mcba_get_strict_sync(self.handle))
         self._chk(self.lib.mcba_set_strict_sync(self.handle, int(bool(on))))
         return old

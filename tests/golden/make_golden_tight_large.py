@@ -3,6 +3,8 @@ section 8c-6 / 8c-8).  Build container only:
 
     python tests/golden/make_golden_tight_large.py 6 1000            # -> tight_6x1000.npz, tight_6x1000_fixed.npz
     python tests/golden/make_golden_tight_large.py 6 10000 --free-only --starts 1   # headline size, time-boxed
+    python tests/golden/make_golden_tight_large.py 6 1000 --free-only --missing 0.3 --scalar-nan-frac 0.01 --suffix _missing   # -> tight_6x1000_missing.npz
+                                                          # (round 6: SURVEY 8d's correctness variant -- Bernoulli(0.3) per (camera, frame) + 1 % single scalars -- at a BASELINE size)
 
 Recipe (per start = per perturbation seed of the synthetic initial guess):
   1. free intrinsics: the reference's own `bundle_adjust(...)` is called with an ANALYTIC sparse `jac=` callable and
@@ -95,9 +97,13 @@ def main():
     ap.add_argument("--only-start", type=int, default=None, help="compute this start only and park it in --part-dir (large sizes: one process per start)")
     ap.add_argument("--merge", action="store_true", help="combine the parked starts of --part-dir into the fixture")
     ap.add_argument("--part-dir", default="/tmp/gold")
+    ap.add_argument("--missing", type=float, default=0.0, help="Bernoulli probability that a whole (camera, frame) detection is NaN (SURVEY 8d's correctness variant: 0.3)")
+    ap.add_argument("--scalar-nan-frac", type=float, default=0.0, help="this fraction of the single (u or v) scalars is NaN as well")
+    ap.add_argument("--suffix", default="", help="appended to the fixture's name (tight_CxF<suffix>.npz)")
     args = ap.parse_args()
     C, F = args.C, args.F
-    tag = f"{C}x{F}"
+    tag = f"{C}x{F}{args.suffix}"
+    gen = dict(missing=args.missing, scalar_nans=int(round(args.scalar_nan_frac * 2 * C * F * 54)))
 
     for mode in ("free", "fixed"):
         if (mode == "free" and args.fixed_only) or (mode == "fixed" and args.free_only):
@@ -111,9 +117,9 @@ def main():
             if args.only_start is not None and s != args.only_start:
                 continue
             pseed = s + 1
-            q = synth.make_problem(C, F, seed=0, perturb_seed=pseed)
+            q = synth.make_problem(C, F, seed=0, perturb_seed=pseed, **gen)
             if mode == "fixed" and s > 0:  # same frozen intrinsics as start 0; only the extrinsics / poses start elsewhere
-                q["intrinsics"] = synth.make_problem(C, F, seed=0, perturb_seed=1)["intrinsics"]
+                q["intrinsics"] = synth.make_problem(C, F, seed=0, perturb_seed=1, **gen)["intrinsics"]
             obj = q["obj"]
             t0 = time.perf_counter()
             if mode == "free":
@@ -165,9 +171,10 @@ def main():
             if s == 0:
                 outs["uvs_checksum"] = np.array(np.nansum(q["uvs"]))
                 outs["shape"] = np.array([C, F, obj.shape[0]])
+                outs["generator"] = np.array([args.missing, gen["scalar_nans"]], dtype=np.float64)   # synth.make_problem(C, F, seed=0, perturb_seed=s + 1, missing=, scalar_nans=)
             if args.only_start is not None:
                 os.makedirs(args.part_dir, exist_ok=True)
-                np.savez_compressed(part(s), **{k: v for k, v in outs.items() if k.startswith(f"s{s}_") or k in ("uvs_checksum", "shape")})
+                np.savez_compressed(part(s), **{k: v for k, v in outs.items() if k.startswith(f"s{s}_") or k in ("uvs_checksum", "shape", "generator")})
                 print("parked", part(s), flush=True)
         if args.only_start is not None:
             continue

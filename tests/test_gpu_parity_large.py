@@ -1,6 +1,7 @@
 """GPU parity above toy size (run with `-m gpu` on an MI355X):
   * converged parameters against reference-certified tight optima at 6 cameras x 1000 frames x 54 points, all parameters
-    free and with the intrinsics frozen (BASELINE configs[1]) -- tests/golden/make_golden_tight_large.py;
+    free, with the intrinsics frozen (BASELINE configs[1]) and with 30 % of the detections + 1 % of the single scalars missing
+    (SURVEY 8d's correctness variant) -- tests/golden/make_golden_tight_large.py;
   * every k_gram launch variant (fused / split roles / fused rounds + split tail / fused rounds + point-chunk tail) against the oracle's normal equations
     on a problem big enough for the two-launch variant to split (24 cameras x 2880 frames);
   * size-independent properties at the shard shapes of BASELINE configs[3] (6 x 12 500 x 54) and configs[4]
@@ -27,7 +28,16 @@ def mc():
 
 
 # ------------------------------------------------------------------ 1e-6 parameter parity at 6 x 1000 x 54
-@pytest.mark.parametrize("size,mode", [("6x1000", "free"), ("6x1000", "fixed"), ("6x10000", "free")])
+def _golden_problem(mc, z):
+    """The inputs of a large golden, regenerated from the seed (and, round 6, the missing-data rates stored with it)."""
+    C, F, N = (int(v) for v in z["shape"])
+    gen = dict(missing=float(z["generator"][0]), scalar_nans=int(z["generator"][1])) if "generator" in z.files else {}
+    p = mc.synth.make_problem(C, F, seed=0, perturb_seed=1, **gen)
+    assert abs(float(z["uvs_checksum"]) - np.nansum(p["uvs"])) <= 1e-9 * abs(float(z["uvs_checksum"]))  # same inputs
+    return p
+
+
+@pytest.mark.parametrize("size,mode", [("6x1000", "free"), ("6x1000", "fixed"), ("6x10000", "free"), ("6x1000_missing", "free")])
 def test_solution_matches_tight_reference_optimum_large(mc, golden, size, mode):
     """north_star: parameters within 1e-6 relative of the reference's least_squares path -- at BASELINE configs[1]'s size
     (6 x 1000, all parameters free and intrinsics frozen) and at the headline size configs[2] (6 x 10 000).
@@ -39,8 +49,10 @@ def test_solution_matches_tight_reference_optimum_large(mc, golden, size, mode):
         pytest.skip(f"{name} not generated (the 6 x 10 000 golden is time-boxed: 35 minutes of CPU per start)")
     z = golden(name)
     C, F, N = (int(v) for v in z["shape"])
-    p = mc.synth.make_problem(C, F, seed=0, perturb_seed=1)
-    assert abs(float(z["uvs_checksum"]) - np.nansum(p["uvs"])) <= 1e-9 * abs(float(z["uvs_checksum"]))  # same inputs
+    p = _golden_problem(mc, z)
+    if size.endswith("_missing"):   # SURVEY 8d's correctness variant at a BASELINE size: Bernoulli(0.3) per (camera, frame) + 1 % of the single scalars
+        gone = np.isnan(p["uvs"])
+        assert 0.28 < gone.all((2, 3)).mean() < 0.32 and 0.3 < gone.mean() < 0.32 and (gone.any((2, 3)) & ~gone.all((2, 3))).mean() > 0.3
     # accuracy of the golden itself: the second start's cameras (and, stored as scalars, its extrinsics / poses)
     if "s1_cam" in z.files:
         c0, c1 = z["s0_x"][:12 * C].reshape(C, 12)[:, :6], z["s1_cam"].reshape(C, 12)[:, :6]

@@ -41,7 +41,7 @@ def test_goldens_are_certified(golden, tag):
     compare_to_golden(zz, z["s1_x"], C, 2e-7, blind=(2,) if tag == "edge_blind_camera" else ())
 
 
-@pytest.mark.parametrize("name", ["tight_6x1000.npz", "tight_6x1000_fixed.npz", "tight_6x10000.npz"])
+@pytest.mark.parametrize("name", ["tight_6x1000.npz", "tight_6x1000_fixed.npz", "tight_6x10000.npz", "tight_6x1000_missing.npz"])
 def test_large_goldens_are_certified(golden, name):
     """Tight optima above toy size (tests/golden/make_golden_tight_large.py): the stored point is a stationary point of the
     ORACLE's robust cost too (analytic gradient, free columns), the reference's finite-difference gradient vanishes there,
@@ -50,7 +50,8 @@ def test_large_goldens_are_certified(golden, name):
         pytest.skip(f"{name} not generated (time-boxed golden)")
     z = golden(name)
     C, F, N = (int(v) for v in z["shape"])
-    p = synth.make_problem(C, F, seed=0, perturb_seed=1)
+    gen = dict(missing=float(z["generator"][0]), scalar_nans=int(z["generator"][1])) if "generator" in z.files else {}   # (round 6: the missing-data variant)
+    p = synth.make_problem(C, F, seed=0, perturb_seed=1, **gen)
     assert abs(float(z["uvs_checksum"]) - np.nansum(p["uvs"])) <= 1e-9 * abs(float(z["uvs_checksum"]))
     x, use = z["s0_x"], z["s0_use"]
     uvs = p["uvs"][:, use]
