@@ -271,6 +271,14 @@ void pool_release_all() {
   (void)hipSetDevice(cur);
 }
 
+// MCBA_POISON (tests): buffers that are handed out WITHOUT a zero fill are filled with a byte pattern instead -- 1: 0xFF (every double a NaN,
+// every byte mask "set"); 2: 0x3F (finite garbage: every double 4.8e-4, every 32-bit count 1 061 109 567 -- what recycled pool memory looks
+// like; NaN is the benign value for several of these buffers, e.g. the errors the median skips: ADVICE r5).  0 / unset: no fill.
+int poison_byte() {
+  static const int b = [] { const char* e = getenv("MCBA_POISON"); const int v = e ? atoi(e) : 0; return v == 1 ? 0xFF : (v == 2 ? 0x3F : 0); }();
+  return b;
+}
+
 // zero-filled device buffer from the pool, registered with the handle (mcba_destroy parks it again).  The fill is
 // enqueued on the handle's stream (no host synchronisation); `zero = false` for buffers a kernel overwrites completely
 // before anything reads them (observation layouts, Jacobian blocks).
@@ -280,7 +288,7 @@ int dalloc(mcba_handle* h, T** p, size_t count, bool zero = true) {
   HIPCHK(pool_malloc(reinterpret_cast<void**>(p), bytes, h->device, h->stream));
   h->bufs.push_back({reinterpret_cast<void**>(p), bytes});
   if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
-  else if (getenv("MCBA_POISON") && atoi(getenv("MCBA_POISON")) != 0) HIPCHK(hipMemsetAsync(*p, 0xFF, bytes, h->stream));  // (tests: whatever relies on a fill that is no longer made shows)
+  else if (int pz = poison_byte()) HIPCHK(hipMemsetAsync(*p, pz, bytes, h->stream));  // (tests: whatever relies on a fill that is no longer made shows)
   return MCBA_OK;
 }
 
@@ -504,10 +512,6 @@ int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
 // Solver buffers, allocated on first use (linearise / reduce / LM entry points): records, partial sums, reduce buffer, the host-
 // mapped state ring.  A handle that only runs the pre-filter (api.select_frames over ALL frames of a long recording) never gets
 // here, so its footprint is the observations alone.
-static bool poison_enabled() {   // MCBA_POISON=1 (tests): buffers that are handed out WITHOUT a zero fill are filled with 0xFF bytes (NaN) instead -- whatever relies on a fill shows
-  static const bool on = [] { const char* e = getenv("MCBA_POISON"); return e && atoi(e) != 0; }();
-  return on;
-}
 static int compose_dscale(mcba_handle* h);
 static int ensure_solver(mcba_handle* h) {
   if (h->have_solver) return MCBA_OK;
@@ -536,7 +540,7 @@ static int ensure_solver(mcba_handle* h) {
     for (auto& pc : plain) if (pc.count) total += padded(pc.count);
     if ((rc = dalloc(h, &h->solver_arena, total, false)) != MCBA_OK) return rc;
     HIPCHK(hipMemsetAsync(h->solver_arena, 0, zero_bytes, h->stream));
-    if (poison_enabled()) HIPCHK(hipMemsetAsync(h->solver_arena + zero_bytes, 0xFF, total - zero_bytes, h->stream));
+    if (poison_byte()) HIPCHK(hipMemsetAsync(h->solver_arena + zero_bytes, poison_byte(), total - zero_bytes, h->stream));
     size_t off = 0;
     for (auto& pc : zeroed) { *pc.p = reinterpret_cast<double*>(h->solver_arena + off); off += padded(pc.count); }
     for (auto& pc : plain) if (pc.count) { *pc.p = reinterpret_cast<double*>(h->solver_arena + off); off += padded(pc.count); }

@@ -16,6 +16,7 @@
 //                    least-squares homography from the undistorted detections to the board plane per (camera, frame),
 //                    reprojections mapped through it, distance to the board points.  Lane = (camera, frame).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <math.h>
 #include <string.h>
 #include <algorithm>
@@ -268,7 +269,7 @@ template <int PASS>
 __global__ __launch_bounds__(1024) void k_pf_pass(const unsigned long long* __restrict__ keys, const double* __restrict__ mean_cf, const double* __restrict__ full_cf, unsigned char* __restrict__ fmask,
                                                   unsigned char* __restrict__ status, double* __restrict__ worst, int C, int F, int N, int Fpad, PrefState* __restrict__ st) {
   constexpr int NH = PASS == 0 ? PF_NA : (PASS == 1 ? 2 * PF_NB : 4 * PF_SEG);   // LDS words: histogram(s), or the two staged candidate lists (u64 = two words each)
-  __shared__ unsigned int s_h[NH];
+  __shared__ __align__(8) unsigned int s_h[NH];   // (pass 2 stages its candidates here as 64-bit words)
   __shared__ unsigned long long s_sum[PASS == 1 ? PF_NA : 64];   // pass 1: pass 0's histogram, summed over its replicas
   __shared__ unsigned long long s_pre[2], s_rank[2];
   __shared__ unsigned int s_n[2], s_base[2];
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(1024) void k_pf_sum(PrefState* __restrict__ st, int
 // prefix, both order statistics in the same sweep; the candidates of the 8 lists are gathered into LDS when they fit (dynamic LDS)
 constexpr int PF_LDS_LIST = 16384;
 size_t prefilter_final_lds_bytes() { return (size_t)PF_LDS_LIST * sizeof(unsigned long long); }
-__global__ __launch_bounds__(1024) void k_pf_final(PrefState* __restrict__ st, double thr_scale) {
+__global__ __launch_bounds__(1024) void k_pf_final(PrefState* __restrict__ st, double thr_scale, unsigned lds_capacity) {   // lds_capacity: candidates the dynamic LDS holds (0: none was granted -- the lists are read where they lie)
   extern __shared__ __align__(16) unsigned long long s_list[];
   __shared__ unsigned int s_h[2][2048];
   __shared__ unsigned int s_off[2][PF_REP + 1];
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(1024) void k_pf_final(PrefState* __restrict__ st, d
   }
   __syncthreads();
   const unsigned n0 = s_off[0][PF_REP], n1 = one_list ? 0u : s_off[1][PF_REP];
-  const bool in_lds = n0 + n1 <= (unsigned)PF_LDS_LIST;
+  const bool in_lds = n0 + n1 <= lds_capacity;
   if (in_lds) {
     for (int k = 0; k < PF_REP; ++k) {
       const unsigned c0 = s_off[0][k + 1] - s_off[0][k];
@@ -885,21 +886,29 @@ void launch_prefilter_select(hipStream_t st, const double* err, const double* me
   if (median) {
     const int R = C * N, nfb = Fpad / 64, items = nfb * ((R + 16 * PF_ROWS - 1) / (16 * PF_ROWS));
     const int g = std::min(PF_G, items);
-    {  // the dynamic-LDS limit of k_pf_final, raised once per device
-      static bool lds_set[64] = {};
+    bool big_lds;
+    {  // the dynamic-LDS limit of k_pf_final (128 KiB next to 16 KiB of static LDS), raised once per device; a part that does not grant it
+       // runs the final selection on the candidate lists where they lie (same result: ADVICE r5)
+      static std::mutex mu;
+      static unsigned char lds_state[64] = {};   // 0 not asked yet, 1 granted, 2 refused
       int dev = 0;
       (void)hipGetDevice(&dev);
-      if (!lds_set[dev & 63]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prefilter_final_lds_bytes());
-        lds_set[dev & 63] = true;
+      std::lock_guard<std::mutex> lk(mu);
+      unsigned char& stt = lds_state[dev & 63];
+      if (!stt) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prefilter_final_lds_bytes());
+        if (e != hipSuccess) (void)hipGetLastError();
+        stt = e == hipSuccess ? 1 : 2;
       }
+      big_lds = stt == 1;
     }
     const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(err);
     k_pf_pass<0><<<dim3(g), dim3(1024), 0, st>>>(keys, mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad, ps);
     k_pf_pass<1><<<dim3(g), dim3(1024), 0, st>>>(keys, mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad, ps);
     k_pf_sum<<<dim3(2 * PF_NB / 256), dim3(1024), 0, st>>>(ps, g);
     k_pf_pass<2><<<dim3(g), dim3(1024), 0, st>>>(keys, mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad, ps);
-    k_pf_final<<<dim3(1), dim3(1024), prefilter_final_lds_bytes(), st>>>(ps, 5.0);
+    if (big_lds) k_pf_final<<<dim3(1), dim3(1024), prefilter_final_lds_bytes(), st>>>(ps, 5.0, (unsigned)PF_LDS_LIST);
+    else k_pf_final<<<dim3(1), dim3(1024), 0, st>>>(ps, 5.0, 0u);
   } else {
     k_pf_mask<<<dim3((Fpad + 255) / 256), dim3(256), 0, st>>>(mean_cf, full_cf, fmask, status, worst, C, F, N, Fpad);
   }

@@ -469,6 +469,7 @@ class Problem:
             if not f_scale > 0:
                 raise ValueError("`f_scale` must be positive.")
             self._loss_fn, self._loss_fs, self._loss_valid = loss, float(f_scale), None
+            self._loss_forget()
             return
         if loss not in LOSSES:
             raise ValueError(f"loss must be one of {sorted(LOSSES)} or a callable")
@@ -481,17 +482,42 @@ class Problem:
 
     def loss_values(self, slot):
         """The caller's rho at the residuals of x[slot], as scipy's loss_function wrapper hands it to the solver (least_squares.py: construct_loss_function):
-        (valid (C,F,N,2) bool, z (m,), rho (3, m)) over the observed scalars in the reference's row order; rho is None if a residual is not finite."""
+        (valid (C,F,N,2) bool, z (m,), rho (3, m)) over the observed scalars in the reference's row order; rho is None if a residual is not finite.
+        The function is called ONCE per point: a trial point's cost and, if the step is accepted, its table come from the same evaluation
+        (the values are kept per parameter slot until that slot is written again)."""
+        hit = self._loss_cache.get(slot) if self._loss_cache is not None else None
+        if hit is not None:
+            return hit
         if self._loss_valid is None:
             self._loss_valid = np.unpackbits(self.seen_bits(), count=2 * self.C * self.F * self.N).astype(bool).reshape(self.C, self.F, self.N, 2)
-        f = self.residuals(slot)[self._loss_valid]
+            self._loss_index = None if self._loss_valid.all() else np.flatnonzero(self._loss_valid)   # (a complete recording needs no gather / scatter)
+        f = self.residuals(slot).reshape(-1)
+        if self._loss_index is not None:
+            f = f.take(self._loss_index)
         if not np.isfinite(f).all():
-            return self._loss_valid, None, None
-        z = (f / self._loss_fs) ** 2
-        rho = np.asarray(self._loss_fn(z), dtype=np.float64)
-        if rho.shape != (3, f.size):
-            raise ValueError("The return value of `loss` callable has wrong shape.")
-        return self._loss_valid, z, rho
+            out = (self._loss_valid, None, None)
+        else:
+            if self._loss_fs != 1.0:
+                f /= self._loss_fs
+            z = np.square(f, out=f)
+            rho = np.asarray(self._loss_fn(z), dtype=np.float64)
+            if rho.shape != (3, z.size):
+                raise ValueError("The return value of `loss` callable has wrong shape.")
+            out = (self._loss_valid, z, rho)
+        if self._loss_cache is None:
+            self._loss_cache = {}
+        self._loss_cache[slot] = out
+        return out
+
+    _loss_cache = None
+
+    def _loss_forget(self, slot=None):
+        """x[slot] is about to change (None: every slot): what the caller's function said about it no longer holds."""
+        if self._loss_cache:
+            if slot is None:
+                self._loss_cache.clear()
+            else:
+                self._loss_cache.pop(slot, None)
 
     def _callable_cost(self, slot):
         _, _, rho = self.loss_values(slot)
@@ -501,16 +527,28 @@ class Problem:
         valid, z, rho = self.loss_values(slot)
         if rho is None:
             raise ValueError("Residuals are not finite in the initial point.")
-        tab = np.zeros((3,) + valid.shape)
-        tab[0][valid] = 0.5 * self._loss_fs**2 * rho[0]
-        tab[1][valid] = rho[1]
-        tab[2][valid] = np.maximum(rho[1] + 2.0 * rho[2] * z, np.finfo(float).eps)   # scipy's J_scale^2 (common.py:720-731; rho''/f_scale^2 * f^2 = rho'' z)
+        # three planes over every scalar of the observation array: 0.5 f_scale^2 rho, rho', scipy's J_scale^2 = max(rho' + 2 rho'' z, EPS)
+        # (common.py:720-731; rho'' / f_scale^2 * f^2 = rho'' z); 0 where nothing is observed
+        js2 = rho[2] * z
+        js2 *= 2.0
+        js2 += rho[1]
+        np.maximum(js2, np.finfo(float).eps, out=js2)
+        if self._loss_index is None:
+            tab = np.empty((3, valid.size))
+            np.multiply(rho[0], 0.5 * self._loss_fs**2, out=tab[0])
+            tab[1], tab[2] = rho[1], js2
+        else:
+            tab = np.zeros((3, valid.size))
+            tab[0][self._loss_index] = 0.5 * self._loss_fs**2 * rho[0]
+            tab[1][self._loss_index] = rho[1]
+            tab[2][self._loss_index] = js2
         self._chk(self.lib.mcba_set_loss_table(self.handle, _p(tab)))
 
     def set_params(self, slot, x):
         x = _f64(x)
         if x.shape != (self.nx,):
             raise ValueError(f"x must have {self.nx} entries")
+        self._loss_forget(slot)
         self._chk(self.lib.mcba_set_params(self.handle, slot, _p(x)))
 
     def get_params(self, slot):
@@ -519,6 +557,7 @@ class Problem:
         return x
 
     def copy_params(self, dst, src):
+        self._loss_forget(dst)
         self._chk(self.lib.mcba_copy_params(self.handle, dst, src))
 
     def cost(self, slot):
@@ -647,6 +686,7 @@ class Problem:
         self._dc[:] = delta_cam
         if self._loss_fn is not None and linearize:
             raise ValueError("a callable loss cannot linearise its trial point speculatively (its table is not known before the step): use speculative=False")
+        self._loss_forget(dst)
         rc = self.lib.mcba_step_fetch(self.handle, self._dc_p, lam, src, dst, 1 if linearize else 0, self._trial_p)
         if rc:
             self._chk(rc)
@@ -656,6 +696,7 @@ class Problem:
 
     def step(self, delta_cam, lam, src, dst):
         d = _f64(delta_cam)
+        self._loss_forget(dst)
         self._chk(self.lib.mcba_step(self.handle, _p(d), float(lam), src, dst))
         if self._loss_fn is not None:
             # the trial cost of THIS shard's frames is the caller's function on their residuals: put in place of the kernel's BEFORE the all-reduce
@@ -667,6 +708,7 @@ class Problem:
     def step_linearize(self, delta_cam, lam, src, dst):
         """Back-substitute, then linearise x[dst] speculatively (its cost becomes trial scalar 0)."""
         d = _f64(delta_cam)
+        self._loss_forget(dst)
         self._chk(self.lib.mcba_step_linearize(self.handle, _p(d), float(lam), src, dst))
 
     def accept_linearization(self):

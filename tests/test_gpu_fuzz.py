@@ -136,6 +136,48 @@ def test_returned_point_is_a_minimiser_of_the_oracle_objective(mc, it):
         assert np.abs(orc.predict_from_x(r.x, C, p["obj"]) - pred).max() < 1e-4, (tag, "flags on the 12-wide block")
 
 
+# The soak's unterminated cases (scripts/fuzz_scan.py 1000 2700, profiles/round6/fuzz_scan_r6a.txt: these 8 of 1 700): recordings of 3-8 frames
+# -- the intrinsics and distortion of up to 20 cameras from three views of a 6-20-point board, barely determined.  Each run slides along a nearly
+# flat, CURVED valley of the objective: accepted steps at a constant gain ratio of ~0.55 (Nielsen's rule then leaves the damping where it is), a
+# relative gain of 1e-6 per step, the gradient not shrinking.  At the sweep's tolerances (1e-13) nothing fires within 400 evaluations -- and
+# nothing fires in scipy's TRF either: the reference's own solver (same objective, analytic Jacobian, same budget) ends with status 0 at a
+# HIGHER cost on every one of them (case 1660: 8.2243 against 8.0068 here; a geodesic-acceleration prototype needs 585 evaluations to get the
+# gradient to 4e-3: profiles/round6/NOTES_round6.md section 5).  What is asserted is what holds: at the reference's default tolerance the runs
+# stop (after ~110 evaluations at most; scipy: 21-103) with a cost at least as low as scipy's, and the tight runs descend monotonically below that and below scipy's tight run.
+VALLEY_CASES = [1473, 1660, 1731, 1790, 1821, 1991, 2427, 2610]
+
+
+@pytest.mark.parametrize("it", VALLEY_CASES)
+def test_flat_valley_cases_are_no_worse_than_the_references_solver(mc, it):
+    from scipy.optimize import least_squares
+
+    mk, opts, fixed = draw(it)
+    assert not fixed
+    p = mc.synth.make_problem(**mk)
+    args = (p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"])
+    use = quiet(orc.prefilter_frames, *args, None, None)[0]
+    uvs = p["uvs"][:, use]
+    x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"][use])
+
+    def scipy_run(**tol):   # the reference's call (bundle_adjustment.py:307-313) on the oracle's residuals, with an analytic Jacobian
+        return least_squares(orc.residuals, x0, jac=lambda x, u, o: orc.jacobian_csr(x, u, o), x_scale="jac", method="trf", loss=opts["loss"], f_scale=opts["f_scale"], args=(uvs, p["obj"]), **tol)
+
+    # the reference's default tolerance: both stop, ours at a cost no higher
+    ref = scipy_run(ftol=1e-4, max_nfev=400)
+    res = quiet(mc.bundle_adjust, *args, n_frames=None, verbose=0, return_jac=False, **opts)[4]
+    assert ref.status > 0 and res.status > 0 and res.nfev <= 200, (it, ref.status, res.status, res.nfev)
+    assert res.cost <= ref.cost * (1 + 1e-9), (it, res.cost, ref.cost)
+    # the sweep's tolerances: neither terminates within 400 evaluations (status 0 is scipy's answer too); ours descends monotonically and further
+    tight = quiet(mc.bundle_adjust, *args, n_frames=None, ftol=1e-13, xtol=1e-13, gtol=1e-11, verbose=0, max_nfev=400, return_jac=False, **opts)[4]
+    ref_tight = scipy_run(ftol=1e-13, xtol=1e-13, gtol=1e-11, max_nfev=150)
+    assert tight.cost <= res.cost and tight.cost <= ref_tight.cost * (1 + 1e-9), (it, tight.cost, res.cost, ref_tight.cost)
+    hist = np.array([(h[1], h[2]) for h in tight.lm["history"]])
+    accepted = hist[:, 1] <= hist[:, 0]
+    assert accepted.sum() > 0.8 * len(hist)   # (a valley, not a fight with the damping: nearly every step is accepted)
+    f = orc.residuals(tight.x, uvs, p["obj"])
+    assert abs(orc.robust_cost(f, opts["loss"], opts["f_scale"]) - tight.cost) <= 1e-11 * tight.cost
+
+
 @pytest.mark.parametrize("it", [2, 8, 14, 21, 23, 30, 37, 41, 48, 55, 62])
 def test_frame_shards_in_one_process_reach_the_same_minimiser(mc, it):
     """The north_star's partition on random problems: the frames dealt out to 3 shards (solver.InProcessShards: one handle and one LM loop

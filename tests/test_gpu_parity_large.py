@@ -52,7 +52,7 @@ def test_solution_matches_tight_reference_optimum_large(mc, golden, size, mode):
     p = _golden_problem(mc, z)
     if size.endswith("_missing"):   # SURVEY 8d's correctness variant at a BASELINE size: Bernoulli(0.3) per (camera, frame) + 1 % of the single scalars
         gone = np.isnan(p["uvs"])
-        assert 0.28 < gone.all((2, 3)).mean() < 0.32 and 0.3 < gone.mean() < 0.32 and (gone.any((2, 3)) & ~gone.all((2, 3))).mean() > 0.3
+        assert 0.28 < gone.all((2, 3)).mean() < 0.32 and 0.29 < gone.mean() < 0.31 and (gone.any((2, 3)) & ~gone.all((2, 3))).mean() > 0.3
     # accuracy of the golden itself: the second start's cameras (and, stored as scalars, its extrinsics / poses)
     if "s1_cam" in z.files:
         c0, c1 = z["s0_x"][:12 * C].reshape(C, 12)[:, :6], z["s1_cam"].reshape(C, 12)[:, :6]
