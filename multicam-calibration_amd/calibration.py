@@ -164,40 +164,66 @@ def _require_planar(obj):
     return obj
 
 
-def intrinsics_from_homographies(H, image_size):
-    """K from the image of the absolute conic (zero skew imposed); falls back to f = max(w, h), c = image centre when
-    the views do not constrain it (fewer than 2 usable views, or a non-positive-definite estimate)."""
+def _fallback_K(image_size):
     w, h = float(image_size[0]), float(image_size[1])
-    fallback = np.array([[max(w, h), 0, (w - 1) / 2], [0, max(w, h), (h - 1) / 2], [0, 0, 1.0]])
-    H = np.asarray(H, dtype=np.float64)
-    H = H[np.isfinite(H).all((1, 2))] if len(H) else H
-    if len(H) < 2:
-        return fallback
+    return np.array([[max(w, h), 0, (w - 1) / 2], [0, max(w, h), (h - 1) / 2], [0, 0, 1.0]])
 
-    def vij(H, i, j):
-        a, b = H[:, :, i], H[:, :, j]
+
+def intrinsics_from_homographies_batch(H, cams, image_sizes):
+    """Zhang's closed form for every camera at once.  H (V,3,3): board-plane homographies of views; cams (V,) int: the camera of each view;
+    image_sizes: one (width, height) per camera.  Returns K (C,3,3): the camera matrix from the image of the absolute conic (zero skew imposed),
+    or the fallback f = max(w, h), c = image centre for a camera whose views do not constrain it (fewer than 2 usable views, or a non-positive-
+    definite estimate).  One stacked SVD for all cameras (their rows padded with zeros to a common count: zero rows do not move a null vector)."""
+    C = len(image_sizes)
+    H = np.asarray(H, dtype=np.float64).reshape(-1, 3, 3)
+    cams = np.asarray(cams, dtype=np.int64).reshape(-1)
+    K = np.stack([_fallback_K(sz) for sz in image_sizes])
+    ok = np.isfinite(H).all((1, 2))
+    H, cams = H[ok], cams[ok]
+    counts = np.bincount(cams, minlength=C)
+    if not len(H) or counts.max() < 2:
+        return K
+    wh = np.asarray(image_sizes, dtype=np.float64).reshape(C, 2)
+    s0 = wh.max(1)   # work in image coordinates of order 1 (pixel-scale entries would spread V over 12 decades)
+    Nrm = np.zeros((C, 3, 3))
+    Nrm[:, 0, 0] = Nrm[:, 1, 1] = 1 / s0
+    Nrm[:, 0, 2], Nrm[:, 1, 2], Nrm[:, 2, 2] = -(wh[:, 0] - 1) / (2 * s0), -(wh[:, 1] - 1) / (2 * s0), 1.0
+    Hs = Nrm[cams] @ H
+    Hs = Hs / np.linalg.norm(Hs[:, :, :2], axis=(1, 2), keepdims=True)
+
+    def vij(i, j):
+        a, b = Hs[:, :, i], Hs[:, :, j]
         return np.stack([a[:, 0] * b[:, 0], a[:, 0] * b[:, 1] + a[:, 1] * b[:, 0], a[:, 1] * b[:, 1],
                          a[:, 2] * b[:, 0] + a[:, 0] * b[:, 2], a[:, 2] * b[:, 1] + a[:, 1] * b[:, 2], a[:, 2] * b[:, 2]], -1)
 
-    s0 = max(w, h)  # work in image coordinates of order 1 (pixel-scale entries would spread V over 12 decades)
-    Nrm = np.array([[1 / s0, 0, -(w - 1) / (2 * s0)], [0, 1 / s0, -(h - 1) / (2 * s0)], [0, 0, 1.0]])
-    Hs = Nrm @ H
-    Hs = Hs / np.linalg.norm(Hs[:, :, :2], axis=(1, 2), keepdims=True)
-    V = np.concatenate([vij(Hs, 0, 1), vij(Hs, 0, 0) - vij(Hs, 1, 1), np.array([[0, 1.0, 0, 0, 0, 0]]) * len(H)])  # last row: skew = 0
-    _, _, Vt = np.linalg.svd(V)
-    b11, b12, b22, b13, b23, b33 = Vt[-1]
-    den = b11 * b22 - b12 * b12
-    if den == 0 or b11 == 0:
-        return fallback
-    v0 = (b12 * b13 - b11 * b23) / den
-    lam = b33 - (b13 * b13 + v0 * (b12 * b13 - b11 * b23)) / b11
-    a2, b2 = lam / b11, lam * b11 / den
-    if not (np.isfinite([a2, b2, v0]).all() and a2 > 0 and b2 > 0):
-        return fallback
-    alpha, beta = np.sqrt(a2), np.sqrt(b2)
-    u0 = -b13 * alpha * alpha / lam
-    K = np.linalg.inv(Nrm) @ np.array([[alpha, 0, u0], [0, beta, v0], [0, 0, 1.0]])
-    return K / K[2, 2]
+    rows = np.stack([vij(0, 1), vij(0, 0) - vij(1, 1)], 1)          # (V, 2, 6)
+    order = np.argsort(cams, kind="stable")
+    slot = np.arange(len(cams)) - np.concatenate([[0], np.cumsum(counts)])[cams[order]]   # position of each (sorted) view inside its camera
+    V = np.zeros((C, 2 * counts.max() + 1, 6))
+    V[cams[order], 2 * slot] = rows[order, 0]
+    V[cams[order], 2 * slot + 1] = rows[order, 1]
+    V[:, -1, 1] = counts                                             # last row: skew = 0, weighted like the reference's single-camera form
+    b = np.linalg.svd(V, full_matrices=False)[2][:, -1]             # (C, 6): b11 b12 b22 b13 b23 b33
+    with np.errstate(all="ignore"):
+        b11, b12, b22, b13, b23, b33 = b.T
+        den = b11 * b22 - b12 * b12
+        v0 = (b12 * b13 - b11 * b23) / den
+        lam = b33 - (b13 * b13 + v0 * (b12 * b13 - b11 * b23)) / b11
+        a2, b2 = lam / b11, lam * b11 / den
+        good = (counts >= 2) & (den != 0) & (b11 != 0) & np.isfinite(a2) & np.isfinite(b2) & np.isfinite(v0) & (a2 > 0) & (b2 > 0)
+        alpha, beta = np.sqrt(np.where(good, a2, 1.0)), np.sqrt(np.where(good, b2, 1.0))
+        u0 = -b13 * alpha * alpha / lam
+    for c in np.flatnonzero(good):
+        Kc = np.linalg.inv(Nrm[c]) @ np.array([[alpha[c], 0, u0[c]], [0, beta[c], v0[c]], [0, 0, 1.0]])
+        K[c] = Kc / Kc[2, 2]
+    return K
+
+
+def intrinsics_from_homographies(H, image_size):
+    """K from the image of the absolute conic (zero skew imposed) for ONE camera's views H (V,3,3); falls back to f = max(w, h), c = image
+    centre when the views do not constrain it (fewer than 2 usable views, or a non-positive-definite estimate)."""
+    H = np.asarray(H, dtype=np.float64).reshape(-1, 3, 3)
+    return intrinsics_from_homographies_batch(H, np.zeros(len(H), dtype=np.int64), [image_size])[0]
 
 
 def _intr9(K, dist=None):
@@ -221,7 +247,7 @@ def _start_on_device(prob, views, image_sizes):
     """Closed-form start for the cameras of `prob` from their sampled views ((V,2) int: camera, frame): per-view homographies on the GPU,
     Zhang's K per camera on the host, per-view poses with that K on the GPU.  Returns (K0 list, poses0 (V,6))."""
     H = prob.calib_homographies(views)
-    K0 = [intrinsics_from_homographies(H[views[:, 0] == c], image_sizes[c]) for c in range(prob.C)]
+    K0 = list(intrinsics_from_homographies_batch(H, views[:, 0], image_sizes))
     poses0 = prob.calib_view_poses(views, np.array([_intr9(K) for K in K0]))
     return K0, poses0
 

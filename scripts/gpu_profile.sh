@@ -6,9 +6,11 @@
 #   the user-level call's wall-clock breakdown, the other shapes DESIGN quotes, kernel stats of the config-5 shard (24 x 6 250 x 200).
 set -e -o pipefail
 TAG=${1:-run}
+PART=${2:-all}   # a gpurun call is limited to 20 minutes: `scripts/gpu_profile.sh TAG a`, then `... TAG b`, then `... TAG c` (all = everything in one go)
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
+if [ "$PART" = "all" ] || [ "$PART" = "a" ]; then
 python3 bench.py --no-cpu-baseline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 echo "bench done"
 # (--no-other-configs: the headline tick alone -- configs[0] runs the same k_syrk / k_solve_backsub instances at a tenth of the size and would be averaged in)
@@ -25,6 +27,8 @@ find $OUT/${TAG}_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_
 MCBA_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_dist_stats -- python3 bench.py --no-cpu-baseline --no-end-to-end > $OUT/${TAG}_dist_bench.json 2> $OUT/${TAG}_dist.err
 find $OUT/${TAG}_dist_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_dist_kernel_stats.csv \;
 echo "forced-dist done"
+fi
+if [ "$PART" = "all" ] || [ "$PART" = "b" ]; then
 python3 scripts/e2e_breakdown.py > $OUT/${TAG}_e2e_breakdown.json 2> $OUT/${TAG}_e2e.err
 # round 5: the user-level call where users are (the reference tutorial's recording, BASELINE configs[0]), its kernels by rocprofv3, and the
 # timelines of the small-shape ticks (what a kernel boundary costs in the stream)
@@ -44,6 +48,8 @@ echo "round-5 e2e done"
 python3 scripts/other_shapes.py > $OUT/${TAG}_other_shapes.json 2> $OUT/${TAG}_shapes.err
 MCBA_SHAPES="24,6250,10,20" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_shard5_stats -- python3 scripts/other_shapes.py > $OUT/${TAG}_shard5.json 2> $OUT/${TAG}_shard5.err
 find $OUT/${TAG}_shard5_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_shard5_kernel_stats.csv \;
+fi
+if [ "$PART" = "all" ] || [ "$PART" = "c" ]; then
 # round 4: the shapes that are not one round of the wavefront slots -- rocprofv3 kernel stats of the LM loop at BASELINE configs[1]
 # (6 x 1 000 x 54, intrinsics held fixed: the 6-wide camera block), the same size with every parameter free, configs[0] (2 x 50), a
 # configs[3] shard (6 x 12 500: fused round + point-split tail); HBM counter passes at configs[1]; the FULL configs[4] problem on one GPU
@@ -58,4 +64,18 @@ MCBA_SHAPE="6,1000,6,9" MCBA_FIXED=1 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_
 python3 scripts/pmc_summary.py $OUT/${TAG}_pmc_config1_summary.json $OUT/${TAG}_pmc_c1_fetch $OUT/${TAG}_pmc_c1_write $OUT/${TAG}_pmc_c1_sq > $OUT/${TAG}_pmc_config1_summary.log
 echo "round-4 shapes done"
 MCBA_SHAPES="24,50000,10,20" python3 scripts/other_shapes.py > $OUT/${TAG}_config5_full.json 2> $OUT/${TAG}_config5_full.err
+# round 6: calibrate() -- wall time with its stages at the tutorial shape and at 6 x 10 000 x 54, rocprofv3 kernel stats of the call and of the dense
+# kernels' fixed launch sequence, HBM counter passes of the latter
+python3 scripts/calibrate_time.py > $OUT/${TAG}_calibrate.json 2> $OUT/${TAG}_calibrate.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_cal_stats -- python3 scripts/calibrate_time.py 6,10000,6,9 > /dev/null 2>> $OUT/${TAG}_calibrate.err
+find $OUT/${TAG}_cal_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_calibrate_kernel_stats.csv \;
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_calk_stats -- python3 scripts/profile_calibrate.py > $OUT/${TAG}_calibrate_kernels.json 2>> $OUT/${TAG}_calibrate.err
+find $OUT/${TAG}_calk_stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_calibrate_dense_kernel_stats.csv \;
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_cal_fetch -- python3 scripts/profile_calibrate.py > $OUT/${TAG}_pmc_cal_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_cal_write -- python3 scripts/profile_calibrate.py > $OUT/${TAG}_pmc_cal_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 --output-format csv -d $OUT/${TAG}_pmc_cal_sq -- python3 scripts/profile_calibrate.py > $OUT/${TAG}_pmc_cal_sq.log 2>&1
+python3 scripts/pmc_summary.py $OUT/${TAG}_pmc_calibrate_summary.json $OUT/${TAG}_pmc_cal_fetch $OUT/${TAG}_pmc_cal_write $OUT/${TAG}_pmc_cal_sq > $OUT/${TAG}_pmc_calibrate_summary.log
+rm -rf $OUT/${TAG}_cal_stats $OUT/${TAG}_calk_stats
+echo "round-6 calibrate done"
+fi
 echo "profile set $TAG done"

@@ -26,7 +26,10 @@ def main(tag, rnd):
                  (f"{tag}_e2e_tutorial.json", f"e2e_breakdown_{tag}_tutorial.json"), (f"{tag}_e2e_config0.json", f"e2e_breakdown_{tag}_config0.json"),
                  (f"{tag}_e2e_missing.json", f"e2e_missing_{tag}.json"), (f"{tag}_e2e_kernel_stats.csv", f"e2e_kernel_stats_{tag}.csv"),
                  (f"{tag}_tick_timeline_config0.txt", f"tick_timeline_config0_{tag}.txt"), (f"{tag}_tick_timeline_config1.txt", f"tick_timeline_config1_{tag}.txt"),
-                 (f"{tag}_tick_timeline_tutorial.txt", f"tick_timeline_tutorial_{tag}.txt")):
+                 (f"{tag}_tick_timeline_tutorial.txt", f"tick_timeline_tutorial_{tag}.txt"),
+                 (f"{tag}_calibrate.json", f"calibrate_{tag}.json"), (f"{tag}_calibrate_kernel_stats.csv", f"calibrate_kernel_stats_{tag}.csv"),
+                 (f"{tag}_calibrate_kernels.json", f"calibrate_dense_kernels_{tag}.json"), (f"{tag}_calibrate_dense_kernel_stats.csv", f"calibrate_dense_kernel_stats_{tag}.csv"),
+                 (f"{tag}_pmc_calibrate_summary.json", f"pmc_calibrate_{tag}_summary.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, b))
         else:

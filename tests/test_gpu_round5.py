@@ -289,6 +289,46 @@ def test_bounds_reach_the_reference_bounded_optimum(mc, golden, tag):
     assert not r0.active_mask.any()
 
 
+def test_bounds_reach_the_reference_bounded_optimum_at_baseline_size(mc, golden):
+    """Round 6: the same pin at a BASELINE size, 6 cameras x 1 000 frames x 54 points (tests/golden/make_golden_bounds_large.py): the unmodified
+    reference's bounded run (scipy's trf_bounds through its **opt_kwargs -- still at optimality 1.3e6 after 80 evaluations and 16 minutes)
+    polished by a sparse active-set Gauss-Newton iteration on the reference's residuals to a KKT residual of 4e-6 and certified by the finite-
+    difference gradient of the reference's cost; 23 bounds active there (k1 / k2 / fx of three cameras, the z-translation of 18 board poses)."""
+    z = golden("tight_bounds_6x1000.npz")
+    C, F, N = (int(v) for v in z["shape"])
+    p = mc.synth.make_problem(C, F, seed=0, perturb_seed=1)
+    assert abs(float(z["uvs_checksum"]) - np.nansum(p["uvs"])) <= 1e-9 * abs(float(z["uvs_checksum"]))
+    lo, hi, xg = z["lo"], z["hi"], z["x"]
+    (e, i, p_, use, res), out = captured(mc.bundle_adjust, p["uvs"], p["extrinsics"], p["intrinsics"], p["obj"], p["poses"], n_frames=None, bounds=(lo, hi), ftol=1e-15, xtol=1e-15, gtol=1e-9, verbose=1,
+                                         max_nfev=400, return_jac=False)
+    np.testing.assert_array_equal(use, z["use"])
+    assert res.status in (1, 2, 3, 4), out
+    assert np.all(res.x >= lo) and np.all(res.x <= hi)
+    assert abs(res.cost - float(z["cost"])) <= 1e-9 * res.cost, (res.cost, float(z["cost"]))
+    intr_idx = np.array([12 * c + k for c in range(C) for k in range(6)])
+    np.testing.assert_array_equal(res.active_mask[intr_idx], z["active_mask"][intr_idx])
+    gold_act = z["active_mask"] != 0
+    np.testing.assert_array_equal(res.active_mask[gold_act], z["active_mask"][gold_act])   # every bound the golden has active is active here
+    np.testing.assert_array_equal(res.x[res.active_mask == -1], lo[res.active_mask == -1])
+    np.testing.assert_array_equal(res.x[res.active_mask == 1], hi[res.active_mask == 1])
+    cam, cam_g = res.x[:12 * C].reshape(C, 12), xg[:12 * C].reshape(C, 12)
+    assert (np.abs(cam[:, :6] - cam_g[:, :6]) / np.abs(cam_g[:, :6])).max() < 1e-6
+    ext_a, _, poses_a = orc.deserialize_params(res.x, C)
+    ext_g, _, poses_g = orc.deserialize_params(xg, C)
+    (cc, cb), (cc_g, cb_g) = orc.invariants(ext_a, poses_a), orc.invariants(ext_g, poses_g)
+    for a, b in ((cc, cc_g), (cb, cb_g)):
+        assert np.abs(a - b)[..., :3, :3].max() < 1e-6
+        assert (np.abs(a - b)[..., :3, 3] / np.abs(b[..., :3, 3]).max()).max() < 1e-6
+    # KKT by the oracle at the returned point
+    act = res.active_mask != 0
+    f = orc.residuals(res.x, p["uvs"][:, use], p["obj"])
+    js, fs = orc.robust_scales(f)
+    g = orc.jacobian_csr(res.x, p["uvs"][:, use], p["obj"]).T @ (js * fs)
+    assert np.abs(g[~act]).max() < 1e-6 * np.abs(g[act]).max()
+    gtol_ = 1e-6 * np.abs(g[act]).max()
+    assert np.all(g[res.active_mask == -1] > -gtol_) and np.all(g[res.active_mask == 1] < gtol_)
+
+
 def test_bounds_with_fixed_intrinsics_and_validation(mc):
     """Bounds together with fix_intrinsics (flags on the 12-wide camera block): a tight box around the START values of every camera's
     extrinsics (single bounded coordinates would be evaded through the gauge freedom) -- the cameras cannot reach their unconstrained

@@ -72,6 +72,32 @@ def test_large_goldens_are_certified(golden, name):
         assert float(z["agree_ext"]) < 1e-8 and float(z["agree_poses"]) < 1e-8
 
 
+def test_large_bounded_golden_is_certified(golden):
+    """tight_bounds_6x1000.npz (tests/golden/make_golden_bounds_large.py): the stored point is feasible, is a KKT point of the ORACLE's robust cost
+    (analytic gradient: zero off the active set, pointing outward on it), the reference's finite-difference gradient agreed when it was made,
+    and its cost lies between the unconstrained optimum's and the start's."""
+    z = golden("tight_bounds_6x1000.npz")
+    C, F, N = (int(v) for v in z["shape"])
+    p = synth.make_problem(C, F, seed=0, perturb_seed=1)
+    assert abs(float(z["uvs_checksum"]) - np.nansum(p["uvs"])) <= 1e-9 * abs(float(z["uvs_checksum"]))
+    x, use, lo, hi, act = z["x"], z["use"], z["lo"], z["hi"], z["active_mask"]
+    assert np.all(x >= lo) and np.all(x <= hi) and (act != 0).sum() == 23 and (act[:12 * C] != 0).sum() >= 3 and (act[12 * C:] != 0).sum() >= 10
+    np.testing.assert_array_equal(x[act == -1], lo[act == -1])
+    np.testing.assert_array_equal(x[act == 1], hi[act == 1])
+    uvs = p["uvs"][:, use]
+    f = orc.residuals(x, uvs, p["obj"])
+    cost = orc.robust_cost(f)
+    assert abs(cost - float(z["cost"])) <= 1e-12 * cost
+    js, fs = orc.robust_scales(f)
+    g = orc.jacobian_csr(x, uvs, p["obj"]).T @ (js * fs)
+    assert np.abs(g[act == 0]).max() < 1e-4 and np.all(g[act == -1] > 0) and np.all(g[act == 1] < 0) and np.abs(g[act != 0]).min() > 1.0
+    assert float(z["kkt_residual"]) < 1e-4 and float(z["fd_grad_free_inf"]) < 1e-4
+    zu = golden("tight_6x1000.npz")
+    x0 = orc.serialize_params(p["extrinsics"], p["intrinsics"], p["poses"][use])
+    assert float(zu["s0_cost"]) < cost < orc.robust_cost(orc.residuals(x0, uvs, p["obj"]))
+    assert np.any(zu["s0_x"] < lo) or np.any(zu["s0_x"] > hi)   # the unconstrained optimum violates the box
+
+
 @pytest.mark.parametrize("tag,kw", [("config1", {}), ("missing3", {}), ("config1_cauchy", dict(loss="cauchy", f_scale=0.5))])
 def test_lm_driver_reaches_reference_optimum(golden, tag, kw):
     z = golden(f"tight_{tag}.npz")
