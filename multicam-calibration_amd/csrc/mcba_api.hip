@@ -471,7 +471,13 @@ int mcba_device_count(int* count) {
 }
 
 int mcba_create(mcba_handle** out, int C, int F, int N, int device) {
-  if (!out || C < 1 || F < 1 || N < 1 || C > 40) return fail(MCBA_ERR_ARG, "mcba_create: need 1 <= C <= 40, F >= 1, N >= 1");
+  if (!out || C < 1 || F < 1 || N < 1) return fail(MCBA_ERR_ARG, "mcba_create: need cameras >= 1, frames >= 1, points >= 1");
+  if (C > 40) {
+    g_err = "mcba_create: " + std::to_string(C) + " cameras -- this build handles at most 40 per handle: the (12 C + 1)-row reduced camera system is factorised by ONE workgroup "
+            "(k_solve_cam: tile tables, LDS and scratch are sized for 481 rows) and k_backsub takes the camera step through the kernel arguments (480 doubles); reduced_solver=\"host\" does not "
+            "lift it (the Schur product's tile grid has the same bound).  The reference has no such limit (scipy's sparse LSMR); split the rig, or calibrate the cameras in overlapping groups of <= 40";
+    return MCBA_ERR_ARG;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MCBA_ERR_NODEVICE, "no HIP device visible");
   if (device < 0 || device >= ndev) return fail(MCBA_ERR_ARG, "device ordinal out of range");

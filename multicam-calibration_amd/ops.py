@@ -491,9 +491,13 @@ class Problem:
         if self._loss_valid is None:
             self._loss_valid = np.unpackbits(self.seen_bits(), count=2 * self.C * self.F * self.N).astype(bool).reshape(self.C, self.F, self.N, 2)
             self._loss_index = None if self._loss_valid.all() else np.flatnonzero(self._loss_valid)   # (a complete recording needs no gather / scatter)
-        f = self.residuals(slot).reshape(-1)
-        if self._loss_index is not None:
-            f = f.take(self._loss_index)
+        # (host buffers of the callable path are kept with the handle: a fresh 52 / 156 MB numpy array per evaluation costs more in page faults
+        #  than the copy that fills it)
+        if self._loss_res_buf is None:
+            self._loss_res_buf = np.empty((self.C, self.F, self.N, 2))
+        self._chk(self.lib.mcba_residuals(self.handle, slot, _p(self._loss_res_buf)))
+        f = self._loss_res_buf.reshape(-1)
+        f = f.take(self._loss_index) if self._loss_index is not None else f.copy()
         if not np.isfinite(f).all():
             out = (self._loss_valid, None, None)
         else:
@@ -510,6 +514,8 @@ class Problem:
         return out
 
     _loss_cache = None
+    _loss_res_buf = None
+    _loss_tab_buf = None
 
     def _loss_forget(self, slot=None):
         """x[slot] is about to change (None: every slot): what the caller's function said about it no longer holds."""
@@ -533,12 +539,13 @@ class Problem:
         js2 *= 2.0
         js2 += rho[1]
         np.maximum(js2, np.finfo(float).eps, out=js2)
+        if self._loss_tab_buf is None:
+            self._loss_tab_buf = np.zeros((3, valid.size))   # (the unobserved scalars stay 0 for good: only the observed ones are ever written)
+        tab = self._loss_tab_buf
         if self._loss_index is None:
-            tab = np.empty((3, valid.size))
             np.multiply(rho[0], 0.5 * self._loss_fs**2, out=tab[0])
             tab[1], tab[2] = rho[1], js2
         else:
-            tab = np.zeros((3, valid.size))
             tab[0][self._loss_index] = 0.5 * self._loss_fs**2 * rho[0]
             tab[1][self._loss_index] = rho[1]
             tab[2][self._loss_index] = js2

@@ -56,3 +56,13 @@ def test_product_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), fn
+
+
+def test_more_than_40_cameras_is_refused_with_the_reason():
+    """The reference has no camera limit; this build's is 40 per handle -- said in the exception a calibrate() / bundle_adjust() user of a bigger
+    rig sees first (checked before any device is touched)."""
+    import numpy as np
+    from multicam_calibration_amd import ops
+
+    with pytest.raises(ops.McbaError, match="at most 40"):
+        ops.Problem(np.zeros((41, 3, 4, 2)), np.zeros((4, 3)))

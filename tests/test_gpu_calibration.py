@@ -402,3 +402,46 @@ def test_trim_keeps_the_box_and_restores_the_scaling(mc):
     a, b = one_step(False), one_step(True)
     np.testing.assert_array_equal(a, b)
     assert np.all(a >= lo) and np.all(a <= hi) and (np.isclose(a, lo) | np.isclose(a, hi)).any()
+
+
+def test_calibrate_edge_cases(mc):
+    """One camera (no pose graph), a camera with two complete views only (the draw takes what there is; Zhang's closed form needs two), a camera
+    with none (the reference fails inside cv2.calibrateCamera; here a ValueError that names the camera's problem), scalar NaNs (such views are
+    skipped as incomplete, calibration.py:55, :107), a 24-camera rig (BASELINE configs[4]'s), a non-planar board."""
+    from multicam_calibration_amd import calibration as cal
+
+    p = mc.synth.make_problem(1, 40, seed=70, noise=0.1)
+    np.random.seed(1)
+    ext, intr, poses, tree = mc.calibrate(p["uvs"], [(1280, 1024)], p["obj"], verbose=False, n_samples_for_intrinsics=30)
+    assert tree == [] and ext.shape == (1, 6) and np.all(ext == 0) and poses.shape == (40, 6) and not np.isnan(poses).any()
+    np.testing.assert_allclose(poses, mc.estimate_pose(p["uvs"][0], p["obj"], *intr[0]), rtol=0, atol=1e-9)   # world = the camera: consensus of one
+
+    q = mc.synth.make_problem(3, 50, seed=71, noise=0.1, scalar_nans=40)
+    keep = np.zeros(50, bool)
+    keep[[4, 17]] = True
+    q["uvs"][2, ~keep] = np.nan        # camera 2 sees the board twice
+    q["uvs"][2, keep] = mc.synth.make_problem(3, 50, seed=71, noise=0.1)["uvs"][2, keep]
+    np.random.seed(2)
+    ext, intr, poses, tree = mc.calibrate(q["uvs"], [(1280, 1024)] * 3, q["obj"], verbose=False)
+    assert len(tree) == 2 and np.isfinite(ext).all() and all(np.isfinite(K).all() and np.isfinite(d).all() for K, d in intr)
+    complete = ~np.isnan(q["uvs"]).any((2, 3))
+    assert np.array_equal(np.isnan(poses).any(1), ~complete.any(0))
+    er, et = _pose_err(ext[1:2], q["true_cam"][1:2, 6:])
+    assert er < 3e-2 and et < 10.0
+    q["uvs"][2] = np.nan
+    with pytest.raises(ValueError, match="no complete detection"):
+        mc.calibrate(q["uvs"], [(1280, 1024)] * 3, q["obj"], verbose=False)
+
+    r = mc.synth.make_problem(24, 60, rows=5, cols=8, seed=72, noise=0.15, missing=0.4)
+    np.random.seed(3)
+    ext, intr, poses, tree = mc.calibrate(r["uvs"], [(1280, 1024)] * 24, r["obj"], verbose=False, n_samples_for_intrinsics=40)
+    assert len(tree) == 23 and {b for _, b in tree} == set(range(1, 24)) and np.isfinite(ext).all()
+    ok = ~np.isnan(poses).any(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = mc.bundle_adjust(r["uvs"][:, ok], ext, intr, r["obj"], poses[ok], n_frames=None, ftol=1e-10, verbose=0, return_jac=False)
+        b = mc.bundle_adjust(r["uvs"][:, ok], r["extrinsics"], r["intrinsics"], r["obj"], r["poses"][ok], n_frames=None, ftol=1e-10, verbose=0, return_jac=False)
+    np.testing.assert_array_equal(a[3], b[3])
+    assert abs(a[4].cost - b[4].cost) <= 1e-6 * b[4].cost   # the same optimum from calibrate()'s start as from a perturbed truth
+
+    with pytest.raises(NotImplementedError):
+        mc.calibrate(p["uvs"], [(1280, 1024)], p["obj"] + np.array([0, 0, 1.0]) * np.arange(54)[:, None], verbose=False)
