@@ -139,31 +139,6 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ v, 
   if (n) atomicAdd(&st->hist[threadIdx.x], n);
 }
 
-// one thread per group: which byte holds the wanted rank; upper == 0 selects rank (n-1)/2, upper == 1 rank n/2
-__global__ void k_sel_pick(SelState* __restrict__ sts, int pass, int upper, int dual, int skey) {
-  SelState* st = sts + blockIdx.x;
-  if (threadIdx.x != 0) return;
-  if (dual) upper = blockIdx.x & 1;
-  unsigned long long total = 0;
-  for (int b = 0; b < 256; ++b) total += st->hist[b];
-  if (pass == 0) {
-    st->count = total;
-    st->rank = total ? (upper ? total / 2 : (total - 1) / 2) : 0;
-    st->prefix = 0;
-  }
-  unsigned long long r = st->rank, below = 0;
-  int digit = 0;
-  for (int b = 0; b < 256; ++b) {
-    const unsigned long long h = st->hist[b];
-    if (r < below + h) { digit = b; break; }
-    below += h;
-  }
-  st->rank = r - below;
-  st->prefix = (st->prefix << 8) | (unsigned long long)digit;
-  if (pass == 7) st->value = skey ? ((st->prefix >> 63) ? (st->prefix & 0x7FFFFFFFFFFFFFFFull) : ~st->prefix) : st->prefix;   // (the key back to the value's bits)
-  for (int b = 0; b < 256; ++b) st->hist[b] = 0;
-}
-
 // ---------------------------------------------------------------- the pre-filter's frame selection, all of it on the device
 // (mcba_prefilter: bundle_adjustment.py:266-285 in ONE host synchronisation).  What the host did between k_frame_err and the
 // gather -- which frames are complete in two cameras (:266), the worst camera's mean error per frame (:279), 5 x nanmedian of the
@@ -238,6 +213,36 @@ __device__ __forceinline__ void wave_pick_bin(const T* hist, unsigned long long 
   }
   digit = __shfl(d, src, 64);
   below = __shfl(bl, src, 64);
+}
+
+// one WAVEFRONT per state: which byte holds the wanted rank (wave_pick_bin: four bins per lane, a prefix scan across the lanes); upper == 0
+// selects rank (n-1)/2, upper == 1 rank n/2.  (Round 6: one thread walking the 256 bins with dependent global loads took 15 us per launch,
+// eight launches per median -- 120 us of the 216 us pairwise-median crossing of calibrate().)
+__global__ __launch_bounds__(64) void k_sel_pick(SelState* __restrict__ sts, int pass, int upper, int dual, int skey) {
+  SelState* st = sts + blockIdx.x;
+  const int lane = threadIdx.x;
+  if (dual) upper = blockIdx.x & 1;
+  unsigned long long mine = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) mine += st->hist[4 * lane + b];
+  unsigned long long total = mine;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off, 64);
+  unsigned long long r = pass == 0 ? (total ? (upper ? total / 2 : (total - 1) / 2) : 0) : st->rank;
+  unsigned digit;
+  unsigned long long below;
+  wave_pick_bin<256>(st->hist, r, lane, digit, below);
+  if (total == 0 || r >= total) { digit = 0; below = 0; }   // (an empty group: the value is never used -- count 0 makes the caller report NaN)
+  const unsigned long long prefix = ((pass == 0 ? 0ull : st->prefix) << 8) | (unsigned long long)digit;
+  __syncthreads();   // (every lane has read its bins and the old state)
+#pragma unroll
+  for (int b = 0; b < 4; ++b) st->hist[4 * lane + b] = 0;
+  if (lane == 0) {
+    if (pass == 0) st->count = total;
+    st->rank = r - below;
+    st->prefix = prefix;
+    if (pass == 7) st->value = skey ? ((prefix >> 63) ? (prefix & 0x7FFFFFFFFFFFFFFFull) : ~prefix) : prefix;   // (the key back to the value's bits)
+  }
 }
 
 // per frame: used (complete in >= 2 cameras, :266), complete in every camera, the worst camera's nan-mean error (np.nanmax, :279)

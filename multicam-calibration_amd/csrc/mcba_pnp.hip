@@ -30,16 +30,18 @@ struct Cam9 { double fx, fy, cx, cy, k1, k2, p1, p2, k3; };
 __device__ __forceinline__ Cam9 load_cam9(const double* __restrict__ p) { return Cam9{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]}; }
 
 // pixel -> undistorted normalised coordinates: OpenCV's undistortPoints iteration x <- (x_d - tangential(x)) / radial(x)
-__device__ __forceinline__ void undistort_norm(double u, double v, const Cam9& k, int iters, double& x, double& y) {
-  const double x0 = (u - k.cx) / k.fx, y0 = (v - k.cy) / k.fy;
+__device__ __forceinline__ void undistort_norm(double u, double v, const Cam9& k, double ifx, double ify, int iters, double& x, double& y) {
+  // (reciprocals by fast_rcp -- hardware estimate + one cubic step, 1.1e-16: a quarter of the instructions of the two IEEE divisions per round,
+  //  which were a fifth of this kernel's instruction stream; ifx / ify are the caller's 1 / fx, 1 / fy)
+  const double x0 = (u - k.cx) * ifx, y0 = (v - k.cy) * ify;
   x = x0; y = y0;
   for (int it = 0; it < iters; ++it) {
     const double s = x * x + y * y;
-    const double d = 1.0 + s * (k.k1 + s * (k.k2 + s * k.k3));
+    const double id = fast_rcp(1.0 + s * (k.k1 + s * (k.k2 + s * k.k3)));
     const double dx = 2.0 * k.p1 * x * y + k.p2 * (s + 2.0 * x * x);
     const double dy = k.p1 * (s + 2.0 * y * y) + 2.0 * k.p2 * x * y;
-    x = (x0 - dx) / d;
-    y = (y0 - dy) / d;
+    x = (x0 - dx) * id;
+    y = (y0 - dy) * id;
   }
 }
 
@@ -173,28 +175,34 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
   const double2* op = a.obs_t + (size_t)c * N * Fpad + (DENSE ? (size_t)f : (size_t)(in_range ? f : 0));
   Cam9 cam{1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   if (MODE == MODE_POSE) cam = load_cam9(a.intr9 + 9 * c);
+  const double ifx = 1.0 / cam.fx, ify = 1.0 / cam.fy;
   auto image_point = [&](int p, double& x, double& y, bool& present) {
     const double2 o = op[(size_t)p * Fpad];
     present = o.x == o.x && o.y == o.y;
-    if (MODE == MODE_POSE) undistort_norm(o.x, o.y, cam, a.und_iters, x, y);
+    if (MODE == MODE_POSE) undistort_norm(o.x, o.y, cam, ifx, ify, a.und_iters, x, y);
     else { x = o.x; y = o.y; }
   };
 
-  // ---- pass 1 / 2: complete?  centroid and rms distance of the image points (Hartley)
+  // ---- pass 1: complete?  centroid and rms distance of the image points (Hartley) from ONE pass: sums of the coordinates relative to the
+  // first point (so that sum d^2 / N - |mean d|^2 cancels the spread against itself, not against the offset of the board in the image)
   bool complete = in_range;
-  double mx = 0.0, my = 0.0;
-  for (int p = 0; p < N; ++p) {
-    double x, y; bool pr;
-    image_point(p, x, y, pr);
-    complete = complete && pr;
-    mx += x; my += y;
-  }
-  mx /= N; my /= N;
-  double ms = 0.0;
-  for (int p = 0; p < N; ++p) {
-    double x, y; bool pr;
-    image_point(p, x, y, pr);
-    ms += (x - mx) * (x - mx) + (y - my) * (y - my);
+  double mx, my, ms;
+  {
+    double x0, y0; bool pr0;
+    image_point(0, x0, y0, pr0);
+    complete = complete && pr0;
+    double sx = 0.0, sy = 0.0, sq = 0.0;
+    for (int p = 1; p < N; ++p) {
+      double x, y; bool pr;
+      image_point(p, x, y, pr);
+      complete = complete && pr;
+      const double dx = x - x0, dy = y - y0;
+      sx += dx; sy += dy;
+      sq = fma(dx, dx, fma(dy, dy, sq));
+    }
+    const double inv_n = 1.0 / N, ax = sx * inv_n, ay = sy * inv_n;
+    mx = x0 + ax; my = y0 + ay;
+    ms = sq - N * (ax * ax + ay * ay);   // = sum |p - mean|^2
   }
   const double ss = complete && ms > 0.0 ? sqrt(2.0) / sqrt(ms / N) : 1.0;
   if (!complete) { mx = 0.0; my = 0.0; }
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
       double Xc[3];
       mv3(pl.R, Xo, Xc);
       Xc[0] += pl.t[0]; Xc[1] += pl.t[1]; Xc[2] += pl.t[2];
-      const double iz = 1.0 / Xc[2];
+      const double iz = fast_rcp(Xc[2]);
       const double x = Xc[0] * iz, y = Xc[1] * iz;
       const double r2 = x * x + y * y;
       const double rad = 1.0 + r2 * (cam.k1 + r2 * (cam.k2 + r2 * cam.k3));

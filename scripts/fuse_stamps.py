@@ -1,5 +1,7 @@
 """Wall-clock stamps of k_solve_backsub (development aid; build with MCBA_HIPCC_FLAGS=-DMCBA_FUSE_TIMING): the solve workgroup
-and back-substitution workgroup 1, 10 ns ticks.   usage: [MCBA_LIB=lib.so] python scripts/fuse_stamps.py"""
+and back-substitution workgroup 1, 10 ns ticks.   usage: [MCBA_LIB=lib.so] python scripts/fuse_stamps.py
+Round 6: the stamps (and the mcba_debug_* export this script reads) live in profiles/round6/patches/experiments_and_stamps.patch, not in the product sources:
+`cd multicam-calibration_amd && git apply -p0 ../profiles/round6/patches/experiments_and_stamps.patch` first."""
 import ctypes
 import os
 import sys

@@ -1,5 +1,7 @@
 """Per-wavefront stamps of k_gram (development aid; needs a build with MCBA_HIPCC_FLAGS=-DMCBA_GRAM_TIMING).
-usage: python scripts/gram_stamps.py [lib.so] [C,F,rows,cols]      (MCBA_GRAM_SPLIT / MCBA_GRAM_NPW select the variant)"""
+usage: python scripts/gram_stamps.py [lib.so] [C,F,rows,cols]      (MCBA_GRAM_SPLIT / MCBA_GRAM_NPW select the variant)
+Round 6: the stamps (and the mcba_debug_* export this script reads) live in profiles/round6/patches/experiments_and_stamps.patch, not in the product sources:
+`cd multicam-calibration_amd && git apply -p0 ../profiles/round6/patches/experiments_and_stamps.patch` first."""
 import ctypes
 import os
 import sys

@@ -1,7 +1,9 @@
 """k_solve_cam phase stamps (build with MCBA_HIPCC_FLAGS=-DMCBA_SOLVE_TIMING) and launch time.
 usage: python scripts/solve_time.py [cameras[:6] ...]      (MCBA_LIB = an alternative build; ":6" = the 6-wide camera block)
 Beyond 9 cameras (right-looking variant) the stamps of slots 27 / 29 / 30 are the backward sweep and intervals A / B of block step
-k = launch number - 1: MCBA_SOLVE_LAUNCHES=N prints them for the first N - 1 launches."""
+k = launch number - 1: MCBA_SOLVE_LAUNCHES=N prints them for the first N - 1 launches.
+Round 6: the stamps (and the mcba_debug_* export this script reads) live in profiles/round6/patches/experiments_and_stamps.patch, not in the product sources:
+`cd multicam-calibration_amd && git apply -p0 ../profiles/round6/patches/experiments_and_stamps.patch` first."""
 import sys
 import time
 

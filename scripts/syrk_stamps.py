@@ -1,5 +1,7 @@
 """Per-workgroup stamps of k_syrk inside the device-resident LM loop (development aid; needs a build with
-MCBA_HIPCC_FLAGS=-DMCBA_SYRK_TIMING).   usage: [MCBA_SHAPE=C,F,rows,cols] python scripts/syrk_stamps.py [lib.so]"""
+MCBA_HIPCC_FLAGS=-DMCBA_SYRK_TIMING).   usage: [MCBA_SHAPE=C,F,rows,cols] python scripts/syrk_stamps.py [lib.so]
+Round 6: the stamps (and the mcba_debug_* export this script reads) live in profiles/round6/patches/experiments_and_stamps.patch, not in the product sources:
+`cd multicam-calibration_amd && git apply -p0 ../profiles/round6/patches/experiments_and_stamps.patch` first."""
 import ctypes
 import os
 import sys
