@@ -23,9 +23,15 @@ the observations (k_gram; its cost decides accept/reject), trial sums + decision
 k_reduce_system, [all-reduce], the (12C)^2 reduced camera solve (k_solve_cam).  Every step linearises its trial
 point, accepted or not (never less work than a real iteration).
 
+`value` is the MEDIAN of `--windows` (default 5) timed regions of exactly `--steps` steps each -- every region bracketed by barrier +
+synchronize on both sides and reduced by MAX over the ranks; all of them are printed (`value_windows`).
+
 Extra objects on the same line: `roofline` (dominant kernel of the timed region, HIP-event timed on the launch stream;
 `bound` names the binding roof), `jacobian_eval` (BASELINE's second figure: ms per materialised Jacobian-eval, with its own
-HBM roofline), `cpu_baseline` (the oracle's scipy path on a bounded sample of the same workload, rank 0 at N = 1 only).
+HBM roofline), `cpu_baseline` (the oracle's scipy path on a bounded sample of the same workload, rank 0 at N = 1 only), `configs` (all
+five BASELINE configs, per iteration), `end_to_end` / `end_to_end_other_shapes` (wall time of the calls users make: `bundle_adjust()`,
+`calibrate()` -- the call that produces its inputs --, the pipeline of the two, the off-default solver paths), `strict_sync` (what the
+relaxed reader of the solve's release word would save against the acquiring one that is the default).
 """
 import argparse
 import json
