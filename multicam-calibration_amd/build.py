@@ -9,7 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmcba.so")
 SOURCES = ["mcba_kernels.hip", "mcba_solve.hip", "mcba_triangulate.hip", "mcba_diag.hip", "mcba_calib.hip", "mcba_pnp.hip", "mcba_api.hip"]
-DEPS = SOURCES + ["mcba_gram_finish.inc", "mcba_math.h", "mcba_device.h", "mcba_backsub.h", "mcba_kernels.h", "mcba_lm.h", "mcba_lm_state.h", os.path.join("..", "..", "include", "mcba.h")]
+DEPS = SOURCES + ["mcba_gram_finish.inc", "mcba_math.h", "mcba_pnp_math.h", "mcba_device.h", "mcba_backsub.h", "mcba_kernels.h", "mcba_lm.h", "mcba_lm_state.h", os.path.join("..", "..", "include", "mcba.h")]
 
 
 # Register-pressure-bound kernels (k_gram keeps 87 FP64 accumulators per lane): LLVM's "unclustered high register pressure"

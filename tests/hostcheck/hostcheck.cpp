@@ -1,11 +1,12 @@
 // Host-side unit harness for csrc/mcba_math.h -- TEST INFRASTRUCTURE ONLY.
 // Compiles the device math header with g++ and walks it over a small problem on the CPU so the
-// algebra (local Gram matrix + chain-rule expansion, Jacobian rows, robust weights, 6x6 solves) and the LM accept /
-// reject decision of csrc/mcba_lm.h
+// algebra (local Gram matrix + chain-rule expansion, Jacobian rows, robust weights, 6x6 solves), the LM accept /
+// reject decision of csrc/mcba_lm.h and (round 6) the per-view arithmetic of calibrate()'s kernels, csrc/mcba_pnp_math.h,
 // can be checked against oracle/ba_oracle.py in the GPU-less build container.
 // It is never loaded by the product (multicam-calibration_amd/ops.py loads libmcba.so only).
 #include "../../multicam-calibration_amd/csrc/mcba_math.h"
 #include "../../multicam-calibration_amd/csrc/mcba_lm.h"
+#include "../../multicam-calibration_amd/csrc/mcba_pnp_math.h"
 #include <cstring>
 
 using namespace mcba;
@@ -130,4 +131,70 @@ void hc_lm_decide(double* lms, const double* trial8, double lam_min, double lam_
   using std::isfinite;
   lm_decide(trial8, DecideArgs{2, 0.0, 0.0, 0.0, lam_min, lam_max, lms, ftol, xtol, dec_floor});
 }
+
+// ---- calibrate()'s per-view arithmetic (csrc/mcba_pnp_math.h, the text k_pnp is made of), one view at a time, as one GPU lane runs it
+// (the kernel's wave-uniform loops "until no lane is left" become plain loops here)
+static void board_norm(const double* obj, int N, double* bn) {   // mcba_api.hip: board_normalisation
+  bn[0] = bn[1] = 0.0; bn[2] = 1.0;
+  for (int p = 0; p < N; ++p) { bn[0] += obj[3 * p]; bn[1] += obj[3 * p + 1]; }
+  bn[0] /= N; bn[1] /= N;
+  double ms = 0.0;
+  for (int p = 0; p < N; ++p) ms += (obj[3 * p] - bn[0]) * (obj[3 * p] - bn[0]) + (obj[3 * p + 1] - bn[1]) * (obj[3 * p + 1] - bn[1]);
+  if (ms > 0.0) bn[2] = sqrt(2.0) / sqrt(ms / N);
+}
+// uv (N,2) detections of one view; intr9 NULL: the homography of the pixel coordinates (cv2.calibrateCamera's start), else of the undistorted
+// normalised ones (cv2.solvePnP's).  H (9) out; returns 1 if the view is complete and H finite.
+int hc_view_homography(int N, const double* uv, const double* obj, const double* intr9, int und_iters, double* H) {
+  Cam9 cam{1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (intr9) cam = load_cam9(intr9);
+  const double ifx = 1.0 / cam.fx, ify = 1.0 / cam.fy;
+  auto image_point = [&](int p, double& x, double& y, bool& present) {
+    const double u = uv[2 * p], v = uv[2 * p + 1];
+    present = u == u && v == v;
+    if (intr9) undistort_norm(u, v, cam, ifx, ify, und_iters, x, y);
+    else { x = u; y = v; }
+  };
+  double bn[3];
+  board_norm(obj, N, bn);
+  bool complete;
+  double mx, my, ss;
+  view_normalisation(image_point, N, true, complete, mx, my, ss);
+  DltFactor dlt;
+  view_dlt_factor(image_point, obj, N, bn[0], bn[1], bn[2], complete, mx, my, ss, dlt);
+  double h[9];
+  dlt_start_vector(h);
+  for (int it = 0; it < 60; ++it) {
+    const double diff = dlt_inverse_iteration(dlt, h);
+    if (!(complete && !(diff <= 4e-16))) break;
+  }
+  homography_denormalise(h, bn[0], bn[1], bn[2], mx, my, ss, H);
+  bool ok = complete;
+  for (int i = 0; i < 9; ++i) ok = ok && pnp_finite(H[i]);
+  return ok ? 1 : 0;
+}
+// cv2.solvePnP's job for one view: start (6) = the pose from the homography, pose (6) = after at most max_evals linearisations; returns the
+// number of linearisations, 0 if the view is incomplete, -1 if no pose came out
+int hc_view_pose(int N, const double* uv, const double* obj, const double* intr9, int und_iters, int max_evals, double* start, double* pose, double* cost) {
+  double H[9];
+  const int complete = hc_view_homography(N, uv, obj, intr9, und_iters, H);
+  pose_from_homography(H, start);
+  const Cam9 cam = load_cam9(intr9);
+  ViewLM lm;
+  view_lm_init(lm, start, complete != 0);
+  auto observation = [&](int p, double& u, double& v) { u = uv[2 * p]; v = uv[2 * p + 1]; };
+  for (int it = 0; it < max_evals; ++it) {
+    double Hn[21], gn[6], cn;
+    view_linearise(lm.trial, cam, obj, N, observation, complete != 0, Hn, gn, cn);
+    view_lm_decide(lm, Hn, gn, cn);
+    if (lm.done) break;
+    view_lm_step(lm);
+  }
+  bool ok = complete && !lm.failed;
+  for (int i = 0; i < 6; ++i) { pose[i] = lm.pose[i]; ok = ok && pnp_finite(lm.pose[i]); }
+  *cost = lm.cost;
+  if (!complete) return 0;
+  return ok ? lm.evals : -1;
+}
+// rotation matrix -> rotation vector as the pose-graph kernels compute it (clamped arccos)
+void hc_rotvec(const double* R, double* w) { rotvec_from_matrix(R, w); }
 }

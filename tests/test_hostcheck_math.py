@@ -22,7 +22,7 @@ def P(a):
 def hc():
     src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
     lib = os.path.join(HERE, "hostcheck", "libhostcheck.so")
-    hdrs = [os.path.join(HERE, "..", "multicam-calibration_amd", "csrc", h) for h in ("mcba_math.h", "mcba_lm.h", "mcba_lm_state.h")]
+    hdrs = [os.path.join(HERE, "..", "multicam-calibration_amd", "csrc", h) for h in ("mcba_math.h", "mcba_lm.h", "mcba_lm_state.h", "mcba_pnp_math.h")]
     flags = ["-O2"]
     if os.environ.get("MCBA_HOSTCHECK_SANITIZE") == "1":   # the run test_hostcheck_under_sanitizers starts: AddressSanitizer + UBSan build of the same text
         lib = os.path.join(HERE, "hostcheck", "libhostcheck_san.so")
@@ -123,6 +123,82 @@ def test_chol6(hc):
     ok = hc.hc_chol_solve(P(V[np.triu_indices(6)].copy()), P(b), P(x))
     assert ok == 1
     np.testing.assert_allclose(x, np.linalg.solve(V, b), rtol=1e-11)
+
+
+# ---- calibrate()'s per-view arithmetic (csrc/mcba_pnp_math.h: the text of k_pnp) against oracle/calibration_oracle.py, on the CPU
+def _pnp_views(seed, noise, n_views=14):
+    p = synth.make_problem(2, n_views, seed=seed, noise=noise)
+    cam = p["true_cam"][1]
+    return p["obj"], p["uvs"][1], np.r_[cam[:6], 0.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.2, 3.0])
+def test_view_homography_is_the_numpy_dlt(hc, noise):
+    """One lane's homography (Hartley-normalised DLT; smallest eigenvector of the 9 x 9 normal matrix by inverse iteration on a block Cholesky
+    factor) = numpy's SVD null vector to 1e-9, in pixel coordinates (cv2.calibrateCamera's start) and in undistorted normalised ones
+    (cv2.solvePnP's); an incomplete view is reported as such."""
+    from oracle import calibration_oracle as co
+
+    obj, uvs, intr9 = _pnp_views(80, noise)
+    K = np.array([[intr9[0], 0, intr9[2]], [0, intr9[1], intr9[3]], [0, 0, 1.0]])
+    hc.hc_view_homography.restype = ctypes.c_int
+    for v, uv in enumerate(uvs):
+        H = np.zeros(9)
+        assert hc.hc_view_homography(len(obj), P(np.ascontiguousarray(uv)), P(obj), None, 0, P(H)) == 1
+        want = co.homographies(obj[:, :2], uv[None])[0].ravel()
+        assert (np.abs(H - want) / np.maximum(1.0, np.abs(want))).max() < 1e-9 and H[8] == 1.0, v
+        assert hc.hc_view_homography(len(obj), P(np.ascontiguousarray(uv)), P(obj), P(intr9), 8, P(H)) == 1
+        want = co.homographies(obj[:, :2], co.undistort_normalized(uv[None], K, intr9[4:]))[0].ravel()
+        assert (np.abs(H - want) / np.maximum(1.0, np.abs(want))).max() < 1e-9, v
+    gone = uvs[0].copy()
+    gone[7, 1] = np.nan
+    assert hc.hc_view_homography(len(obj), P(gone), P(obj), None, 0, P(np.zeros(9))) == 0
+
+
+@pytest.mark.parametrize("five", [False, True])
+def test_view_pose_is_the_reprojection_minimiser(hc, five):
+    """One lane's cv2.solvePnP: the start = numpy's pose from the homography (polar factor by SVD, the reference's rodrigues_inv) to 1e-8, the
+    result = scipy's minimiser of the pixel reprojection error to 1e-9 in cost (two- and five-coefficient intrinsics), the truth on noise-free
+    detections, a handful of linearisations."""
+    from oracle import calibration_oracle as co
+
+    hc.hc_view_pose.restype = ctypes.c_int
+    intr_extra = np.array([1.5e-3, -8e-4, -0.03]) if five else np.zeros(3)
+    rng = np.random.default_rng(3)
+    obj = synth.board_points()
+    intr9 = np.r_[1180.0, 1170.0, 650.0, 505.0, -0.09, 0.03, intr_extra]
+    K = np.array([[intr9[0], 0, intr9[2]], [0, intr9[1], intr9[3]], [0, 0, 1.0]])
+    for v in range(12):
+        pose_true = np.r_[rng.normal(0, 0.4, 3), rng.normal(0, 40, 2) - 40.0, rng.uniform(450, 800)]
+        for noise in (0.0, 0.3):
+            uv = co.project5(obj, pose_true, intr9) + rng.normal(0, noise, (len(obj), 2))
+            start, pose, cost = np.zeros(6), np.zeros(6), np.zeros(1)
+            n = hc.hc_view_pose(len(obj), P(np.ascontiguousarray(uv)), P(obj), P(intr9), 8, 60, P(start), P(pose), P(cost))
+            assert 1 <= n <= 25, (v, noise, n)   # (noise-free: the homography start IS the minimiser -- one linearisation sees a zero gradient)
+            want0 = co.poses_from_homographies(co.homographies(obj[:, :2], co.undistort_normalized(uv[None], K, intr9[4:])), np.eye(3))[0]
+            np.testing.assert_allclose(start, want0, rtol=0, atol=1e-8 * max(1.0, np.abs(want0).max()))
+            mine = 0.5 * np.sum((uv - co.project5(obj, pose, intr9)) ** 2)
+            assert abs(mine - cost[0]) <= 1e-9 * max(mine, 1e-20) + 1e-22
+            if noise == 0.0:
+                assert np.abs(co.project5(obj, pose, intr9) - uv).max() < 1e-8
+            else:
+                _, c_ref = co.solve_pnp(uv, obj, intr9, want0)
+                assert abs(mine - c_ref) <= 1e-9 * c_ref, (v, mine, c_ref)
+    # an incomplete view: no pose is attempted
+    uv[3, 0] = np.nan
+    assert hc.hc_view_pose(len(obj), P(np.ascontiguousarray(uv)), P(obj), P(intr9), 8, 60, P(np.zeros(6)), P(np.zeros(6)), P(np.zeros(1))) == 0
+
+
+def test_rotvec_from_matrix_is_the_references_formula(hc):
+    from oracle import calibration_oracle as co
+
+    rng = np.random.default_rng(4)
+    for r in np.r_[rng.normal(0, 1.0, (20, 3)), np.zeros((1, 3)), [[1e-9, 0, 0]]]:
+        R = np.ascontiguousarray(co.rodrigues(r))
+        w = np.zeros(3)
+        hc.hc_rotvec(P(R), P(w))
+        want = np.nan_to_num(co.rodrigues_inv(R))   # (the reference's arccos is unclamped: NaN when rounding pushes the trace past 3 -- the kernels clamp)
+        np.testing.assert_allclose(w, want, rtol=0, atol=1e-12)
 
 
 def test_hostcheck_under_sanitizers():
