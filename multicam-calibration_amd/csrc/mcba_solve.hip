@@ -330,20 +330,25 @@ __device__ __forceinline__ void solve_right_looking(const SolveArgs& a, const do
 #pragma unroll
       for (int c = 0; c < 16; ++c) r[c] = lane < 16 ? dtile[li * 17 + c] : ((lane < 32 && c == li) ? 1.0 : 0.0);
       double myinv = 1.0;
+      // (round 6) the block that holds the right-hand-side row is the last one: its rows from row n on are the right-hand side (not a pivot)
+      // and identity padding -- columns whose elimination step multiplies by 1 and subtracts 0.  The steps j >= n - r0 are skipped: exact
+      // (bit-identical), and they are the longest ones of the block (step j is j broadcasts + FMAs deep)
+      const int jmax = r0 + 16 <= n ? 16 : n - r0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        double s0 = 0.0, s1 = 0.0;
+        if (j < jmax) {   // (wave-uniform; a `break` here would keep the loop from unrolling and r[] from living in registers)
+          double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int qq = 0; qq < j; ++qq) {
-          const double ljq = lane_bcast(r[qq], j);
-          if (qq & 1) s1 = fma(r[qq], ljq, s1); else s0 = fma(r[qq], ljq, s0);
+          for (int qq = 0; qq < j; ++qq) {
+            const double ljq = lane_bcast(r[qq], j);
+            if (qq & 1) s1 = fma(r[qq], ljq, s1); else s0 = fma(r[qq], ljq, s0);
+          }
+          r[j] -= s0 + s1;
+          const double pj = lane_bcast(r[j], j);
+          const double inv = rsqrt_cubic(pj);
+          r[j] *= inv;
+          myinv = lane == j ? inv : myinv;
         }
-        r[j] -= s0 + s1;
-        double pj = lane_bcast(r[j], j);
-        if (r0 + j == n) pj = 1.0;  // right-hand-side row: not a pivot
-        const double inv = rsqrt_cubic(pj);
-        r[j] *= inv;
-        myinv = lane == j ? inv : myinv;
       }
       if (lane < 16) {
         invd[r0 + lane] = myinv;
@@ -783,6 +788,11 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
           }
         }
         double myinv = 1.0;
+        // (round 6) the block that holds the right-hand-side row is the last one: from row n on its rows are the right-hand side (not a pivot)
+        // and identity padding -- elimination steps that multiply by 1 and subtract 0.  They are skipped: exact (bit-identical), and they are
+        // the longest steps of the block (step j is j broadcasts + FMAs deep): 4 of 16 steps remain at 6 cameras with the intrinsics fixed
+        // (n = 36), 8 of 16 at 2 and at 6 cameras with every parameter free (n = 24, 72)
+        const int jmax = r0 + 16 <= n ? 16 : n - r0;
         // left-looking: column j of every row is finished at step j; L[r0+j][q'] (q' < j) is lane j's finished r[q'].
         // A non-positive pivot turns into NaN / inf here and surfaces as a non-finite step below.
         // (Round 3, measured and withdrawn: lane j carrying its pivot-to-be a_jj - sum L[j][q]^2 as a running accumulator, so that
@@ -790,18 +800,19 @@ __device__ __forceinline__ void solve_cam_body(const SolveArgs& a) {
         // the stream is bound by its 616 instructions per block, 240 of them v_readlane, not by the chain.)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          double s0 = 0.0, s1 = 0.0;
+          if (j < jmax) {   // (wave-uniform; a `break` here would keep the loop from unrolling and r[] from living in registers)
+            double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-          for (int qq = 0; qq < j; ++qq) {
-            const double ljq = lane_bcast(r[qq], j);
-            if (qq & 1) s1 = fma(r[qq], ljq, s1); else s0 = fma(r[qq], ljq, s0);
+            for (int qq = 0; qq < j; ++qq) {
+              const double ljq = lane_bcast(r[qq], j);
+              if (qq & 1) s1 = fma(r[qq], ljq, s1); else s0 = fma(r[qq], ljq, s0);
+            }
+            r[j] -= s0 + s1;
+            const double pj = lane_bcast(r[j], j);
+            const double inv = rsqrt_cubic(pj);
+            r[j] *= inv;
+            myinv = lane == j ? inv : myinv;
           }
-          r[j] -= s0 + s1;
-          double pj = lane_bcast(r[j], j);
-          if (r0 + j == n) pj = 1.0;  // right-hand-side row: not a pivot
-          const double inv = rsqrt_cubic(pj);
-          r[j] *= inv;
-          myinv = lane == j ? inv : myinv;
         }
         if (rv && (lane >= 16 || wave == 0)) {
           double* wr = W + (size_t)(r0 + q) * ldw + r0;
