@@ -445,3 +445,39 @@ def test_calibrate_edge_cases(mc):
 
     with pytest.raises(NotImplementedError):
         mc.calibrate(p["uvs"], [(1280, 1024)], p["obj"] + np.array([0, 0, 1.0]) * np.arange(54)[:, None], verbose=False)
+
+
+def test_calibrate_entry_points_refuse_bad_arguments(mc):
+    """The C ABI's argument checks (int status + mcba_last_error, never a fault): views out of range, the pose graph before any poses exist,
+    a camera pair out of range, a non-planar board, a handle without observations."""
+    p = mc.synth.make_problem(2, 20, seed=75)
+    prob = mc.ops.Problem(p["uvs"], p["obj"], loss="linear")
+    for bad in ([[2, 0]], [[0, 20]], [[-1, 3]]):
+        with pytest.raises(mc.ops.McbaError, match="out of range"):
+            prob.calib_homographies(bad)
+        with pytest.raises(mc.ops.McbaError, match="out of range"):
+            prob.calib_view_poses(bad, np.ones((2, 9)))
+    with pytest.raises(mc.ops.McbaError, match="mcba_calib_poses first"):
+        prob.calib_pairwise([(0, 1)])
+    with pytest.raises(mc.ops.McbaError, match="mcba_calib_poses first"):
+        prob.calib_consensus(np.zeros((2, 6)))
+    intr9 = np.c_[p["true_cam"][:, :6], np.zeros((2, 3))]
+    prob.calib_poses(intr9)
+    with pytest.raises(mc.ops.McbaError, match="out of range"):
+        prob.calib_pairwise([(0, 2)])
+    prob.trim()   # the poses go with the other lazily allocated buffers: the graph calls say so instead of reading freed memory
+    with pytest.raises(mc.ops.McbaError, match="mcba_calib_poses first"):
+        prob.calib_pairwise([(0, 1)])
+    prob.close()
+    bent = p["obj"].copy()
+    bent[5, 2] = 1.0
+    q = mc.ops.Problem(p["uvs"], bent, loss="linear")
+    with pytest.raises(mc.ops.McbaError, match="planar"):
+        q.calib_complete()
+    q.close()
+    empty = mc.ops.Problem(p["uvs"], p["obj"], loss="linear", upload=False)
+    with pytest.raises(mc.ops.McbaError, match="upload observations first"):
+        empty.calib_complete()
+    empty.close()
+    with pytest.raises(mc.ops.McbaError):
+        mc.ops.pose_pairwise(np.zeros((2, 5, 6)), [(0, 3)])
