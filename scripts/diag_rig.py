@@ -1,0 +1,32 @@
+"""Diagnostic: one randomised rig of tests/test_gpu_calibration.py::test_calibrate_random_rigs, the per-view pose kernel's exits written out."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import multicam_calibration_amd as mc
+from multicam_calibration_amd import ops, calibration as cal
+from oracle import calibration_oracle as co
+from test_gpu_calibration import _draw_rig
+
+for it in [int(a) for a in sys.argv[1:]]:
+    mk, root, ns = _draw_rig(it)
+    p = mc.synth.make_problem(**mk)
+    C = p["uvs"].shape[0]
+    np.random.seed(it)
+    ext, intr, poses, tree = mc.calibrate(p["uvs"], [(1280, 1024)] * C, p["obj"], root=root, verbose=False, n_samples_for_intrinsics=ns)
+    out = {}
+    for c in range(C):
+        K, d = intr[c]
+        k9 = np.r_[K[0, 0], K[1, 1], K[0, 2], K[1, 2], d]
+        print(it, "camera", c, "intrinsics", k9[:6], "truth", p["intrinsics"][c][0][[0, 1, 0, 1], [0, 1, 2, 2]], p["intrinsics"][c][1][:2])
+        complete = ~np.isnan(p["uvs"][c]).any((1, 2))
+        got = mc.estimate_pose(p["uvs"][c], p["obj"], K, d)
+        for f in np.flatnonzero(complete):
+            x_ref, c_ref = co.solve_pnp(p["uvs"][c, f], p["obj"], k9, got[f])
+            mine = 0.5 * np.sum((p["uvs"][c, f] - co.project5(p["obj"], got[f], k9)) ** 2)
+            if abs(mine - c_ref) > 1e-8 * c_ref:
+                print("   view", f, "mine", mine, "scipy from mine", c_ref, "pose", got[f], "scipy", x_ref)
+                out[f"{it}_{c}_{f}"] = np.r_[k9, got[f], x_ref, mine, c_ref]
+                out[f"{it}_{c}_{f}_uv"] = p["uvs"][c, f]
+                out[f"{it}_obj"] = p["obj"]
+    np.savez(f"gpurun_out/diag_rig_{it}.npz", **out)
