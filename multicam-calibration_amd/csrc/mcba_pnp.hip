@@ -18,6 +18,9 @@
 // FP64 throughout.  Nothing here is in the LM loop of bundle_adjust(); it is the initialiser that produces its inputs.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
+#include "mcba_device.h"
 #include "mcba_kernels.h"
 #include "mcba_math.h"
 #include "mcba_pnp_math.h"   // the per-view arithmetic (shared with the host harness tests/hostcheck/hostcheck.cpp)
@@ -42,16 +45,37 @@ struct PnpArgs {
   unsigned char* nit;       // LM evaluations the view took (diagnostics), same indexing, or nullptr
 };
 
-template <int MODE, bool DENSE>
+// a view's points dealt out to four neighbouring lanes (mcba_pnp_math.h: WholeView is the one-lane form): partial sums meet by two quad_perm
+// DPP steps, after which the four lanes hold the same bits.  Every loop of k_pnp is wave-uniform, so the four lanes are always active together.
+struct QuadView {
+  static constexpr int parts = 4;
+  int lane;
+  __device__ __forceinline__ int part() const { return lane & 3; }
+  __device__ __forceinline__ double sum(double v) const {
+    v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    return dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  }
+  __device__ __forceinline__ bool all(bool b) const { return ((__ballot(b) >> (lane & ~3)) & 0xFull) == 0xFull; }
+};
+template <int PARTS> struct ViewSplit;
+template <> struct ViewSplit<1> { using type = WholeView; __device__ static WholeView make(int) { return WholeView{}; } };
+template <> struct ViewSplit<4> { using type = QuadView; __device__ static QuadView make(int lane) { return QuadView{lane}; } };
+
+// PARTS = lanes per view (1 or 4): 64 / PARTS views per wavefront.  The per-view dependent chain is what a launch takes, and the point loops are
+// nine tenths of it: four lanes per view cut them in four (which form runs: pnp_lanes_per_view below).
+template <int MODE, bool DENSE, int PARTS>
 __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
+  constexpr int VPW = 64 / PARTS;
   const int lane = threadIdx.x;
+  const auto split = ViewSplit<PARTS>::make(lane);
+  const bool writer = lane % PARTS == 0;
   int c, f, vi;
   bool in_range;
   if (DENSE) {
-    c = blockIdx.y; f = blockIdx.x * 64 + lane; vi = 0;
+    c = blockIdx.y; f = blockIdx.x * VPW + lane / PARTS; vi = 0;
     in_range = f < a.F;
   } else {
-    vi = blockIdx.x * 64 + lane;
+    vi = blockIdx.x * VPW + lane / PARTS;
     in_range = vi < a.nviews;
     c = in_range ? a.views[2 * vi] : 0;
     f = in_range ? a.views[2 * vi + 1] : 0;
@@ -71,9 +95,9 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
   // ---- pass 1: complete?  Hartley normalisation of the image points;  pass 2: the DLT's normal matrix and its block Cholesky factor
   bool complete;
   double mx, my, ss;
-  view_normalisation(image_point, N, in_range, complete, mx, my, ss);
+  view_normalisation(image_point, N, in_range, split, complete, mx, my, ss);
   DltFactor dlt;
-  view_dlt_factor(image_point, a.obj, N, a.bmx, a.bmy, a.bs, complete, mx, my, ss, dlt);
+  view_dlt_factor(image_point, a.obj, N, a.bmx, a.bmy, a.bs, complete, mx, my, ss, split, dlt);
   // inverse iteration for the smallest eigenvector, until no lane of the wavefront moves any more
   double h[9];
   dlt_start_vector(h);
@@ -89,7 +113,7 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
     bool ok = complete;
 #pragma unroll
     for (int i = 0; i < 9; ++i) ok = ok && pnp_finite(H[i]);
-    if (in_range) {
+    if (in_range && writer) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) a.out[(size_t)vi * 9 + i] = ok ? H[i] : nan;
       if (a.valid) a.valid[vi] = ok ? 1 : 0;
@@ -108,7 +132,7 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
   };
   for (int it = 0; it < a.lm_iters; ++it) {
     double Hn[21], gn[6], cn;
-    view_linearise(lm.trial, cam, a.obj, N, observation, complete, Hn, gn, cn);
+    view_linearise(lm.trial, cam, a.obj, N, observation, complete, split, Hn, gn, cn);
     view_lm_decide(lm, Hn, gn, cn);
     if (!__any(!lm.done)) break;
     view_lm_step(lm);
@@ -121,6 +145,7 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
   bool ok = complete && !failed;
 #pragma unroll
   for (int i = 0; i < 6; ++i) ok = ok && pnp_finite(pose[i]);
+  if (!writer) return;
   if (!in_range) {
     if (DENSE && a.poses_t && f < a.Fpad) {
 #pragma unroll
@@ -247,6 +272,17 @@ void launch_view_complete(hipStream_t st, const double* obs_t, unsigned char* ou
   k_view_complete<<<dim3((F + 255) / 256, C), dim3(256), 0, st>>>(reinterpret_cast<const double2*>(obs_t), out, C, F, N, Fpad);
 }
 
+// Lanes per view.  Measured on one box (profiles/round6/NOTES_round6.md 1.2): four lanes win wherever the serial chain per view counts -- 0.67 ->
+// 0.32 ms for the tutorial's 12 780 views, 2.11 -> 1.77 ms at 240 000 views of 54 points -- and lose where the launch is a stream of point
+// loops over more data than the caches hold (300 000 views of 200 points: 5.0 -> 6.3 ms; a quad's loads are 256-byte pieces of four rows).
+// MCBA_PNP_LANES = 1 | 4 overrides (read per launch: the tests run both forms in one process).
+int pnp_lanes_per_view(long views, int N) {
+  const char* e = getenv("MCBA_PNP_LANES");
+  const int forced = e ? atoi(e) : 0;
+  if (forced == 1 || forced == 4) return forced;
+  return (double)views * N <= 2.4e7 ? 4 : 1;
+}
+
 void launch_pnp(hipStream_t st, int mode, const double* obs_t, const double* obj, const double* intr9, const int* views, int nviews, const double* bn3, int C, int F, int N, int Fpad, int und_iters, int lm_iters,
                 double* out, double* poses_t, unsigned char* valid, unsigned char* nit) {
   PnpArgs a;
@@ -254,13 +290,20 @@ void launch_pnp(hipStream_t st, int mode, const double* obs_t, const double* obj
   a.bmx = bn3[0]; a.bmy = bn3[1]; a.bs = bn3[2];
   a.nviews = nviews; a.C = C; a.F = F; a.N = N; a.Fpad = Fpad; a.und_iters = und_iters; a.lm_iters = lm_iters;
   a.out = out; a.poses_t = poses_t; a.valid = valid; a.nit = nit;
+  const long total = views ? (long)nviews : (long)C * F;
+  const bool quad = pnp_lanes_per_view(total, N) == 4;
   if (views) {
-    const dim3 grid((nviews + 63) / 64);
-    if (mode == MODE_HOMOGRAPHY) k_pnp<MODE_HOMOGRAPHY, false><<<grid, dim3(64), 0, st>>>(a);
-    else k_pnp<MODE_POSE, false><<<grid, dim3(64), 0, st>>>(a);
+    const dim3 grid1((nviews + 63) / 64), grid4((nviews + 15) / 16);
+    if (mode == MODE_HOMOGRAPHY) {
+      if (quad) k_pnp<MODE_HOMOGRAPHY, false, 4><<<grid4, dim3(64), 0, st>>>(a);
+      else k_pnp<MODE_HOMOGRAPHY, false, 1><<<grid1, dim3(64), 0, st>>>(a);
+    } else {
+      if (quad) k_pnp<MODE_POSE, false, 4><<<grid4, dim3(64), 0, st>>>(a);
+      else k_pnp<MODE_POSE, false, 1><<<grid1, dim3(64), 0, st>>>(a);
+    }
   } else {
-    const dim3 grid(Fpad / 64, C);
-    k_pnp<MODE_POSE, true><<<grid, dim3(64), 0, st>>>(a);
+    if (quad) k_pnp<MODE_POSE, true, 4><<<dim3(Fpad / 16, C), dim3(64), 0, st>>>(a);
+    else k_pnp<MODE_POSE, true, 1><<<dim3(Fpad / 64, C), dim3(64), 0, st>>>(a);
   }
 }
 

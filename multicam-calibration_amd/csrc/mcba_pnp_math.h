@@ -125,17 +125,27 @@ MCBA_HD void make_pose_lin(const double* pose, PoseLin& pl) {
 }
 
 
+// ---- how a view's points are dealt out.  WholeView: one lane (or the host's plain loop) walks all N points.  The kernel's QuadView
+// (csrc/mcba_pnp.hip) gives the points p = part, part + 4, ... to four neighbouring lanes and adds the partial sums up with two DPP steps, after
+// which the four lanes hold bit-identical totals and run the serial arithmetic (factorisations, the LM decision) redundantly and in step.
+struct WholeView {
+  static constexpr int parts = 1;
+  MCBA_HD int part() const { return 0; }
+  MCBA_HD double sum(double v) const { return v; }
+  MCBA_HD bool all(bool b) const { return b; }
+};
+
 // ---- Hartley normalisation of a view's image points from ONE pass: sums of the coordinates relative to the first point (so that
 // sum d^2 / N - |mean d|^2 cancels the spread against itself, not against the offset of the board in the image).  image_point(p, x, y, present)
 // hands out point p (undistorted normalised coordinates, or pixels).  Out: complete (every scalar present), centroid, sqrt(2) / rms distance.
-template <class Fetch>
-MCBA_HD void view_normalisation(Fetch& image_point, int N, bool in_range, bool& complete, double& mx, double& my, double& ss) {
+template <class Fetch, class Split>
+MCBA_HD void view_normalisation(Fetch& image_point, int N, bool in_range, const Split& sp, bool& complete, double& mx, double& my, double& ss) {
   complete = in_range;
   double x0, y0; bool pr0;
   image_point(0, x0, y0, pr0);
   complete = complete && pr0;
   double sx = 0.0, sy = 0.0, sq = 0.0;
-  for (int p = 1; p < N; ++p) {
+  for (int p = 1 + sp.part(); p < N; p += Split::parts) {
     double x, y; bool pr;
     image_point(p, x, y, pr);
     complete = complete && pr;
@@ -143,6 +153,8 @@ MCBA_HD void view_normalisation(Fetch& image_point, int N, bool in_range, bool& 
     sx += dx; sy += dy;
     sq = fma(dx, dx, fma(dy, dy, sq));
   }
+  complete = sp.all(complete);
+  sx = sp.sum(sx); sy = sp.sum(sy); sq = sp.sum(sq);
   const double inv_n = 1.0 / N, ax = sx * inv_n, ay = sy * inv_n;
   mx = x0 + ax; my = y0 + ay;
   const double ms = sq - N * (ax * ax + ay * ay);   // = sum |p - mean|^2
@@ -153,10 +165,11 @@ MCBA_HD void view_normalisation(Fetch& image_point, int N, bool in_range, bool& 
 // ---- the DLT: normal matrix of the rows [p 0 -u p], [0 p -v p] (p = (X, Y, 1) normalised; bn = the board's centroid and scale) as four
 // 3 x 3 blocks Spp, -Su, -Sv, Sw, and its block Cholesky factor  [[Spp, 0, -Su], [0, Spp, -Sv], [-Su, -Sv, Sw]] + eps I
 struct DltFactor { double L11[6], L31[9], L32[9], L33[6]; };
-template <class Fetch>
-MCBA_HD void view_dlt_factor(Fetch& image_point, const double* obj, int N, double bmx, double bmy, double bs, bool complete, double mx, double my, double ss, DltFactor& F) {
+template <class Fetch, class Split>
+MCBA_HD void view_dlt_factor(Fetch& image_point, const double* obj, int N, double bmx, double bmy, double bs, bool complete, double mx, double my, double ss, const Split& sp,
+                             DltFactor& F) {
   double Spp[6] = {0, 0, 0, 0, 0, 0}, Su[6] = {0, 0, 0, 0, 0, 0}, Sv[6] = {0, 0, 0, 0, 0, 0}, Sw[6] = {0, 0, 0, 0, 0, 0};
-  for (int p = 0; p < N; ++p) {
+  for (int p = sp.part(); p < N; p += Split::parts) {
     double x, y; bool pr;
     image_point(p, x, y, pr);
     const double u = complete ? (x - mx) * ss : 0.0, v = complete ? (y - my) * ss : 0.0;
@@ -171,6 +184,8 @@ MCBA_HD void view_dlt_factor(Fetch& image_point, const double* obj, int N, doubl
       Sw[i] = fma(w, pp[i], Sw[i]);
     }
   }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { Spp[i] = sp.sum(Spp[i]); Su[i] = sp.sum(Su[i]); Sv[i] = sp.sum(Sv[i]); Sw[i] = sp.sum(Sw[i]); }
   const double eps = 1e-13 * (2.0 * (Spp[0] + Spp[3] + Spp[5]) + Sw[0] + Sw[3] + Sw[5]) / 9.0;
   chol3(Spp, eps, F.L11);
 #pragma unroll
@@ -275,8 +290,8 @@ MCBA_HD void pose_from_homography(const double* H, double* pose) {
 
 // ---- one linearisation of a view's pixel reprojection error at `trial` (five-coefficient model): Gauss-Newton block (packed upper triangle),
 // gradient J^T e, cost 0.5 sum e^2.  observation(p, u, v) hands out the detection of point p.
-template <class Obs>
-MCBA_HD void view_linearise(const double* trial, const Cam9& cam, const double* obj, int N, Obs& observation, bool complete, double* Hn, double* gn, double& cn) {
+template <class Obs, class Split>
+MCBA_HD void view_linearise(const double* trial, const Cam9& cam, const double* obj, int N, Obs& observation, bool complete, const Split& sp, double* Hn, double* gn, double& cn) {
   PoseLin pl;
   make_pose_lin(trial, pl);
 #pragma unroll
@@ -284,7 +299,7 @@ MCBA_HD void view_linearise(const double* trial, const Cam9& cam, const double* 
 #pragma unroll
   for (int i = 0; i < 6; ++i) gn[i] = 0.0;
   cn = 0.0;
-  for (int p = 0; p < N; ++p) {
+  for (int p = sp.part(); p < N; p += Split::parts) {
     double ou, ov;
     observation(p, ou, ov);
     const double Xo[3] = {obj[3 * p], obj[3 * p + 1], obj[3 * p + 2]};
@@ -324,7 +339,11 @@ MCBA_HD void view_linearise(const double* trial, const Cam9& cam, const double* 
     }
     cn = fma(eu, eu, fma(ev, ev, cn));
   }
-  cn *= 0.5;
+#pragma unroll
+  for (int i = 0; i < 21; ++i) Hn[i] = sp.sum(Hn[i]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) gn[i] = sp.sum(gn[i]);
+  cn = 0.5 * sp.sum(cn);
 }
 
 // ---- the per-view Levenberg-Marquardt state and its decision: after a linearisation at `trial`, accept / reject, Nielsen's damping, scipy's

@@ -158,9 +158,9 @@ int hc_view_homography(int N, const double* uv, const double* obj, const double*
   board_norm(obj, N, bn);
   bool complete;
   double mx, my, ss;
-  view_normalisation(image_point, N, true, complete, mx, my, ss);
+  view_normalisation(image_point, N, true, mcba::WholeView{}, complete, mx, my, ss);
   DltFactor dlt;
-  view_dlt_factor(image_point, obj, N, bn[0], bn[1], bn[2], complete, mx, my, ss, dlt);
+  view_dlt_factor(image_point, obj, N, bn[0], bn[1], bn[2], complete, mx, my, ss, mcba::WholeView{}, dlt);
   double h[9];
   dlt_start_vector(h);
   for (int it = 0; it < 60; ++it) {
@@ -184,7 +184,7 @@ int hc_view_pose(int N, const double* uv, const double* obj, const double* intr9
   auto observation = [&](int p, double& u, double& v) { u = uv[2 * p]; v = uv[2 * p + 1]; };
   for (int it = 0; it < max_evals; ++it) {
     double Hn[21], gn[6], cn;
-    view_linearise(lm.trial, cam, obj, N, observation, complete != 0, Hn, gn, cn);
+    view_linearise(lm.trial, cam, obj, N, observation, complete != 0, mcba::WholeView{}, Hn, gn, cn);
     view_lm_decide(lm, Hn, gn, cn);
     if (lm.done) break;
     view_lm_step(lm);

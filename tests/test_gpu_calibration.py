@@ -199,12 +199,14 @@ def test_get_intrinsics_five_coefficient_model(mc, fix_k3, zero_tangent):
     np.testing.assert_allclose(k_s[4:], got[4:], rtol=2e-5, atol=1e-9)
 
 
-def test_estimate_pose_with_five_coefficients(mc):
+@pytest.mark.parametrize("lanes", [1, 4])
+def test_estimate_pose_with_five_coefficients(mc, lanes, monkeypatch):
     """estimate_pose with tangential / k3 coefficients (what get_intrinsics returns with a flag off): NaN rows where the detection is incomplete,
     the truth from noise-free detections, scipy's per-view optimum with noise."""
     from oracle import calibration_oracle as co
     from scipy.optimize import least_squares
 
+    monkeypatch.setenv("MCBA_PNP_LANES", str(lanes))
     obj, poses, uvs = _views(24, 21, TRUE9)
     uvs[5, 3] = np.nan
     K = np.array([[TRUE9[0], 0, TRUE9[2]], [0, TRUE9[1], TRUE9[3]], [0, 0, 1.0]])
@@ -230,11 +232,14 @@ def _all_complete_views(uvs):
     return np.stack([c, f], 1).astype(np.int32)
 
 
+@pytest.mark.parametrize("lanes", [1, 4])
 @pytest.mark.parametrize("noise", [0.0, 0.2, 3.0])
-def test_homographies_on_device_match_the_numpy_dlt(mc, noise):
+def test_homographies_on_device_match_the_numpy_dlt(mc, noise, lanes, monkeypatch):
     """mcba_calib_homographies = the smallest singular vector of the Hartley-normalised 2N x 9 DLT system (numpy: SVD) to 1e-9, on every complete
-    view; NaN for an incomplete one."""
+    view; NaN for an incomplete one.  Both forms of k_pnp: one lane per view, and a view's points dealt out to four lanes."""
     from oracle import calibration_oracle as co
+
+    monkeypatch.setenv("MCBA_PNP_LANES", str(lanes))
 
     p = mc.synth.make_problem(3, 150, seed=60, noise=noise, missing=0.2, scalar_nans=3)
     prob = mc.ops.Problem(p["uvs"], p["obj"], loss="linear")
@@ -250,12 +255,15 @@ def test_homographies_on_device_match_the_numpy_dlt(mc, noise):
     prob.close()
 
 
-def test_view_poses_are_the_reprojection_minimisers(mc):
+@pytest.mark.parametrize("lanes", [1, 4])
+def test_view_poses_are_the_reprojection_minimisers(mc, lanes, monkeypatch):
     """mcba_calib_view_poses / mcba_calib_poses = cv2.solvePnP's minimiser per view: the truth on noise-free detections, scipy's optimum of the same
     objective with noise (two-coefficient and five-coefficient intrinsics), NaN rows exactly where the detection is incomplete; the homography
-    start itself against the numpy restatement."""
+    start itself against the numpy restatement.  Both forms of k_pnp (one lane / four lanes per view)."""
     from multicam_calibration_amd import calibration as cal
     from oracle import calibration_oracle as co
+
+    monkeypatch.setenv("MCBA_PNP_LANES", str(lanes))
 
     p = mc.synth.make_problem(3, 90, seed=61, noise=0.25, missing=0.25)
     intr9 = np.c_[p["true_cam"][:, :6], np.zeros((3, 3))]
