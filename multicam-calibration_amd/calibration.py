@@ -268,7 +268,9 @@ def _refine_intrinsics_on_device(prob, views, K0, poses0):
     free.reshape(prob.C, 12)[~np.isin(np.arange(prob.C), views[:, 0])] = False   # (a camera without a usable view keeps its start)
     sub = prob.view_subset(views, loss="linear")
     try:
-        res = solver.lm_solve(sub, np.concatenate([cam0.ravel(), poses0.ravel()]), ftol=1e-12, xtol=1e-12, gtol=1e-10, max_nfev=200, verbose=0, free_cam_mask=free)
+        # (1e-9: the cost is then stationary to 2e-10 of itself and the intrinsics to 1e-7 px -- next to the 4-9 px a hundred views leave them
+        #  uncertain by; 1e-12 costs five more evaluations of 67 us for the same numbers: scripts/joint_lm_probe.py)
+        res = solver.lm_solve(sub, np.concatenate([cam0.ravel(), poses0.ravel()]), ftol=1e-9, xtol=1e-9, gtol=1e-10, max_nfev=200, verbose=0, free_cam_mask=free)
     finally:
         sub.close()
     return res.x[: 12 * prob.C].reshape(prob.C, 12)

@@ -380,8 +380,11 @@ def test_calibrate_equals_its_stages_in_numpy(mc):
     np.random.seed(9)
     for c in range(5):
         K, dist = mc.get_intrinsics(p["uvs"][c], p["obj"], (1280, 1024), n_samples=60)
-        np.testing.assert_allclose(np.r_[K[0, 0], K[1, 1], K[0, 2], K[1, 2]], np.r_[intr[c][0][0, 0], intr[c][0][1, 1], intr[c][0][0, 2], intr[c][0][1, 2]], rtol=1e-7)
-        np.testing.assert_allclose(dist[:2], intr[c][1][:2], rtol=1e-5)   # (k2 of 60 noisy views is the flattest direction: two LM runs stopped at ftol = 1e-12 agree to ~4e-7 in it)
+        # (the joint run and a camera's own run stop on their own costs, at ftol = xtol = 1e-9: the valley along focal length / k1 / k2 of 60 noisy
+        #  views is flat -- the two stopping points are 2e-4 px apart here, 2.5e-3 px from a run at 1e-12 at the tutorial's shape, next to the
+        #  4-9 px such a sample leaves the focal length uncertain by: scripts/joint_lm_probe.py)
+        np.testing.assert_allclose(np.r_[K[0, 0], K[1, 1], K[0, 2], K[1, 2]], np.r_[intr[c][0][0, 0], intr[c][0][1, 1], intr[c][0][0, 2], intr[c][0][1, 2]], rtol=5e-6)
+        np.testing.assert_allclose(dist[:2], intr[c][1][:2], rtol=1e-3)
 
 
 def test_trim_keeps_the_box_and_restores_the_scaling(mc):
