@@ -6,7 +6,7 @@
 #   the user-level call's wall-clock breakdown, the other shapes DESIGN quotes, kernel stats of the config-5 shard (24 x 6 250 x 200).
 set -e -o pipefail
 TAG=${1:-run}
-PART=${2:-all}   # a gpurun call is limited to 20 minutes: `scripts/gpu_profile.sh TAG a`, then `... TAG b`, then `... TAG c` (all = everything in one go)
+PART=${2:-all}   # a gpurun call is limited to 20 minutes: `scripts/gpu_profile.sh TAG a`, then `... TAG b`, then `... TAG c` (all = everything in one go; d = the calibrate() section of c alone)
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -64,6 +64,8 @@ MCBA_SHAPE="6,1000,6,9" MCBA_FIXED=1 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_
 python3 scripts/pmc_summary.py $OUT/${TAG}_pmc_config1_summary.json $OUT/${TAG}_pmc_c1_fetch $OUT/${TAG}_pmc_c1_write $OUT/${TAG}_pmc_c1_sq > $OUT/${TAG}_pmc_config1_summary.log
 echo "round-4 shapes done"
 MCBA_SHAPES="24,50000,10,20" python3 scripts/other_shapes.py > $OUT/${TAG}_config5_full.json 2> $OUT/${TAG}_config5_full.err
+fi
+if [ "$PART" = "all" ] || [ "$PART" = "c" ] || [ "$PART" = "d" ]; then
 # round 6: calibrate() -- wall time with its stages at the tutorial shape and at 6 x 10 000 x 54, rocprofv3 kernel stats of the call and of the dense
 # kernels' fixed launch sequence, HBM counter passes of the latter
 python3 scripts/calibrate_time.py > $OUT/${TAG}_calibrate.json 2> $OUT/${TAG}_calibrate.err
