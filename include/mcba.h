@@ -52,7 +52,7 @@ typedef struct mcba_handle mcba_handle;
 typedef struct mcba_buffer mcba_buffer;   /* a device array that outlives its handle (mcba_residuals_detach) */
 
 /* ---- library ------------------------------------------------------------------------------- */
-int mcba_abi_version(void);            /* 7.  Bumped when this header changes: 7 (round 6) ADDS the mcba_calib_* / mcba_pose_* / mcba_create_views block below (calibrate() on the device) and leaves every ABI-6 entry point as it was; 6 (round 5) ADDED mcba_prefilter, mcba_prefilter_subset, mcba_lm_run, mcba_lm_history, mcba_lm_result, mcba_set_bounds / _frozen, mcba_set_loss_table, mcba_set_trial, mcba_calib_normal_equations (and the diagnostics / life-cycle helpers declared below as ABI 6) and leaves every
+int mcba_abi_version(void);            /* 7.  Bumped when this header changes: 7 (round 6) ADDS the mcba_calib_* (incl. mcba_calib_start) / mcba_pose_* / mcba_create_views block below (calibrate() on the device) and leaves every ABI-6 entry point as it was; 6 (round 5) ADDED mcba_prefilter, mcba_prefilter_subset, mcba_lm_run, mcba_lm_history, mcba_lm_result, mcba_set_bounds / _frozen, mcba_set_loss_table, mcba_set_trial, mcba_calib_normal_equations (and the diagnostics / life-cycle helpers declared below as ABI 6) and leaves every
                                         * ABI-5 entry point as it was.  (ABI 5 gave LM-state slots 25 / 26 -- "reserved" before -- their meaning: curvature floor / switch
                                         * fraction; a caller that zeroes them gets the handle's floor, fixed.) */
 const char* mcba_last_error(void);
@@ -374,8 +374,9 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
  * The initialiser that produces bundle_adjust()'s inputs: reference multicam_calibration/calibration.py:280-373.  Its two OpenCV calls per
  * view (cv2.calibrateCamera :68 on <= 100 sampled views per camera, cv2.solvePnP :108 on every complete view) and its pose graph
  * (:116-277) run on the detections a handle already holds (mcba_upload_observations).  A call of calibrate() is
- *   mcba_calib_complete -> [host: np.random.choice per camera, as the reference draws it :57-60] -> mcba_calib_homographies (sampled views)
- *   -> [host: Zhang's closed form for K, a 6-unknown null vector per camera] -> mcba_calib_view_poses (sampled views, K0, no distortion)
+ *   mcba_calib_complete -> [host: np.random.choice per camera, as the reference draws it :57-60] -> mcba_calib_start (the sampled views'
+ *   homographies, Zhang's closed form for every camera's K from them, the views' poses with that K and no distortion: one crossing; its
+ *   first and last step alone are mcba_calib_homographies and mcba_calib_view_poses)
  *   -> mcba_create_views + mcba_lm_run + mcba_lm_result (EVERY camera's fx fy cx cy k1 k2 and its views' poses in one device-resident LM run)
  *   -> mcba_calib_poses (every (camera, frame): one launch, the poses stay on the device) -> [host: maximum spanning tree of the C x C
  *   co-detection counts :146-197] -> mcba_calib_pairwise (tree edges) -> [host: chain C - 1 transforms :230-235] -> mcba_calib_consensus.
@@ -392,6 +393,14 @@ int mcba_calib_homographies(mcba_handle* h, const int* views, int n_views, doubl
  * Levenberg-Marquardt on the pixel reprojection error (at most max_evaluations linearisations per view, every view its own damping).
  * poses_out n_views x 6, ok_out n_views bytes or NULL. */
 int mcba_calib_view_poses(mcba_handle* h, const int* views, int n_views, const double* intr9, int undistort_iterations, int max_evaluations, double* poses_out, unsigned char* ok_out);
+/* The closed-form start of cv2.calibrateCamera (:68) for EVERY camera in one crossing: homographies of the listed views; Zhang's camera matrix
+ * per camera from its views (image of the absolute conic with the skew held at zero: the null vector of a 6-column system, found as the
+ * smallest eigenvector of its 6 x 6 normal matrix by cyclic Jacobi; image_sizes = C x (width, height) in pixels sets the normalisation and
+ * the fallback f = max(w, h), c = ((w - 1) / 2, (h - 1) / 2) for a camera with fewer than two usable views or a non-positive-definite
+ * estimate); then mcba_calib_view_poses' work with that K and zero distortion.  k4_out C x (fx fy cx cy); closed_out C bytes or NULL (1 = the
+ * closed form was used); poses_out n_views x 6 (NaN rows = none); ok_out n_views bytes or NULL. */
+int mcba_calib_start(mcba_handle* h, const int* views, int n_views, const double* image_sizes, int undistort_iterations, int max_evaluations, double* k4_out, unsigned char* closed_out,
+                     double* poses_out, unsigned char* ok_out);
 /* estimate_pose (:74-113) of EVERY camera at once.  The poses stay on the device for the two calls below; poses_out (C,F,6), ok_out (C,F)
  * bytes, evals_out (C,F) bytes (linearisations a view took) are optional -- with all three NULL the call does not synchronise. */
 int mcba_calib_poses(mcba_handle* h, const double* intr9, int undistort_iterations, int max_evaluations, double* poses_out, unsigned char* ok_out, unsigned char* evals_out);

@@ -1832,6 +1832,42 @@ int mcba_calib_view_poses(mcba_handle* h, const int* views, int n_views, const d
   return MCBA_OK;
 }
 
+// The closed-form start of get_intrinsics for every camera at once, ONE crossing (what cv2.calibrateCamera does before it refines, calibration.py:68):
+// homographies of the listed views -> Zhang's K per camera from its views (k_zhang; image_sizes = C x (width, height)) -> cv2.solvePnP's job
+// for the same views with that K and no distortion.  k4_out C x (fx fy cx cy); closed_out (C bytes, optional) = 1 where the closed form was used
+// (0: the fallback f = max(w, h), c = the image centre); poses_out n_views x 6 (NaN = none); ok_out (n_views bytes, optional).
+int mcba_calib_start(mcba_handle* h, const int* views, int n_views, const double* image_sizes, int undistort_iterations, int max_evaluations, double* k4_out, unsigned char* closed_out,
+                     double* poses_out, unsigned char* ok_out) {
+  int rc = calib_ready(h, "mcba_calib_start");
+  if (rc) return rc;
+  if (!views || n_views < 1 || !image_sizes || !k4_out || !poses_out || undistort_iterations < 0 || max_evaluations < 1) return fail(MCBA_ERR_ARG, "mcba_calib_start: bad argument");
+  for (int c = 0; c < h->C; ++c)
+    if (!(image_sizes[2 * c] >= 1.0 && image_sizes[2 * c + 1] >= 1.0 && image_sizes[2 * c] < 1e9 && image_sizes[2 * c + 1] < 1e9)) return fail(MCBA_ERR_ARG, "mcba_calib_start: image sizes must be finite and >= 1");
+  if ((rc = upload_views(h, views, n_views, "mcba_calib_start"))) return rc;
+  if (!h->cal_intr && (rc = dalloc(h, &h->cal_intr, (size_t)9 * h->C, false))) return rc;
+  const size_t tail = (size_t)10 * n_views + 8;   // [0, 9 n) homographies, then poses; [9 n, 10 n) the views' valid bytes; then sizes (2 C) and closed bytes (C)
+  if ((rc = dgrow(h, &h->cal_out, &h->cal_out_cap, tail + (size_t)3 * h->C + 8))) return rc;
+  unsigned char* okd = reinterpret_cast<unsigned char*>(h->cal_out + (size_t)9 * n_views);
+  double* sizes_d = h->cal_out + tail;
+  unsigned char* closed_d = reinterpret_cast<unsigned char*>(sizes_d + (size_t)2 * h->C);
+  HIPCHK(hipMemcpyAsync(sizes_d, image_sizes, (size_t)2 * h->C * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  double bn[3];
+  board_normalisation(h->obj_host, h->N, bn);
+  mcba::launch_pnp(h->stream, 0, h->obs_t, h->obj, nullptr, h->cal_views, n_views, bn, h->C, h->F, h->N, h->Fpad, 0, 0, h->cal_out, nullptr, okd, nullptr);
+  mcba::launch_zhang(h->stream, h->cal_out, okd, h->cal_views, n_views, sizes_d, h->C, h->cal_intr, closed_d);
+  mcba::launch_pnp(h->stream, 1, h->obs_t, h->obj, h->cal_intr, h->cal_views, n_views, bn, h->C, h->F, h->N, h->Fpad, undistort_iterations, max_evaluations, h->cal_out, nullptr, okd, nullptr);
+  if ((rc = check_launch())) return rc;
+  std::vector<double> intr((size_t)9 * h->C);
+  HIPCHK(hipMemcpyAsync(intr.data(), h->cal_intr, intr.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(poses_out, h->cal_out, (size_t)6 * n_views * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (ok_out) HIPCHK(hipMemcpyAsync(ok_out, okd, (size_t)n_views, hipMemcpyDeviceToHost, h->stream));
+  if (closed_out) HIPCHK(hipMemcpyAsync(closed_out, closed_d, (size_t)h->C, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int c = 0; c < h->C; ++c)
+    for (int k = 0; k < 4; ++k) k4_out[4 * c + k] = intr[(size_t)9 * c + k];
+  return MCBA_OK;
+}
+
 // estimate_pose (calibration.py:74-113) of EVERY camera in one launch: the board pose of every (camera, frame) with a complete detection.
 // The poses stay on the device for mcba_calib_pairwise / mcba_calib_consensus; poses_out (C, F, 6) (NaN rows = no pose), ok_out (C, F) bytes
 // and evals_out (C, F) bytes (LM evaluations a view took) are optional.

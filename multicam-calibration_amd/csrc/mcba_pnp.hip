@@ -171,6 +171,37 @@ __global__ __launch_bounds__(64) void k_pnp(PnpArgs a) {
   }
 }
 
+// Zhang's closed form (mcba_pnp_math.h) for every camera of a sampled view list: block = camera, the lanes share out the list and add their
+// views' rows to the 6 x 6 normal matrix, lane 63 holds the wave's sums and solves.  intr9 [C][9] <- fx fy cx cy 0 0 0 0 0 (the start of the
+// per-view poses and of the joint refinement); closed [C] <- 1 where the closed form was used, 0 for the fallback.
+__global__ __launch_bounds__(64) void k_zhang(const double* __restrict__ H, const unsigned char* __restrict__ ok, const int* __restrict__ views, int nviews, const double* __restrict__ sizes,
+                                              double* __restrict__ intr9, unsigned char* __restrict__ closed) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const double w = sizes[2 * c], h = sizes[2 * c + 1];
+  const double s0 = w > h ? w : h, ox = 0.5 * (w - 1.0), oy = 0.5 * (h - 1.0), is0 = 1.0 / s0;
+  double M[21];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) M[i] = 0.0;
+  double n = 0.0;
+  for (int i = lane; i < nviews; i += 64) {
+    if (views[2 * i] != c || !ok[i]) continue;
+    double Hv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Hv[k] = H[(size_t)9 * i + k];
+    zhang_accumulate(Hv, ox, oy, is0, M);
+    n += 1.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 21; ++i) M[i] = wave_sum63(M[i]);
+  n = wave_sum63(n);
+  if (lane != 63) return;
+  double K4[4];
+  const bool used = zhang_solve(M, (int)n, w, h, K4);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) intr9[9 * c + i] = i < 4 ? K4[i] : 0.0;
+  if (closed) closed[c] = used ? 1 : 0;
+}
+
 // per (camera, frame): every scalar of the detection present?
 __global__ __launch_bounds__(256) void k_view_complete(const double2* __restrict__ obs_t, unsigned char* __restrict__ out, int C, int F, int N, int Fpad) {
   const int c = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
@@ -305,6 +336,10 @@ void launch_pnp(hipStream_t st, int mode, const double* obs_t, const double* obj
     if (quad) k_pnp<MODE_POSE, true, 4><<<dim3(Fpad / 16, C), dim3(64), 0, st>>>(a);
     else k_pnp<MODE_POSE, true, 1><<<dim3(Fpad / 64, C), dim3(64), 0, st>>>(a);
   }
+}
+
+void launch_zhang(hipStream_t st, const double* H, const unsigned char* ok, const int* views, int nviews, const double* sizes, int C, double* intr9, unsigned char* closed) {
+  k_zhang<<<dim3(C), dim3(64), 0, st>>>(H, ok, views, nviews, sizes, intr9, closed);
 }
 
 void launch_pose_pairs(hipStream_t st, const double* poses, size_t sc, size_t sf, size_t sk, const int* edges, int n_edges, int F, int Fpad, double* rel) {

@@ -288,6 +288,106 @@ MCBA_HD void pose_from_homography(const double* H, double* pose) {
   pose[3] = H[2] * lam; pose[4] = H[5] * lam; pose[5] = H[8] * lam;
 }
 
+// ---- Zhang's closed form for a camera matrix from the board-plane homographies of its views (the start cv2.calibrateCamera computes before it
+// refines, calibration.py:68): every view gives two rows v_01 and v_00 - v_11 of a 6-column system V b = 0 in the image of the absolute conic
+// b = (B11 B12 B22 B13 B23 B33); one more row holds the skew at zero.  The null vector is the eigenvector of the smallest eigenvalue of V^T V
+// (6 x 6, accumulated view by view; cyclic Jacobi, which finds the small eigenvalues of a positive semi-definite matrix to high relative
+// accuracy).  Coordinates of order 1: x' = (x - (w - 1) / 2) / max(w, h).
+// One view's contribution to the packed upper triangle M (21) of V^T V.  H row-major 3 x 3 in pixels.
+MCBA_HD void zhang_accumulate(const double* H, double ox, double oy, double is0, double* M) {
+  double a[3], b[3];   // columns 0 and 1 of N H
+  a[0] = (H[0] - ox * H[6]) * is0; a[1] = (H[3] - oy * H[6]) * is0; a[2] = H[6];
+  b[0] = (H[1] - ox * H[7]) * is0; b[1] = (H[4] - oy * H[7]) * is0; b[2] = H[7];
+  const double nrm = 1.0 / sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { a[i] *= nrm; b[i] *= nrm; }
+  const double r0[6] = {a[0] * b[0], a[0] * b[1] + a[1] * b[0], a[1] * b[1], a[2] * b[0] + a[0] * b[2], a[2] * b[1] + a[1] * b[2], a[2] * b[2]};
+  const double r1[6] = {a[0] * a[0] - b[0] * b[0], 2.0 * (a[0] * a[1] - b[0] * b[1]), a[1] * a[1] - b[1] * b[1],
+                        2.0 * (a[2] * a[0] - b[2] * b[0]), 2.0 * (a[2] * a[1] - b[2] * b[1]), a[2] * a[2] - b[2] * b[2]};
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) M[tri<6>(i, j)] = fma(r0[i], r0[j], fma(r1[i], r1[j], M[tri<6>(i, j)]));
+}
+// eigenvector of the smallest eigenvalue of a symmetric 6 x 6 matrix (packed upper triangle, not changed): cyclic Jacobi rotations
+MCBA_HD void smallest_eigenvector6(const double* M, double* vec) {
+  double A[6][6], V[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { A[i][j] = M[i <= j ? tri<6>(i, j) : tri<6>(j, i)]; V[i][j] = i == j ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    double off = 0.0, dia = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      dia = fma(A[i][i], A[i][i], dia);
+#pragma unroll
+      for (int j = i + 1; j < 6; ++j) off = fma(A[i][j], A[i][j], off);
+    }
+    if (!(off > 1e-34 * dia)) break;
+#pragma unroll
+    for (int p = 0; p < 5; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 6; ++q) {
+        const double apq = A[p][q];
+        const bool rotate = apq != 0.0;
+        const double theta = rotate ? (A[q][q] - A[p][p]) / (2.0 * apq) : 0.0;
+        const double t = rotate ? (theta < 0.0 ? -1.0 : 1.0) / (fabs(theta) + sqrt(fma(theta, theta, 1.0))) : 0.0;
+        const double c = 1.0 / sqrt(fma(t, t, 1.0)), sn = t * c;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {   // A <- A J (columns p, q)
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - sn * akq;
+          A[k][q] = sn * akp + c * akq;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {   // A <- J^T A (rows p, q);  V <- V J
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - sn * aqk;
+          A[q][k] = sn * apk + c * aqk;
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - sn * vkq;
+          V[k][q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  double best = A[0][0];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vec[k] = V[k][0];
+#pragma unroll
+  for (int j = 1; j < 6; ++j) {
+    const bool take = A[j][j] < best;
+    best = take ? A[j][j] : best;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vec[k] = take ? V[k][j] : vec[k];
+  }
+}
+// K (fx fy cx cy) of an image of w x h pixels from M = V^T V over n usable views (the skew row is added here, weighted by n as the views'
+// rows are by their count); the fallback f = max(w, h), c = the image centre when the views do not constrain it (fewer than two, or an
+// estimate that is not positive definite).  Returns whether the closed form was used.
+MCBA_HD bool zhang_solve(const double* M, int n, double w, double h, double* K4) {
+  const double s0 = w > h ? w : h, ox = 0.5 * (w - 1.0), oy = 0.5 * (h - 1.0);
+  K4[0] = s0; K4[1] = s0; K4[2] = ox; K4[3] = oy;
+  if (n < 2) return false;
+  double Ms[21];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) Ms[i] = M[i];
+  Ms[tri<6>(1, 1)] += (double)n * (double)n;
+  double b[6];
+  smallest_eigenvector6(Ms, b);
+  const double b11 = b[0], b12 = b[1], b22 = b[2], b13 = b[3], b23 = b[4], b33 = b[5];
+  const double den = b11 * b22 - b12 * b12;
+  const double v0 = (b12 * b13 - b11 * b23) / den;
+  const double lam = b33 - (b13 * b13 + v0 * (b12 * b13 - b11 * b23)) / b11;
+  const double a2 = lam / b11, b2 = lam * b11 / den;
+  const bool good = den != 0.0 && b11 != 0.0 && pnp_finite(a2) && pnp_finite(b2) && pnp_finite(v0) && a2 > 0.0 && b2 > 0.0;
+  if (!good) return false;
+  const double alpha = sqrt(a2), beta = sqrt(b2), u0 = -b13 * alpha * alpha / lam;
+  if (!(pnp_finite(u0))) return false;
+  K4[0] = s0 * alpha; K4[1] = s0 * beta; K4[2] = fma(s0, u0, ox); K4[3] = fma(s0, v0, oy);
+  return true;
+}
+
 // ---- one linearisation of a view's pixel reprojection error at `trial` (five-coefficient model): Gauss-Newton block (packed upper triangle),
 // gradient J^T e, cost 0.5 sum e^2.  observation(p, u, v) hands out the detection of point p.
 template <class Obs, class Split>

@@ -93,6 +93,7 @@ SYMBOLS = [
     ("mcba_calib_complete", ctypes.c_int, [_h, ctypes.POINTER(ctypes.c_ubyte)]),
     ("mcba_calib_homographies", ctypes.c_int, [_h, _ip, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte)]),
     ("mcba_calib_view_poses", ctypes.c_int, [_h, _ip, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte)]),
+    ("mcba_calib_start", ctypes.c_int, [_h, _ip, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte), _dp, ctypes.POINTER(ctypes.c_ubyte)]),
     ("mcba_calib_poses", ctypes.c_int, [_h, _dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_ubyte)]),
     ("mcba_calib_pairwise", ctypes.c_int, [_h, _ip, ctypes.c_int, _dp, _dp]),
     ("mcba_calib_consensus", ctypes.c_int, [_h, _dp, _dp]),
@@ -370,6 +371,18 @@ class Problem:
         out = np.empty((len(v), 6))
         self._chk(self.lib.mcba_calib_view_poses(self.handle, v.ctypes.data_as(_ip), len(v), _p(k), int(undistort_iterations), int(max_evaluations), _p(out), None))
         return out
+
+    def calib_start(self, views, image_sizes, undistort_iterations=8, max_evaluations=60, want_closed=False):
+        """The closed-form start of every camera from its sampled views, one crossing (include/mcba.h: mcba_calib_start): homographies, Zhang's K
+        per camera, the views' poses with it.  image_sizes (C,2) = (width, height).  Returns (k4 (C,4) fx fy cx cy, poses (V,6))
+        [+ closed (C,) bool: the closed form was used, not the fallback]."""
+        v = np.ascontiguousarray(views, dtype=np.int32).reshape(-1, 2)
+        sz = _f64(image_sizes).reshape(self.C, 2)
+        k4, poses = np.empty((self.C, 4)), np.empty((len(v), 6))
+        closed = np.empty(self.C, np.uint8)
+        self._chk(self.lib.mcba_calib_start(self.handle, v.ctypes.data_as(_ip), len(v), _p(sz), int(undistort_iterations), int(max_evaluations), _p(k4),
+                                            closed.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), _p(poses), None))
+        return (k4, poses, closed.astype(bool)) if want_closed else (k4, poses)
 
     def calib_poses(self, intr9, undistort_iterations=8, max_evaluations=60, want_poses=False, want_evals=False):
         """Board pose of every (camera, frame) with a complete detection, left on the device for calib_pairwise / calib_consensus.

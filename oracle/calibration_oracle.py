@@ -214,3 +214,74 @@ def solve_pnp(uv, obj, intr9, pose0):
     by scipy from the given start."""
     res = least_squares(lambda p: (np.asarray(uv, dtype=float) - project5(obj, p, intr9)).ravel(), np.asarray(pose0, dtype=float), xtol=1e-15, ftol=1e-15, gtol=1e-12)
     return res.x, res.cost
+
+
+# ---- Zhang's closed form (the start cv2.calibrateCamera computes before it refines, calibration.py:68), numpy restatement: the checker of
+# csrc/mcba_pnp_math.h: zhang_accumulate / zhang_solve (the product finds the null vector as an eigenvector of the 6 x 6 normal matrix on the
+# GPU; here it is the last right singular vector of the stacked system).  Until round 6 this was the product's host code.
+def _fallback_K(image_size):
+    w, h = float(image_size[0]), float(image_size[1])
+    return np.array([[max(w, h), 0, (w - 1) / 2], [0, max(w, h), (h - 1) / 2], [0, 0, 1.0]])
+
+
+def intrinsics_from_homographies_batch(H, cams, image_sizes):
+    """Zhang's closed form for every camera at once.  H (V,3,3): board-plane homographies of views; cams (V,) int: the camera of each view;
+    image_sizes: one (width, height) per camera.  Returns K (C,3,3): the camera matrix from the image of the absolute conic (zero skew imposed),
+    or the fallback f = max(w, h), c = image centre for a camera whose views do not constrain it (fewer than 2 usable views, or a non-positive-
+    definite estimate).  One stacked SVD for all cameras (their rows padded with zeros to a common count: zero rows do not move a null vector)."""
+    C = len(image_sizes)
+    H = np.asarray(H, dtype=np.float64).reshape(-1, 3, 3)
+    cams = np.asarray(cams, dtype=np.int64).reshape(-1)
+    K = np.stack([_fallback_K(sz) for sz in image_sizes])
+    ok = np.isfinite(H).all((1, 2))
+    H, cams = H[ok], cams[ok]
+    counts = np.bincount(cams, minlength=C)
+    if not len(H) or counts.max() < 2:
+        return K
+    wh = np.asarray(image_sizes, dtype=np.float64).reshape(C, 2)
+    s0 = wh.max(1)   # work in image coordinates of order 1 (pixel-scale entries would spread V over 12 decades): x' = (x - (w - 1) / 2) / s0
+    ox, oy = (wh[:, 0] - 1) / 2, (wh[:, 1] - 1) / 2
+    sv, oxv, oyv = (1 / s0)[cams, None], ox[cams, None], oy[cams, None]
+    Hs = np.empty_like(H)
+    Hs[:, 0] = (H[:, 0] - oxv * H[:, 2]) * sv
+    Hs[:, 1] = (H[:, 1] - oyv * H[:, 2]) * sv
+    Hs[:, 2] = H[:, 2]
+    Hs /= np.sqrt(np.einsum("vij,vij->v", Hs[:, :, :2], Hs[:, :, :2]))[:, na, None]
+    # Zhang's rows v_01 and v_00 - v_11 of every view, written straight into the cameras' stacked systems (views of a camera in list order; the
+    # cameras' row counts padded with zeros to a common one: zero rows do not move a null vector)
+    order = np.argsort(cams, kind="stable")
+    cs = cams[order]
+    slot = np.arange(len(cams)) - (np.cumsum(counts) - counts)[cs]   # position of each (sorted) view inside its camera
+    V = np.zeros((C, max(2 * counts.max() + 1, 6), 6))   # (six rows at least: the reduced SVD of a 5 x 6 stack has no sixth right vector)
+    a, b = Hs[order, :, 0], Hs[order, :, 1]
+    r0, r1 = V[cs, 2 * slot], V[cs, 2 * slot + 1]   # (copies: fancy indexing), filled and written back
+    r0[:, 0], r0[:, 1], r0[:, 2] = a[:, 0] * b[:, 0], a[:, 0] * b[:, 1] + a[:, 1] * b[:, 0], a[:, 1] * b[:, 1]
+    r0[:, 3], r0[:, 4], r0[:, 5] = a[:, 2] * b[:, 0] + a[:, 0] * b[:, 2], a[:, 2] * b[:, 1] + a[:, 1] * b[:, 2], a[:, 2] * b[:, 2]
+    r1[:, 0], r1[:, 1], r1[:, 2] = a[:, 0] * a[:, 0] - b[:, 0] * b[:, 0], 2 * (a[:, 0] * a[:, 1] - b[:, 0] * b[:, 1]), a[:, 1] * a[:, 1] - b[:, 1] * b[:, 1]
+    r1[:, 3], r1[:, 4], r1[:, 5] = 2 * (a[:, 2] * a[:, 0] - b[:, 2] * b[:, 0]), 2 * (a[:, 2] * a[:, 1] - b[:, 2] * b[:, 1]), a[:, 2] * a[:, 2] - b[:, 2] * b[:, 2]
+    V[cs, 2 * slot], V[cs, 2 * slot + 1] = r0, r1
+    V[:, -1, 1] = counts                                             # last row: skew = 0, weighted like the reference's single-camera form
+    bvec = np.linalg.svd(V, full_matrices=False)[2][:, -1]          # (C, 6): b11 b12 b22 b13 b23 b33
+    with np.errstate(all="ignore"):
+        b11, b12, b22, b13, b23, b33 = bvec.T
+        den = b11 * b22 - b12 * b12
+        v0 = (b12 * b13 - b11 * b23) / den
+        lam = b33 - (b13 * b13 + v0 * (b12 * b13 - b11 * b23)) / b11
+        a2, b2 = lam / b11, lam * b11 / den
+        good = (counts >= 2) & (den != 0) & (b11 != 0) & np.isfinite(a2) & np.isfinite(b2) & np.isfinite(v0) & (a2 > 0) & (b2 > 0)
+        alpha, beta = np.sqrt(np.where(good, a2, 1.0)), np.sqrt(np.where(good, b2, 1.0))
+        u0 = -b13 * alpha * alpha / lam
+        # back to pixels: K = N^-1 K', N^-1 = [[s0, 0, ox], [0, s0, oy], [0, 0, 1]]
+        Kg = np.zeros((C, 3, 3))
+        Kg[:, 0, 0], Kg[:, 1, 1], Kg[:, 0, 2], Kg[:, 1, 2], Kg[:, 2, 2] = s0 * alpha, s0 * beta, s0 * u0 + ox, s0 * v0 + oy, 1.0
+    K[good] = Kg[good]
+    return K
+
+
+def intrinsics_from_homographies(H, image_size):
+    """K from the image of the absolute conic (zero skew imposed) for ONE camera's views H (V,3,3); falls back to f = max(w, h), c = image
+    centre when the views do not constrain it (fewer than 2 usable views, or a non-positive-definite estimate)."""
+    H = np.asarray(H, dtype=np.float64).reshape(-1, 3, 3)
+    return intrinsics_from_homographies_batch(H, np.zeros(len(H), dtype=np.int64), [image_size])[0]
+
+

@@ -195,6 +195,22 @@ int hc_view_pose(int N, const double* uv, const double* obj, const double* intr9
   if (!complete) return 0;
   return ok ? lm.evals : -1;
 }
+// Zhang's closed form for one camera: H (n x 9) homographies in pixels (a NaN one is skipped), image size -> K4 (fx fy cx cy); returns 1 if the
+// closed form was used, 0 for the fallback
+int hc_zhang(int n, const double* H, double w, double h, double* K4) {
+  double M[21];
+  for (int i = 0; i < 21; ++i) M[i] = 0.0;
+  const double s0 = w > h ? w : h;
+  int used = 0;
+  for (int v = 0; v < n; ++v) {
+    bool ok = true;
+    for (int i = 0; i < 9; ++i) ok = ok && pnp_finite(H[9 * v + i]);
+    if (!ok) continue;
+    zhang_accumulate(H + 9 * v, 0.5 * (w - 1.0), 0.5 * (h - 1.0), 1.0 / s0, M);
+    ++used;
+  }
+  return zhang_solve(M, used, w, h, K4) ? 1 : 0;
+}
 // rotation matrix -> rotation vector as the pose-graph kernels compute it (clamped arccos)
 void hc_rotvec(const double* R, double* w) { rotvec_from_matrix(R, w); }
 }

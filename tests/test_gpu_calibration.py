@@ -255,6 +255,41 @@ def test_homographies_on_device_match_the_numpy_dlt(mc, noise, lanes, monkeypatc
     prob.close()
 
 
+def test_closed_form_start_in_one_crossing(mc):
+    """mcba_calib_start = its three steps: the homographies of the sampled views, Zhang's K per camera from them (numpy restatement: the last
+    right singular vector of the stacked system, 1e-9), the views' poses with that K (the same bits as mcba_calib_view_poses with the K it
+    returns); cameras with different image sizes, a camera with a single view (fallback), views listed in any order; bad arguments refused."""
+    from oracle import calibration_oracle as co
+
+    p = mc.synth.make_problem(4, 80, seed=64, noise=0.2, missing=0.2)
+    prob = mc.ops.Problem(p["uvs"], p["obj"], loss="linear")
+    complete = prob.calib_complete()
+    rng = np.random.default_rng(1)
+    views = []
+    for c, n in enumerate((40, 25, 1, 2)):
+        fr = rng.choice(np.flatnonzero(complete[c]), n, replace=False)
+        views += [(c, f) for f in fr]
+    views = np.array(views, dtype=np.int32)[rng.permutation(len(views))]
+    sizes = np.array([(1280, 1024), (1920, 1080), (640, 480), (1280, 1024)], dtype=np.float64)
+    k4, poses, closed = prob.calib_start(views, sizes, want_closed=True)
+    H = prob.calib_homographies(views)
+    want = co.intrinsics_from_homographies_batch(H, views[:, 0], [tuple(s) for s in sizes])
+    np.testing.assert_allclose(k4, np.stack([want[:, 0, 0], want[:, 1, 1], want[:, 0, 2], want[:, 1, 2]], 1), rtol=1e-9)
+    assert closed.tolist() == [True, True, False, True]
+    assert np.array_equal(k4[2], [640.0, 640.0, 319.5, 239.5])
+    intr9 = np.c_[k4, np.zeros((4, 5))]
+    np.testing.assert_array_equal(poses, prob.calib_view_poses(views, intr9))
+    assert np.isfinite(poses).all()
+    # near the truth already (noise 0.2 px, no distortion in the start's model: a few per cent)
+    assert np.abs(k4[[0, 1]][:, :2] / p["true_cam"][[0, 1], :2] - 1).max() < 0.1
+    for bad in (np.array([[1280, 1024]] * 3 + [[0, 10]], float), np.array([[1280, 1024]] * 3 + [[np.nan, 10]], float)):
+        with pytest.raises(mc.ops.McbaError, match="image sizes"):
+            prob.calib_start(views, bad)
+    with pytest.raises(mc.ops.McbaError, match="out of range"):
+        prob.calib_start(np.array([[4, 0]], np.int32), sizes)
+    prob.close()
+
+
 @pytest.mark.parametrize("lanes", [1, 4])
 def test_view_poses_are_the_reprojection_minimisers(mc, lanes, monkeypatch):
     """mcba_calib_view_poses / mcba_calib_poses = cv2.solvePnP's minimiser per view: the truth on noise-free detections, scipy's optimum of the same

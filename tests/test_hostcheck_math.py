@@ -189,6 +189,41 @@ def test_view_pose_is_the_reprojection_minimiser(hc, five):
     assert hc.hc_view_pose(len(obj), P(np.ascontiguousarray(uv)), P(obj), P(intr9), 8, 60, P(np.zeros(6)), P(np.zeros(6)), P(np.zeros(1))) == 0
 
 
+def test_zhang_closed_form_is_the_numpy_null_vector(hc):
+    """k_zhang's arithmetic for one camera (normal matrix of Zhang's rows view by view, smallest eigenvector by cyclic Jacobi, the closed form) =
+    the numpy restatement's K (last right singular vector of the stacked system): noise-free views give the true camera matrix, noisy ones the
+    same estimate to 1e-9; two views suffice; one view, and views that leave the conic indefinite, take the fallback; NaN homographies are skipped."""
+    from oracle import calibration_oracle as co
+
+    hc.hc_zhang.restype = ctypes.c_int
+    hc.hc_zhang.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+    rng = np.random.default_rng(5)
+    for (w, h), n, noise in (((1280, 1024), 100, 0.0), ((1280, 1024), 100, 0.3), ((640, 480), 7, 0.1), ((1080, 1920), 2, 0.0), ((800, 800), 25, 2.0)):
+        p = synth.make_problem(2, n, seed=int(rng.integers(1 << 30)), noise=0.0)
+        cam = p["true_cam"][1].copy()
+        cam[4:6] = 0.0
+        cam[6:] = 0.0
+        cam[2], cam[3] = 0.5 * w + 7.0, 0.5 * h - 5.0
+        uv = synth.project(cam[None], p["true_poses"] + np.r_[0, 0, 0, 0, 0, 400.0], p["obj"])[0] + rng.normal(0, noise, (n, len(p["obj"]), 2))
+        H = np.ascontiguousarray(co.homographies(p["obj"][:, :2], uv))
+        if n == 7:
+            H[3] = np.nan
+        K4 = np.zeros(4)
+        used = hc.hc_zhang(len(H), P(H), float(w), float(h), P(K4))
+        want = co.intrinsics_from_homographies(H, (w, h))
+        assert used == 1, (w, h, n, noise)
+        np.testing.assert_allclose(K4, [want[0, 0], want[1, 1], want[0, 2], want[1, 2]], rtol=1e-9)
+        if noise == 0.0:
+            np.testing.assert_allclose(K4, cam[:4], rtol=1e-7)
+    K4 = np.zeros(4)
+    assert hc.hc_zhang(1, P(H[:1].copy()), 1280.0, 1024.0, P(K4)) == 0 and np.array_equal(K4, [1280.0, 1280.0, 639.5, 511.5])
+    junk = np.ascontiguousarray(rng.normal(size=(6, 3, 3)))
+    used = hc.hc_zhang(6, P(junk), 1280.0, 1024.0, P(K4))
+    want = co.intrinsics_from_homographies(junk, (1280, 1024))
+    np.testing.assert_allclose(K4, [want[0, 0], want[1, 1], want[0, 2], want[1, 2]], rtol=1e-7)
+    assert used == (0 if want[0, 0] == 1280.0 and want[0, 2] == 639.5 else 1)
+
+
 def test_rotvec_from_matrix_is_the_references_formula(hc):
     from oracle import calibration_oracle as co
 
