@@ -3,11 +3,12 @@
 Reference: multicam_calibration/calibration.py.  Same signatures, same return values, same use of the global numpy
 RNG, same printed progress lines (the tqdm bars are not reproduced).  This image has no cv2, and a GPU is there anyway: everything
 per view and per frame runs in libmcba.so (include/mcba.h: the mcba_calib_* block, csrc/mcba_pnp.hip); the host keeps what is a
-handful of numbers per CAMERA.
+handful of numbers per CAMERA (the reference's RNG draw, the spanning tree, the chaining of C - 1 transforms).
 
   get_intrinsics (calibration.py:11-71, cv2.calibrateCamera with CALIB_FIX_K3 | CALIB_ZERO_TANGENT_DIST)
-      per sampled view the board-plane homography (GPU: normalised DLT, lane = view) -> Zhang's closed form for K (host: the null vector
-      of a 6-column system per camera) -> per-view pose (GPU: cv2.solvePnP's job with K0) -> joint refinement of (fx, fy, cx, cy, k1, k2)
+      per sampled view the board-plane homography (GPU: normalised DLT, lane = view) -> Zhang's closed form for K (GPU: the null vector
+      of a 6-column system per camera, by cyclic Jacobi on its normal matrix) -> per-view pose (GPU: cv2.solvePnP's job with K0) -- these
+      three in one crossing, mcba_calib_start -> joint refinement of (fx, fy, cx, cy, k1, k2)
       and the views' poses by the library's own device-resident LM loop: the bundle adjustment of cameras whose extrinsics are held at
       the identity, plain least squares.  calibrate() refines EVERY camera in one such run (the sampled views of all cameras side by
       side: the normal equations are block-diagonal over the cameras).
