@@ -230,8 +230,8 @@ def calibrate_timing(m, p, reps=5):
     stages = {"upload": [(ops.Problem, "__init__"), (ops.Problem, "calib_complete")],
               "intrinsics_sampled_views": [(cal, "_sample_all_cameras"), (cal, "_start_on_device"), (cal, "_refine_intrinsics_on_device")],
               "poses_every_view": [(ops.Problem, "calib_poses")],
-              "pose_graph_and_consensus": [(cal, "_pose_graph_on_device"), (ops.Problem, "calib_consensus")]}
-    extra = [(ops.Problem, "calib_start"), (ops.Problem, "lm_run"), (ops.Problem, "calib_pairwise")]
+              "pose_graph_and_consensus": [(cal, "_pose_graph_on_device")]}
+    extra = [(ops.Problem, "calib_start"), (ops.Problem, "lm_run"), (ops.Problem, "calib_graph")]
     saved = []
     for owner, n in [x for v in stages.values() for x in v] + extra:
         saved.append((owner, n, getattr(owner, n)))
@@ -272,7 +272,7 @@ def calibrate_timing(m, p, reps=5):
     br = {name: sum(ms.get(n, 0.0) for _, n in members) for name, members in stages.items()}
     br["python_rest"] = total - sum(br.values())
     br["of_which"] = {"closed_form_start_crossing_homographies_zhang_view_poses": ms.get("calib_start", 0.0), "joint_refinement_lm_run": ms.get("lm_run", 0.0),
-                      "pairwise_medians_crossing": ms.get("calib_pairwise", 0.0)}
+                      "pose_graph_crossing_medians_chain_consensus": ms.get("calib_graph", 0.0)}
     ba_ms = float(np.median(ba[1:]))
     return {"calibrate_ms": total, "calibrate_ms_min": float(min(times)), "reps": reps, "breakdown_ms": br, "bundle_adjust_from_calibrate_ms": ba_ms, "pipeline_ms": total + ba_ms,
             "bundle_adjust_from_calibrate": {"nfev": int(out[4].nfev), "status": int(out[4].status), "cost": float(out[4].cost), "frames": int(ok.sum())},

@@ -52,7 +52,7 @@ typedef struct mcba_handle mcba_handle;
 typedef struct mcba_buffer mcba_buffer;   /* a device array that outlives its handle (mcba_residuals_detach) */
 
 /* ---- library ------------------------------------------------------------------------------- */
-int mcba_abi_version(void);            /* 7.  Bumped when this header changes: 7 (round 6) ADDS the mcba_calib_* (incl. mcba_calib_start) / mcba_pose_* / mcba_create_views block below (calibrate() on the device) and leaves every ABI-6 entry point as it was; 6 (round 5) ADDED mcba_prefilter, mcba_prefilter_subset, mcba_lm_run, mcba_lm_history, mcba_lm_result, mcba_set_bounds / _frozen, mcba_set_loss_table, mcba_set_trial, mcba_calib_normal_equations (and the diagnostics / life-cycle helpers declared below as ABI 6) and leaves every
+int mcba_abi_version(void);            /* 7.  Bumped when this header changes: 7 (round 6) ADDS the mcba_calib_* (incl. mcba_calib_start, mcba_calib_graph) / mcba_pose_* / mcba_create_views block below (calibrate() on the device) and leaves every ABI-6 entry point as it was; 6 (round 5) ADDED mcba_prefilter, mcba_prefilter_subset, mcba_lm_run, mcba_lm_history, mcba_lm_result, mcba_set_bounds / _frozen, mcba_set_loss_table, mcba_set_trial, mcba_calib_normal_equations (and the diagnostics / life-cycle helpers declared below as ABI 6) and leaves every
                                         * ABI-5 entry point as it was.  (ABI 5 gave LM-state slots 25 / 26 -- "reserved" before -- their meaning: curvature floor / switch
                                         * fraction; a caller that zeroes them gets the handle's floor, fixed.) */
 const char* mcba_last_error(void);
@@ -379,7 +379,8 @@ int mcba_create_subset(mcba_handle** out, mcba_handle* src, const int* frames, i
  *   first and last step alone are mcba_calib_homographies and mcba_calib_view_poses)
  *   -> mcba_create_views + mcba_lm_run + mcba_lm_result (EVERY camera's fx fy cx cy k1 k2 and its views' poses in one device-resident LM run)
  *   -> mcba_calib_poses (every (camera, frame): one launch, the poses stay on the device) -> [host: maximum spanning tree of the C x C
- *   co-detection counts :146-197] -> mcba_calib_pairwise (tree edges) -> [host: chain C - 1 transforms :230-235] -> mcba_calib_consensus.
+ *   co-detection counts :146-197] -> mcba_calib_graph (the tree's pairwise medians, the chain of C - 1 transforms :230-235 and the consensus in
+ *   one crossing; its pieces alone: mcba_calib_pairwise, mcba_calib_consensus).
  * Views are (camera, frame) int pairs.  intr9 = C x (fx fy cx cy k1 k2 p1 p2 k3) (OpenCV's five-coefficient model; the reference's defaults
  * leave p1 = p2 = k3 = 0).  Poses are board -> camera 6-vectors (rotation vector, translation), NaN rows where there is none.  The board must
  * be planar (z = 0), as the reference's chessboards are.  cv2 is absent from the build image: parity with OpenCV's numbers is unpinned; the
@@ -411,6 +412,12 @@ int mcba_calib_pairwise(mcba_handle* h, const int* edges, int n_edges, double* t
 /* consensus_calib_poses (:239-277): extrinsics (C,6) world -> camera; poses_out (F,6) = per-coordinate nan-median over the cameras of
  * T_ext^-1 T_pose; NaN rows for frames no camera has a pose for. */
 int mcba_calib_consensus(mcba_handle* h, const double* extrinsics, double* poses_out);
+/* The pose graph of calibrate() (:200-277) in ONE crossing: mcba_calib_pairwise's medians for the spanning tree's edges, chained from `root` into
+ * the world -> camera extrinsics ON THE DEVICE (:226-235), and mcba_calib_consensus with them.  edges = n_edges x (c1, c2) ordered so that c1 is
+ * `root` or the c2 of an earlier edge and every camera is reached exactly once (the reference's tree sorted by distance from the root; n_edges =
+ * C - 1, none for one camera).  extrinsics_out (C, 6), the root's row exactly 0; poses_out (F, 6); transforms_out (n_edges, 6) and counts_out
+ * (n_edges) or NULL. */
+int mcba_calib_graph(mcba_handle* h, const int* edges, int n_edges, int root, double* extrinsics_out, double* poses_out, double* transforms_out, double* counts_out);
 /* A new handle of C cameras x n_views frames: frame j holds view j's detection in ITS camera alone (NaN in the others) -- the sampled views of
  * every camera side by side, so that one LM run (12 C camera parameters of which the extrinsics are held fixed at 0, 6 per view) is
  * get_intrinsics of every camera.  Gathered device to device; does not synchronise. */

@@ -364,11 +364,11 @@ def _sample_all_cameras(complete, n_samples):
 
 
 def _pose_graph_on_device(prob, detected, root):
-    """calibration.py:200-277 on the poses prob.calib_poses left on the device: (all_extrinsics, consensus poses, spanning tree)."""
+    """calibration.py:200-277 on the poses prob.calib_poses left on the device: the spanning tree here (C x C counts), the tree's pairwise medians,
+    their chain from the root and the consensus in one crossing.  Returns (all_extrinsics, consensus poses, spanning tree)."""
     tree = _spanning_tree(detected, root=root)
-    transforms = prob.calib_pairwise(tree)[0] if tree else []
-    ext = _chain_extrinsics(prob.C, tree, transforms, root)
-    return ext, tree
+    ext, poses = prob.calib_graph(tree, root)
+    return ext, poses, tree
 
 
 def calibrate(all_calib_uvs, img_sizes, calib_objpoints, root=0, verbose=True, n_samples_for_intrinsics=100, device=0):
@@ -391,10 +391,9 @@ def calibrate(all_calib_uvs, img_sizes, calib_objpoints, root=0, verbose=True, n
         detected, _, _ = prob.calib_poses(np.array([_intr9(K, d) for K, d in all_intrinsics]))
         if verbose:
             print("Estimating camera extrinsics")
-        all_extrinsics, spanning_tree = _pose_graph_on_device(prob, detected, root)
+        all_extrinsics, calib_poses, spanning_tree = _pose_graph_on_device(prob, detected, root)
         if verbose:
             print("Merging calibration object poses")
-        calib_poses = prob.calib_consensus(all_extrinsics)
     finally:
         prob.close()
     return all_extrinsics, all_intrinsics, calib_poses, spanning_tree

@@ -1930,6 +1930,52 @@ int mcba_calib_consensus(mcba_handle* h, const double* extrinsics, double* poses
   return MCBA_OK;
 }
 
+// calibration.py:200-277 in ONE crossing on the poses mcba_calib_poses left on the device: the medians of the pairwise transforms of the spanning
+// tree's edges (mcba_calib_pairwise's work), chained from `root` into the world -> camera extrinsics on the device (k_pose_chain; :226-235), and the
+// consensus board poses with them (mcba_calib_consensus' work).  edges = n_edges x (c1, c2), ordered so that c1 is `root` or the c2 of an earlier
+// edge, every camera reached exactly once (n_edges = C - 1; C = 1: none): the reference's tree, sorted by distance from the root.
+// extrinsics_out (C, 6), the root's row exactly 0; poses_out (F, 6); transforms_out (n_edges, 6) and counts_out (n_edges) optional.
+int mcba_calib_graph(mcba_handle* h, const int* edges, int n_edges, int root, double* extrinsics_out, double* poses_out, double* transforms_out, double* counts_out) {
+  int rc = calib_ready(h, "mcba_calib_graph");
+  if (rc) return rc;
+  if (!extrinsics_out || !poses_out || n_edges < 0 || (n_edges > 0 && !edges) || root < 0 || root >= h->C) return fail(MCBA_ERR_ARG, "mcba_calib_graph: bad argument");
+  if (!h->have_cal_poses) return fail(MCBA_ERR_ARG, "mcba_calib_graph: call mcba_calib_poses first");
+  if (n_edges != h->C - 1) return fail(MCBA_ERR_ARG, "mcba_calib_graph: a spanning tree of C cameras has C - 1 edges");
+  {
+    std::vector<char> placed((size_t)h->C, 0);
+    placed[(size_t)root] = 1;
+    for (int e = 0; e < n_edges; ++e) {
+      const int c1 = edges[2 * e], c2 = edges[2 * e + 1];
+      if (c1 < 0 || c1 >= h->C || c2 < 0 || c2 >= h->C) return fail(MCBA_ERR_ARG, "mcba_calib_graph: camera index out of range");
+      if (!placed[(size_t)c1] || placed[(size_t)c2]) return fail(MCBA_ERR_ARG, "mcba_calib_graph: edges must lead away from the root, every camera reached once");
+      placed[(size_t)c2] = 1;
+    }
+  }
+  const int E = n_edges;
+  if (!h->cal_world && (rc = dalloc(h, &h->cal_world, (size_t)6 * h->C * h->Fpad, false))) return rc;
+  if ((rc = dgrow(h, &h->cal_out, &h->cal_out_cap, (size_t)6 * h->F + (size_t)6 * h->C + (size_t)7 * E + 8))) return rc;
+  double* d_ext = h->cal_out + (size_t)6 * h->F;
+  double* d_tr = d_ext + (size_t)6 * h->C;
+  double* d_cnt = d_tr + (size_t)6 * E;
+  if (E > 0) {
+    if ((rc = dgrow(h, &h->cal_views, &h->cal_views_cap, (size_t)2 * E))) return rc;
+    if ((rc = dgrow(h, &h->cal_rel, &h->cal_rel_cap, (size_t)6 * E * h->Fpad))) return rc;
+    if ((rc = dgrow(h, &h->cal_sel, &h->cal_sel_cap, mcba::select_state_bytes(12 * E)))) return rc;
+    HIPCHK(hipMemcpyAsync(h->cal_views, edges, (size_t)2 * E * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    mcba::launch_pose_pairs(h->stream, h->cal_poses_t, (size_t)6 * h->Fpad, 1, (size_t)h->Fpad, h->cal_views, E, h->F, h->Fpad, h->cal_rel);
+    mcba::launch_select(h->stream, h->cal_rel, nullptr, (size_t)h->Fpad, 6 * E, h->Fpad, h->cal_sel, 2, 1);
+  }
+  mcba::launch_pose_chain(h->stream, h->cal_sel, mcba::select_state_bytes(1), h->cal_views, E, root, h->C, d_ext, d_tr, d_cnt);
+  mcba::launch_pose_consensus(h->stream, h->cal_poses_t, (size_t)6 * h->Fpad, 1, (size_t)h->Fpad, d_ext, h->C, h->F, h->Fpad, h->cal_world, h->cal_out);
+  if ((rc = check_launch())) return rc;
+  HIPCHK(hipMemcpyAsync(extrinsics_out, d_ext, (size_t)6 * h->C * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(poses_out, h->cal_out, (size_t)6 * h->F * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (transforms_out && E > 0) HIPCHK(hipMemcpyAsync(transforms_out, d_tr, (size_t)6 * E * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (counts_out && E > 0) HIPCHK(hipMemcpyAsync(counts_out, d_cnt, (size_t)E * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MCBA_OK;
+}
+
 // The same two pose-graph steps for a caller's own (C, F, 6) pose array (NaN rows = no detection): what the reference's public
 // estimate_pairwise_camera_transform / consensus_calib_poses take.  Stateless; host arrays in, host arrays out.
 int mcba_pose_pairwise(int n_cameras, int n_frames, const double* poses, const int* edges, int n_edges, int device, double* transforms_out, double* counts_out) {

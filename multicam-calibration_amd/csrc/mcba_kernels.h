@@ -143,6 +143,7 @@ void launch_pnp(hipStream_t st, int mode, const double* obs_t, const double* obj
 // poses addressed as p[c * sc + f * sf + k * sk]; rel [n_edges][6][Fpad]; world [C][6][Fpad] scratch; out (F, 6)
 void launch_zhang(hipStream_t st, const double* H, const unsigned char* ok, const int* views, int nviews, const double* sizes, int C, double* intr9, unsigned char* closed);
 void launch_pose_pairs(hipStream_t st, const double* poses, size_t sc, size_t sf, size_t sk, const int* edges, int n_edges, int F, int Fpad, double* rel);
+void launch_pose_chain(hipStream_t st, const void* sel, size_t sel_state_bytes, const int* edges, int n_edges, int root, int C, double* ext, double* transforms, double* counts);
 void launch_pose_consensus(hipStream_t st, const double* poses, size_t sc, size_t sf, size_t sk, const double* ext, int C, int F, int Fpad, double* world, double* out);
 // triangulation (mcba_triangulate.hip): up to 8 cameras; P = K [R | t] row-major 3x4, K = (fx, fy, cx, cy), dist = (k1 k2 p1 p2 k3)
 struct TriCams {

@@ -254,6 +254,69 @@ __global__ __launch_bounds__(64) void k_pose_pairs(PoseView pv, const int* __res
   for (int k = 0; k < 6; ++k) rel[((size_t)e * 6 + k) * Fpad + f] = ok ? w[k] : nan;
 }
 
+// calibration.py:226-235 on the device: the medians of the tree's pairwise transforms (the two middle order statistics the radix select left in
+// its states: word 2 = count, word 3 = the value's bits, `stride` words per state, two states per component) chained from the root --
+// T_world->c2 = T_c1->c2 T_world->c1, edges ordered so that c1 is placed before c2 (the caller checks) -- into ext [C][6]; transforms [E][6] and
+// counts [E] (frames the pair shares) for the caller.  One wavefront; only the C - 1 products of the chain itself run on one lane.
+__global__ __launch_bounds__(64) void k_pose_chain(const unsigned long long* __restrict__ sel, int stride, const int* __restrict__ edges, int n_edges, int root, int C,
+                                                   double* __restrict__ ext, double* __restrict__ transforms, double* __restrict__ counts) {
+  __shared__ double Tm[40][12];   // world -> camera: R (9, row-major), t (3)
+  __shared__ double Te[39][12];   // the edges' transforms as matrices
+  __shared__ double med[39 * 6];
+  const int lane = threadIdx.x;
+  const double nan = __builtin_nan("");
+  // the medians: lane = (edge, component) -- every lane's loads in flight together, not 12 E round trips of one lane
+  for (int i = lane; i < 6 * n_edges; i += 64) {
+    const unsigned long long cnt = sel[(size_t)(2 * i) * stride + 2];
+    const unsigned long long a = sel[(size_t)(2 * i) * stride + 3], b = sel[(size_t)(2 * i + 1) * stride + 3];
+    const double m = cnt ? 0.5 * (__longlong_as_double((long long)a) + __longlong_as_double((long long)b)) : nan;   // np.median: the mean of the two middle values
+    med[i] = m;
+    transforms[i] = m;
+    if (i % 6 == 0) counts[i / 6] = (double)cnt;
+  }
+  __syncthreads();
+  for (int e = lane; e < n_edges; e += 64) {   // lane = edge: its rotation matrix
+    double t[3] = {med[6 * e], med[6 * e + 1], med[6 * e + 2]}, Re[9];
+    rot_only(t, Re);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Te[e][k] = Re[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Te[e][9 + k] = med[6 * e + 3 + k];
+  }
+  for (int c = lane; c < C; c += 64)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Tm[c][k] = c == root ? (k == 0 || k == 4 || k == 8 ? 1.0 : 0.0) : nan;
+  __syncthreads();
+  if (lane == 0) {   // the chain itself is sequential: C - 1 products
+    for (int e = 0; e < n_edges; ++e) {
+      const int c1 = edges[2 * e], c2 = edges[2 * e + 1];
+      double Re[9], R1[9], t1[3], R2[9], t2[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { Re[k] = Te[e][k]; R1[k] = Tm[c1][k]; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t1[k] = Tm[c1][9 + k];
+      mm33(Re, R1, R2);
+      mv3(Re, t1, t2);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Tm[c2][k] = R2[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Tm[c2][9 + k] = t2[k] + Te[e][9 + k];
+    }
+  }
+  __syncthreads();
+  for (int c = lane; c < C; c += 64) {   // lane = camera: rotation vector (the root's: exactly 0)
+    double R[9], w[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = Tm[c][k];
+    rotvec_from_matrix(R, w);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      ext[6 * c + k] = w[k];
+      ext[6 * c + 3 + k] = Tm[c][9 + k];
+    }
+  }
+}
+
 // calibration.py:239-277: every camera's board pose mapped to world coordinates (T_ext^-1 T_pose), nan-median over the cameras per coordinate.
 // world: scratch [C][6][Fpad].  Lane = frame; the median by rank counting among the <= C values of the lane (C <= 64).
 __global__ __launch_bounds__(64) void k_pose_consensus(PoseView pv, const double* __restrict__ ext, int C, int F, int Fpad, double* __restrict__ world, double* __restrict__ out) {
@@ -344,6 +407,10 @@ void launch_zhang(hipStream_t st, const double* H, const unsigned char* ok, cons
 
 void launch_pose_pairs(hipStream_t st, const double* poses, size_t sc, size_t sf, size_t sk, const int* edges, int n_edges, int F, int Fpad, double* rel) {
   k_pose_pairs<<<dim3(Fpad / 64, n_edges), dim3(64), 0, st>>>(PoseView{poses, sc, sf, sk}, edges, F, Fpad, rel);
+}
+
+void launch_pose_chain(hipStream_t st, const void* sel, size_t sel_state_bytes, const int* edges, int n_edges, int root, int C, double* ext, double* transforms, double* counts) {
+  k_pose_chain<<<dim3(1), dim3(64), 0, st>>>(static_cast<const unsigned long long*>(sel), (int)(sel_state_bytes / 8), edges, n_edges, root, C, ext, transforms, counts);
 }
 
 void launch_pose_consensus(hipStream_t st, const double* poses, size_t sc, size_t sf, size_t sk, const double* ext, int C, int F, int Fpad, double* world, double* out) {

@@ -93,6 +93,7 @@ SYMBOLS = [
     ("mcba_calib_complete", ctypes.c_int, [_h, ctypes.POINTER(ctypes.c_ubyte)]),
     ("mcba_calib_homographies", ctypes.c_int, [_h, _ip, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte)]),
     ("mcba_calib_view_poses", ctypes.c_int, [_h, _ip, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte)]),
+    ("mcba_calib_graph", ctypes.c_int, [_h, _ip, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),
     ("mcba_calib_start", ctypes.c_int, [_h, _ip, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte), _dp, ctypes.POINTER(ctypes.c_ubyte)]),
     ("mcba_calib_poses", ctypes.c_int, [_h, _dp, ctypes.c_int, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_ubyte)]),
     ("mcba_calib_pairwise", ctypes.c_int, [_h, _ip, ctypes.c_int, _dp, _dp]),
@@ -402,6 +403,15 @@ class Problem:
         out, cnt = np.empty((len(e), 6)), np.empty(len(e))
         self._chk(self.lib.mcba_calib_pairwise(self.handle, e.ctypes.data_as(_ip), len(e), _p(out), _p(cnt)))
         return out, cnt
+
+    def calib_graph(self, tree, root, want_transforms=False):
+        """The pose graph in one crossing (include/mcba.h: mcba_calib_graph): (extrinsics (C,6) chained down `tree` from `root`, consensus board
+        poses (F,6)) [+ the tree edges' median transforms (E,6) and shared-frame counts (E,)]."""
+        e = np.ascontiguousarray(tree, dtype=np.int32).reshape(-1, 2)
+        ext, poses = np.empty((self.C, 6)), np.empty((self.F, 6))
+        tr, cnt = np.empty((len(e), 6)), np.empty(len(e))
+        self._chk(self.lib.mcba_calib_graph(self.handle, e.ctypes.data_as(_ip), len(e), int(root), _p(ext), _p(poses), _p(tr), _p(cnt)))
+        return (ext, poses, tr, cnt) if want_transforms else (ext, poses)
 
     def calib_consensus(self, extrinsics):
         """(F,6) consensus board poses in world coordinates for the extrinsics (C,6)."""

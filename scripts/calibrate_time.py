@@ -40,7 +40,7 @@ from multicam_calibration_amd import ops
 # the stages of calibrate(): the C-ABI crossings (ops.Problem methods) and the host-side pieces between them
 for n in ("_sample_all_cameras", "_start_on_device", "_refine_intrinsics_on_device", "_spanning_tree", "_chain_extrinsics", "_pose_graph_on_device"):
     setattr(cal, n, timed(n, getattr(cal, n)))
-for n in ("__init__", "calib_complete", "calib_start", "calib_homographies", "calib_view_poses", "view_subset", "calib_poses", "calib_pairwise", "calib_consensus", "lm_run", "lm_result", "close"):
+for n in ("__init__", "calib_complete", "calib_start", "calib_homographies", "calib_view_poses", "view_subset", "calib_poses", "calib_graph", "calib_pairwise", "calib_consensus", "lm_run", "lm_result", "close"):
     setattr(ops.Problem, n, timed("ops." + n, getattr(ops.Problem, n)))
 
 out = {}

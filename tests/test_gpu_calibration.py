@@ -493,6 +493,47 @@ def test_calibrate_edge_cases(mc):
         mc.calibrate(p["uvs"], [(1280, 1024)], p["obj"] + np.array([0, 0, 1.0]) * np.arange(54)[:, None], verbose=False)
 
 
+@pytest.mark.parametrize("root", [0, 3])
+def test_pose_graph_in_one_crossing_equals_its_pieces(mc, root):
+    """mcba_calib_graph = mcba_calib_pairwise on the tree's edges (the same bits), those medians chained from the root in numpy (1e-12: the device
+    chains C - 1 products of 3 x 3 matrices, the rotation vector by the clamped arccos), mcba_calib_consensus with the chained extrinsics; a
+    pair of cameras that share no frame gives NaN extrinsics down its branch, as the reference's chain does; one camera: no edges."""
+    from multicam_calibration_amd import calibration as cal
+
+    p = mc.synth.make_problem(5, 70, seed=76, noise=0.2, missing=0.3)
+    intr9 = np.c_[p["true_cam"][:, :6], np.zeros((5, 3))]
+    prob = mc.ops.Problem(p["uvs"], p["obj"], loss="linear")
+    detected, _, _ = prob.calib_poses(intr9)
+    tree = cal._spanning_tree(detected, root=root)
+    ext, poses, tr, cnt = prob.calib_graph(tree, root, want_transforms=True)
+    tr2, cnt2 = prob.calib_pairwise(tree)
+    np.testing.assert_array_equal(tr, tr2)
+    np.testing.assert_array_equal(cnt, cnt2)
+    want_ext = cal._chain_extrinsics(5, tree, tr2, root)
+    np.testing.assert_allclose(ext, want_ext, rtol=0, atol=1e-12)
+    assert np.all(ext[root] == 0)
+    want = prob.calib_consensus(ext)
+    np.testing.assert_array_equal(poses, want)
+    prob.close()
+    # a branch without a common frame
+    q = mc.synth.make_problem(3, 40, seed=77, noise=0.1)
+    uv = q["uvs"].copy()
+    uv[2, :20] = np.nan
+    uv[1, 20:] = np.nan
+    prob = mc.ops.Problem(uv, q["obj"], loss="linear")
+    prob.calib_poses(np.c_[q["true_cam"][:, :6], np.zeros((3, 3))])
+    ext, poses, tr, cnt = prob.calib_graph([(0, 1), (1, 2)], 0, want_transforms=True)
+    assert cnt.tolist() == [20.0, 0.0] and np.isfinite(ext[1]).all() and np.isnan(ext[2]).all() and np.isnan(tr[1]).all()
+    want = prob.calib_consensus(ext)
+    assert np.array_equal(np.isnan(poses), np.isnan(want)) and np.array_equal(poses[~np.isnan(want)], want[~np.isnan(want)])
+    prob.close()
+    one = mc.ops.Problem(q["uvs"][:1], q["obj"], loss="linear")
+    one.calib_poses(np.c_[q["true_cam"][:1, :6], np.zeros((1, 3))])
+    ext, poses = one.calib_graph([], 0)
+    assert np.all(ext == 0) and np.isfinite(poses).all()
+    one.close()
+
+
 def test_calibrate_entry_points_refuse_bad_arguments(mc):
     """The C ABI's argument checks (int status + mcba_last_error, never a fault): views out of range, the pose graph before any poses exist,
     a camera pair out of range, a non-planar board, a handle without observations."""
@@ -511,6 +552,12 @@ def test_calibrate_entry_points_refuse_bad_arguments(mc):
     prob.calib_poses(intr9)
     with pytest.raises(mc.ops.McbaError, match="out of range"):
         prob.calib_pairwise([(0, 2)])
+    with pytest.raises(mc.ops.McbaError, match="C - 1 edges"):
+        prob.calib_graph([(0, 1), (1, 0)], 0)
+    with pytest.raises(mc.ops.McbaError, match="away from the root"):
+        prob.calib_graph([(0, 1)], 1)
+    with pytest.raises(mc.ops.McbaError, match="bad argument"):
+        prob.calib_graph([(0, 1)], 2)
     prob.trim()   # the poses go with the other lazily allocated buffers: the graph calls say so instead of reading freed memory
     with pytest.raises(mc.ops.McbaError, match="mcba_calib_poses first"):
         prob.calib_pairwise([(0, 1)])
