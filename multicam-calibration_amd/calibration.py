@@ -199,7 +199,9 @@ def _start_on_device(prob, views, image_sizes):
     """Closed-form start for the cameras of `prob` from their sampled views ((V,2) int: camera, frame), ONE crossing (include/mcba.h:
     mcba_calib_start): per-view homographies, Zhang's K per camera from them (image of the absolute conic, zero skew; the fallback f = max(w, h),
     c = the image centre for a camera its views do not constrain), per-view poses with that K.  Returns (K0 list, poses0 (V,6))."""
-    k4, poses0 = prob.calib_start(views, np.asarray(image_sizes, dtype=np.float64).reshape(prob.C, 2))
+    # (four linearisations per view: K0 is a closed-form estimate without distortion -- poses converged against it to 1e-13 are not better starts;
+    #  the joint refinement takes the same number of evaluations from poses after 1, 4 or 60, scripts/start_evals_probe.py)
+    k4, poses0 = prob.calib_start(views, np.asarray(image_sizes, dtype=np.float64).reshape(prob.C, 2), max_evaluations=4)
     return [np.array([[q[0], 0, q[2]], [0, q[1], q[3]], [0, 0, 1.0]]) for q in k4], poses0
 
 
