@@ -659,10 +659,13 @@ def test_calibrate_random_rigs(mc, it):
         if a[4].status > 0 and b[4].status > 0 and a[3].size:
             np.testing.assert_array_equal(a[3], b[3])
             if abs(a[4].cost - b[4].cost) > 1e-6 * b[4].cost + 1e-12:
-                # two different minima.  One cause is the data's, not the start's: a small board under noise has TWO poses per view that explain
-                # its image almost equally (the planar two-fold ambiguity; cv2.solvePnP's iterative method, which the reference calls, settles
-                # in either as well), and a frame that enters bundle_adjust mirrored stays mirrored.  Look for it: board poses in camera
-                # coordinates (gauge-free) that differ between the two solutions by a large rotation.  Soak cases 464, 1021, 1204 of 1 440.
+                # two different minima.  One cause is the reference algorithm's, and calibrate() reproduces it (the consensus poses above equal the
+                # numpy restatement's on every frame): consensus_calib_poses takes the component-wise median of ROTATION VECTORS
+                # (calibration.py:239-277); for a frame whose board is turned by nearly pi in world coordinates the cameras' vectors straddle the
+                # wrap (r and -r describe almost the same rotation there) and their median -- with two cameras: their mean -- is a rotation pi
+                # away from both.  Such a frame enters bundle_adjust upside down and stays there.  Look for it: board rotations in camera
+                # coordinates (gauge-free) that differ between the two solutions by a large angle.  Soak cases 464, 1021, 1204 of 1 440
+                # (scripts/pose_ambiguity_probe.py: one or two frames 3.1 rad off in the start, every per-view pose within 0.07 rad of the truth).
                 def cam_board(e, q):
                     return co.rodrigues_batch(np.asarray(e)[:, None, :3]) @ co.rodrigues_batch(np.asarray(q)[None, :, :3])
                 Ra, Rb = cam_board(a[0], a[2]), cam_board(b[0], b[2])
