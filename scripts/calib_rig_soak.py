@@ -1,5 +1,5 @@
 """Soak of tests/test_gpu_calibration.py::test_calibrate_random_rigs beyond its 40 committed cases: python scripts/calib_rig_soak.py 40 400"""
-import sys, traceback
+import sys
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
 import multicam_calibration_amd as mc

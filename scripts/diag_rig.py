@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import multicam_calibration_amd as mc
-from multicam_calibration_amd import ops, calibration as cal
+
 from oracle import calibration_oracle as co
 from test_gpu_calibration import _draw_rig
 
