@@ -665,7 +665,7 @@ def test_calibrate_random_rigs(mc, it):
                 # wrap (r and -r describe almost the same rotation there) and their median -- with two cameras: their mean -- is a rotation pi
                 # away from both.  Such a frame enters bundle_adjust upside down and stays there.  Look for it: board rotations in camera
                 # coordinates (gauge-free) that differ between the two solutions by a large angle.  Soak cases 464, 1021, 1204 of 1 440
-                # (scripts/pose_ambiguity_probe.py: one or two frames 3.1 rad off in the start, every per-view pose within 0.07 rad of the truth).
+                # (tests/tools/pose_ambiguity_probe.py: one or two frames 3.1 rad off in the start, every per-view pose within 0.07 rad of the truth).
                 def cam_board(e, q):
                     return co.rodrigues_batch(np.asarray(e)[:, None, :3]) @ co.rodrigues_batch(np.asarray(q)[None, :, :3])
                 Ra, Rb = cam_board(a[0], a[2]), cam_board(b[0], b[2])

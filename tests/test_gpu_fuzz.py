@@ -136,7 +136,7 @@ def test_returned_point_is_a_minimiser_of_the_oracle_objective(mc, it):
         assert np.abs(orc.predict_from_x(r.x, C, p["obj"]) - pred).max() < 1e-4, (tag, "flags on the 12-wide block")
 
 
-# The soak's unterminated cases (scripts/fuzz_scan.py 1000 2700, profiles/round6/fuzz_scan_r6a.txt: these 8 of 1 700): recordings of 3-8 frames
+# The soak's unterminated cases (tests/tools/fuzz_scan.py 1000 2700, profiles/round6/fuzz_scan_r6a.txt: these 8 of 1 700): recordings of 3-8 frames
 # -- the intrinsics and distortion of up to 20 cameras from three views of a 6-20-point board, barely determined.  Each run slides along a nearly
 # flat, CURVED valley of the objective: accepted steps at a constant gain ratio of ~0.55 (Nielsen's rule then leaves the damping where it is), a
 # relative gain of 1e-6 per step, the gradient not shrinking.  At the sweep's tolerances (1e-13) nothing fires within 400 evaluations -- and

@@ -1,4 +1,4 @@
-"""Soak of tests/test_gpu_calibration.py::test_calibrate_random_rigs beyond its 40 committed cases: python scripts/calib_rig_soak.py 40 400"""
+"""Soak of tests/test_gpu_calibration.py::test_calibrate_random_rigs beyond its 40 committed cases: python tests/tools/calib_rig_soak.py 40 400"""
 import sys
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")

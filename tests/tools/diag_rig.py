@@ -1,7 +1,7 @@
 """Diagnostic: one randomised rig of tests/test_gpu_calibration.py::test_calibrate_random_rigs, the per-view pose kernel's exits written out."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, ".")   # run from the repository root
+sys.path.insert(0, "tests")
 import numpy as np
 import multicam_calibration_amd as mc
 

@@ -1,6 +1,6 @@
 """Which seeded cases of tests/test_gpu_fuzz.py's sweep do not terminate?  Runs bundle_adjust() on the cases [lo, hi) with the sweep's settings
 (ftol = xtol = 1e-13, gtol = 1e-11, max_nfev = 400) and prints one line per case that ends with status 0, plus a summary.  No oracle: seconds per
-hundred cases.   usage: python scripts/fuzz_scan.py lo hi [extra bundle_adjust keywords as key=value ...]"""
+hundred cases.   usage: python tests/tools/fuzz_scan.py lo hi [extra bundle_adjust keywords as key=value ...]"""
 import contextlib
 import io
 import json
