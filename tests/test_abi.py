@@ -58,6 +58,17 @@ def test_product_never_imports_the_oracle():
             assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), fn
 
 
+def test_measurement_scripts_do_not_touch_the_oracle():
+    """scripts/ holds the measurement programs behind profiles/: none of them imports or runs anything under oracle/ (diagnostics that use it as
+    their checker live in tests/tools/)."""
+    sdir = os.path.join(ROOT, "scripts")
+    for base, _, files in os.walk(sdir):
+        for fn in files:
+            if fn.endswith((".py", ".sh")):
+                src = open(os.path.join(base, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|oracle/|oracle\.", src, flags=re.M), os.path.join(base, fn)
+
+
 def test_more_than_40_cameras_is_refused_with_the_reason():
     """The reference has no camera limit; this build's is 40 per handle -- said in the exception a calibrate() / bundle_adjust() user of a bigger
     rig sees first (checked before any device is touched)."""
